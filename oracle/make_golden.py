@@ -1,0 +1,163 @@
+"""ORACLE tooling: generate tests/golden/*.npz from the REAL reference (build container only).
+
+    python oracle/make_golden.py
+
+Imports the reference archs from /root/reference (oracle/ref_import.py), loads the keyed
+deterministic weights (dcpt_amd/keyed_init.py) into them with ``load_state_dict(strict=True)``
+and records outputs + gradients.  The fixtures are data only (inputs are regenerated from
+keys; outputs/gradients are stored); no reference source is stored.  The reference publishes
+no golden vectors of its own, so these are the pins.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from dcpt_amd.keyed_init import fill_module_, keyed_input, keyed_tensor  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def _grad_summary(module):
+    names, l2, s, a = [], [], [], []
+    for k, p in module.named_parameters():
+        g = p.grad.detach().double()
+        names.append(k)
+        l2.append(float(g.pow(2).sum().sqrt()))
+        s.append(float(g.sum()))
+        a.append(float(g.abs().sum()))
+    return np.array(names), np.array(l2), np.array(s), np.array(a)
+
+
+def gen_ln(ref):
+    out = {}
+    for tag, shape in [("a", (2, 64, 8, 8)), ("b", (1, 512, 4, 4)), ("c", (3, 8, 5, 7))]:
+        C = shape[1]
+        x = keyed_input(f"ln.{tag}.x", shape, lo=-2.0, hi=3.0).requires_grad_(True)
+        w = keyed_tensor(f"ln.{tag}.norm.weight", (C,)).requires_grad_(True)
+        b = keyed_tensor(f"ln.{tag}.norm.bias", (C,)).requires_grad_(True)
+        go = keyed_input(f"ln.{tag}.go", shape, lo=-1.0, hi=1.0)
+        y = ref.nafnet.LayerNormFunction.apply(x, w, b, 1e-6)
+        y.backward(go)
+        out[f"{tag}.y"] = _np(y)
+        out[f"{tag}.dx"] = _np(x.grad)
+        out[f"{tag}.dw"] = _np(w.grad)
+        out[f"{tag}.db"] = _np(b.grad)
+    np.savez_compressed(os.path.join(OUT, "ln2d.npz"), **out)
+
+
+def gen_nafblock(ref):
+    for c in (16, 64):
+        blk = ref.nafnet.NAFBlock(c)
+        # keys are prefixed so that different fixtures get different weights
+        sd = {k: keyed_tensor(f"blk{c}." + k, tuple(v.shape)) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd, strict=True)
+        x = keyed_input(f"blk{c}.x", (2, c, 16, 16), lo=-1.0, hi=1.0).requires_grad_(True)
+        go = keyed_input(f"blk{c}.go", (2, c, 16, 16), lo=-1.0, hi=1.0)
+        y = blk(x)
+        y.backward(go)
+        out = {"y": _np(y), "dx": _np(x.grad)}
+        for k, p in blk.named_parameters():
+            out["g." + k] = _np(p.grad)
+        np.savez_compressed(os.path.join(OUT, f"nafblock_c{c}.npz"), **out)
+
+
+TINY = dict(img_channel=3, width=8, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 2], dec_blk_nums=[1, 1, 1, 1])
+FULL = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1])
+
+
+def gen_nafnet_tiny(ref):
+    net = ref.nafnet.NAFNetBaseline(**TINY)
+    fill_module_(net, seed=0)
+    x = keyed_input("tiny.x", (2, 3, 32, 32)).requires_grad_(True)
+    gw = keyed_input("tiny.gw", (2, 3, 32, 32), lo=-1.0, hi=1.0)
+    taps = []
+    hooks = [getattr(net, f"decoder{i}").register_forward_hook(lambda m, i, o: taps.append(o)) for i in range(4)]
+    y = net(x)
+    (y * gw).sum().backward()
+    out = {"y": _np(y), "dx": _np(x.grad)}
+    for i, t in enumerate(taps):
+        out[f"tap{i}"] = _np(t)
+    names, l2, s, a = _grad_summary(net)
+    out["g_names"], out["g_l2"], out["g_sum"], out["g_abs"] = names, l2, s, a
+    for k in ("intro.weight", "intro.bias", "ending.weight", "ending.bias", "downs.0.weight", "downs.3.bias",
+              "ups.0.0.weight", "ups.3.0.weight", "encoders.0.0.conv1.weight", "encoders.0.0.conv2.weight",
+              "encoders.0.0.beta", "encoders.3.1.gamma", "middle_blks.0.sca.1.weight", "middle_blks.0.sca.1.bias",
+              "decoder3.0.norm1.weight", "decoder3.0.norm2.bias", "decoder0.0.conv5.weight", "decoder2.0.conv3.bias"):
+        out["g." + k] = _np(dict(net.named_parameters())[k].grad)
+    # hook=True path returns None (nafnet_arch.py:269-274)
+    for h in hooks:
+        h.remove()
+    assert net(x.detach(), hook=True) is None
+    np.savez_compressed(os.path.join(OUT, "nafnet_tiny.npz"), **out)
+
+
+def gen_nafnet_full(ref):
+    """Full-size NAFNet-64 [1,1,1,28] (options/all_in_one/test/test_NAFNet_5d.yml:50-56) on one
+    256x256 image: sub-sampled output + grad summaries (weights are regenerable from keys)."""
+    torch.manual_seed(0)
+    net = ref.nafnet.NAFNetBaseline(**FULL)
+    fill_module_(net, seed=0)
+    x = keyed_input("full.x", (1, 3, 256, 256)).requires_grad_(True)
+    gt = keyed_input("full.gt", (1, 3, 256, 256))
+    y = net(x)
+    loss = (y - gt).abs().mean()
+    loss.backward()
+    names, l2, s, a = _grad_summary(net)
+    out = {
+        "y_sub": _np(y[..., ::16, ::16]),
+        "y_mean": np.float64(y.double().mean().item()),
+        "y_absmean": np.float64(y.double().abs().mean().item()),
+        "loss": np.float64(loss.item()),
+        "dx_sub": _np(x.grad[..., ::16, ::16]),
+        "dx_l2": np.float64(x.grad.double().pow(2).sum().sqrt().item()),
+        "g_names": names, "g_l2": l2, "g_sum": s, "g_abs": a,
+        "n_params": np.int64(sum(p.numel() for p in net.parameters())),
+        "n_keys": np.int64(len(net.state_dict())),
+    }
+    np.savez_compressed(os.path.join(OUT, "nafnet_full.npz"), **out)
+
+
+def gen_tlsc(ref):
+    pool = ref.arch_util.AvgPool2d(base_size=(24, 20), train_size=(1, 3, 32, 32), fast_imp=False)
+    x = keyed_input("tlsc.x", (2, 8, 48, 40), lo=-1.0, hi=1.0)
+    y = pool(x)
+    np.savez_compressed(os.path.join(OUT, "tlsc.npz"), y=_np(y), kernel=np.array(pool.kernel_size))
+    # NAFNet (Local_Base) end-to-end on a tiny config
+    net = ref.nafnet.NAFNet(train_size=(1, 3, 16, 16), **TINY)
+    fill_module_(net, seed=0)
+    xi = keyed_input("tlsc.img", (1, 3, 48, 32))
+    with torch.no_grad():
+        yo = net(xi)
+    np.savez_compressed(os.path.join(OUT, "nafnet_local_tiny.npz"), y=_np(yo))
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_import.load_reference_archs()
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    gen_ln(ref)
+    gen_nafblock(ref)
+    gen_nafnet_tiny(ref)
+    gen_nafnet_full(ref)
+    gen_tlsc(ref)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

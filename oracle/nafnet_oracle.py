@@ -1,0 +1,201 @@
+"""ORACLE (test infrastructure, not product code) -- CPU restatement of the reference's
+NAFNet hot path in plain PyTorch fp32.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product path (``dcpt_amd`` / ``basicsr``) never does.
+
+Pinned: ``oracle/make_golden.py`` imports the real reference from /root/reference (only in
+the build container), loads the same keyed weights into it and stores its outputs and
+gradients under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this restatement
+against those vectors.
+
+Each function cites the reference lines it restates.  Everything is functional: the
+parameters come in as a flat dict keyed by the reference's ``state_dict`` names, so there
+is no nn.Module tree here and nothing shared with the product's module code.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-6  # reference nafnet_arch.py:57 (LayerNorm2d default eps)
+
+
+def layernorm2d(x, weight, bias, eps: float = EPS):
+    """Per-pixel LayerNorm over the channel axis of an NCHW tensor.
+
+    reference basicsr/archs/nafnet_arch.py:27-35: mu = mean_c x; var = mean_c (x-mu)^2
+    (biased); y = (x-mu)/sqrt(var+eps); out = w[c]*y + b[c].
+    """
+    mu = x.mean(dim=1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=1, keepdim=True)
+    y = xc / torch.sqrt(var + eps)
+    return y * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+def simple_gate(x):
+    """reference nafnet_arch.py:77-80: first half of the channels times the second half."""
+    c = x.shape[1] // 2
+    return x[:, :c] * x[:, c:]
+
+
+def nafblock(inp, P: dict, pre: str):
+    """reference nafnet_arch.py:165-186 (NAFBlock.forward), dropout rate 0 (Identity)."""
+    g = lambda n: P[pre + n]
+    c2 = g("conv2.weight").shape[0]
+    x = layernorm2d(inp, g("norm1.weight"), g("norm1.bias"))
+    x = F.conv2d(x, g("conv1.weight"), g("conv1.bias"))                       # 1x1 c -> 2c
+    x = F.conv2d(x, g("conv2.weight"), g("conv2.bias"), padding=1, groups=c2)  # dw 3x3
+    x = simple_gate(x)
+    pooled = x.mean(dim=(2, 3), keepdim=True)                                  # AdaptiveAvgPool2d(1)
+    x = x * F.conv2d(pooled, g("sca.1.weight"), g("sca.1.bias"))               # SCA
+    x = F.conv2d(x, g("conv3.weight"), g("conv3.bias"))
+    y = inp + x * g("beta")
+    x = F.conv2d(layernorm2d(y, g("norm2.weight"), g("norm2.bias")), g("conv4.weight"), g("conv4.bias"))
+    x = simple_gate(x)
+    x = F.conv2d(x, g("conv5.weight"), g("conv5.bias"))
+    return y + x * g("gamma")
+
+
+def pixel_shuffle2(x):
+    """out[n, k, 2h+i, 2w+j] = in[n, 4k+2i+j, h, w] (torch.nn.PixelShuffle(2))."""
+    n, c4, h, w = x.shape
+    c = c4 // 4
+    return x.view(n, c, 2, 2, h, w).permute(0, 1, 4, 2, 5, 3).reshape(n, c, 2 * h, 2 * w)
+
+
+def nafnet_cfg_from_params(P: dict):
+    """Recover (enc_blk_nums, middle_blk_num, dec_blk_nums) from state-dict key names."""
+    def count(prefix):
+        idx = set()
+        for k in P:
+            if k.startswith(prefix):
+                idx.add(int(k[len(prefix):].split(".")[0]))
+        return len(idx)
+
+    n_levels = count("downs.")
+    enc = [count(f"encoders.{i}.") for i in range(n_levels)]
+    mid = count("middle_blks.")
+    dec = [count(f"decoder{i}.") for i in range(count("ups."))]
+    return enc, mid, dec
+
+
+def nafnet_forward(inp, P: dict, hook: bool = False):
+    """reference nafnet_arch.py:250-274 (NAFNetBaseline.forward).
+
+    Returns (output_or_None, taps) where taps are the decoder{i} group outputs, in the
+    order the reference's forward hooks would record them (decoder0 first).
+    """
+    enc_nums, mid_num, dec_nums = nafnet_cfg_from_params(P)
+    x = F.conv2d(inp, P["intro.weight"], P["intro.bias"], padding=1)
+    encs = []
+    for i, nb in enumerate(enc_nums):
+        for j in range(nb):
+            x = nafblock(x, P, f"encoders.{i}.{j}.")
+        encs.append(x)
+        x = F.conv2d(x, P[f"downs.{i}.weight"], P[f"downs.{i}.bias"], stride=2)
+    for j in range(mid_num):
+        x = nafblock(x, P, f"middle_blks.{j}.")
+    taps = []
+    for i, nb in enumerate(dec_nums):
+        x = pixel_shuffle2(F.conv2d(x, P[f"ups.{i}.0.weight"]))
+        x = x + encs[len(encs) - 1 - i]
+        for j in range(nb):
+            x = nafblock(x, P, f"decoder{i}.{j}.")
+        taps.append(x)
+    if hook:
+        return None, taps
+    x = F.conv2d(x, P["ending.weight"], P["ending.bias"], padding=1) + inp
+    return x, taps
+
+
+def nafnet_param_shapes(img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=(), dec_blk_nums=()):
+    """State-dict key -> shape, in the reference's registration order
+    (nafnet_arch.py:200-248; NAFBlock.__init__ :84-163)."""
+    shapes = {}
+
+    def block(pre, c):
+        shapes[pre + "beta"] = (1, c, 1, 1)
+        shapes[pre + "gamma"] = (1, c, 1, 1)
+        shapes[pre + "conv1.weight"] = (2 * c, c, 1, 1)
+        shapes[pre + "conv1.bias"] = (2 * c,)
+        shapes[pre + "conv2.weight"] = (2 * c, 1, 3, 3)
+        shapes[pre + "conv2.bias"] = (2 * c,)
+        shapes[pre + "conv3.weight"] = (c, c, 1, 1)
+        shapes[pre + "conv3.bias"] = (c,)
+        shapes[pre + "sca.1.weight"] = (c, c, 1, 1)
+        shapes[pre + "sca.1.bias"] = (c,)
+        shapes[pre + "conv4.weight"] = (2 * c, c, 1, 1)
+        shapes[pre + "conv4.bias"] = (2 * c,)
+        shapes[pre + "conv5.weight"] = (c, c, 1, 1)
+        shapes[pre + "conv5.bias"] = (c,)
+        shapes[pre + "norm1.weight"] = (c,)
+        shapes[pre + "norm1.bias"] = (c,)
+        shapes[pre + "norm2.weight"] = (c,)
+        shapes[pre + "norm2.bias"] = (c,)
+
+    shapes["intro.weight"] = (width, img_channel, 3, 3)
+    shapes["intro.bias"] = (width,)
+    shapes["ending.weight"] = (img_channel, width, 3, 3)
+    shapes["ending.bias"] = (img_channel,)
+    chan = width
+    for i, num in enumerate(enc_blk_nums):
+        for j in range(num):
+            block(f"encoders.{i}.{j}.", chan)
+        chan *= 2
+    for j in range(middle_blk_num):
+        block(f"middle_blks.{j}.", chan)
+    c = chan
+    for i, num in enumerate(dec_blk_nums):
+        shapes[f"ups.{i}.0.weight"] = (2 * c, c, 1, 1)
+        c //= 2
+    c = width
+    for i, _ in enumerate(enc_blk_nums):
+        shapes[f"downs.{i}.weight"] = (2 * c, c, 2, 2)
+        shapes[f"downs.{i}.bias"] = (2 * c,)
+        c *= 2
+    c = chan
+    for i, num in enumerate(dec_blk_nums):
+        c //= 2
+        for j in range(num):
+            block(f"decoder{i}.{j}.", c)
+    return shapes
+
+
+def tlsc_avgpool(x, kernel_size):
+    """TLSC local average pool used by the ``NAFNet`` (Local_Base) variant.
+
+    reference basicsr/archs/arch_util.py:352-396 (non-fast path): global mean when the
+    kernel covers the image, else a k1 x k2 box mean from a 2-D prefix sum, replicate-padded
+    back to H x W.
+    """
+    n, c, h, w = x.shape
+    k1, k2 = kernel_size
+    if k1 >= h and k2 >= w:
+        return x.mean(dim=(2, 3), keepdim=True)
+    s = x.cumsum(dim=-1).cumsum(dim=-2)
+    s = F.pad(s, (1, 0, 1, 0))
+    k1, k2 = min(h, k1), min(w, k2)
+    out = (s[:, :, k1:, k2:] + s[:, :, :-k1, :-k2] - s[:, :, :-k1, k2:] - s[:, :, k1:, :-k2]) / (k1 * k2)
+    _h, _w = out.shape[2:]
+    pad = ((w - _w) // 2, (w - _w + 1) // 2, (h - _h) // 2, (h - _h + 1) // 2)
+    return F.pad(out, pad, mode="replicate")
+
+
+def l1_loss(a, b):
+    """reference basicsr/losses/basic_loss.py L1Loss with reduction='mean'."""
+    return (a - b).abs().mean()
+
+
+def psnr_uint8(a, b):
+    """reference basicsr/metrics/psnr_ssim.py:47-75 as used by the YAMLs: clamp to [0,1],
+    x255, round to uint8, full RGB, crop_border 0, float64 mse, 10*log10(255^2/mse)."""
+    import numpy as np
+
+    a8 = (a.detach().clamp(0, 1) * 255.0).round().to(torch.uint8).numpy().astype(np.float64)
+    b8 = (b.detach().clamp(0, 1) * 255.0).round().to(torch.uint8).numpy().astype(np.float64)
+    mse = ((a8 - b8) ** 2).mean()
+    if mse == 0:
+        return float("inf")
+    return float(10.0 * np.log10(255.0 * 255.0 / mse))
