@@ -1,0 +1,136 @@
+"""NAFNet for the DCPT restoration encoder, MI355X-native.
+
+Same registry names, constructor kwargs, ``forward(inp, hook=False)`` contract, module tree and
+``state_dict`` keys/shapes as the reference (basicsr/archs/nafnet_arch.py), so checkpoints load
+with ``strict=True`` and forward hooks on ``decoder{i}`` see the block-group outputs.  The math does
+not run through torch ops: every NAFBlock is ONE autograd node backed by ``dcpt_nafblock_fwd/bwd``
+(LayerNorm fused into the MFMA GEMM loaders, depthwise 3x3 + SimpleGate + pooling in one pass,
+SCA / residual scales in GEMM epilogues), and the convs between blocks are ``dcpt_conv3x3_*``,
+``dcpt_down2x2_*`` and ``dcpt_up_ps_*``.  Feature maps are channels_last (NHWC) tensors.
+
+The child ``nn.Conv2d`` / ``LayerNorm2d`` modules below only OWN the parameters (for state-dict and
+optimizer compatibility); they are never called on the fused path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from basicsr.utils.registry import ARCH_REGISTRY
+from dcpt_amd import functional as DF
+
+
+class LayerNorm2d(nn.Module):
+    """Per-pixel channel LayerNorm (reference nafnet_arch.py:56-64); weight/bias shape (C,)."""
+
+    def __init__(self, channels, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.eps = eps
+
+    def forward(self, x):
+        return DF.layernorm2d(x, self.weight, self.bias, self.eps)
+
+
+class SimpleGate(nn.Module):
+    """x[:, :c] * x[:, c:] (reference nafnet_arch.py:77-80).  Inside NAFBlock it is fused into the
+    depthwise-conv kernel and the conv5 GEMM loader; the module exists for API parity."""
+
+    def forward(self, x):
+        x1, x2 = x.chunk(2, dim=1)
+        return x1 * x2
+
+
+class NAFBlock(nn.Module):
+    """reference nafnet_arch.py:83-186.  drop_out_rate must be 0 (the reference never sets it)."""
+
+    def __init__(self, c, DW_Expand=2, FFN_Expand=2, drop_out_rate=0.0):
+        super().__init__()
+        if DW_Expand != 2 or FFN_Expand != 2:
+            raise NotImplementedError("dcpt_amd NAFBlock kernels implement DW_Expand = FFN_Expand = 2")
+        if drop_out_rate > 0.0:
+            raise NotImplementedError("dcpt_amd NAFBlock kernels implement drop_out_rate = 0 (the reference default)")
+        if c % 4:
+            raise ValueError(f"NAFBlock width {c} must be a multiple of 4 for the NHWC float4 kernels")
+        dw = 2 * c
+        self.conv1 = nn.Conv2d(c, dw, 1, bias=True)
+        self.conv2 = nn.Conv2d(dw, dw, 3, padding=1, groups=dw, bias=True)
+        self.conv3 = nn.Conv2d(dw // 2, c, 1, bias=True)
+        self.sca = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(dw // 2, dw // 2, 1, bias=True))
+        self.sg = SimpleGate()
+        self.conv4 = nn.Conv2d(c, 2 * c, 1, bias=True)
+        self.conv5 = nn.Conv2d(c, c, 1, bias=True)
+        self.norm1 = LayerNorm2d(c)
+        self.norm2 = LayerNorm2d(c)
+        self.dropout1 = nn.Identity()
+        self.dropout2 = nn.Identity()
+        self.beta = nn.Parameter(torch.zeros((1, c, 1, 1)), requires_grad=True)
+        self.gamma = nn.Parameter(torch.zeros((1, c, 1, 1)), requires_grad=True)
+
+    def fused_params(self):
+        return {
+            "norm1_w": self.norm1.weight, "norm1_b": self.norm1.bias,
+            "conv1_w": self.conv1.weight, "conv1_b": self.conv1.bias,
+            "conv2_w": self.conv2.weight, "conv2_b": self.conv2.bias,
+            "conv3_w": self.conv3.weight, "conv3_b": self.conv3.bias,
+            "sca_w": self.sca[1].weight, "sca_b": self.sca[1].bias,
+            "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias,
+            "conv4_w": self.conv4.weight, "conv4_b": self.conv4.bias,
+            "conv5_w": self.conv5.weight, "conv5_b": self.conv5.bias,
+            "beta": self.beta, "gamma": self.gamma,
+        }
+
+    def forward(self, inp):
+        return DF.nafblock(inp, self.fused_params())
+
+
+class _Down(nn.Conv2d):
+    """Conv2d(c, 2c, 2, 2) run as a gathered MFMA GEMM (reference nafnet_arch.py:230)."""
+
+    def forward(self, x):
+        return DF.down2x2(x, self.weight, self.bias)
+
+
+class _UpConv(nn.Conv2d):
+    """The 1x1 conv of an ``ups[i]`` Sequential; the PixelShuffle and the skip add are fused into its
+    epilogue by NAFNetBaseline.forward (reference nafnet_arch.py:238-242, :264-265)."""
+
+
+@ARCH_REGISTRY.register()
+class NAFNetBaseline(nn.Module):
+    def __init__(self, img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=[], dec_blk_nums=[], window_size=8):
+        super().__init__()
+        self.intro = nn.Conv2d(img_channel, width, 3, padding=1, bias=True)
+        self.ending = nn.Conv2d(width, img_channel, 3, padding=1, bias=True)
+        self.encoders = nn.ModuleList()
+        self.middle_blks = nn.ModuleList()
+        self.ups = nn.ModuleList()
+        self.downs = nn.ModuleList()
+
+        chan = width
+        for num in enc_blk_nums:
+            self.encoders.append(nn.Sequential(*[NAFBlock(chan) for _ in range(num)]))
+            self.downs.append(_Down(chan, 2 * chan, 2, 2))
+            chan *= 2
+        self.middle_blks = nn.Sequential(*[NAFBlock(chan) for _ in range(middle_blk_num)])
+        for i, num in enumerate(dec_blk_nums):
+            self.ups.append(nn.Sequential(_UpConv(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2)))
+            chan //= 2
+            setattr(self, f"decoder{i}", nn.Sequential(*[NAFBlock(chan) for _ in range(num)]))
+        self._n_dec = len(dec_blk_nums)
+
+    def forward(self, inp, hook=False):
+        x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias)
+        encs = []
+        for encoder, down in zip(self.encoders, self.downs):
+            x = encoder(x)
+            encs.append(x)
+            x = down(x)
+        x = self.middle_blks(x)
+        for i, (up, enc_skip) in enumerate(zip(self.ups, encs[::-1])):
+            x = DF.up_ps(x, up[0].weight, enc_skip)  # conv1x1 + PixelShuffle(2) + skip add, one kernel
+            x = getattr(self, f"decoder{i}")(x)
+        if not hook:
+            return DF.conv3x3_out(x, self.ending.weight, self.ending.bias, inp)
+        return None

@@ -1,0 +1,112 @@
+"""ctypes binding of libdcpt_hip.so (C ABI in include/dcpt_hip.h).
+
+The library is the product: there is NO CPU / eager fallback.  If it cannot be loaded, or a tensor
+is not on a HIP device, the callers raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+f32p = C.c_void_p  # device pointers travel as integers
+i64 = C.c_int64
+cint = C.c_int
+sz = C.c_size_t
+stream_t = C.c_void_p
+
+_PARAM_FIELDS = [
+    "norm1_w", "norm1_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b",
+    "sca_w", "sca_b", "norm2_w", "norm2_b", "conv4_w", "conv4_b", "conv5_w", "conv5_b", "beta", "gamma",
+]
+_SAVED_FIELDS = ["t1", "t2", "y", "v", "mu1", "rstd1", "mu2", "rstd2", "pooled", "s"]
+
+
+class NafBlockParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PARAM_FIELDS]
+
+
+class NafBlockGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PARAM_FIELDS]
+
+
+class NafBlockSaved(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _SAVED_FIELDS]
+
+
+PARAM_FIELDS = tuple(_PARAM_FIELDS)
+SAVED_FIELDS = tuple(_SAVED_FIELDS)
+
+# name -> (restype, argtypes); mirrors include/dcpt_hip.h one to one
+SIGNATURES = {
+    "dcpt_last_error": (C.c_char_p, []),
+    "dcpt_abi_version": (cint, []),
+    "dcpt_ln2d_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, i64, cint, C.c_float, stream_t]),
+    "dcpt_ln2d_bwd_ws_bytes": (sz, [i64, cint]),
+    "dcpt_ln2d_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, i64, cint, stream_t]),
+    "dcpt_nafblock_fwd_ws_bytes": (sz, [cint, cint, cint, cint]),
+    "dcpt_nafblock_bwd_ws_bytes": (sz, [cint, cint, cint, cint]),
+    "dcpt_nafblock_fwd": (cint, [C.POINTER(NafBlockParams), f32p, f32p, C.POINTER(NafBlockSaved), C.c_void_p, sz,
+                                 cint, cint, cint, cint, stream_t]),
+    "dcpt_nafblock_bwd": (cint, [C.POINTER(NafBlockParams), C.POINTER(NafBlockGrads), f32p, C.POINTER(NafBlockSaved),
+                                 f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_in_fwd": (cint, [f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_in_bwd_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_conv3x3_in_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_out_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_out_bwd_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_conv3x3_out_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_down2x2_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_down2x2_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_down2x2_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_up_ps_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_up_ps_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_up_ps_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_fused_bias_act": (cint, [f32p, f32p, f32p, f32p, i64, cint, i64, cint, cint, C.c_float, C.c_float, stream_t]),
+    "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
+    "dcpt_nhwc_to_nchw": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
+}
+
+
+class DcptHipError(RuntimeError):
+    pass
+
+
+def lib_exists() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises DcptHipError if the .so is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DcptHipError(
+                f"{LIB_PATH} not found: build it with `python -m dcpt_amd.build` (hipcc, gfx950). "
+                "dcpt_amd has no CPU/eager fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dcpt_abi_version() != 1:
+            raise DcptHipError("libdcpt_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dcpt_last_error()
+        raise DcptHipError(f"{what}: rc={rc}: {msg.decode() if msg else ''}")

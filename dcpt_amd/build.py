@@ -1,0 +1,75 @@
+"""Build libdcpt_hip.so (gfx950 only) in-tree with hipcc.  No torch, no cmake: the library has a
+plain C ABI (include/dcpt_hip.h) and links only against the HIP runtime.
+
+    python -m dcpt_amd.build [--force]
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libdcpt_hip.so")
+ARCH = "gfx950"
+SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (needed to build libdcpt_hip.so for gfx950)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    names = sorted(os.listdir(CSRC)) + ["../../include/dcpt_hip.h"]
+    for n in names:
+        p = os.path.join(CSRC, n)
+        if os.path.isfile(p):
+            h.update(n.encode())
+            with open(p, "rb") as f:
+                h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "libdcpt_hip.digest")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,92 @@
+// Shared device/host helpers for the dcpt_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define DCPT_OK 0
+#define DCPT_ERR_ARG 1
+#define DCPT_ERR_WS 2
+#define DCPT_ERR_HIP 3
+
+void dcpt_set_error(const char* fmt, ...);
+
+#define DCPT_CHECK_ARG(cond, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            dcpt_set_error(__VA_ARGS__);     \
+            return DCPT_ERR_ARG;             \
+        }                                    \
+    } while (0)
+
+#define DCPT_CHECK_LAUNCH(name)                                                     \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            dcpt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return DCPT_ERR_HIP;                                                    \
+        }                                                                           \
+    } while (0)
+
+#define DCPT_TRY(expr)            \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != DCPT_OK) return rc__; \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-owned workspace (the caller -- PyTorch -- owns every buffer).
+struct WsAlloc {
+    char* base;
+    size_t cap;
+    size_t off;
+    bool ok;
+    WsAlloc(void* p, size_t bytes) : base((char*)p), cap(bytes), off(0), ok(true) {}
+    template <typename T>
+    T* get(size_t n) {
+        size_t bytes = align_up(n * sizeof(T), 256);
+        if (off + bytes > cap) {
+            ok = false;
+            off += bytes;
+            return nullptr;
+        }
+        T* r = (T*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float f4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// XOR-butterfly sum over `width` consecutive lanes (width a power of two <= 64).
+__device__ __forceinline__ float group_sum(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that land on the same XCD (bid % 8 by
+// observed dispatch) get a contiguous range of logical ids, so neighbouring tiles share that
+// XCD's private L2.  Only a speed choice; any placement is correct.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+#endif

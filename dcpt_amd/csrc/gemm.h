@@ -1,0 +1,64 @@
+// fp32 MFMA GEMM family for NHWC activations (rows = pixels, columns = channels).
+//
+//   NT : C[m][n]  = sum_k A'(m,k) * Bw[n][k]        (1x1-conv forward; dgrad with Bw = W^T)
+//   TN : G[n][k]  = sum_m X'(m,n) * Y'(m,k)          (wgrad, split over m into slabs)
+//
+// Both run on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak of gfx950).
+// A'/X'/Y' are produced by fused operand loaders, C is consumed by fused epilogues.
+#pragma once
+#include "dcpt_common.h"
+
+enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4 };
+enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5 };
+
+struct GemmNT {
+    const float* A;   // [M][lda]   (A_SG: 2K columns; A_GATHER: fine NHWC image, see g*)
+    const float* Bw;  // [N][K] row-major (K contiguous)
+    float* C;         // [M][ldc]   (E_SGBWD: 2N columns; E_SCATTER*: fine NHWC image)
+    int64_t M;
+    int N, K;
+    int lda, ldc;
+    // A_LN: a = (x - mu[m]) * rstd[m] * lnw[k] + lnb[k]
+    const float* mu;
+    const float* rstd;
+    const float* lnw;
+    const float* lnb;
+    // A_SCALE: a = x * simg[(m / P) * K + k]   (P = pixels per image)
+    const float* simg;
+    int P;
+    // A_GATHER / E_SCATTER*: coarse grid gH x gW per image, fine image is 2gH x 2gW with gC channels;
+    // column index = (2*i + j) * gC + ch  <->  fine pixel (2h+i, 2w+j), channel ch
+    int gH, gW, gC;
+    // epilogues
+    const float* bias;    // [N]
+    const float* res;     // E_RESID: [M][ldc]; E_SCATTER_ADD: fine image like C
+    const float* cscale;  // E_RESID: [N]
+    const float* aux;     // E_SGBWD: v [M][2N]
+};
+
+int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t stream);
+
+struct GemmTN {
+    const float* X;  // [M][ldx]  -> rows of G (n index)
+    const float* Y;  // [M][ldy]  -> cols of G (k index)
+    float* slab;     // [splits][N][K]
+    float* colsum;   // [splits][N] column sums of X' (may be null)
+    int64_t M;
+    int N, K;
+    int ldx, ldy;
+    int splits;        // number of m-chunks (grid.y)
+    int64_t rows_per_split;  // multiple of 32
+    // Y loader (GemmALoad kinds)
+    const float* mu;
+    const float* rstd;
+    const float* lnw;
+    const float* lnb;
+    const float* simg;
+    int P;
+    int gH, gW, gC;  // gather geometry for whichever operand is gathered
+};
+
+// xload in {A_PLAIN, A_GATHER}; yload any GemmALoad kind
+int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t stream);
+// choose a split count / rows_per_split for a TN problem
+void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split);

@@ -1,0 +1,178 @@
+// TN GEMM on fp32 MFMA (weight gradients):  G[n][k] = sum_m X'(m,n) * Y'(m,k).
+//
+// Both operands are NHWC activations/gradients: the reduction index m (pixels) is the slow axis,
+// so MFMA operand fragments are plain ds_read_b32 of consecutive floats (lane i reads column i of
+// row mm + lane>>5): no transposition anywhere.  The pixel range is split into `splits` chunks
+// (grid.y); every chunk writes its own [N][K] slab and a deterministic reduce kernel (misc.hip)
+// sums the slabs -- no float atomics.  Blocks of the first k-tile column also emit the column sums
+// of X' (bias gradients) from the LDS tile they already hold.
+#include "gemm_operand.h"
+
+namespace {
+
+constexpr int BR = 32;  // reduction rows per LDS tile
+
+template <int BN, int BKo, int WN, int WK, int XK, int YK>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+    static_assert(WN * WK == 4, "4 waves");
+    constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
+    constexpr int LDX = BN + 4, LDY = BKo + 4;
+    constexpr int XQ = BN / 4, YQ = BKo / 4;           // float4 per tile row
+    constexpr int XR = 256 / XQ, YR = 256 / YQ;        // rows covered per pass
+    constexpr int X_IT = BR / XR, Y_IT = BR / YR;
+    __shared__ __attribute__((aligned(16))) float Xs[2][BR * LDX];
+    __shared__ __attribute__((aligned(16))) float Ys[2][BR * LDY];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WK, wk = wave % WK;
+    const int tilesK = (p.K + BKo - 1) / BKo;
+    const int tile_n = blockIdx.x / tilesK, tile_k = blockIdx.x % tilesK;
+    const int n0 = tile_n * BN, k0 = tile_k * BKo;
+    const int split = blockIdx.y;
+    const int64_t mbeg = (int64_t)split * p.rows_per_split;
+    int64_t mend = mbeg + p.rows_per_split;
+    if (mend > p.M) mend = p.M;
+
+    Operand ox, oy;
+    ox.ptr = p.X; ox.M = mend; ox.ncols = p.N; ox.ld = p.ldx;
+    ox.mu = nullptr; ox.rstd = nullptr; ox.lnw = nullptr; ox.lnb = nullptr; ox.simg = nullptr; ox.P = 1;
+    ox.gH = p.gH; ox.gW = p.gW; ox.gC = p.gC;
+    oy.ptr = p.Y; oy.M = mend; oy.ncols = p.K; oy.ld = p.ldy;
+    oy.mu = p.mu; oy.rstd = p.rstd; oy.lnw = p.lnw; oy.lnb = p.lnb; oy.simg = p.simg; oy.P = p.P;
+    oy.gH = p.gH; oy.gW = p.gW; oy.gC = p.gC;
+
+    const int xrow = tid / XQ, xc = (tid % XQ) * 4;
+    const int yrow = tid / YQ, yc = (tid % YQ) * 4;
+    float4 rx[X_IT], ry[Y_IT];
+    auto gload = [&](int64_t mt) {
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            RowCtx rc;
+            make_row<XK>(ox, mt + xrow + XR * i, rc);
+            rx[i] = load_op<XK>(ox, rc, n0 + xc);
+        }
+#pragma unroll
+        for (int i = 0; i < Y_IT; ++i) {
+            RowCtx rc;
+            make_row<YK>(oy, mt + yrow + YR * i, rc);
+            ry[i] = load_op<YK>(oy, rc, k0 + yc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) *reinterpret_cast<float4*>(&Xs[buf][(xrow + XR * i) * LDX + xc]) = rx[i];
+#pragma unroll
+        for (int i = 0; i < Y_IT; ++i) *reinterpret_cast<float4*>(&Ys[buf][(yrow + YR * i) * LDY + yc]) = ry[i];
+    };
+
+    floatx16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float cs = 0.f;
+    const bool do_cs = (p.colsum != nullptr) && (tile_k == 0) && (tid < BN);
+
+    const int64_t nmt = (mend - mbeg + BR - 1) / BR;
+    if (nmt > 0) {
+        gload(mbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    const int x_off = (lane >> 5) * LDX + wn * TN * 32 + (lane & 31);
+    const int y_off = (lane >> 5) * LDY + wk * TK * 32 + (lane & 31);
+    for (int64_t t = 0; t < nmt; ++t) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < nmt) gload(mbeg + (t + 1) * BR);
+        const float* xs = &Xs[buf][x_off];
+        const float* ys = &Ys[buf][y_off];
+#pragma unroll
+        for (int mm = 0; mm < BR; mm += 2) {
+            float a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = xs[mm * LDX + i * 32];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = ys[mm * LDY + j * 32];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_cs) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BR; ++r) s += Xs[buf][r * LDX + tid];
+            cs += s;
+        }
+        if (t + 1 < nmt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* slab = p.slab + (int64_t)split * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int k = k0 + (wk * TK + j) * 32 + (lane & 31);
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < p.N) slab[(int64_t)n * p.K + k] = acc[i][j][r];
+            }
+        }
+    if (do_cs && n0 + tid < p.N) p.colsum[(int64_t)split * p.N + n0 + tid] = cs;
+}
+
+template <int XK, int YK>
+int launch_cfg(const GemmTN& p, hipStream_t s) {
+    if (p.N <= 64 && p.K <= 64) {
+        const int tiles = cdiv(p.N, 64) * cdiv(p.K, 64);
+        gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+    } else if (p.K <= 64) {
+        const int tiles = cdiv(p.N, 128) * cdiv(p.K, 64);
+        gemm_tn_kernel<128, 64, 4, 1, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+    } else if (p.N <= 64) {
+        const int tiles = cdiv(p.N, 64) * cdiv(p.K, 128);
+        gemm_tn_kernel<64, 128, 1, 4, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+    } else {
+        const int tiles = cdiv(p.N, 128) * cdiv(p.K, 128);
+        gemm_tn_kernel<128, 128, 2, 2, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+    }
+    DCPT_CHECK_LAUNCH("gemm_tn");
+    return DCPT_OK;
+}
+
+}  // namespace
+
+void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split) {
+    const int bn = (N <= 64) ? 64 : 128, bk = (K <= 64) ? 64 : 128;
+    const int64_t tiles = (int64_t)cdiv(N, bn) * cdiv(K, bk);
+    int64_t want = cdiv64(768, tiles);          // ~3 blocks per CU in total
+    const int64_t max_by_rows = cdiv64(M, 256);  // at least 256 rows per split
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    if (want > 65535) want = 65535;
+    int64_t rps = cdiv64(cdiv64(M, want), 32) * 32;
+    *rows_per_split = rps;
+    *splits = (int)cdiv64(M, rps);
+}
+
+int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t s) {
+    DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_tn: empty problem");
+    DCPT_CHECK_ARG(p.N % 4 == 0 && p.K % 4 == 0, "gemm_tn: N=%d, K=%d must be multiples of 4", p.N, p.K);
+    DCPT_CHECK_ARG(p.splits >= 1 && p.splits <= 65535 && p.rows_per_split % 32 == 0, "gemm_tn: bad split plan");
+#define CASE(XK, YK) \
+    if (xload == XK && yload == YK) return launch_cfg<XK, YK>(p, s);
+    CASE(A_PLAIN, A_PLAIN)
+    CASE(A_PLAIN, A_LN)
+    CASE(A_PLAIN, A_SCALE)
+    CASE(A_PLAIN, A_SG)
+    CASE(A_PLAIN, A_GATHER)
+    CASE(A_GATHER, A_PLAIN)
+#undef CASE
+    dcpt_set_error("gemm_tn: unsupported loader combination %d/%d", xload, yload);
+    return DCPT_ERR_ARG;
+}

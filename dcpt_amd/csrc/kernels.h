@@ -1,0 +1,83 @@
+// Internal launchers for the non-GEMM kernels (all NHWC fp32; every launcher enqueues on `s`,
+// never synchronises, returns DCPT_OK or sets the error string).
+#pragma once
+#include "dcpt_common.h"
+
+// ---- ln.hip -------------------------------------------------------------------------------
+int launch_ln_stats(const float* x, float* mu, float* rstd, int64_t M, int C, float eps, hipStream_t s);
+int launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* mu, float* rstd, int64_t M, int C,
+                  float eps, hipStream_t s);
+// dx = LN-backward(gy; x, mu, rstd, w) (+ dres if non-null).  Column sums go to part[nblk][3][C]
+// (0: sum gy*xhat, 1: sum gy, 2: sum dx_total); returns nblk through *nblk_out.
+int ln_bwd_num_blocks(int64_t M, int C);
+int launch_ln_bwd(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
+                  float* dx, float* part, int nblk, int64_t M, int C, hipStream_t s);
+// out[j][c] = sum_r part[r][j][c], j < nj  (deterministic order); out rows may be null to skip
+int launch_colpart_reduce(const float* part, int R, int nj, int C, float* out0, float* out1, float* out2, hipStream_t s);
+
+// ---- dwconv.hip ---------------------------------------------------------------------------
+struct DwGeom {
+    int B, H, W, C;  // C = gated channels (t1 has 2C)
+};
+int dw_num_blocks_per_image(const DwGeom& g);            // NBLK for fwd / bwd_a (quads of C)
+int dw_num_blocks_per_image_b(const DwGeom& g);          // NBLK for bwd_b (quads of 2C)
+int launch_dw_pack_weights(const float* w2, float* w2p, int C2, hipStream_t s);  // [C2][9] -> [9][C2]
+// t2 = SG(dw3x3(t1) + b2); pool_part[B][NBLK][C] partial sums of t2
+int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2, float* pool_part, const DwGeom& g,
+                  hipStream_t s);
+// da = SimpleGate-backward(dts * s + dpool; a = dw3x3(t1) + b2)     da: [M][2C]
+int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg,
+                    const float* dpool, float* da, const DwGeom& g, hipStream_t s);
+// dt1 = dw3x3^T(da); wpart[B*NBLKb][10][2C] partial sums for dw2 (taps 0..8) and db2 (9)
+int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* dt1, float* wpart, const DwGeom& g,
+                    hipStream_t s);
+// dw2[ch*9+tap] and db2[ch] from wpart[R][10][C2]
+int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float* db2, hipStream_t s);
+
+// ---- misc.hip -----------------------------------------------------------------------------
+// pooled[b][k] = (sum_blk pool_part[b][blk][k]) / P ;  s[b][n] = sum_k Wsca[n][k]*pooled[b][k] + bsca[n]
+int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const float* bsca, float* pooled, float* simg,
+                   int B, int C, int P, hipStream_t s);
+// ds[b][k] = sum_{m in image b} dts[m][k] * t2[m][k]   (two-stage, deterministic)
+int sca_ds_num_blocks(int P);
+int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, int B, int C, int P, hipStream_t s);
+// dpool[b][k] = (sum_n Wsca[n][k]*ds[b][n]) / P ; dWsca[n][k] = sum_b ds[b][n]*pooled[b][k] ; dbsca[n] = sum_b ds[b][n]
+int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, float* dpool, float* dWsca, float* dbsca,
+                   int B, int C, int P, hipStream_t s);
+
+enum WPackMode {
+    WP_TRANSPOSE = 0,   // out[k][n] = in[n][k] * (rs ? rs[n] : 1)             in: [N][K]
+    WP_DOWN = 1,        // out[oc][ij*C + ic] = in[oc][ic][ij]                  in: [N=2C][C][2][2]  (K = 4C)
+    WP_DOWN_T = 2,      // out[ij*C + ic][oc] = in[oc][ic][ij]
+    WP_UP = 3,          // out[ij*G + kk][ic] = in[4kk+ij][ic]                  in: [N=4G][K]
+    WP_UP_T = 4         // out[ic][ij*G + kk] = in[4kk+ij][ic]
+};
+int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int mode, hipStream_t s);
+
+enum WReduceMode { WR_PLAIN = 0, WR_DOWN = 1, WR_UP = 2 };
+// dW = rowscale[n] * sum_s slab[s][n][k] (layout per mode)
+// optional: dgain[n] = sum_k W[n][k]*G[n][k] + wbias[n]*cs[n];  dbias[n] = rowscale[n]*cs[n]   (cs = sum_s colsum[s][n])
+int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int N, int K, const float* rowscale,
+                        const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s);
+
+// ---- conv3x3.hip ----------------------------------------------------------------------------
+// small (NCHW, Cs <= 4) -> big (NHWC, Cb % 4 == 0):  y[p][c] = sum_{s,tap} x[p+off(tap)][s] * W(c,s,tap) (+ bias[c])
+//   wmode 0: W(c,s,tap) = w[(c*Cs+s)*9+tap]      (forward of a Cs->Cb conv, weight [Cb][Cs][3][3])
+//   wmode 1: W(c,s,tap) = w[(s*Cb+c)*9+(8-tap)]  (dgrad of a Cb->Cs conv, weight [Cs][Cb][3][3])
+int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cs, int Cb,
+                       int wmode, hipStream_t s);
+// big (NHWC) -> small (NCHW): y[p][s] = sum_{c,tap} x[p+off(tap)][c] * W(s,c,tap) (+ bias[s]) (+ res[p][s])
+//   wmode 0: W(s,c,tap) = w[(s*Cb+c)*9+tap]      (forward of a Cb->Cs conv)
+//   wmode 1: W(s,c,tap) = w[(c*Cs+s)*9+(8-tap)]  (dgrad of a Cs->Cb conv)
+int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W,
+                       int Cs, int Cb, int wmode, hipStream_t s);
+// G[c][s][tap] = sum_p big[p][c] * small[p+off(tap)][s];  bsum[c] = sum_p big[p][c]
+//   omode 0: dW[(c*Cs+s)*9+tap] = G      omode 1: dW[(s*Cb+c)*9+(8-tap)] = G
+int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb);
+int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H,
+                         int W, int Cs, int Cb, int omode, hipStream_t s);
+// out[c] = sum_{b,h,w} x[b][c][h][w]   (NCHW, tiny C)
+int launch_nchw_channel_sum(const float* x, float* out, int B, int C, int HW, hipStream_t s);
+// layout converters for arbitrary C
+int launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t s);
+int launch_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, hipStream_t s);

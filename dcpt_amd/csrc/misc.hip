@@ -1,0 +1,233 @@
+// Small kernels around the GEMMs: SCA (simplified channel attention) forward/backward pieces,
+// weight packing/transposition, and the deterministic split-slab reduction of weight gradients.
+// Reference: basicsr/archs/nafnet_arch.py:116-127,173 (SCA), :162-163,178,186 (beta/gamma).
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// SCA forward. grid (B, row-chunks of 64 outputs); every block first rebuilds pooled[b][:] in LDS.
+__global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ pool_part, int nblk,
+                                                      const float* __restrict__ Wsca, const float* __restrict__ bsca,
+                                                      float* __restrict__ pooled, float* __restrict__ simg, int C, float invP) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];  // [C]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < C; k += 256) {
+        float s = 0.f;
+        for (int j = 0; j < nblk; ++j) s += pool_part[((int64_t)b * nblk + j) * C + k];
+        s *= invP;
+        pl[k] = s;
+        if (blockIdx.y == 0) pooled[(int64_t)b * C + k] = s;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nbeg = blockIdx.y * 64;
+    for (int n = nbeg + wave; n < nbeg + 64 && n < C; n += 4) {
+        float s = 0.f;
+        for (int k = 4 * lane; k < C; k += 256) {
+            const float4 w = ldg4(Wsca + (int64_t)n * C + k);
+            const float4 v = *reinterpret_cast<const float4*>(&pl[k]);
+            s += f4_sum(f4_mul(w, v));
+        }
+        s = group_sum(s, 64);
+        if (lane == 0) simg[(int64_t)b * C + n] = s + bsca[n];
+    }
+}
+
+// ds stage 1: part[b][j][k] = sum over the j-th pixel slice of image b of dts*t2
+__global__ __launch_bounds__(256) void sca_ds_part_kernel(const float* __restrict__ dts, const float* __restrict__ t2,
+                                                          float* __restrict__ part, int C, int P, int nslices) {
+    __shared__ float4 red[256];
+    const int b = blockIdx.z, j = blockIdx.y;
+    const int nq = C / 4;
+    int qb = 1;
+    while (qb < nq && qb < 256) qb <<= 1;
+    const int pb = 256 / qb;
+    const int tid = threadIdx.x, ql = tid % qb, pl = tid / qb;
+    const int q = blockIdx.x * qb + ql;
+    const bool qok = q < nq;
+    const int per = (P + nslices - 1) / nslices;
+    const int pbeg = j * per;
+    int pend = pbeg + per;
+    if (pend > P) pend = P;
+    float4 acc = f4_zero();
+    if (qok)
+        for (int px = pbeg + pl; px < pend; px += pb) {
+            const int64_t o = ((int64_t)b * P + px) * C + 4 * q;
+            acc = f4_fma(ldg4(dts + o), ldg4(t2 + o), acc);
+        }
+    red[tid] = acc;
+    __syncthreads();
+    if (pl == 0 && qok) {
+        float4 s = red[ql];
+        for (int i = 1; i < pb; ++i) s = f4_add(s, red[i * qb + ql]);
+        stg4(part + ((int64_t)b * nslices + j) * C + 4 * q, s);
+    }
+}
+
+__global__ void sca_ds_final_kernel(const float* __restrict__ part, float* __restrict__ ds, int BC, int C, int nslices) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, k = i % C;
+    float s = 0.f;
+    for (int j = 0; j < nslices; ++j) s += part[((int64_t)b * nslices + j) * C + k];
+    ds[i] = s;
+}
+
+// SCA backward (tiny): blockIdx.y selects the role
+//   role 0: dpool[b][k] = invP * sum_n Wsca[n][k] * ds[b][n]
+//   role 1: dWsca[n][k] = sum_b ds[b][n] * pooled[b][k]
+//   role 2: dbsca[n]    = sum_b ds[b][n]
+__global__ __launch_bounds__(256) void sca_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
+                                                      const float* __restrict__ Wsca, float* __restrict__ dpool,
+                                                      float* __restrict__ dWsca, float* __restrict__ dbsca, int B, int C,
+                                                      float invP) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.y == 0) {
+        if (i >= (int64_t)B * C) return;
+        const int b = (int)(i / C), k = (int)(i % C);
+        float s = 0.f;
+        for (int n = 0; n < C; ++n) s = fmaf(Wsca[(int64_t)n * C + k], ds[(int64_t)b * C + n], s);
+        dpool[i] = s * invP;
+    } else if (blockIdx.y == 1) {
+        if (i >= (int64_t)C * C) return;
+        const int n = (int)(i / C), k = (int)(i % C);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(ds[(int64_t)b * C + n], pooled[(int64_t)b * C + k], s);
+        dWsca[i] = s;
+    } else {
+        if (i >= C) return;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += ds[(int64_t)b * C + i];
+        dbsca[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void wpack_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ rs, int N,
+                             int K, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    // i indexes the OUTPUT (coalesced writes)
+    if (mode == WP_TRANSPOSE) {
+        const int k = (int)(i / N), n = (int)(i % N);
+        const float v = in[(int64_t)n * K + k];
+        out[i] = rs ? v * rs[n] : v;
+    } else if (mode == WP_DOWN) {  // out[oc][ij*C + ic], K = 4C
+        const int C = K / 4;
+        const int oc = (int)(i / K), r = (int)(i % K);
+        const int ij = r / C, ic = r % C;
+        out[i] = in[((int64_t)oc * C + ic) * 4 + ij];
+    } else if (mode == WP_DOWN_T) {  // out[ij*C + ic][oc]
+        const int C = K / 4;
+        const int r = (int)(i / N), oc = (int)(i % N);
+        const int ij = r / C, ic = r % C;
+        out[i] = in[((int64_t)oc * C + ic) * 4 + ij];
+    } else if (mode == WP_UP) {  // out[ij*G + kk][ic] = in[4kk+ij][ic]
+        const int G = N / 4;
+        const int r = (int)(i / K), ic = (int)(i % K);
+        const int ij = r / G, kk = r % G;
+        out[i] = in[(int64_t)(4 * kk + ij) * K + ic];
+    } else {  // WP_UP_T: out[ic][ij*G + kk] = in[4kk+ij][ic]
+        const int G = N / 4;
+        const int ic = (int)(i / N), r = (int)(i % N);
+        const int ij = r / G, kk = r % G;
+        out[i] = in[(int64_t)(4 * kk + ij) * K + ic];
+    }
+}
+
+// one block per output row n
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ colsum,
+                                                           int splits, int N, int K, const float* __restrict__ rowscale,
+                                                           const float* __restrict__ W, const float* __restrict__ wbias,
+                                                           float* __restrict__ dW, float* __restrict__ dgain,
+                                                           float* __restrict__ dbias, int mode) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float rsc = rowscale ? rowscale[n] : 1.f;
+    float dot = 0.f;
+    for (int k = 4 * tid; k < K; k += 1024) {
+        float4 g = f4_zero();
+        for (int s = 0; s < splits; ++s) g = f4_add(g, ldg4(slab + ((int64_t)s * N + n) * K + k));
+        if (dgain) dot += f4_sum(f4_mul(g, ldg4(W + (int64_t)n * K + k)));
+        const float4 o = f4_scale(g, rsc);
+        if (mode == WR_PLAIN) {
+            stg4(dW + (int64_t)n * K + k, o);
+        } else if (mode == WR_DOWN) {  // packed k = ij*C + ic  ->  dW[n][ic][ij]
+            const int C = K / 4;
+            const int ij = k / C, ic = k % C;
+            float* d = dW + ((int64_t)n * C + ic) * 4 + ij;
+            d[0] = o.x; d[4] = o.y; d[8] = o.z; d[12] = o.w;
+        } else {  // WR_UP: packed row n = ij*G + kk -> dW[4kk+ij][k]
+            const int G = N / 4;
+            const int ij = n / G, kk = n % G;
+            stg4(dW + (int64_t)(4 * kk + ij) * K + k, o);
+        }
+    }
+    if (dgain == nullptr && dbias == nullptr) return;
+    float cs = 0.f;
+    if (colsum)
+        for (int s = 0; s < splits; ++s) cs += colsum[(int64_t)s * N + n];
+    if (dgain) {
+        dot = group_sum(dot, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = dot;
+        __syncthreads();
+        if (tid == 0) dgain[n] = ((red[0] + red[1]) + (red[2] + red[3])) + (wbias ? wbias[n] * cs : 0.f);
+    }
+    if (dbias && tid == 0) dbias[n] = rsc * cs;
+}
+
+}  // namespace
+
+int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const float* bsca, float* pooled, float* simg,
+                   int B, int C, int P, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 4 == 0 && C * 4 <= 65536, "sca_fwd: C=%d unsupported", C);
+    sca_fwd_kernel<<<dim3(B, cdiv(C, 64)), dim3(256), C * sizeof(float), s>>>(pool_part, nblk, Wsca, bsca, pooled, simg, C,
+                                                                                1.0f / (float)P);
+    DCPT_CHECK_LAUNCH("sca_fwd");
+    return DCPT_OK;
+}
+
+int sca_ds_num_blocks(int P) {
+    int n = P / 64;
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, int B, int C, int P, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 4 == 0 && B <= 65535, "sca_ds: C=%d", C);
+    const int nsl = sca_ds_num_blocks(P);
+    const int nq = C / 4;
+    int qb = 1;
+    while (qb < nq && qb < 256) qb <<= 1;
+    sca_ds_part_kernel<<<dim3(cdiv(nq, qb), nsl, B), dim3(256), 0, s>>>(dts, t2, ds_part, C, P, nsl);
+    DCPT_CHECK_LAUNCH("sca_ds_part");
+    sca_ds_final_kernel<<<dim3(cdiv(B * C, 256)), dim3(256), 0, s>>>(ds_part, ds, B * C, C, nsl);
+    DCPT_CHECK_LAUNCH("sca_ds_final");
+    return DCPT_OK;
+}
+
+int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, float* dpool, float* dWsca, float* dbsca, int B,
+                   int C, int P, hipStream_t s) {
+    const int64_t mx = (int64_t)C * C > (int64_t)B * C ? (int64_t)C * C : (int64_t)B * C;
+    sca_bwd_kernel<<<dim3((unsigned)cdiv64(mx, 256), 3), dim3(256), 0, s>>>(ds, pooled, Wsca, dpool, dWsca, dbsca, B, C,
+                                                                             1.0f / (float)P);
+    DCPT_CHECK_LAUNCH("sca_bwd");
+    return DCPT_OK;
+}
+
+int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int mode, hipStream_t s) {
+    wpack_kernel<<<dim3((unsigned)cdiv64((int64_t)N * K, 256)), dim3(256), 0, s>>>(in, out, rs, N, K, mode);
+    DCPT_CHECK_LAUNCH("wpack");
+    return DCPT_OK;
+}
+
+int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int N, int K, const float* rowscale,
+                        const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s) {
+    DCPT_CHECK_ARG(K % 4 == 0, "wgrad_reduce: K=%d", K);
+    DCPT_CHECK_ARG(!(dgain || dbias) || colsum, "wgrad_reduce: gain/bias gradients need column sums");
+    wgrad_reduce_kernel<<<dim3(N), dim3(256), 0, s>>>(slab, colsum, splits, N, K, rowscale, W, wbias, dW, dgain, dbias, mode);
+    DCPT_CHECK_LAUNCH("wgrad_reduce");
+    return DCPT_OK;
+}

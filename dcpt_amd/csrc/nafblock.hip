@@ -1,0 +1,235 @@
+// NAFBlock forward / backward composition (reference basicsr/archs/nafnet_arch.py:165-186).
+//
+// Forward (NHWC, M = B*H*W pixels):
+//   stats1 = LN-stats(inp)                                   ln_stats
+//   t1  = conv1(LN1(inp))            LN fused into the A loader   gemm_nt<A_LN, E_BIAS>
+//   t2  = SG(dw3x3(t1)+b2), pool partial sums                dw_fwd
+//   s   = Wsca * mean(t2) + bsca                             sca_fwd
+//   y   = inp + (conv3(t2*s)+b3)*beta                        gemm_nt<A_SCALE, E_RESID>
+//   stats2 = LN-stats(y)
+//   v   = conv4(LN2(y))                                      gemm_nt<A_LN, E_BIAS>
+//   out = y + (conv5(SG(v))+b5)*gamma                        gemm_nt<A_SG, E_RESID>
+//
+// Backward never materialises the conv3/conv5 outputs: with G[n][k] = sum_m dO[m][n]*A'[m][k]
+// (the un-scaled weight gradient) one has  dW = gain[n]*G,  dgain[n] = sum_k W[n][k]*G[n][k] +
+// b[n]*sum_m dO[m][n],  db = gain[n]*sum_m dO[m][n]   (gain = beta or gamma), which also stays exact
+// for the reference's zero-initialised beta/gamma.
+#include "gemm.h"
+#include "kernels.h"
+#include "../../include/dcpt_hip.h"
+
+namespace {
+
+struct FwdWs {
+    float* w2p;
+    float* pool_part;
+    int nblk_pool;
+};
+
+size_t fwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWs* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    DwGeom g{B, H, W, C};
+    const int nblk = dw_num_blocks_per_image(g);
+    float* w2p = a.get<float>((size_t)9 * 2 * C);
+    float* pp = a.get<float>((size_t)B * nblk * C);
+    if (out) {
+        out->w2p = w2p;
+        out->pool_part = pp;
+        out->nblk_pool = nblk;
+    }
+    return a.off;
+}
+
+struct BwdWs {
+    float *wT5, *wT4, *wT3, *wT1, *w2p;
+    float *b2a, *b2b;       // [M][2C]
+    float *bca, *bcb, *bcc; // [M][C]
+    float* slab;
+    float* colsum;
+    float* lnpart;
+    float *ds_part, *ds, *dpool;
+    float* wpart;
+    int ln_nblk, nblk_b;
+};
+
+size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    const int64_t M = (int64_t)B * H * W;
+    const int P = H * W;
+    DwGeom g{B, H, W, C};
+    BwdWs w;
+    w.wT5 = a.get<float>((size_t)C * C);
+    w.wT4 = a.get<float>((size_t)2 * C * C);
+    w.wT3 = a.get<float>((size_t)C * C);
+    w.wT1 = a.get<float>((size_t)2 * C * C);
+    w.w2p = a.get<float>((size_t)18 * C);
+    w.b2a = a.get<float>((size_t)M * 2 * C);
+    w.b2b = a.get<float>((size_t)M * 2 * C);
+    w.bca = a.get<float>((size_t)M * C);
+    w.bcb = a.get<float>((size_t)M * C);
+    w.bcc = a.get<float>((size_t)M * C);
+    // slabs: the largest of (N=2C,K=C) and (N=C,K=C) plans
+    int sp1, sp2;
+    int64_t r1, r2;
+    gemm_tn_plan(M, 2 * C, C, &sp1, &r1);
+    gemm_tn_plan(M, C, C, &sp2, &r2);
+    const size_t slab1 = (size_t)sp1 * 2 * C * C, slab2 = (size_t)sp2 * C * C;
+    w.slab = a.get<float>(slab1 > slab2 ? slab1 : slab2);
+    const size_t cs1 = (size_t)sp1 * 2 * C, cs2 = (size_t)sp2 * C;
+    w.colsum = a.get<float>(cs1 > cs2 ? cs1 : cs2);
+    w.ln_nblk = ln_bwd_num_blocks(M, C);
+    w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * C);
+    w.ds_part = a.get<float>((size_t)B * sca_ds_num_blocks(P) * C);
+    w.ds = a.get<float>((size_t)B * C);
+    w.dpool = a.get<float>((size_t)B * C);
+    w.nblk_b = dw_num_blocks_per_image_b(g);
+    w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
+    if (out) *out = w;
+    return a.off;
+}
+
+int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yload, const GemmTN& proto, int64_t M,
+          float* slab, float* colsum, const float* rowscale, const float* Wfor_gain, const float* wbias, float* dW,
+          float* dgain, float* dbias, hipStream_t s) {
+    GemmTN t = proto;
+    t.X = X; t.ldx = ldx; t.N = N; t.Y = Y; t.ldy = ldy; t.K = K; t.M = M;
+    t.slab = slab; t.colsum = colsum;
+    gemm_tn_plan(M, N, K, &t.splits, &t.rows_per_split);
+    DCPT_TRY(launch_gemm_tn(t, A_PLAIN, yload, s));
+    DCPT_TRY(launch_wgrad_reduce(slab, colsum, t.splits, N, K, rowscale, Wfor_gain, wbias, dW, dgain, dbias, WR_PLAIN, s));
+    return DCPT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C) { return fwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
+extern "C" size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C) { return bwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
+
+extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp, float* out, const dcpt_nafblock_saved* sv,
+                                 void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(p && inp && out && sv, "nafblock_fwd: null argument");
+    DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nafblock_fwd: bad shape B=%d H=%d W=%d C=%d (C %% 4 == 0)", B, H, W, C);
+    FwdWs w;
+    const size_t need = fwd_ws_layout(B, H, W, C, ws, ws_bytes, &w);
+    if (need > ws_bytes || ws == nullptr) {
+        dcpt_set_error("nafblock_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DCPT_ERR_WS;
+    }
+    const int64_t M = (int64_t)B * H * W;
+    const int P = H * W;
+    const float eps = 1e-6f;  // nafnet_arch.py:57
+
+    DCPT_TRY(launch_ln_stats(inp, sv->mu1, sv->rstd1, M, C, eps, s));
+    GemmNT g{};
+    g.M = M;
+    // t1 = conv1(LN1(inp))
+    g.A = inp; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C;
+    g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.lnb = p->norm1_b; g.bias = p->conv1_b;
+    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    // t2 = SG(dw(t1)+b2) and pooling partials
+    DwGeom dg{B, H, W, C};
+    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
+    DCPT_TRY(launch_dw_fwd(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
+    DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
+    // y = inp + (conv3(t2*s)+b3)*beta
+    g = GemmNT{};
+    g.M = M; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = p->conv3_w; g.N = C; g.C = sv->y; g.ldc = C;
+    g.simg = sv->s; g.P = P; g.bias = p->conv3_b; g.res = inp; g.cscale = p->beta;
+    DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESID, s));
+    DCPT_TRY(launch_ln_stats(sv->y, sv->mu2, sv->rstd2, M, C, eps, s));
+    // v = conv4(LN2(y))
+    g = GemmNT{};
+    g.M = M; g.A = sv->y; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C;
+    g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.lnb = p->norm2_b; g.bias = p->conv4_b;
+    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    // out = y + (conv5(SG(v))+b5)*gamma
+    g = GemmNT{};
+    g.M = M; g.A = sv->v; g.lda = 2 * C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
+    g.bias = p->conv5_b; g.res = sv->y; g.cscale = p->gamma;
+    DCPT_TRY(launch_gemm_nt(g, A_SG, E_RESID, s));
+    return DCPT_OK;
+}
+
+extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* gr, const float* inp,
+                                 const dcpt_nafblock_saved* sv, const float* dout, float* dinp, void* ws, size_t ws_bytes,
+                                 int B, int H, int W, int C, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(p && gr && inp && sv && dout && dinp, "nafblock_bwd: null argument");
+    DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nafblock_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+    BwdWs w;
+    const size_t need = bwd_ws_layout(B, H, W, C, ws, ws_bytes, &w);
+    if (need > ws_bytes || ws == nullptr) {
+        dcpt_set_error("nafblock_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DCPT_ERR_WS;
+    }
+    const int64_t M = (int64_t)B * H * W;
+    const int P = H * W;
+    const int C2 = 2 * C;
+    DwGeom dg{B, H, W, C};
+
+    // transposed (and gain-scaled) weights for the dgrad GEMMs
+    DCPT_TRY(launch_wpack(p->conv5_w, w.wT5, p->gamma, C, C, WP_TRANSPOSE, s));
+    DCPT_TRY(launch_wpack(p->conv4_w, w.wT4, nullptr, C2, C, WP_TRANSPOSE, s));
+    DCPT_TRY(launch_wpack(p->conv3_w, w.wT3, p->beta, C, C, WP_TRANSPOSE, s));
+    DCPT_TRY(launch_wpack(p->conv1_w, w.wT1, nullptr, C2, C, WP_TRANSPOSE, s));
+    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, C2, s));
+
+    float* dv = w.b2a;
+    float* gln = w.bca;
+    float* dy = w.bcb;
+    float* dts = w.bcc;
+    float* da = w.b2a;   // dv is dead once B4 is done
+    float* dt1 = w.b2b;
+
+    GemmNT g{};
+    GemmTN tp{};
+    // B1: dv = SG'(dout*gamma * W5; v)
+    g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = dv; g.ldc = C2; g.aux = sv->v;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SGBWD, s));
+    // B2: conv5 / gamma gradients
+    tp = GemmTN{};
+    DCPT_TRY(wgrad(dout, C, C, sv->v, C2, C, A_SG, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w,
+                   gr->gamma, gr->conv5_b, s));
+    // B3: grad w.r.t. LN2 output
+    g = GemmNT{};
+    g.M = M; g.A = dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = gln; g.ldc = C;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    // B4: conv4 gradients (Y = LN2(y))
+    tp = GemmTN{};
+    tp.mu = sv->mu2; tp.rstd = sv->rstd2; tp.lnw = p->norm2_w; tp.lnb = p->norm2_b;
+    DCPT_TRY(wgrad(dv, C2, C2, sv->y, C, C, A_LN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
+                   gr->conv4_b, s));
+    // B5: dy = dout + LN2-backward
+    DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, s));
+    // B6: dts = d(t2*s)
+    g = GemmNT{};
+    g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = dts; g.ldc = C;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    // B7: conv3 / beta gradients (Y = t2*s)
+    tp = GemmTN{};
+    tp.simg = sv->s; tp.P = P;
+    DCPT_TRY(wgrad(dy, C, C, sv->t2, C, C, A_SCALE, tp, M, w.slab, w.colsum, p->beta, p->conv3_w, p->conv3_b, gr->conv3_w,
+                   gr->beta, gr->conv3_b, s));
+    // B8: SCA backward
+    DCPT_TRY(launch_sca_ds(dts, sv->t2, w.ds_part, w.ds, B, C, P, s));
+    DCPT_TRY(launch_sca_bwd(w.ds, sv->pooled, p->sca_w, w.dpool, gr->sca_w, gr->sca_b, B, C, P, s));
+    // B9/B10: SimpleGate + depthwise conv backward
+    DCPT_TRY(launch_dw_bwd_a(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, da, dg, s));
+    DCPT_TRY(launch_dw_bwd_b(da, sv->t1, w.w2p, dt1, w.wpart, dg, s));
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, s));
+    // B11: grad w.r.t. LN1 output
+    g = GemmNT{};
+    g.M = M; g.A = dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = gln; g.ldc = C;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    // B12: conv1 gradients (Y = LN1(inp))
+    tp = GemmTN{};
+    tp.mu = sv->mu1; tp.rstd = sv->rstd1; tp.lnw = p->norm1_w; tp.lnb = p->norm1_b;
+    DCPT_TRY(wgrad(dt1, C2, C2, inp, C, C, A_LN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
+                   gr->conv1_b, s));
+    // B13: dinp = dy + LN1-backward
+    DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart, w.ln_nblk, M, C, s));
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, s));
+    return DCPT_OK;
+}

@@ -1,0 +1,386 @@
+"""torch.autograd bindings over the C ABI (include/dcpt_hip.h).
+
+PyTorch is plumbing here: it owns device memory (activations, saved tensors, workspaces), the
+stream, and autograd's graph.  All arithmetic happens in libdcpt_hip.so.
+
+Layout: feature maps are ordinary torch tensors of logical shape (N, C, H, W) in
+``torch.channels_last`` memory (= NHWC), so forward hooks, DDP and user code see the reference's
+shapes while the kernels see contiguous channel rows.  The 3-channel image stays NCHW-contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NafBlockGrads, NafBlockParams, NafBlockSaved, PARAM_FIELDS, check
+
+CL = torch.channels_last
+_ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream); kernels using it are stream-ordered."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _ws_cache.clear()
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DcptHipError(
+                "dcpt_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise _lib.DcptHipError(f"dcpt_amd kernels are fp32 (got {t.dtype})")
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) tensor whose memory is dense NHWC."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got {tuple(x.shape)}")
+    n, c, h, w = x.shape
+    if x.stride() == (h * w * c, 1, w * c, c):
+        return x
+    return x.contiguous(memory_format=CL) if (c > 1 and h * w > 1) else _force_nhwc(x)
+
+
+def _force_nhwc(x):
+    n, c, h, w = x.shape
+    out = torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=x.dtype, device=x.device)
+    out.copy_(x)
+    return out
+
+
+def _empty_nhwc(n, c, h, w, dev) -> torch.Tensor:
+    return torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=torch.float32, device=dev)
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+class _NAFBlockFn(torch.autograd.Function):
+    """reference basicsr/archs/nafnet_arch.py:165-186 (NAFBlock.forward) -> dcpt_nafblock_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, inp, *params):
+        lib = _lib.load()
+        _require_gpu(inp, *params)
+        inp = _nhwc(inp)
+        params = tuple(_contig(p.detach()) for p in params)
+        B, Cc, H, W = inp.shape
+        dev = inp.device
+        M = B * H * W
+        out = _empty_nhwc(B, Cc, H, W, dev)
+        t1 = _empty_nhwc(B, 2 * Cc, H, W, dev)
+        t2 = _empty_nhwc(B, Cc, H, W, dev)
+        y = _empty_nhwc(B, Cc, H, W, dev)
+        v = _empty_nhwc(B, 2 * Cc, H, W, dev)
+        stats = torch.empty((4, M), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        s = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        ps = NafBlockParams(*[p.data_ptr() for p in params])
+        sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
+                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr())
+        nws = lib.dcpt_nafblock_fwd_ws_bytes(B, H, W, Cc)
+        ws = _workspace(dev, nws)
+        check(lib.dcpt_nafblock_fwd(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
+                                    B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd")
+        ctx.save_for_backward(inp, t1, t2, y, v, stats, pooled, s, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        inp, t1, t2, y, v, stats, pooled, s, *params = ctx.saved_tensors
+        dout = _nhwc(dout)
+        B, Cc, H, W = inp.shape
+        dev = inp.device
+        grads = [torch.empty_like(p) for p in params]
+        dinp = _empty_nhwc(B, Cc, H, W, dev)
+        ps = NafBlockParams(*[p.data_ptr() for p in params])
+        gs = NafBlockGrads(*[g.data_ptr() for g in grads])
+        sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
+                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr())
+        nws = lib.dcpt_nafblock_bwd_ws_bytes(B, H, W, Cc)
+        ws = _workspace(dev, nws)
+        check(lib.dcpt_nafblock_bwd(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(),
+                                    dinp.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)),
+              "dcpt_nafblock_bwd")
+        return (dinp, *grads)
+
+
+def nafblock(inp: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """params: dict with the keys of _lib.PARAM_FIELDS (reference state-dict tensors)."""
+    return _NAFBlockFn.apply(inp, *[params[k] for k in PARAM_FIELDS])
+
+
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm2dFn(torch.autograd.Function):
+    """reference nafnet_arch.py:25-53 (LayerNormFunction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        _require_gpu(x, weight, bias)
+        x = _nhwc(x)
+        B, Cc, H, W = x.shape
+        M = B * H * W
+        y = _empty_nhwc(B, Cc, H, W, x.device)
+        stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+        w_, b_ = _contig(weight.detach()), _contig(bias.detach())
+        check(lib.dcpt_ln2d_fwd(x.data_ptr(), w_.data_ptr(), b_.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                stats[1].data_ptr(), M, Cc, float(eps), _stream(x.device)), "dcpt_ln2d_fwd")
+        ctx.save_for_backward(x, stats, w_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, w_ = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        M = B * H * W
+        dx = _empty_nhwc(B, Cc, H, W, x.device)
+        dw = torch.empty_like(w_)
+        db = torch.empty_like(w_)
+        nws = lib.dcpt_ln2d_bwd_ws_bytes(M, Cc)
+        ws = _workspace(x.device, nws)
+        check(lib.dcpt_ln2d_bwd(dy.data_ptr(), x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w_.data_ptr(),
+                                dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), M, Cc,
+                                _stream(x.device)), "dcpt_ln2d_bwd")
+        return dx, dw, db, None
+
+
+def layernorm2d(x, weight, bias, eps=1e-6):
+    return _LayerNorm2dFn.apply(x, weight, bias, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+class _IntroFn(torch.autograd.Function):
+    """3x3 conv, image NCHW -> features NHWC (reference nafnet_arch.py:202-210, :252)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _require_gpu(x, weight, bias)
+        x = _contig(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        y = _empty_nhwc(B, Cout, H, W, x.device)
+        check(lib.dcpt_conv3x3_in_fwd(x.data_ptr(), w_.data_ptr(), _p(b_), y.data_ptr(), B, H, W, Cin, Cout,
+                                      _stream(x.device)), "dcpt_conv3x3_in_fwd")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        dw = torch.empty_like(w_)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nws = lib.dcpt_conv3x3_in_bwd_ws_bytes(B, H, W, Cin, Cout)
+        ws = _workspace(dev, nws)
+        check(lib.dcpt_conv3x3_in_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv3x3_in_bwd")
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+class _EndingFn(torch.autograd.Function):
+    """3x3 conv, features NHWC -> image NCHW, + residual image (reference nafnet_arch.py:211-219, :271-272)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res):
+        lib = _lib.load()
+        _require_gpu(x, weight, bias, res)
+        x = _nhwc(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        res_ = None if res is None else _contig(res)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        check(lib.dcpt_conv3x3_out_fwd(x.data_ptr(), w_.data_ptr(), _p(b_), _p(res_), y.data_ptr(), B, H, W, Cin, Cout,
+                                       _stream(x.device)), "dcpt_conv3x3_out_fwd")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias = bias is not None
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        dy = _contig(dy)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        dx = _empty_nhwc(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        nws = lib.dcpt_conv3x3_out_bwd_ws_bytes(B, H, W, Cin, Cout)
+        ws = _workspace(dev, nws)
+        check(lib.dcpt_conv3x3_out_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                       db.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, _stream(dev)),
+              "dcpt_conv3x3_out_bwd")
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
+
+
+def conv3x3_in(x, weight, bias):
+    return _IntroFn.apply(x, weight, bias)
+
+
+def conv3x3_out(x, weight, bias, res=None):
+    return _EndingFn.apply(x, weight, bias, res)
+
+
+# ------------------------------------------------------------------------------------------------
+class _DownFn(torch.autograd.Function):
+    """Conv2d(C, 2C, 2, 2) (reference nafnet_arch.py:230)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _require_gpu(x, weight, bias)
+        x = _nhwc(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        B, Cc, H, W = x.shape
+        if H % 2 or W % 2:
+            raise ValueError(f"down2x2: H={H}, W={W} must be even")
+        y = _empty_nhwc(B, 2 * Cc, H // 2, W // 2, x.device)
+        nws = lib.dcpt_down2x2_ws_bytes(B, H, W, Cc, 0)
+        ws = _workspace(x.device, nws)
+        check(lib.dcpt_down2x2_fwd(x.data_ptr(), w_.data_ptr(), _p(b_), y.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W,
+                                   Cc, _stream(x.device)), "dcpt_down2x2_fwd")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = _empty_nhwc(B, Cc, H, W, dev)
+        dw = torch.empty_like(w_)
+        db = torch.empty((2 * Cc,), dtype=torch.float32, device=dev)
+        nws = lib.dcpt_down2x2_ws_bytes(B, H, W, Cc, 1)
+        ws = _workspace(dev, nws)
+        check(lib.dcpt_down2x2_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_down2x2_bwd")
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+class _UpFn(torch.autograd.Function):
+    """Conv2d(C, 2C, 1, bias=False) + PixelShuffle(2) + skip add (reference nafnet_arch.py:238-242, :264-265)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, skip):
+        lib = _lib.load()
+        _require_gpu(x, weight, skip)
+        x = _nhwc(x)
+        w_ = _contig(weight.detach())
+        skip_ = None if skip is None else _nhwc(skip)
+        B, Cc, H, W = x.shape
+        y = _empty_nhwc(B, Cc // 2, 2 * H, 2 * W, x.device)
+        nws = lib.dcpt_up_ps_ws_bytes(B, H, W, Cc, 0)
+        ws = _workspace(x.device, nws)
+        check(lib.dcpt_up_ps_fwd(x.data_ptr(), w_.data_ptr(), _p(skip_), y.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W,
+                                 Cc, _stream(x.device)), "dcpt_up_ps_fwd")
+        ctx.save_for_backward(x, w_)
+        ctx.has_skip = skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = _empty_nhwc(B, Cc, H, W, dev)
+        dw = torch.empty_like(w_)
+        nws = lib.dcpt_up_ps_ws_bytes(B, H, W, Cc, 1)
+        ws = _workspace(dev, nws)
+        check(lib.dcpt_up_ps_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_up_ps_bwd")
+        return dx, dw, (dy if ctx.has_skip else None)
+
+
+def down2x2(x, weight, bias):
+    return _DownFn.apply(x, weight, bias)
+
+
+def up_ps(x, weight, skip=None):
+    return _UpFn.apply(x, weight, skip)
+
+
+# ------------------------------------------------------------------------------------------------
+def fused_bias_act(x, bias, ref, act: int, grad: int, alpha: float, scale: float):
+    """API parity with the reference's fused_act_ext.fused_bias_act
+    (basicsr/ops/fused_act/src/fused_bias_act.cpp:14-26): NCHW input, bias over dim 1."""
+    lib = _lib.load()
+    _require_gpu(x)
+    x = _contig(x)
+    y = torch.empty_like(x)
+    use_bias = bias is not None and bias.numel() > 0
+    use_ref = ref is not None and ref.numel() > 0
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= int(d)
+    b_ = _contig(bias) if use_bias else None
+    r_ = _contig(ref) if use_ref else None
+    check(lib.dcpt_fused_bias_act(x.data_ptr(), _p(b_), _p(r_), y.data_ptr(), x.numel(), x.shape[1] if x.dim() > 1 else 1,
+                                  step_b, act, grad, float(alpha), float(scale), _stream(x.device)), "dcpt_fused_bias_act")
+    return y
+
+
+class _FusedLeakyReLUFn(torch.autograd.Function):
+    """reference basicsr/ops/fused_act/fused_act.py:55-82 (first-order part)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, negative_slope, scale):
+        out = fused_bias_act(x, bias, None, 3, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (out,) = ctx.saved_tensors
+        gi = fused_bias_act(grad_output, None, out, 3, 1, ctx.negative_slope, ctx.scale)
+        dims = [0] + list(range(2, gi.dim()))
+        return gi, gi.sum(dims), None, None
+
+
+def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+    return _FusedLeakyReLUFn.apply(x, bias, negative_slope, scale)

@@ -1,0 +1,137 @@
+/* dcpt_hip.h -- C ABI of libdcpt_hip.so: the MI355X (gfx950) implementation of the DCPT
+ * restoration-encoder hot path (NAFNet blocks and the layers between them).
+ *
+ * Drop-in boundary.  The reference (MILab-PKU/dcpt) has no FFI of its own on this path: its
+ * archs call ATen ops from Python (basicsr/archs/nafnet_arch.py) and its only native bindings
+ * are the unused JIT extensions under basicsr/ops (layernorm: ops/layernorm/src/layernorm_kernel.cpp
+ * :57-60 pybind `forward`/`backward`; fused_act: ops/fused_act/src/fused_bias_act.cpp:14-26).  The
+ * entry points below are what a maintainer would bind from the arch modules instead of those ATen
+ * calls; each one cites the reference code it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 data unless it says otherwise; the caller (PyTorch)
+ *    owns all buffers, including workspaces and tensors saved for backward;
+ *  - feature maps are NHWC ([B][H][W][C], C contiguous; torch `channels_last` memory); only the
+ *    network's image input/output is NCHW (3 channels);
+ *  - weights keep the reference's state-dict layouts (conv: [out][in][kh][kw]);
+ *  - every call enqueues work on `stream` (a hipStream_t) and returns immediately: 0 on success,
+ *    non-zero on error (dcpt_last_error() gives the message).  No call synchronises, allocates or
+ *    keeps state between calls; all of them are re-entrant.
+ *  - channel counts must be multiples of 4.
+ */
+#ifndef DCPT_HIP_H
+#define DCPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dcpt_stream_t; /* hipStream_t */
+
+const char* dcpt_last_error(void);
+int dcpt_abi_version(void);
+
+/* ---- LayerNorm2d --------------------------------------------------------------------------
+ * replaces nafnet_arch.py:25-64 (LayerNormFunction / LayerNorm2d) and ops/layernorm
+ * (layernorm_kernel.cpp:14-55).  x,y: [M][C] rows = pixels.  mu/rstd: [M] saved statistics. */
+int dcpt_ln2d_fwd(const float* x, const float* weight, const float* bias, float* y, float* mu, float* rstd,
+                  int64_t M, int C, float eps, dcpt_stream_t stream);
+size_t dcpt_ln2d_bwd_ws_bytes(int64_t M, int C);
+int dcpt_ln2d_bwd(const float* dy, const float* x, const float* mu, const float* rstd, const float* weight,
+                  float* dx, float* dweight, float* dbias, void* ws, size_t ws_bytes, int64_t M, int C,
+                  dcpt_stream_t stream);
+
+/* ---- NAFBlock -----------------------------------------------------------------------------
+ * replaces nafnet_arch.py:83-186 (NAFBlock.forward and its autograd backward). */
+typedef struct {
+    const float* norm1_w; const float* norm1_b;   /* [C] */
+    const float* conv1_w; const float* conv1_b;   /* [2C][C][1][1], [2C] */
+    const float* conv2_w; const float* conv2_b;   /* [2C][1][3][3], [2C]  (depthwise) */
+    const float* conv3_w; const float* conv3_b;   /* [C][C][1][1], [C] */
+    const float* sca_w;   const float* sca_b;     /* [C][C][1][1], [C] */
+    const float* norm2_w; const float* norm2_b;   /* [C] */
+    const float* conv4_w; const float* conv4_b;   /* [2C][C][1][1], [2C] */
+    const float* conv5_w; const float* conv5_b;   /* [C][C][1][1], [C] */
+    const float* beta;    const float* gamma;     /* [1][C][1][1] */
+} dcpt_nafblock_params;
+
+typedef struct {   /* same shapes as dcpt_nafblock_params; all written (not accumulated) */
+    float* norm1_w; float* norm1_b;
+    float* conv1_w; float* conv1_b;
+    float* conv2_w; float* conv2_b;
+    float* conv3_w; float* conv3_b;
+    float* sca_w;   float* sca_b;
+    float* norm2_w; float* norm2_b;
+    float* conv4_w; float* conv4_b;
+    float* conv5_w; float* conv5_b;
+    float* beta;    float* gamma;
+} dcpt_nafblock_grads;
+
+typedef struct {   /* activations kept for backward (M = B*H*W pixels) */
+    float* t1;      /* [M][2C]  conv1(LN1(inp)) */
+    float* t2;      /* [M][C]   SimpleGate(dwconv(t1)) */
+    float* y;       /* [M][C]   inp + conv3(t2*s)*beta */
+    float* v;       /* [M][2C]  conv4(LN2(y)) */
+    float* mu1; float* rstd1; float* mu2; float* rstd2;   /* [M] */
+    float* pooled;  /* [B][C]   mean_{h,w} t2 */
+    float* s;       /* [B][C]   SCA scale */
+} dcpt_nafblock_saved;
+
+size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C);
+size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C);
+/* inp,out: [B][H][W][C].  `saved` buffers are always written (inference callers may recycle them). */
+int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp, float* out, const dcpt_nafblock_saved* saved,
+                      void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
+/* dout,dinp: [B][H][W][C]; dinp may alias dout. */
+int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* g, const float* inp,
+                      const dcpt_nafblock_saved* saved, const float* dout, float* dinp, void* ws, size_t ws_bytes,
+                      int B, int H, int W, int C, dcpt_stream_t stream);
+
+/* ---- network-edge 3x3 convs ------------------------------------------------------------------
+ * intro: nafnet_arch.py:202-210,252  x NCHW [B][Cin][H][W] -> y NHWC [B][H][W][Cout]
+ * ending: nafnet_arch.py:211-219,271-272  x NHWC -> y NCHW [B][Cout][H][W] (+ res NCHW, may be NULL) */
+int dcpt_conv3x3_in_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                        int Cout, dcpt_stream_t stream);
+size_t dcpt_conv3x3_in_bwd_ws_bytes(int B, int H, int W, int Cin, int Cout);
+/* dx (NCHW) may be NULL when the image does not need a gradient */
+int dcpt_conv3x3_in_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws,
+                        size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+int dcpt_conv3x3_out_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H,
+                         int W, int Cin, int Cout, dcpt_stream_t stream);
+size_t dcpt_conv3x3_out_bwd_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int dcpt_conv3x3_out_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws,
+                         size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+
+/* ---- down: Conv2d(C, 2C, 2, 2) (nafnet_arch.py:230) ------------------------------------------
+ * x [B][H][W][C] -> y [B][H/2][W/2][2C];  w [2C][C][2][2] */
+size_t dcpt_down2x2_ws_bytes(int B, int H, int W, int C, int backward);
+int dcpt_down2x2_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                     int H, int W, int C, dcpt_stream_t stream);
+int dcpt_down2x2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws,
+                     size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
+
+/* ---- up: Conv2d(C, 2C, 1, bias=False) + PixelShuffle(2) + skip add (nafnet_arch.py:238-242,264-265)
+ * x [B][H][W][C], skip/y [B][2H][2W][C/2];  w [2C][C][1][1].  The skip gradient equals dy. */
+size_t dcpt_up_ps_ws_bytes(int B, int H, int W, int C, int backward);
+int dcpt_up_ps_fwd(const float* x, const float* w, const float* skip, float* y, void* ws, size_t ws_bytes, int B, int H,
+                   int W, int C, dcpt_stream_t stream);
+int dcpt_up_ps_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, void* ws, size_t ws_bytes,
+                   int B, int H, int W, int C, dcpt_stream_t stream);
+
+/* ---- fused bias + leaky-ReLU (API parity with basicsr/ops/fused_act/src/fused_bias_act.cpp:14-26,
+ * kernel fused_bias_act_kernel.cu:20-50): y = act(x + bias[(i / step_b) % size_b]) * scale, act in
+ * {1: linear, 3: leaky relu(alpha)}; grad 0: forward, 1: first derivative w.r.t. x using `ref` sign. */
+int dcpt_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, int64_t n, int size_b,
+                        int64_t step_b, int act, int grad, float alpha, float scale, dcpt_stream_t stream);
+
+/* ---- layout helpers (arbitrary C) ----------------------------------------------------------- */
+int dcpt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, dcpt_stream_t stream);
+int dcpt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, dcpt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCPT_HIP_H */

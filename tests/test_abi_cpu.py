@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/dcpt_hip.h declares;
+the Python binding table mirrors the header; the product path refuses CPU tensors (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dcpt_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcpt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from dcpt_amd import _lib, build
+
+    build.build()
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in dcpt_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES.keys()) == syms, "ctypes table and header disagree"
+    assert lib.dcpt_abi_version() == 1
+
+
+def test_workspace_queries_need_no_gpu():
+    from dcpt_amd import _lib
+
+    lib = _lib.load()
+    assert lib.dcpt_nafblock_fwd_ws_bytes(32, 256, 256, 64) > 0
+    assert lib.dcpt_nafblock_bwd_ws_bytes(32, 32, 32, 512) > lib.dcpt_nafblock_fwd_ws_bytes(32, 32, 32, 512)
+    assert lib.dcpt_down2x2_ws_bytes(2, 8, 8, 16, 1) > lib.dcpt_down2x2_ws_bytes(2, 8, 8, 16, 0)
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    from dcpt_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.dcpt_ln2d_fwd(None, None, None, None, None, None, 4, 8, 1e-6, None)
+    assert rc != 0 and b"null" in lib.dcpt_last_error()
+
+
+def test_no_cpu_fallback():
+    from dcpt_amd import _lib
+    from dcpt_amd import functional as DF
+
+    x = torch.zeros(1, 8, 4, 4)
+    with pytest.raises(_lib.DcptHipError):
+        DF.layernorm2d(x, torch.ones(8), torch.zeros(8))
+
+
+def test_product_never_imports_oracle():
+    for base in ("dcpt_amd", "basicsr"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(d, f)).read()
+                    assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{d}/{f} mentions the oracle"
