@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Headline benchmark: megapixels/s, forward+backward, NAFNet-64 (enc [1,1,1,28], mid 1, dec [1,1,1,1]),
+256x256, batch 32 per GPU, fp32 (BASELINE.json metric; configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward + L1 loss + backward of the whole network (every NAFBlock / conv through
+libdcpt_hip.so), gradient all-reduce over RCCL when N > 1 (torch DDP buckets, overlapped with
+backward), and the fused AdamW update.  Inputs are synthetic (torch.rand, resident in HBM before the
+timed region), weights are the keyed deterministic init.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1])
+BATCH, SIZE = 32, 256
+# algorithmic work of one 256x256 image, fwd+bwd
+FLOP_PER_IMAGE = 378.3e9
+BYTES_PER_IMAGE = 3.50e9
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
+PEAK_HBM_TBS = 8.0
+
+ALOAD = {0: "plain", 1: "ln", 2: "scale", 3: "sg", 4: "gather"}
+EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_add"}
+
+
+def prof_class_name(cls: int) -> str:
+    if cls >= 512:
+        c = cls - 512
+        return f"gemm_tn<x={ALOAD.get(c // 8, c // 8)},y={ALOAD.get(c % 8, c % 8)}>"
+    return f"gemm_nt<a={ALOAD.get(cls // 8, cls // 8)},epi={EPI.get(cls % 8, cls % 8)}>"
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The oracle (CPU restatement of the reference path, proven equal to the reference in the build
+    container) timed on this box's host cores: forward + L1 + backward at batch 1, 256x256."""
+    from dcpt_amd.keyed_init import keyed_input, keyed_state_dict
+    from oracle import nafnet_oracle as O
+
+    nthreads = torch.get_num_threads()
+    P = {k: v.requires_grad_(True) for k, v in keyed_state_dict(O.nafnet_param_shapes(**CFG), seed=0).items()}
+    x = keyed_input("bench.cpu.x", (1, 3, SIZE, SIZE))
+    gt = keyed_input("bench.cpu.gt", (1, 3, SIZE, SIZE))
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        y, _ = O.nafnet_forward(x, P)
+        O.l1_loss(y, gt).backward()
+
+    step()  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < seconds_budget and len(times) < 8):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": round(SIZE * SIZE / 1e6 / med, 5),
+        "unit": "megapixels/s",
+        "cores": nthreads,
+        "kind": "port",
+        "sample": f"oracle (PyTorch-CPU fp32 restatement) fwd+L1+bwd, batch 1 x 256x256, median of {len(times)} steps "
+                  f"({med:.2f} s/step), {nthreads} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (the metric is quoted at 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
+
+    from basicsr.archs import build_network
+    from dcpt_amd import _lib
+    from dcpt_amd.keyed_init import fill_module_
+
+    lib = _lib.load()
+    net = build_network(dict(type="NAFNetBaseline", **CFG))
+    fill_module_(net, seed=0)
+    net = net.to(dev)
+    model = net
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        # reference base_model.py:108-115; buckets all-reduce on RCCL's stream while backward continues
+        model = DDP(net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0, fused=True)
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    lq = torch.rand((args.batch, 3, SIZE, SIZE), generator=g, device=dev)
+    gt = torch.rand((args.batch, 3, SIZE, SIZE), generator=g, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(lq)
+        loss = (out - gt).abs().mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_prof = (not args.no_prof)
+    barrier()
+    if use_prof:
+        lib.dcpt_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    loss_val = float(loss)
+    prof_rows = []
+    if use_prof:
+        buf = (ctypes.c_double * (5 * 128))()
+        n = lib.dcpt_prof_read(buf, 128)
+        lib.dcpt_prof_enable(0)
+        for i in range(n):
+            cls, cnt, ms, fl, by = (buf[i * 5 + j] for j in range(5))
+            prof_rows.append(dict(kernel=prof_class_name(int(cls)), launches=int(cnt), ms=ms, flops=fl, bytes=by))
+        prof_rows.sort(key=lambda r: -r["ms"])
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        mp = world * args.batch * SIZE * SIZE / 1e6
+        value = mp / (dt / args.steps)
+        res = {
+            "metric": "megapixels/sec fwd+bwd NAFNet-64 256px bs=32",
+            "value": round(value, 3),
+            "unit": "megapixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (torch.rand images, keyed deterministic weights)",
+            "config": {
+                "workload": "NAFNet-width64 enc[1,1,1,28] mid1 dec[1,1,1,1] fwd+L1+bwd(+all-reduce)+AdamW, 256x256, fp32 "
+                            "(BASELINE.json configs[1])",
+                "per_gpu_batch": args.batch, "global_batch": world * args.batch, "image": [SIZE, SIZE],
+                "parallelism": f"dp{world}", "loss": round(loss_val, 6),
+            },
+        }
+        step_s = dt / args.steps
+        whole = {
+            "mfma_frac": round(args.batch * FLOP_PER_IMAGE / step_s / (PEAK_F32_TFLOPS * 1e12), 4),
+            "hbm_frac": round(args.batch * BYTES_PER_IMAGE / step_s / (PEAK_HBM_TBS * 1e12), 4),
+        }
+        if prof_rows:
+            top = prof_rows[0]
+            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            gemm_ms = sum(r["ms"] for r in prof_rows)
+            res["roofline"] = {
+                "bound": "mfma", "kernel": top["kernel"],
+                "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
+                "traffic": None,
+                "launches": top["launches"], "avg_launch_us": round(top["ms"] * 1e3 / max(1, top["launches"]), 2),
+                "alg_flops_per_launch": round(top["flops"] / max(1, top["launches"])),
+                "alg_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
+                "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
+                "all_gemm_tflops": round(sum(r["flops"] for r in prof_rows) / (gemm_ms * 1e-3) / 1e12, 2),
+                "whole_step": whole,
+                "by_kernel": [dict(kernel=r["kernel"], launches=r["launches"], ms_per_step=round(r["ms"] / args.steps, 3),
+                                   tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                   alg_gbs=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)) for r in prof_rows[:12]],
+            }
+        else:
+            res["roofline"] = {"bound": "mfma", "achieved": round(whole["mfma_frac"] * PEAK_F32_TFLOPS, 2),
+                               "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": whole["mfma_frac"], "traffic": None,
+                               "whole_step": whole}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

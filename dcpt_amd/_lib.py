@@ -69,6 +69,8 @@ SIGNATURES = {
     "dcpt_up_ps_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_up_ps_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_fused_bias_act": (cint, [f32p, f32p, f32p, f32p, i64, cint, i64, cint, cint, C.c_float, C.c_float, stream_t]),
+    "dcpt_prof_enable": (cint, [cint]),
+    "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
     "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
     "dcpt_nhwc_to_nchw": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
 }

@@ -11,6 +11,7 @@
 // Block id -> tile: XCD-aware (dcpt_common.h xcd_remap); consecutive logical ids walk the N tiles of
 // one M panel so an A panel is fetched from HBM once per XCD and re-read from that XCD's L2.
 #include "gemm_operand.h"
+#include "prof.h"
 
 namespace {
 
@@ -175,6 +176,11 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
     DCPT_CHECK_ARG(p.K % 4 == 0, "gemm_nt: K=%d must be a multiple of 4", p.K);
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 64) < (1ll << 31), "gemm_nt: grid too large");
     if (aload == A_GATHER) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 4 * p.gC, "gemm_nt: gather needs K == 4*gC, gC %% 4 == 0");
+    // algorithmic work of this launch (for the live roofline in bench.py)
+    const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
+    double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : 1) + (double)p.N * p.K;
+    if (epi == E_RESID || epi == E_SCATTER_ADD) bytes += mn;
+    ProfScope prof(s, PROF_NT + aload * 8 + epi, 2.0 * mn * p.K, bytes * 4.0);
 #define CASE(AK, EK) \
     if (aload == AK && epi == EK) return launch_cfg<AK, EK>(p, s);
     CASE(A_LN, E_BIAS)

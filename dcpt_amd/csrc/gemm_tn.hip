@@ -7,6 +7,7 @@
 // sums the slabs -- no float atomics.  Blocks of the first k-tile column also emit the column sums
 // of X' (bias gradients) from the LDS tile they already hold.
 #include "gemm_operand.h"
+#include "prof.h"
 
 namespace {
 
@@ -164,6 +165,8 @@ int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t s) {
     DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_tn: empty problem");
     DCPT_CHECK_ARG(p.N % 4 == 0 && p.K % 4 == 0, "gemm_tn: N=%d, K=%d must be multiples of 4", p.N, p.K);
     DCPT_CHECK_ARG(p.splits >= 1 && p.splits <= 65535 && p.rows_per_split % 32 == 0, "gemm_tn: bad split plan");
+    const double bytes = (double)p.M * p.N + (double)p.M * p.K * (yload == A_SG ? 2 : 1) + (double)p.splits * p.N * p.K;
+    ProfScope prof(s, PROF_TN + xload * 8 + yload, 2.0 * (double)p.M * p.N * p.K, bytes * 4.0);
 #define CASE(XK, YK) \
     if (xload == XK && yload == YK) return launch_cfg<XK, YK>(p, s);
     CASE(A_PLAIN, A_PLAIN)

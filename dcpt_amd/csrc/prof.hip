@@ -1,0 +1,85 @@
+#include "prof.h"
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/dcpt_hip.h"
+
+namespace {
+struct Rec {
+    int cls;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;         // records of the current session
+std::vector<hipEvent_t> g_pool;  // reusable events
+size_t g_pool_next = 0;
+int g_open = -1;
+constexpr size_t MAXREC = 1 << 16;
+
+hipEvent_t get_event() {
+    if (g_pool_next < g_pool.size()) return g_pool[g_pool_next++];
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_pool.push_back(e);
+    g_pool_next++;
+    return e;
+}
+}  // namespace
+
+void prof_begin(hipStream_t s, int cls, double flops, double bytes) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_open = -1;
+    if (g_recs.size() >= MAXREC) return;
+    Rec r{cls, flops, bytes, get_event(), get_event()};
+    if (!r.e0 || !r.e1) return;
+    hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+    g_open = (int)g_recs.size() - 1;
+}
+
+void prof_end(hipStream_t s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_open >= 0) hipEventRecord(g_recs[g_open].e1, s);
+    g_open = -1;
+}
+
+extern "C" int dcpt_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    if (g_on) {
+        g_recs.clear();
+        g_pool_next = 0;
+    }
+    return DCPT_OK;
+}
+
+// Synchronises the recorded events and aggregates per class.  out: [max_classes][5] =
+// {class id, launches, total ms, total flops, total bytes}; returns the number of classes written.
+extern "C" int dcpt_prof_read(double* out, int max_classes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (const Rec& r : g_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        int j = 0;
+        for (; j < n; ++j)
+            if ((int)out[j * 5] == r.cls) break;
+        if (j == n) {
+            if (n >= max_classes) continue;
+            out[j * 5] = r.cls;
+            out[j * 5 + 1] = out[j * 5 + 2] = out[j * 5 + 3] = out[j * 5 + 4] = 0.0;
+            n++;
+        }
+        out[j * 5 + 1] += 1.0;
+        out[j * 5 + 2] += ms;
+        out[j * 5 + 3] += r.flops;
+        out[j * 5 + 4] += r.bytes;
+    }
+    return n;
+}

@@ -131,6 +131,13 @@ int dcpt_fused_bias_act(const float* x, const float* bias, const float* ref, flo
 int dcpt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, dcpt_stream_t stream);
 int dcpt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, dcpt_stream_t stream);
 
+/* ---- optional launch profiling (bench.py) -------------------------------------------------------
+ * While enabled, every MFMA GEMM launch is bracketed by HIP events on its own stream.
+ * dcpt_prof_read waits for them and writes rows {class id, launches, total ms, algorithmic flops,
+ * algorithmic bytes}; class id = (0: NT | 512: TN) + 8*loaderA + epilogue/loaderB. */
+int dcpt_prof_enable(int on);
+int dcpt_prof_read(double* out, int max_classes);
+
 #ifdef __cplusplus
 }
 #endif
