@@ -50,7 +50,10 @@ def cpu_baseline(seconds_budget: float = 25.0):
     from dcpt_amd.keyed_init import keyed_input, keyed_state_dict
     from oracle import nafnet_oracle as O
 
-    nthreads = torch.get_num_threads()
+    # 16 threads is the fastest setting for this graph on the GPU box's EPYC (probed: 16 -> 0.48 s/step,
+    # 32 -> 1.15, 64 -> 2.1, 128 -> 9.0 at batch 1): the ops are small and oversubscription hurts.
+    nthreads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(nthreads)
     P = {k: v.requires_grad_(True) for k, v in keyed_state_dict(O.nafnet_param_shapes(**CFG), seed=0).items()}
     x = keyed_input("bench.cpu.x", (1, 3, SIZE, SIZE))
     gt = keyed_input("bench.cpu.gt", (1, 3, SIZE, SIZE))
@@ -154,12 +157,13 @@ def main():
     loss_val = float(loss)
     prof_rows = []
     if use_prof:
-        buf = (ctypes.c_double * (5 * 128))()
-        n = lib.dcpt_prof_read(buf, 128)
+        buf = (ctypes.c_double * (8 * 512))()
+        n = lib.dcpt_prof_read(buf, 512)
         lib.dcpt_prof_enable(0)
         for i in range(n):
-            cls, cnt, ms, fl, by = (buf[i * 5 + j] for j in range(5))
-            prof_rows.append(dict(kernel=prof_class_name(int(cls)), launches=int(cnt), ms=ms, flops=fl, bytes=by))
+            cls, M, N, K, cnt, ms, fl, by = (buf[i * 8 + j] for j in range(8))
+            prof_rows.append(dict(kernel=prof_class_name(int(cls)), M=int(M), N=int(N), K=int(K), launches=int(cnt), ms=ms,
+                                  flops=fl, bytes=by))
         prof_rows.sort(key=lambda r: -r["ms"])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -200,7 +204,7 @@ def main():
             ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
             gemm_ms = sum(r["ms"] for r in prof_rows)
             res["roofline"] = {
-                "bound": "mfma", "kernel": top["kernel"],
+                "bound": "mfma", "kernel": top["kernel"], "MNK": [top["M"], top["N"], top["K"]],
                 "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
                 "traffic": None,
                 "launches": top["launches"], "avg_launch_us": round(top["ms"] * 1e3 / max(1, top["launches"]), 2),
@@ -209,9 +213,10 @@ def main():
                 "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
                 "all_gemm_tflops": round(sum(r["flops"] for r in prof_rows) / (gemm_ms * 1e-3) / 1e12, 2),
                 "whole_step": whole,
-                "by_kernel": [dict(kernel=r["kernel"], launches=r["launches"], ms_per_step=round(r["ms"] / args.steps, 3),
+                "by_kernel": [dict(kernel=r["kernel"], MNK=[r["M"], r["N"], r["K"]], launches=r["launches"],
+                                   ms_per_step=round(r["ms"] / args.steps, 3),
                                    tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
-                                   alg_gbs=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)) for r in prof_rows[:12]],
+                                   alg_gbs=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)) for r in prof_rows[:16]],
             }
         else:
             res["roofline"] = {"bound": "mfma", "achieved": round(whole["mfma_frac"] * PEAK_F32_TFLOPS, 2),

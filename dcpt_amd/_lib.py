@@ -97,6 +97,14 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -m dcpt_amd.build` (hipcc, gfx950). "
                 "dcpt_amd has no CPU/eager fallback."
             )
+        # One HIP runtime per process: make sure torch's bundled libamdhip64 is the one already
+        # loaded before our library's DT_NEEDED libamdhip64.so.7 is resolved (loading ours first would
+        # bring in /opt/rocm's copy and torch's streams/pointers would belong to another runtime).
+        import torch
+
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly

@@ -78,7 +78,8 @@ extern "C" int dcpt_conv3x3_out_fwd(const float* x, const float* w, const float*
 }
 
 extern "C" size_t dcpt_conv3x3_out_bwd_ws_bytes(int B, int H, int W, int Cin, int Cout) {
-    return align_up((size_t)conv3x3_wgrad_num_blocks(B, H, W, Cin) * (Cout * 9 + 1) * Cin * sizeof(float), 256);
+    return align_up((size_t)conv3x3_wgrad_num_blocks(B, H, W, Cin) * (Cout * 9 + 1) * Cin * sizeof(float), 256) +
+           align_up((size_t)Cout * 128 * sizeof(float), 256);
 }
 
 extern "C" int dcpt_conv3x3_out_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
@@ -94,7 +95,8 @@ extern "C" int dcpt_conv3x3_out_bwd(const float* dy, const float* x, const float
     // dW[s][c][tap] = sum_p dy[p][s]*x[p+off][c] = sum_p' x[p'][c]*dy[p'-off][s]  (flipped-tap form)
     const int nblk = conv3x3_wgrad_num_blocks(B, H, W, Cin);
     DCPT_TRY(launch_conv3x3_wgrad(x, dy, (float*)ws, nblk, dw, nullptr, B, H, W, Cout, Cin, 1, s));
-    DCPT_TRY(launch_nchw_channel_sum(dy, dbias, B, Cout, H * W, s));
+    float* cspart = (float*)((char*)ws + align_up((size_t)nblk * (Cout * 9 + 1) * Cin * sizeof(float), 256));
+    DCPT_TRY(launch_nchw_channel_sum(dy, cspart, dbias, B, Cout, H * W, s));
     return DCPT_OK;
 }
 

@@ -195,14 +195,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
     }
 }
 
+// stage 1: part[c][j] = sum over the j-th slice of (b, hw);  stage 2 (gridDim.y == 1 launch): out[c] = sum_j part[c][j]
 __global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
-                                                               int C, int HW) {
+                                                               int C, int HW, int nsl, int stage) {
     __shared__ float red[256];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* p = x + ((int64_t)b * C + c) * HW;
-        for (int i = tid; i < HW; i += 256) s += p[i];
+    if (stage == 0) {
+        const int64_t tot = (int64_t)B * HW;
+        const int64_t per = (tot + nsl - 1) / nsl;
+        const int64_t beg = j * per;
+        int64_t end = beg + per;
+        if (end > tot) end = tot;
+        for (int64_t i = beg + tid; i < end; i += 256) {
+            const int64_t b = i / HW, p = i - b * HW;
+            s += x[(b * C + c) * HW + p];
+        }
+    } else {
+        for (int i = tid; i < nsl; i += 256) s += x[(int64_t)c * nsl + i];
     }
     red[tid] = s;
     __syncthreads();
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const float* __re
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) out[c] = red[0];
+    if (tid == 0) out[(stage == 0) ? (int64_t)c * nsl + j : c] = red[0];
 }
 
 // tiled transposes between [B][C][HW] and [B][HW][C]
@@ -302,9 +312,11 @@ int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int 
     return DCPT_OK;
 }
 
-int launch_nchw_channel_sum(const float* x, float* out, int B, int C, int HW, hipStream_t s) {
-    nchw_channel_sum_kernel<<<dim3(C), dim3(256), 0, s>>>(x, out, B, C, HW);
+int launch_nchw_channel_sum(const float* x, float* part, float* out, int B, int C, int HW, hipStream_t s) {
+    nchw_channel_sum_kernel<<<dim3(C, 128), dim3(256), 0, s>>>(x, part, B, C, HW, 128, 0);
     DCPT_CHECK_LAUNCH("nchw_channel_sum");
+    nchw_channel_sum_kernel<<<dim3(C, 1), dim3(256), 0, s>>>(part, out, B, C, HW, 128, 1);
+    DCPT_CHECK_LAUNCH("nchw_channel_sum2");
     return DCPT_OK;
 }
 

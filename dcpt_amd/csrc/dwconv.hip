@@ -234,17 +234,19 @@ __global__ void dw_pack_kernel(const float* __restrict__ w2, float* __restrict__
 // dw2[ch*9+tap] = sum_r wpart[r][tap][ch];  db2[ch] = sum_r wpart[r][9][ch]
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ wpart, int R, int C2,
                                                               float* __restrict__ dw2, float* __restrict__ db2) {
-    __shared__ float red[4][64];
+    __shared__ float red[8][32];
     const int t = blockIdx.y;
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
     if (c < C2)
-        for (int r = rg; r < R; r += 4) s += wpart[((int64_t)r * 10 + t) * C2 + c];
+        for (int r = rg; r < R; r += 8) s += wpart[((int64_t)r * 10 + t) * C2 + c];
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < C2) {
-        const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float v = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v += red[i][cl];
         if (t < 9) dw2[c * 9 + t] = v;
         else db2[c] = v;
     }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __res
 
 int nblk_for(const DwGeom& g, int quads) {
     const DwMap mp = dw_map(g.H, g.W, quads);
-    int64_t want = cdiv64(2048, (int64_t)g.B * mp.nqc);
+    int64_t want = cdiv64(1024, (int64_t)g.B * mp.nqc);
     if (want > mp.items) want = mp.items;
     if (want < 1) want = 1;
     return (int)want;
@@ -306,7 +308,7 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
 }
 
 int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float* db2, hipStream_t s) {
-    dw_wgrad_reduce_kernel<<<dim3(cdiv(C2, 64), 10), dim3(256), 0, s>>>(wpart, R, C2, dw2, db2);
+    dw_wgrad_reduce_kernel<<<dim3(cdiv(C2, 32), 10), dim3(256), 0, s>>>(wpart, R, C2, dw2, db2);
     DCPT_CHECK_LAUNCH("dw_wgrad_reduce");
     return DCPT_OK;
 }

@@ -92,17 +92,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         brow[i] = p.Bw + (int64_t)(bval[i] ? n : 0) * p.K;
     }
 
-    float4 ra[A_IT], rb[B_IT];
+    RawVec ra[A_IT];
+    float4 rb[B_IT];
     auto gload = [&](int kt) {
         const int k = kt * BK + lk;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = load_op<AK>(oa, rca[i], k);
+        for (int i = 0; i < A_IT; ++i) load_raw<AK>(oa, rca[i], k, ra[i]);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[i] = (bval[i] && k < p.K) ? ldg4(brow[i] + k) : f4_zero();
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDS_LD + lk]) = ra[i];
+        for (int i = 0; i < A_IT; ++i)
+            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDS_LD + lk]) = finish<AK>(rca[i], ra[i]);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * i) * LDS_LD + lk]) = rb[i];
     };
@@ -180,7 +182,7 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : 1) + (double)p.N * p.K;
     if (epi == E_RESID || epi == E_SCATTER_ADD) bytes += mn;
-    ProfScope prof(s, PROF_NT + aload * 8 + epi, 2.0 * mn * p.K, bytes * 4.0);
+    ProfScope prof(s, PROF_NT + aload * 8 + epi, p.M, p.N, p.K, 2.0 * mn * p.K, bytes * 4.0);
 #define CASE(AK, EK) \
     if (aload == AK && epi == EK) return launch_cfg<AK, EK>(p, s);
     CASE(A_LN, E_BIAS)

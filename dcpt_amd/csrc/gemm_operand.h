@@ -47,34 +47,53 @@ __device__ __forceinline__ void make_row(const Operand& o, int64_t m, RowCtx& rc
     if constexpr (KIND == A_SCALE) rc.img = (int)(mm / o.P);
 }
 
-// loads logical columns [c, c+4) of the row; zero outside the matrix
+// Operand access is split in two so that the global loads of the NEXT tile can stay in flight
+// across the current tile's MFMAs: load_raw() only issues loads (no dependent math), finish() applies
+// the fused transform right before the value is written to LDS.
+struct RawVec {
+    float4 a, b, c;
+};
+
 template <int KIND>
-__device__ __forceinline__ float4 load_op(const Operand& o, const RowCtx& rc, int c) {
-    if (!rc.valid || c >= o.ncols) return f4_zero();
+__device__ __forceinline__ void load_raw(const Operand& o, const RowCtx& rc, int c, RawVec& r) {
+    const bool ok = rc.valid && c < o.ncols;
     if constexpr (KIND == A_PLAIN) {
-        return ldg4(o.ptr + rc.off + c);
+        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
     } else if constexpr (KIND == A_LN) {
-        const float4 x = ldg4(o.ptr + rc.off + c);
-        const float4 w = ldg4(o.lnw + c);
-        const float4 b = ldg4(o.lnb + c);
-        float4 r;
-        r.x = fmaf((x.x - rc.mu) * rc.rstd, w.x, b.x);
-        r.y = fmaf((x.y - rc.mu) * rc.rstd, w.y, b.y);
-        r.z = fmaf((x.z - rc.mu) * rc.rstd, w.z, b.z);
-        r.w = fmaf((x.w - rc.mu) * rc.rstd, w.w, b.w);
-        return r;
+        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
+        r.b = ok ? ldg4(o.lnw + c) : f4_zero();
+        r.c = ok ? ldg4(o.lnb + c) : f4_zero();
     } else if constexpr (KIND == A_SCALE) {
-        const float4 x = ldg4(o.ptr + rc.off + c);
-        const float4 s = ldg4(o.simg + (int64_t)rc.img * o.ncols + c);
-        return f4_mul(x, s);
+        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
+        r.b = ok ? ldg4(o.simg + (int64_t)rc.img * o.ncols + c) : f4_zero();
     } else if constexpr (KIND == A_SG) {
-        const float4 x1 = ldg4(o.ptr + rc.off + c);
-        const float4 x2 = ldg4(o.ptr + rc.off + o.ncols + c);
-        return f4_mul(x1, x2);
+        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
+        r.b = ok ? ldg4(o.ptr + rc.off + o.ncols + c) : f4_zero();
     } else {  // A_GATHER
-        const int ij = c / o.gC;
-        const int ch = c - ij * o.gC;
-        const int64_t a = rc.off + ((int64_t)(ij >> 1) * (2 * o.gW) + (ij & 1)) * o.gC + ch;
-        return ldg4(o.ptr + a);
+        if (ok) {
+            const int ij = c / o.gC;
+            const int ch = c - ij * o.gC;
+            const int64_t a = rc.off + ((int64_t)(ij >> 1) * (2 * o.gW) + (ij & 1)) * o.gC + ch;
+            r.a = ldg4(o.ptr + a);
+        } else {
+            r.a = f4_zero();
+        }
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ float4 finish(const RowCtx& rc, const RawVec& r) {
+    if constexpr (KIND == A_LN) {
+        // zero-padded lanes have b = c = 0, so they stay exactly 0
+        float4 o;
+        o.x = fmaf((r.a.x - rc.mu) * rc.rstd, r.b.x, r.c.x);
+        o.y = fmaf((r.a.y - rc.mu) * rc.rstd, r.b.y, r.c.y);
+        o.z = fmaf((r.a.z - rc.mu) * rc.rstd, r.b.z, r.c.z);
+        o.w = fmaf((r.a.w - rc.mu) * rc.rstd, r.b.w, r.c.w);
+        return o;
+    } else if constexpr (KIND == A_SCALE || KIND == A_SG) {
+        return f4_mul(r.a, r.b);
+    } else {
+        return r.a;
     }
 }

@@ -44,26 +44,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 
     const int xrow = tid / XQ, xc = (tid % XQ) * 4;
     const int yrow = tid / YQ, yc = (tid % YQ) * 4;
-    float4 rx[X_IT], ry[Y_IT];
+    RawVec rx[X_IT], ry[Y_IT];
+    RowCtx rcx[X_IT], rcy[Y_IT];
     auto gload = [&](int64_t mt) {
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
-            RowCtx rc;
-            make_row<XK>(ox, mt + xrow + XR * i, rc);
-            rx[i] = load_op<XK>(ox, rc, n0 + xc);
+            make_row<XK>(ox, mt + xrow + XR * i, rcx[i]);
+            load_raw<XK>(ox, rcx[i], n0 + xc, rx[i]);
         }
 #pragma unroll
         for (int i = 0; i < Y_IT; ++i) {
-            RowCtx rc;
-            make_row<YK>(oy, mt + yrow + YR * i, rc);
-            ry[i] = load_op<YK>(oy, rc, k0 + yc);
+            make_row<YK>(oy, mt + yrow + YR * i, rcy[i]);
+            load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < X_IT; ++i) *reinterpret_cast<float4*>(&Xs[buf][(xrow + XR * i) * LDX + xc]) = rx[i];
+        for (int i = 0; i < X_IT; ++i)
+            *reinterpret_cast<float4*>(&Xs[buf][(xrow + XR * i) * LDX + xc]) = finish<XK>(rcx[i], rx[i]);
 #pragma unroll
-        for (int i = 0; i < Y_IT; ++i) *reinterpret_cast<float4*>(&Ys[buf][(yrow + YR * i) * LDY + yc]) = ry[i];
+        for (int i = 0; i < Y_IT; ++i)
+            *reinterpret_cast<float4*>(&Ys[buf][(yrow + YR * i) * LDY + yc]) = finish<YK>(rcy[i], ry[i]);
     };
 
     floatx16 acc[TN][TK];
@@ -151,7 +152,9 @@ int launch_cfg(const GemmTN& p, hipStream_t s) {
 void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split) {
     const int bn = (N <= 64) ? 64 : 128, bk = (K <= 64) ? 64 : 128;
     const int64_t tiles = (int64_t)cdiv(N, bn) * cdiv(K, bk);
-    int64_t want = cdiv64(768, tiles);          // ~3 blocks per CU in total
+    // 2 blocks are co-resident per CU (LDS), 256 CUs: aim at exactly one full wave of 512 blocks so
+    // that no partially filled second wave trails the launch
+    int64_t want = 512 / tiles;
     const int64_t max_by_rows = cdiv64(M, 256);  // at least 256 rows per split
     if (want > max_by_rows) want = max_by_rows;
     if (want < 1) want = 1;
@@ -166,7 +169,7 @@ int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t s) {
     DCPT_CHECK_ARG(p.N % 4 == 0 && p.K % 4 == 0, "gemm_tn: N=%d, K=%d must be multiples of 4", p.N, p.K);
     DCPT_CHECK_ARG(p.splits >= 1 && p.splits <= 65535 && p.rows_per_split % 32 == 0, "gemm_tn: bad split plan");
     const double bytes = (double)p.M * p.N + (double)p.M * p.K * (yload == A_SG ? 2 : 1) + (double)p.splits * p.N * p.K;
-    ProfScope prof(s, PROF_TN + xload * 8 + yload, 2.0 * (double)p.M * p.N * p.K, bytes * 4.0);
+    ProfScope prof(s, PROF_TN + xload * 8 + yload, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K, bytes * 4.0);
 #define CASE(XK, YK) \
     if (xload == XK && yload == YK) return launch_cfg<XK, YK>(p, s);
     CASE(A_PLAIN, A_PLAIN)

@@ -76,8 +76,8 @@ int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const 
 int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb);
 int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H,
                          int W, int Cs, int Cb, int omode, hipStream_t s);
-// out[c] = sum_{b,h,w} x[b][c][h][w]   (NCHW, tiny C)
-int launch_nchw_channel_sum(const float* x, float* out, int B, int C, int HW, hipStream_t s);
+// out[c] = sum_{b,h,w} x[b][c][h][w]   (NCHW, tiny C); part: [C][128] scratch
+int launch_nchw_channel_sum(const float* x, float* part, float* out, int B, int C, int HW, hipStream_t s);
 // layout converters for arbitrary C
 int launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, hipStream_t s);

@@ -74,22 +74,31 @@ __global__ void sca_ds_final_kernel(const float* __restrict__ part, float* __res
     ds[i] = s;
 }
 
-// SCA backward (tiny): blockIdx.y selects the role
-//   role 0: dpool[b][k] = invP * sum_n Wsca[n][k] * ds[b][n]
-//   role 1: dWsca[n][k] = sum_b ds[b][n] * pooled[b][k]
-//   role 2: dbsca[n]    = sum_b ds[b][n]
-__global__ __launch_bounds__(256) void sca_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
-                                                      const float* __restrict__ Wsca, float* __restrict__ dpool,
-                                                      float* __restrict__ dWsca, float* __restrict__ dbsca, int B, int C,
-                                                      float invP) {
+// SCA backward (tiny)
+//   dpool[b][k] = invP * sum_n Wsca[n][k] * ds[b][n]        grid (C/32, B): 32 k-columns x 8 n-groups
+__global__ __launch_bounds__(256) void sca_bwd_dpool_kernel(const float* __restrict__ ds, const float* __restrict__ Wsca,
+                                                            float* __restrict__ dpool, int C, float invP) {
+    __shared__ float red[8][32];
+    const int b = blockIdx.y;
+    const int kl = threadIdx.x & 31, ng = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kl;
+    float s = 0.f;
+    if (k < C)
+        for (int n = ng; n < C; n += 8) s = fmaf(Wsca[(int64_t)n * C + k], ds[(int64_t)b * C + n], s);
+    red[ng][kl] = s;
+    __syncthreads();
+    if (ng == 0 && k < C) {
+        float t = red[0][kl];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i][kl];
+        dpool[(int64_t)b * C + k] = t * invP;
+    }
+}
+//   role 0: dWsca[n][k] = sum_b ds[b][n] * pooled[b][k]     role 1: dbsca[n] = sum_b ds[b][n]
+__global__ __launch_bounds__(256) void sca_bwd_w_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
+                                                        float* __restrict__ dWsca, float* __restrict__ dbsca, int B, int C) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.y == 0) {
-        if (i >= (int64_t)B * C) return;
-        const int b = (int)(i / C), k = (int)(i % C);
-        float s = 0.f;
-        for (int n = 0; n < C; ++n) s = fmaf(Wsca[(int64_t)n * C + k], ds[(int64_t)b * C + n], s);
-        dpool[i] = s * invP;
-    } else if (blockIdx.y == 1) {
         if (i >= (int64_t)C * C) return;
         const int n = (int)(i / C), k = (int)(i % C);
         float s = 0.f;
@@ -136,19 +145,33 @@ __global__ void wpack_kernel(const float* __restrict__ in, float* __restrict__ o
     }
 }
 
-// one block per output row n
+// one block per output row n; threads = (split group, k quad)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ colsum,
                                                            int splits, int N, int K, const float* __restrict__ rowscale,
                                                            const float* __restrict__ W, const float* __restrict__ wbias,
                                                            float* __restrict__ dW, float* __restrict__ dgain,
-                                                           float* __restrict__ dbias, int mode) {
+                                                           float* __restrict__ dbias, int mode, int tpr) {
+    __shared__ float4 red4[256];
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
+    const int sg = 256 / tpr;             // split groups
+    const int ql = tid % tpr, sgi = tid / tpr;
     const float rsc = rowscale ? rowscale[n] : 1.f;
     float dot = 0.f;
-    for (int k = 4 * tid; k < K; k += 1024) {
+    for (int kb = 0; kb < K; kb += 4 * tpr) {
+        const int k = kb + 4 * ql;
         float4 g = f4_zero();
-        for (int s = 0; s < splits; ++s) g = f4_add(g, ldg4(slab + ((int64_t)s * N + n) * K + k));
+        if (k < K)
+            for (int s = sgi; s < splits; s += sg) g = f4_add(g, ldg4(slab + ((int64_t)s * N + n) * K + k));
+        if (sg > 1) {
+            __syncthreads();
+            red4[tid] = g;
+            __syncthreads();
+            if (sgi == 0) {
+                for (int i = 1; i < sg; ++i) g = f4_add(g, red4[i * tpr + ql]);
+            }
+        }
+        if (sgi != 0 || k >= K) continue;
         if (dgain) dot += f4_sum(f4_mul(g, ldg4(W + (int64_t)n * K + k)));
         const float4 o = f4_scale(g, rsc);
         if (mode == WR_PLAIN) {
@@ -170,6 +193,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int s = 0; s < splits; ++s) cs += colsum[(int64_t)s * N + n];
     if (dgain) {
         dot = group_sum(dot, 64);
+        __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = dot;
         __syncthreads();
         if (tid == 0) dgain[n] = ((red[0] + red[1]) + (red[2] + red[3])) + (wbias ? wbias[n] * cs : 0.f);
@@ -210,10 +234,11 @@ int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, 
 
 int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, float* dpool, float* dWsca, float* dbsca, int B,
                    int C, int P, hipStream_t s) {
-    const int64_t mx = (int64_t)C * C > (int64_t)B * C ? (int64_t)C * C : (int64_t)B * C;
-    sca_bwd_kernel<<<dim3((unsigned)cdiv64(mx, 256), 3), dim3(256), 0, s>>>(ds, pooled, Wsca, dpool, dWsca, dbsca, B, C,
-                                                                             1.0f / (float)P);
-    DCPT_CHECK_LAUNCH("sca_bwd");
+    DCPT_CHECK_ARG(B <= 65535, "sca_bwd: B too large");
+    sca_bwd_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), 0, s>>>(ds, Wsca, dpool, C, 1.0f / (float)P);
+    DCPT_CHECK_LAUNCH("sca_bwd_dpool");
+    sca_bwd_w_kernel<<<dim3((unsigned)cdiv64((int64_t)C * C, 256), 2), dim3(256), 0, s>>>(ds, pooled, dWsca, dbsca, B, C);
+    DCPT_CHECK_LAUNCH("sca_bwd_w");
     return DCPT_OK;
 }
 
@@ -227,7 +252,10 @@ int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int 
                         const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s) {
     DCPT_CHECK_ARG(K % 4 == 0, "wgrad_reduce: K=%d", K);
     DCPT_CHECK_ARG(!(dgain || dbias) || colsum, "wgrad_reduce: gain/bias gradients need column sums");
-    wgrad_reduce_kernel<<<dim3(N), dim3(256), 0, s>>>(slab, colsum, splits, N, K, rowscale, W, wbias, dW, dgain, dbias, mode);
+    int tpr = 1;
+    while (tpr < K / 4 && tpr < 256) tpr <<= 1;
+    wgrad_reduce_kernel<<<dim3(N), dim3(256), 0, s>>>(slab, colsum, splits, N, K, rowscale, W, wbias, dW, dgain, dbias, mode,
+                                                      tpr);
     DCPT_CHECK_LAUNCH("wgrad_reduce");
     return DCPT_OK;
 }

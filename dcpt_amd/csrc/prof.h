@@ -3,12 +3,14 @@
 #pragma once
 #include "dcpt_common.h"
 
-void prof_begin(hipStream_t s, int cls, double flops, double bytes);
+void prof_begin(hipStream_t s, int cls, int64_t M, int N, int K, double flops, double bytes);
 void prof_end(hipStream_t s);
 
 struct ProfScope {
     hipStream_t s;
-    ProfScope(hipStream_t st, int cls, double flops, double bytes) : s(st) { prof_begin(s, cls, flops, bytes); }
+    ProfScope(hipStream_t st, int cls, int64_t M, int N, int K, double flops, double bytes) : s(st) {
+        prof_begin(s, cls, M, N, K, flops, bytes);
+    }
     ~ProfScope() { prof_end(s); }
 };
 

@@ -8,6 +8,8 @@
 namespace {
 struct Rec {
     int cls;
+    int64_t M;
+    int N, K;
     double flops, bytes;
     hipEvent_t e0, e1;
 };
@@ -29,12 +31,12 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-void prof_begin(hipStream_t s, int cls, double flops, double bytes) {
+void prof_begin(hipStream_t s, int cls, int64_t M, int N, int K, double flops, double bytes) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     g_open = -1;
     if (g_recs.size() >= MAXREC) return;
-    Rec r{cls, flops, bytes, get_event(), get_event()};
+    Rec r{cls, M, N, K, flops, bytes, get_event(), get_event()};
     if (!r.e0 || !r.e1) return;
     hipEventRecord(r.e0, s);
     g_recs.push_back(r);
@@ -58,9 +60,9 @@ extern "C" int dcpt_prof_enable(int on) {
     return DCPT_OK;
 }
 
-// Synchronises the recorded events and aggregates per class.  out: [max_classes][5] =
-// {class id, launches, total ms, total flops, total bytes}; returns the number of classes written.
-extern "C" int dcpt_prof_read(double* out, int max_classes) {
+// Synchronises the recorded events and aggregates per (class, M, N, K).  out: [max_rows][8] =
+// {class id, M, N, K, launches, total ms, total flops, total bytes}; returns the number of rows.
+extern "C" int dcpt_prof_read(double* out, int max_rows) {
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     for (const Rec& r : g_recs) {
@@ -69,17 +71,22 @@ extern "C" int dcpt_prof_read(double* out, int max_classes) {
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
         int j = 0;
         for (; j < n; ++j)
-            if ((int)out[j * 5] == r.cls) break;
+            if ((int)out[j * 8] == r.cls && (int64_t)out[j * 8 + 1] == r.M && (int)out[j * 8 + 2] == r.N &&
+                (int)out[j * 8 + 3] == r.K)
+                break;
         if (j == n) {
-            if (n >= max_classes) continue;
-            out[j * 5] = r.cls;
-            out[j * 5 + 1] = out[j * 5 + 2] = out[j * 5 + 3] = out[j * 5 + 4] = 0.0;
+            if (n >= max_rows) continue;
+            out[j * 8] = r.cls;
+            out[j * 8 + 1] = (double)r.M;
+            out[j * 8 + 2] = r.N;
+            out[j * 8 + 3] = r.K;
+            out[j * 8 + 4] = out[j * 8 + 5] = out[j * 8 + 6] = out[j * 8 + 7] = 0.0;
             n++;
         }
-        out[j * 5 + 1] += 1.0;
-        out[j * 5 + 2] += ms;
-        out[j * 5 + 3] += r.flops;
-        out[j * 5 + 4] += r.bytes;
+        out[j * 8 + 4] += 1.0;
+        out[j * 8 + 5] += ms;
+        out[j * 8 + 6] += r.flops;
+        out[j * 8 + 7] += r.bytes;
     }
     return n;
 }

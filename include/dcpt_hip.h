@@ -133,10 +133,11 @@ int dcpt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, dcpt_strea
 
 /* ---- optional launch profiling (bench.py) -------------------------------------------------------
  * While enabled, every MFMA GEMM launch is bracketed by HIP events on its own stream.
- * dcpt_prof_read waits for them and writes rows {class id, launches, total ms, algorithmic flops,
- * algorithmic bytes}; class id = (0: NT | 512: TN) + 8*loaderA + epilogue/loaderB. */
+ * dcpt_prof_read waits for them and writes rows of 8 doubles {class id, M, N, K, launches, total ms,
+ * algorithmic flops, algorithmic bytes}, one per (class, shape); class id = (0: NT | 512: TN) +
+ * 8*loaderA + epilogue/loaderB. */
 int dcpt_prof_enable(int on);
-int dcpt_prof_read(double* out, int max_classes);
+int dcpt_prof_read(double* out, int max_rows);
 
 #ifdef __cplusplus
 }
