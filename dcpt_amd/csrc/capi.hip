@@ -118,7 +118,7 @@ size_t down_layout(int B, int H, int W, int C, int backward, void* base, size_t 
         const int64_t Mc = (int64_t)B * (H / 2) * (W / 2);
         gemm_tn_plan(Mc, 2 * C, 4 * C, &w.splits, &w.rps);
         w.slab = a.get<float>((size_t)w.splits * 8 * C * C);
-        w.colsum = a.get<float>((size_t)w.splits * 2 * C);
+        w.colsum = a.get<float>((size_t)w.splits * gemm_tn_tiles_k(2 * C, 4 * C) * 2 * C);
     }
     if (out) *out = w;
     return a.off;
@@ -172,7 +172,8 @@ extern "C" int dcpt_down2x2_bwd(const float* dy, const float* x, const float* w,
     t.gH = H / 2; t.gW = W / 2; t.gC = C;
     t.slab = d.slab; t.colsum = d.colsum; t.splits = d.splits; t.rows_per_split = d.rps;
     DCPT_TRY(launch_gemm_tn(t, A_PLAIN, A_GATHER, s));
-    DCPT_TRY(launch_wgrad_reduce(d.slab, d.colsum, d.splits, 2 * C, 4 * C, nullptr, nullptr, nullptr, dw, nullptr, dbias, WR_DOWN, s));
+    DCPT_TRY(launch_wgrad_reduce(d.slab, d.colsum, d.splits, d.splits * gemm_tn_tiles_k(2 * C, 4 * C), 2 * C, 4 * C, nullptr, nullptr,
+                                 nullptr, dw, nullptr, dbias, WR_DOWN, s));
     return DCPT_OK;
 }
 
@@ -242,7 +243,7 @@ extern "C" int dcpt_up_ps_bwd(const float* dy, const float* x, const float* w, f
     t.M = M; t.X = dy; t.N = 2 * C; t.Y = x; t.ldy = C; t.K = C; t.gH = H; t.gW = W; t.gC = C / 2;
     t.slab = u.slab; t.colsum = nullptr; t.splits = u.splits; t.rows_per_split = u.rps;
     DCPT_TRY(launch_gemm_tn(t, A_GATHER, A_PLAIN, s));
-    DCPT_TRY(launch_wgrad_reduce(u.slab, nullptr, u.splits, 2 * C, C, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_UP, s));
+    DCPT_TRY(launch_wgrad_reduce(u.slab, nullptr, u.splits, 0, 2 * C, C, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_UP, s));
     return DCPT_OK;
 }
 

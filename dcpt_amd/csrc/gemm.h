@@ -42,7 +42,7 @@ struct GemmTN {
     const float* X;  // [M][ldx]  -> rows of G (n index)
     const float* Y;  // [M][ldy]  -> cols of G (k index)
     float* slab;     // [splits][N][K]
-    float* colsum;   // [splits][N] column sums of X' (may be null)
+    float* colsum;   // [splits * gemm_tn_tiles_k(N, K)][N] partial column sums of X' (may be null)
     int64_t M;
     int N, K;
     int ldx, ldy;
@@ -62,3 +62,5 @@ struct GemmTN {
 int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t stream);
 // choose a split count / rows_per_split for a TN problem
 void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split);
+// number of k-tile columns of the TN grid for this shape (= partial colsum rows per split)
+int gemm_tn_tiles_k(int N, int K);

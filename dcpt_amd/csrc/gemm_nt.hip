@@ -18,12 +18,24 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int EK>
-__device__ __forceinline__ void epilogue_tile(const GemmNT& p, const floatx16& acc, int64_t mbase, int n, int lane) {
+// Epilogue: the accumulators are first parked in LDS ([BM][BN+4] floats, reusing the operand tiles'
+// space), then every thread owns one float4 column group of 16 rows: global loads (residual / gate
+// inputs) and stores are 16 B per lane and 512 B contiguous per row, and all the loads of a thread are
+// issued before the LDS round trip so their latency overlaps it.
+template <int EK, int BM, int BN>
+__device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0, int tid) {
+    constexpr int LDC = BN + 4;
+    constexpr int Q = BN / 4;          // float4 groups per row
+    constexpr int RPP = 256 / Q;       // rows per pass
+    constexpr int IT = BM / RPP;
+    const int q = tid % Q, r0 = tid / Q;
+    const int n = n0 + 4 * q;
     if (n >= p.N) return;
-    float bias = 0.f, cs = 1.f;
-    if constexpr (EK == E_BIAS || EK == E_RESID) bias = p.bias ? p.bias[n] : 0.f;
-    if constexpr (EK == E_RESID) cs = p.cscale[n];
+    float4 bias = f4_zero(), cs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (EK == E_BIAS || EK == E_RESID) {
+        if (p.bias) bias = ldg4(p.bias + n);
+    }
+    if constexpr (EK == E_RESID) cs = ldg4(p.cscale + n);
     int si = 0, sj = 0, ch = 0;
     if constexpr (EK == E_SCATTER || EK == E_SCATTER_ADD) {
         const int ij = n / p.gC;
@@ -31,30 +43,59 @@ __device__ __forceinline__ void epilogue_tile(const GemmNT& p, const floatx16& a
         si = ij >> 1;
         sj = ij & 1;
     }
+    constexpr int HALF = (EK == E_SGBWD) ? 2 : 1;   // SGBWD needs two loads per row: do it in two halves
+    constexpr int ITH = IT / HALF;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
-        const float v = acc[r];
-        if constexpr (EK == E_PLAIN) {
-            p.C[m * p.ldc + n] = v;
-        } else if constexpr (EK == E_BIAS) {
-            p.C[m * p.ldc + n] = v + bias;
-        } else if constexpr (EK == E_RESID) {
-            p.C[m * p.ldc + n] = fmaf(v + bias, cs, p.res[m * p.ldc + n]);
-        } else if constexpr (EK == E_SGBWD) {
-            const float a1 = p.aux[m * (2 * (int64_t)p.N) + n];
-            const float a2 = p.aux[m * (2 * (int64_t)p.N) + p.N + n];
-            p.C[m * p.ldc + n] = v * a2;
-            p.C[m * p.ldc + p.N + n] = v * a1;
-        } else {  // scatter to the fine image
-            const int w = (int)(m % p.gW);
-            const int64_t t = m / p.gW;
-            const int h = (int)(t % p.gH);
-            const int64_t b = t / p.gH;
-            const int64_t a = ((b * (2 * p.gH) + 2 * h + si) * (int64_t)(2 * p.gW) + 2 * w + sj) * p.gC + ch;
-            if constexpr (EK == E_SCATTER) p.C[a] = v;
-            else p.C[a] = v + p.res[a];
+    for (int hh = 0; hh < HALF; ++hh) {
+        float4 pre1[ITH], pre2[ITH];
+        int64_t addr[ITH];
+#pragma unroll
+        for (int it = 0; it < ITH; ++it) {
+            const int64_t m = m0 + r0 + (int64_t)(hh * ITH + it) * RPP;
+            const bool ok = m < p.M;
+            pre1[it] = f4_zero();
+            pre2[it] = f4_zero();
+            if constexpr (EK == E_RESID) {
+                addr[it] = m * p.ldc + n;
+                if (ok) pre1[it] = ldg4(p.res + addr[it]);
+            } else if constexpr (EK == E_SGBWD) {
+                addr[it] = m * p.ldc + n;
+                if (ok) {
+                    pre1[it] = ldg4(p.aux + m * (2 * (int64_t)p.N) + n);
+                    pre2[it] = ldg4(p.aux + m * (2 * (int64_t)p.N) + p.N + n);
+                }
+            } else if constexpr (EK == E_SCATTER || EK == E_SCATTER_ADD) {
+                const int64_t mm = ok ? m : 0;
+                const int w = (int)(mm % p.gW);
+                const int64_t t = mm / p.gW;
+                const int h = (int)(t % p.gH);
+                const int64_t b = t / p.gH;
+                addr[it] = ((b * (2 * p.gH) + 2 * h + si) * (int64_t)(2 * p.gW) + 2 * w + sj) * p.gC + ch;
+                if constexpr (EK == E_SCATTER_ADD) {
+                    if (ok) pre1[it] = ldg4(p.res + addr[it]);
+                }
+            } else {
+                addr[it] = m * p.ldc + n;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITH; ++it) {
+            const int rl = r0 + (hh * ITH + it) * RPP;
+            const int64_t m = m0 + rl;
+            if (m >= p.M) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * LDC + 4 * q]);
+            if constexpr (EK == E_PLAIN || EK == E_SCATTER) {
+                stg4(p.C + addr[it], v);
+            } else if constexpr (EK == E_BIAS) {
+                stg4(p.C + addr[it], f4_add(v, bias));
+            } else if constexpr (EK == E_RESID) {
+                stg4(p.C + addr[it], f4_fma(f4_add(v, bias), cs, pre1[it]));
+            } else if constexpr (EK == E_SGBWD) {
+                stg4(p.C + addr[it], f4_mul(v, pre2[it]));
+                stg4(p.C + addr[it] + p.N, f4_mul(v, pre1[it]));
+            } else {  // E_SCATTER_ADD
+                stg4(p.C + addr[it], f4_add(v, pre1[it]));
+            }
         }
     }
 }
@@ -64,8 +105,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+    constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD;
+    constexpr int OP_SZ = 2 * (A_SZ + B_SZ), C_SZ = BM * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float smem[OP_SZ > C_SZ ? OP_SZ : C_SZ];
+    float* const As0 = smem;               // [2][A_SZ]
+    float* const Bs0 = smem + 2 * A_SZ;    // [2][B_SZ]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -104,9 +148,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDS_LD + lk]) = finish<AK>(rca[i], ra[i]);
+            *reinterpret_cast<float4*>(&As0[buf * A_SZ + (lrow + 32 * i) * LDS_LD + lk]) = finish<AK>(rca[i], ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * i) * LDS_LD + lk]) = rb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs0[buf * B_SZ + (lrow + 32 * i) * LDS_LD + lk]) = rb[i];
     };
 
     floatx16 acc[TM][TN];
@@ -126,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) gload(kt + 1);
-        const float* as = &As[buf][a_off];
-        const float* bs = &Bs[buf][b_off];
+        const float* as = As0 + buf * A_SZ + a_off;
+        const float* bs = Bs0 + buf * B_SZ + b_off;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
             float4 af[TM], bf[TN];
@@ -149,11 +193,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         __syncthreads();
     }
 
+    // park the accumulators in LDS (the last k-tile's barrier already separates us from the MFMA reads)
+    constexpr int LDC = BN + 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            epilogue_tile<EK>(p, acc[i][j], m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32 + (lane & 31), lane);
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                smem[ml * LDC + nl] = acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    epilogue_rows<EK, BM, BN>(p, smem, m0, n0, tid);
 }
 
 template <int AK, int EK>

@@ -26,10 +26,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WK, wk = wave % WK;
+    // 1-D grid, XCD-aware: the tiles of one pixel chunk (split) get consecutive logical ids, i.e. run
+    // on one XCD at about the same time, so its X/Y row panels are fetched from HBM once and re-read
+    // from that XCD's L2 by the other tiles.
     const int tilesK = (p.K + BKo - 1) / BKo;
-    const int tile_n = blockIdx.x / tilesK, tile_k = blockIdx.x % tilesK;
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / (tilesN * tilesK);
+    const int tile = lin % (tilesN * tilesK);
+    const int tile_n = tile / tilesK, tile_k = tile % tilesK;
     const int n0 = tile_n * BN, k0 = tile_k * BKo;
-    const int split = blockIdx.y;
     const int64_t mbeg = (int64_t)split * p.rows_per_split;
     int64_t mend = mbeg + p.rows_per_split;
     if (mend > p.M) mend = p.M;
@@ -75,7 +81,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float cs = 0.f;
-    const bool do_cs = (p.colsum != nullptr) && (tile_k == 0) && (tid < BN);
+    // column sums of X' (bias gradients): the tilesK blocks that share an (n-tile, split) take turns,
+    // one pixel tile each, so no block carries the whole extra cost; their partial rows are summed by
+    // the slab reducer.  colsum layout: [split * tilesK + tile_k][N].
+    const bool do_cs = (p.colsum != nullptr) && (tid < BN);
 
     const int64_t nmt = (mend - mbeg + BR - 1) / BR;
     if (nmt > 0) {
@@ -90,19 +99,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         if (t + 1 < nmt) gload(mbeg + (t + 1) * BR);
         const float* xs = &Xs[buf][x_off];
         const float* ys = &Ys[buf][y_off];
+        // software-pipelined fragments: the ds_reads of step s+1 are issued before the MFMAs of step s
+        float a[2][TN], b[2][TK];
 #pragma unroll
-        for (int mm = 0; mm < BR; mm += 2) {
-            float a[TN], b[TK];
+        for (int i = 0; i < TN; ++i) a[0][i] = xs[i * 32];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) a[i] = xs[mm * LDX + i * 32];
+        for (int j = 0; j < TK; ++j) b[0][j] = ys[j * 32];
 #pragma unroll
-            for (int j = 0; j < TK; ++j) b[j] = ys[mm * LDY + j * 32];
+        for (int st = 0; st < BR / 2; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < BR / 2) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) a[nxt][i] = xs[(2 * st + 2) * LDX + i * 32];
+#pragma unroll
+                for (int j = 0; j < TK; ++j) b[nxt][j] = ys[(2 * st + 2) * LDY + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_cs) {
+        if (do_cs && (int)(t % tilesK) == tile_k) {
             float s = 0.f;
 #pragma unroll 8
             for (int r = 0; r < BR; ++r) s += Xs[buf][r * LDX + tid];
@@ -125,29 +145,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
                 if (n < p.N) slab[(int64_t)n * p.K + k] = acc[i][j][r];
             }
         }
-    if (do_cs && n0 + tid < p.N) p.colsum[(int64_t)split * p.N + n0 + tid] = cs;
+    if (do_cs && n0 + tid < p.N) p.colsum[((int64_t)split * tilesK + tile_k) * p.N + n0 + tid] = cs;
 }
 
 template <int XK, int YK>
 int launch_cfg(const GemmTN& p, hipStream_t s) {
     if (p.N <= 64 && p.K <= 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 64);
-        gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
     } else if (p.K <= 64) {
         const int tiles = cdiv(p.N, 128) * cdiv(p.K, 64);
-        gemm_tn_kernel<128, 64, 4, 1, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<128, 64, 4, 1, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
     } else if (p.N <= 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 128);
-        gemm_tn_kernel<64, 128, 1, 4, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<64, 128, 1, 4, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
     } else {
         const int tiles = cdiv(p.N, 128) * cdiv(p.K, 128);
-        gemm_tn_kernel<128, 128, 2, 2, XK, YK><<<dim3(tiles, p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<128, 128, 2, 2, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
     }
     DCPT_CHECK_LAUNCH("gemm_tn");
     return DCPT_OK;
 }
 
 }  // namespace
+
+int gemm_tn_tiles_k(int N, int K) {
+    (void)N;
+    const int bk = (K <= 64) ? 64 : 128;
+    return cdiv(K, bk);
+}
 
 void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split) {
     const int bn = (N <= 64) ? 64 : 128, bk = (K <= 64) ? 64 : 128;

@@ -56,8 +56,9 @@ int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int
 
 enum WReduceMode { WR_PLAIN = 0, WR_DOWN = 1, WR_UP = 2 };
 // dW = rowscale[n] * sum_s slab[s][n][k] (layout per mode)
-// optional: dgain[n] = sum_k W[n][k]*G[n][k] + wbias[n]*cs[n];  dbias[n] = rowscale[n]*cs[n]   (cs = sum_s colsum[s][n])
-int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int N, int K, const float* rowscale,
+// optional: dgain[n] = sum_k W[n][k]*G[n][k] + wbias[n]*cs[n];  dbias[n] = rowscale[n]*cs[n]
+//           (cs = sum over the cs_rows partial rows colsum[r][n])
+int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int cs_rows, int N, int K, const float* rowscale,
                         const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s);
 
 // ---- conv3x3.hip ----------------------------------------------------------------------------

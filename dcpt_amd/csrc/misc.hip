@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int splits, int N, int K, const float* __restrict__ rowscale,
                                                            const float* __restrict__ W, const float* __restrict__ wbias,
                                                            float* __restrict__ dW, float* __restrict__ dgain,
-                                                           float* __restrict__ dbias, int mode, int tpr) {
+                                                           float* __restrict__ dbias, int mode, int tpr, int cs_rows) {
     __shared__ float4 red4[256];
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (dgain == nullptr && dbias == nullptr) return;
     float cs = 0.f;
     if (colsum)
-        for (int s = 0; s < splits; ++s) cs += colsum[(int64_t)s * N + n];
+        for (int s = 0; s < cs_rows; ++s) cs += colsum[(int64_t)s * N + n];
     if (dgain) {
         dot = group_sum(dot, 64);
         __syncthreads();
@@ -248,14 +248,14 @@ int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int
     return DCPT_OK;
 }
 
-int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int N, int K, const float* rowscale,
+int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int cs_rows, int N, int K, const float* rowscale,
                         const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s) {
     DCPT_CHECK_ARG(K % 4 == 0, "wgrad_reduce: K=%d", K);
     DCPT_CHECK_ARG(!(dgain || dbias) || colsum, "wgrad_reduce: gain/bias gradients need column sums");
     int tpr = 1;
     while (tpr < K / 4 && tpr < 256) tpr <<= 1;
     wgrad_reduce_kernel<<<dim3(N), dim3(256), 0, s>>>(slab, colsum, splits, N, K, rowscale, W, wbias, dW, dgain, dbias, mode,
-                                                      tpr);
+                                                      tpr, cs_rows);
     DCPT_CHECK_LAUNCH("wgrad_reduce");
     return DCPT_OK;
 }

@@ -75,7 +75,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     gemm_tn_plan(M, C, C, &sp2, &r2);
     const size_t slab1 = (size_t)sp1 * 2 * C * C, slab2 = (size_t)sp2 * C * C;
     w.slab = a.get<float>(slab1 > slab2 ? slab1 : slab2);
-    const size_t cs1 = (size_t)sp1 * 2 * C, cs2 = (size_t)sp2 * C;
+    const size_t cs1 = (size_t)sp1 * gemm_tn_tiles_k(2 * C, C) * 2 * C, cs2 = (size_t)sp2 * gemm_tn_tiles_k(C, C) * C;
     w.colsum = a.get<float>(cs1 > cs2 ? cs1 : cs2);
     w.ln_nblk = ln_bwd_num_blocks(M, C);
     w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * C);
@@ -96,7 +96,8 @@ int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yl
     t.slab = slab; t.colsum = colsum;
     gemm_tn_plan(M, N, K, &t.splits, &t.rows_per_split);
     DCPT_TRY(launch_gemm_tn(t, A_PLAIN, yload, s));
-    DCPT_TRY(launch_wgrad_reduce(slab, colsum, t.splits, N, K, rowscale, Wfor_gain, wbias, dW, dgain, dbias, WR_PLAIN, s));
+    DCPT_TRY(launch_wgrad_reduce(slab, colsum, t.splits, t.splits * gemm_tn_tiles_k(N, K), N, K, rowscale, Wfor_gain, wbias, dW,
+                                 dgain, dbias, WR_PLAIN, s));
     return DCPT_OK;
 }
 
