@@ -150,24 +150,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
     }
 }
 
-// out_j[c] = sum_r part[r][j][c]; block = 32 columns x 8 row groups (fixed order: deterministic)
+// out_j[c] = sum_r part[r][j][c]; block = 16 columns x 16 row groups (fixed order: deterministic)
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int R, int nj, int C,
                                                              float* out0, float* out1, float* out2) {
-    __shared__ float red[8][32];
+    __shared__ float red[16][16];
     const int j = blockIdx.y;
     float* out = (j == 0) ? out0 : (j == 1) ? out1 : out2;
     if (out == nullptr) return;
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < C)
-        for (int r = rg; r < R; r += 8) s += part[((int64_t)r * nj + j) * C + c];
+        for (int r = rg; r < R; r += 16) s += part[((int64_t)r * nj + j) * C + c];
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < C) {
         float t = red[0][cl];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) t += red[i][cl];
+        for (int i = 1; i < 16; ++i) t += red[i][cl];
         out[c] = t;
     }
 }
@@ -194,7 +194,7 @@ int launch_ln_fwd(const float* x, const float* w, const float* b, float* y, floa
 int ln_bwd_num_blocks(int64_t M, int C) {
     const int G = ln_group(C), gpb = 256 / G;
     int64_t nb = cdiv64(M, gpb);
-    if (nb > 256) nb = 256;
+    if (nb > 1024) nb = 1024;  // HBM-bound: keep >= 4 blocks per CU in flight
     return (int)nb;
 }
 
@@ -217,7 +217,7 @@ int launch_ln_bwd(const float* gy, const float* x, const float* mu, const float*
 
 int launch_colpart_reduce(const float* part, int R, int nj, int C, float* out0, float* out1, float* out2, hipStream_t s) {
     DCPT_CHECK_ARG(nj >= 1 && nj <= 3, "colpart_reduce: nj=%d", nj);
-    colpart_reduce_kernel<<<dim3(cdiv(C, 32), nj), dim3(256), 0, s>>>(part, R, nj, C, out0, out1, out2);
+    colpart_reduce_kernel<<<dim3(cdiv(C, 16), nj), dim3(256), 0, s>>>(part, R, nj, C, out0, out1, out2);
     DCPT_CHECK_LAUNCH("colpart_reduce");
     return DCPT_OK;
 }

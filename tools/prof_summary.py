@@ -1,0 +1,53 @@
+"""Summarise a tools/profile_gpu.sh output directory: per-kernel time (kernel trace) and per-kernel
+PMC counters (averaged per launch), with the gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE is
+in KiB and reads 1/2 of a wide coalesced stream -> x2; WRITE_SIZE in KiB, uncalibrated)."""
+import csv, glob, os, re, sys
+from collections import defaultdict
+
+root = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'^void ', '', n)
+    return n.split('(')[0][:70]
+
+ktime = defaultdict(lambda: [0, 0.0])
+for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r['Kernel_Name']); d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        ktime[k][0] += 1; ktime[k][1] += d
+tot = sum(v[1] for v in ktime.values())
+print(f"== kernel trace: {tot/1e3:.2f} ms total over {steps:g} steps = {tot/1e3/steps:.2f} ms/step")
+top = sorted(ktime.items(), key=lambda kv: -kv[1][1])
+for k, (c, us) in top[:30]:
+    print(f"{us/1e3/steps:8.3f} ms/step {100*us/tot:5.1f}%  launches/step={c/steps:6.1f}  avg={us/c:9.1f} us  {k}")
+
+pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for f in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r['Kernel_Name']); c = r['Counter_Name']; v = float(r['Counter_Value'])
+        pmc[k][c][0] += 1; pmc[k][c][1] += v
+print("\n== PMC, average per launch (top kernels by time)")
+for k, (c, us) in top[:14]:
+    if k not in pmc: continue
+    d = {cn: v[1] / max(1, v[0]) for cn, v in pmc[k].items()}
+    avg_us = us / c
+    line = f"{k}\n    avg {avg_us:8.1f} us"
+    if 'FETCH_SIZE' in d:
+        rd = d['FETCH_SIZE'] * 1024 * 2
+        line += f" | HBM read {rd/1e6:8.1f} MB (FETCH_SIZE x2)"
+    if 'WRITE_SIZE' in d:
+        wr = d['WRITE_SIZE'] * 1024
+        line += f" | write {wr/1e6:8.1f} MB"
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        line += f" | {(rd+wr)/avg_us/1e6:6.2f} TB/s"
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d and d['GRBM_GUI_ACTIVE'] > 0:
+        # busy cycles are summed over SIMDs: 256 CUs x 4 SIMDs
+        line += f" | MfmaUtil {100*d['SQ_VALU_MFMA_BUSY_CYCLES']/(d['GRBM_GUI_ACTIVE']*1024):5.1f}%"
+    if 'TCC_HIT_sum' in d:
+        h, m = d['TCC_HIT_sum'], d.get('TCC_MISS_sum', 0.0)
+        line += f" | L2 hit {100*h/max(1.0,h+m):5.1f}%"
+    if 'SQ_LDS_BANK_CONFLICT' in d and d.get('SQ_LDS_IDX_ACTIVE', 0) > 0:
+        line += f" | LDS conflict {100*d['SQ_LDS_BANK_CONFLICT']/d['SQ_LDS_IDX_ACTIVE']:5.1f}%"
+    print(line)
+    print("    raw: " + ", ".join(f"{cn}={v:.4g}" for cn, v in sorted(d.items())))
