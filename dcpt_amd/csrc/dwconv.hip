@@ -27,8 +27,10 @@ struct DwMap {
 __host__ __device__ inline DwMap dw_map(int H, int W, int quads) {
     DwMap m;
     m.QW = quads;
+    // at most 32 quads (512 B of channels) per block row, so a block spans >= 8 pixel columns and the
+    // left/right halo columns are mostly served by the same CU's L1 instead of another XCD's HBM fetch
     int qb = 1;
-    while (qb < quads && qb < 256) qb <<= 1;
+    while (qb < quads && qb < 32) qb <<= 1;
     m.QB = qb;
     m.PB = 256 / qb;
     m.nqc = (quads + qb - 1) / qb;

@@ -42,8 +42,9 @@ for k, (c, us) in top[:14]:
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         line += f" | {(rd+wr)/avg_us/1e6:6.2f} TB/s"
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d and d['GRBM_GUI_ACTIVE'] > 0:
-        # busy cycles are summed over SIMDs: 256 CUs x 4 SIMDs
-        line += f" | MfmaUtil {100*d['SQ_VALU_MFMA_BUSY_CYCLES']/(d['GRBM_GUI_ACTIVE']*1024):5.1f}%"
+        # MFMA busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        line += f" | MfmaUtil {100*d['SQ_VALU_MFMA_BUSY_CYCLES']/(d['GRBM_GUI_ACTIVE']/8*1024):5.1f}%"
+        line += f" | clk {d['GRBM_GUI_ACTIVE']/8/avg_us/1e3:4.2f} GHz"
     if 'TCC_HIT_sum' in d:
         h, m = d['TCC_HIT_sum'], d.get('TCC_MISS_sum', 0.0)
         line += f" | L2 hit {100*h/max(1.0,h+m):5.1f}%"
