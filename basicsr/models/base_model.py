@@ -1,0 +1,178 @@
+"""Caller-side base class of the hot path (reference basicsr/models/base_model.py): device placement and
+the DDP wrap (:100-118), optimizer factory (:120-139), EMA (:86-95), checkpoint IO with the reference's
+key conventions (:249-369), loss reduction to rank 0 (:432-457)."""
+from __future__ import annotations
+
+import os
+import time
+from collections import OrderedDict
+from copy import deepcopy
+
+import torch
+from torch.nn.parallel import DataParallel, DistributedDataParallel
+
+from basicsr.utils import get_root_logger
+from basicsr.utils.dist_util import master_only
+
+
+class BaseModel:
+    def __init__(self, opt):
+        self.opt = opt
+        self.device = torch.device("cuda" if opt["num_gpu"] != 0 else "cpu")
+        self.is_train = opt["is_train"]
+        self.schedulers = []
+        self.optimizers = []
+        self.log_dict = OrderedDict()
+
+    # -- protocol ---------------------------------------------------------------------------
+    def feed_data(self, data):
+        pass
+
+    def optimize_parameters(self, current_iter):
+        pass
+
+    def get_current_visuals(self):
+        pass
+
+    def save(self, epoch, current_iter):
+        pass
+
+    def validation(self, dataloader, current_iter, tb_logger, save_img=False, clamp=True):
+        if self.opt["dist"]:
+            return self.dist_validation(dataloader, current_iter, tb_logger, save_img, clamp)
+        return self.nondist_validation(dataloader, current_iter, tb_logger, save_img, clamp)
+
+    def get_current_log(self):
+        return self.log_dict
+
+    # -- networks -----------------------------------------------------------------------------
+    def model_to_device(self, net, dist=True, find_unused_parameters=None):
+        """One process per GPU; gradients are averaged by DDP's bucketed all-reduce over RCCL/xGMI,
+        overlapped with the remaining backward kernels (each fused block returns its gradients at once)."""
+        net = net.to(self.device)
+        if self.opt["dist"] and dist:
+            if find_unused_parameters is None:
+                find_unused_parameters = self.opt.get("find_unused_parameters", False)
+            kwargs = dict(find_unused_parameters=find_unused_parameters)
+            if self.device.type == "cuda":
+                kwargs["device_ids"] = [torch.cuda.current_device()]
+                kwargs["bucket_cap_mb"] = self.opt.get("ddp_bucket_cap_mb", 64)
+                kwargs["gradient_as_bucket_view"] = True
+            net = DistributedDataParallel(net, **kwargs)
+        elif self.opt["num_gpu"] > 1 and dist:
+            net = DataParallel(net)
+        return net
+
+    def get_bare_model(self, net):
+        return net.module if isinstance(net, (DataParallel, DistributedDataParallel)) else net
+
+    def get_optimizer(self, optim_type, params, lr, **kwargs):
+        table = {"Adam": torch.optim.Adam, "AdamW": torch.optim.AdamW, "Adamax": torch.optim.Adamax,
+                 "SGD": torch.optim.SGD, "ASGD": torch.optim.ASGD, "RMSprop": torch.optim.RMSprop,
+                 "Rprop": torch.optim.Rprop}
+        if optim_type not in table:
+            raise NotImplementedError(f"optimizer {optim_type} is not supported yet.")
+        return table[optim_type](params, lr, **kwargs)
+
+    def setup_schedulers(self):
+        train_opt = self.opt["train"]
+        sched = dict(train_opt["scheduler"])
+        kind = sched.pop("type")
+        for optimizer in self.optimizers:
+            if kind in ("MultiStepLR", "MultiStepRestartLR"):
+                self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(optimizer, sched["milestones"], sched.get("gamma", 0.1)))
+            elif kind == "CosineAnnealingRestartLR":
+                period = sched["periods"][0]
+                self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, period, sched.get("eta_min", 0)))
+            else:
+                raise NotImplementedError(f"Scheduler {kind} is not implemented yet.")
+
+    def update_learning_rate(self, current_iter, warmup_iter=-1):
+        if current_iter > 1:
+            for scheduler in self.schedulers:
+                scheduler.step()
+        if current_iter < warmup_iter:
+            for optimizer in self.optimizers:
+                for group in optimizer.param_groups:
+                    group["lr"] = group["initial_lr"] / warmup_iter * current_iter
+
+    def get_current_learning_rate(self):
+        return [g["lr"] for g in self.optimizers[0].param_groups]
+
+    def model_ema(self, decay=0.999):
+        src = dict(self.get_bare_model(self.net_g).named_parameters())
+        dst = dict(self.net_g_ema.named_parameters())
+        keys = list(dst.keys())
+        with torch.no_grad():  # one multi-tensor launch pair instead of the reference's 664 mul_/add_ pairs
+            torch._foreach_mul_([dst[k].data for k in keys], decay)
+            torch._foreach_add_([dst[k].data for k in keys], [src[k].data for k in keys], alpha=1 - decay)
+
+    # -- checkpoints ------------------------------------------------------------------------------
+    @master_only
+    def save_network(self, net, net_label, current_iter, param_key="params"):
+        name = "latest" if current_iter == -1 else current_iter
+        path = os.path.join(self.opt["path"]["models"], f"net_{net_label}_{name}.pth")
+        nets = net if isinstance(net, list) else [net]
+        keys = param_key if isinstance(param_key, list) else [param_key]
+        assert len(nets) == len(keys), "The lengths of net and param_key should be the same."
+        payload = {}
+        for n, k in zip(nets, keys):
+            sd = self.get_bare_model(n).state_dict()
+            payload[k] = OrderedDict((kk[7:] if kk.startswith("module.") else kk, v.cpu()) for kk, v in sd.items())
+        logger = get_root_logger()
+        for attempt in range(3):
+            try:
+                torch.save(payload, path)
+                return
+            except Exception as e:  # noqa: BLE001
+                logger.warning(f"Save model error: {e}, remaining retry times: {2 - attempt}")
+                time.sleep(1)
+        logger.warning(f"Still cannot save {path}. Just ignore it.")
+
+    def _print_different_keys_loading(self, crt_net, load_net, strict=True):
+        crt = self.get_bare_model(crt_net).state_dict()
+        a, b = set(crt.keys()), set(load_net.keys())
+        logger = get_root_logger()
+        if a != b:
+            logger.warning("Current net - loaded net:")
+            for v in sorted(a - b):
+                logger.warning(f"  {v}")
+            logger.warning("Loaded net - current net:")
+            for v in sorted(b - a):
+                logger.warning(f"  {v}")
+        if not strict:
+            for k in a & b:
+                if crt[k].size() != load_net[k].size():
+                    logger.warning(f"Size different, ignore [{k}]: crt_net: {crt[k].shape}; load_net: {load_net[k].shape}")
+                    load_net[k + ".ignore"] = load_net.pop(k)
+
+    def load_network(self, net, load_path, strict=True, param_key="params", remove_norm=False):
+        logger = get_root_logger()
+        net = self.get_bare_model(net)
+        load_net = torch.load(load_path, map_location="cpu")
+        if param_key is not None:
+            if param_key not in load_net and "params" in load_net:
+                param_key = "params"
+                logger.info("Loading: params_ema does not exist, use params.")
+            load_net = load_net[param_key]
+        logger.info(f"Loading {net.__class__.__name__} model from {load_path}, with param key: [{param_key}].")
+        for k, v in deepcopy(load_net).items():
+            if "norm" in k and remove_norm:
+                continue
+            if k.startswith("module."):
+                load_net[k[7:]] = v
+                load_net.pop(k)
+        self._print_different_keys_loading(net, load_net, strict)
+        net.load_state_dict(load_net, strict=strict)
+
+    # -- logging ----------------------------------------------------------------------------------
+    def reduce_loss_dict(self, loss_dict):
+        with torch.no_grad():
+            if self.opt["dist"]:
+                keys = list(loss_dict.keys())
+                losses = torch.stack([loss_dict[k] for k in keys], 0)
+                torch.distributed.reduce(losses, dst=0)
+                if self.opt["rank"] == 0:
+                    losses /= self.opt["world_size"]
+                loss_dict = {k: v for k, v in zip(keys, losses)}
+            return OrderedDict((k, v.mean().item()) for k, v in loss_dict.items())

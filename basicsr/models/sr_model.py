@@ -1,0 +1,208 @@
+"""Restoration model: the caller of the encoder hot path (reference basicsr/models/sr_model.py):
+train step (:132-174), test (:176-185), reflect padding to the window multiple (:244-271), tiled inference
+(:273-361), validation with uint8 PSNR/SSIM (:375-499)."""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from os import path as osp
+
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from basicsr.archs import build_network
+from basicsr.losses import build_loss
+from basicsr.metrics import calculate_metric
+from basicsr.utils import get_root_logger
+from basicsr.utils.registry import MODEL_REGISTRY
+
+from .base_model import BaseModel
+
+
+def tensor2img_rgb(t: torch.Tensor) -> np.ndarray:
+    """(1,C,H,W) or (C,H,W) float in [0,1] -> HWC uint8 (round), the pixel convention of tensor2img."""
+    t = t.detach().float().cpu().clamp_(0, 1)
+    if t.dim() == 4:
+        t = t[0]
+    return (t.permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)
+
+
+@MODEL_REGISTRY.register()
+class SRModel(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.net_g = self.model_to_device(build_network(opt["network_g"]))
+        self.grad_clip = opt.get("grad_clip", 0)
+        self.scale = opt.get("scale", 1)
+        self.mod_pad_h = self.mod_pad_w = 0
+        load_path = self.opt["path"].get("pretrain_network_g", None)
+        if load_path is not None:
+            if osp.exists(load_path):
+                self.load_network(self.net_g, load_path, self.opt["path"].get("strict_load_g", True),
+                                  self.opt["path"].get("param_key_g", "params"), self.opt.get("remove_norm", False))
+            elif self.opt.get("allow_missing_pretrain", False):
+                get_root_logger().warning(f"pretrain_network_g {load_path} not found: keeping the initial weights.")
+            else:
+                raise FileNotFoundError(load_path)
+        if self.is_train:
+            self.init_training_settings()
+
+    def init_training_settings(self):
+        self.net_g.train()
+        train_opt = self.opt["train"]
+        self.ema_decay = train_opt.get("ema_decay", 0)
+        if self.ema_decay > 0:
+            self.net_g_ema = build_network(self.opt["network_g"]).to(self.device)
+            self.model_ema(0)
+            self.net_g_ema.eval()
+        self.cri_pix = build_loss(train_opt["pixel_opt"]).to(self.device) if train_opt.get("pixel_opt") else None
+        if self.cri_pix is None:
+            raise ValueError("Both pixel and perceptual losses are None.")
+        self.setup_optimizers()
+        if train_opt.get("scheduler"):
+            self.setup_schedulers()
+
+    def setup_optimizers(self):
+        train_opt = self.opt["train"]
+        params = []
+        for k, v in self.net_g.named_parameters():
+            if v.requires_grad:
+                params.append(v)
+            else:
+                get_root_logger().warning(f"Params {k} will not be optimized.")
+        cfg = dict(train_opt["optim_g"])
+        self.optimizer_g = self.get_optimizer(cfg.pop("type"), params, **cfg)
+        self.optimizers.append(self.optimizer_g)
+
+    def feed_data(self, data):
+        self.lq = data["lq"].to(self.device, non_blocking=True)
+        if "gt" in data:
+            self.gt = data["gt"].to(self.device, non_blocking=True)
+
+    def optimize_parameters(self, current_iter):
+        self.net_g.train()
+        self.optimizer_g.zero_grad()
+        self.output = self.net_g(self.lq)
+        loss_dict = OrderedDict()
+        l_pix = self.cri_pix(self.output, self.gt)
+        loss_dict["l_pix"] = l_pix
+        l_pix.backward()
+        if self.grad_clip:
+            torch.nn.utils.clip_grad_norm_(self.net_g.parameters(), self.grad_clip)
+        self.optimizer_g.step()
+        self.log_dict = self.reduce_loss_dict(loss_dict)
+        if getattr(self, "ema_decay", 0) > 0:
+            self.model_ema(decay=self.ema_decay)
+
+    # -- inference -----------------------------------------------------------------------------
+    def _net(self):
+        return self.net_g_ema if hasattr(self, "net_g_ema") else self.net_g
+
+    def test(self):
+        net = self._net()
+        was_training = net.training
+        net.eval()
+        with torch.no_grad():
+            self.output = net(self.lq)
+        if was_training and net is self.net_g:
+            net.train()
+
+    def pre_test(self):
+        """reflect-pad right/bottom to a multiple of ``network_g.window_size`` (sr_model.py:244-260)"""
+        _, _, h, w = self.lq.size()
+        self.mod_pad_h = self.mod_pad_w = 0
+        if "window_size" not in self.opt["network_g"]:
+            return
+        ws = self.opt["network_g"]["window_size"]
+        ws = max(ws) if isinstance(ws, (list, tuple)) else int(ws)
+        self.scale = self.opt.get("scale", 1)
+        if h % ws:
+            self.mod_pad_h = ws - h % ws
+        if w % ws:
+            self.mod_pad_w = ws - w % ws
+        self.lq = F.pad(self.lq, (0, self.mod_pad_w, 0, self.mod_pad_h), "reflect")
+
+    def post_test(self):
+        if "window_size" not in self.opt["network_g"]:
+            return
+        _, _, h, w = self.output.size()
+        self.output = self.output[:, :, 0:h - self.mod_pad_h * self.scale, 0:w - self.mod_pad_w * self.scale]
+
+    def test_tile(self):
+        """independent ``infer_size`` tiles with ``tile_pad`` context, centre pasted back (sr_model.py:273-361)"""
+        net = self._net()
+        net.eval()
+        size, pad, sc = self.opt["tile"]["infer_size"], self.opt["tile"]["tile_pad"], self.opt.get("scale", 1)
+        b, c, height, width = self.lq.shape
+        self.output = self.lq.new_zeros((b, c, height * sc, width * sc))
+        for ty in range(math.ceil(height / size)):
+            for tx in range(math.ceil(width / size)):
+                x0, y0 = tx * size, ty * size
+                x1, y1 = min(x0 + size, width), min(y0 + size, height)
+                xp0, yp0 = max(x0 - pad, 0), max(y0 - pad, 0)
+                xp1, yp1 = min(x1 + pad, width), min(y1 + pad, height)
+                with torch.no_grad():
+                    out = net(self.lq[:, :, yp0:yp1, xp0:xp1])
+                ox, oy = (x0 - xp0) * sc, (y0 - yp0) * sc
+                self.output[:, :, y0 * sc:y1 * sc, x0 * sc:x1 * sc] = out[:, :, oy:oy + (y1 - y0) * sc, ox:ox + (x1 - x0) * sc]
+        if net is self.net_g:
+            net.train()
+
+    def get_current_visuals(self):
+        out = OrderedDict(lq=self.lq.detach().cpu(), result=self.output.detach().cpu())
+        if hasattr(self, "gt"):
+            out["gt"] = self.gt.detach().cpu()
+        return out
+
+    def dist_validation(self, dataloader, current_iter, tb_logger, save_img, clamp=True):
+        if self.opt["rank"] == 0:
+            return self.nondist_validation(dataloader, current_iter, tb_logger, save_img, clamp)
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img, clamp=True):
+        name = dataloader.dataset.opt["name"]
+        metrics_opt = self.opt["val"].get("metrics") or {}
+        results = OrderedDict((m, 0.0) for m in metrics_opt)
+        n = 0
+        for val_data in dataloader:
+            self.feed_data(val_data)
+            self.pre_test()
+            if "tile" in self.opt:
+                self.test_tile()
+            else:
+                self.test()
+            self.post_test()
+            vis = self.get_current_visuals()
+            sr = tensor2img_rgb(vis["result"])
+            if save_img:
+                from PIL import Image
+
+                stem = osp.splitext(osp.basename(val_data["lq_path"][0]))[0]
+                folder = osp.join(self.opt["path"]["visualization"], name)
+                import os
+
+                os.makedirs(folder, exist_ok=True)
+                Image.fromarray(sr).save(osp.join(folder, f"{stem}_{self.opt['name']}.png"))
+            if "gt" in vis and metrics_opt:
+                gt = tensor2img_rgb(vis["gt"])
+                for m, mo in metrics_opt.items():
+                    results[m] += calculate_metric(dict(img=sr, img2=gt), mo)
+            n += 1
+            del self.lq, self.output
+            if hasattr(self, "gt"):
+                del self.gt
+        for m in results:
+            results[m] /= max(1, n)
+        self.metric_results = results
+        log = f"Validation {name}\n" + "".join(f"\t # {m}: {v:.4f}\n" for m, v in results.items())
+        get_root_logger().info(log)
+        if tb_logger:
+            for m, v in results.items():
+                tb_logger.add_scalar(f"metrics/{name}/{m}", v, current_iter)
+        return results
+
+    def save(self, epoch, current_iter):
+        if hasattr(self, "net_g_ema"):
+            self.save_network([self.net_g, self.net_g_ema], "net_g", current_iter, param_key=["params", "params_ema"])
+        else:
+            self.save_network(self.net_g, "net_g", current_iter)

@@ -1,0 +1,234 @@
+"""CPU: host-side logic of the drop-in surface -- registries, options, state-dict contract, SRModel
+padding / tiling / validation arithmetic, metrics, the test.py CLI, and the 2-rank (gloo) DDP step.
+A tiny pure-torch arch is registered HERE (tests only) to exercise the callers without a GPU; the
+product archs themselves refuse CPU tensors."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from basicsr.utils.registry import ARCH_REGISTRY, Registry  # noqa: E402
+
+
+@ARCH_REGISTRY.register()
+class _TestConvArch(nn.Module):
+    """3x3 conv + residual; ``hook`` kwarg like the reference archs."""
+
+    def __init__(self, img_channel=3, window_size=8, width=4):
+        super().__init__()
+        self.body = nn.Conv2d(img_channel, img_channel, 3, padding=1)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(0)
+            self.body.weight.copy_(torch.randn(self.body.weight.shape, generator=g) * 0.1)
+            self.body.bias.fill_(0.01)
+
+    def forward(self, x, hook=False):
+        return None if hook else self.body(x) + x
+
+
+def _opt(**over):
+    opt = dict(name="t", model_type="SRModel", scale=1, num_gpu=0, dist=False, rank=0, world_size=1, is_train=False,
+               network_g=dict(type="_TestConvArch", window_size=16), path=dict(pretrain_network_g=None),
+               val=dict(save_img=False, metrics=dict(psnr=dict(type="calculate_psnr", crop_border=0, test_y_channel=False),
+                                                     ssim=dict(type="calculate_ssim", crop_border=0, test_y_channel=False))))
+    opt.update(over)
+    return opt
+
+
+def test_registry_contract():
+    r = Registry("x")
+
+    @r.register()
+    class A:  # noqa: D401
+        pass
+
+    class B_basicsr:  # noqa: N801
+        pass
+
+    r.register(B_basicsr)
+    assert r.get("A") is A and "A" in r and list(r.keys()) == ["A", "B_basicsr"]
+    assert r.get("B") is B_basicsr  # falls back to <name>_basicsr
+    with pytest.raises(KeyError):
+        r.get("nope")
+    with pytest.raises(AssertionError):
+        r.register(A)
+
+
+def test_parse_options_and_force_yml(tmp_path):
+    from basicsr.utils.options import parse_options
+
+    yml = os.path.join(ROOT, "options", "all_in_one", "test", "test_NAFNet_5d.yml")
+    opt, args = parse_options(str(tmp_path), is_train=False,
+                              argv=["-opt", yml, "--force_yml", "num_gpu=0", "network_g:width=32", "val:save_img=true"])
+    assert opt["dist"] is False and opt["rank"] == 0 and opt["world_size"] == 1 and opt["is_train"] is False
+    assert opt["num_gpu"] == 0 and opt["network_g"]["width"] == 32 and opt["val"]["save_img"] is True
+    assert opt["network_g"]["enc_blk_nums"] == [1, 1, 1, 28] and opt["network_g"]["window_size"] == 16
+    assert opt["path"]["results_root"].endswith(os.path.join("results", "NAFNet_5d"))
+    assert opt["datasets"]["test_1"]["phase"] == "test"
+    with pytest.raises(KeyError):
+        parse_options(str(tmp_path), is_train=False, argv=["-opt", yml, "--force_yml", "brand_new_key=1"])
+
+
+def test_nafnet_state_dict_contract():
+    from basicsr.archs import build_network
+    from oracle import nafnet_oracle as O
+
+    cfg = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1], window_size=16)
+    net = build_network(dict(type="NAFNetBaseline", **cfg))
+    sd = net.state_dict()
+    cfg.pop("window_size")
+    shapes = O.nafnet_param_shapes(**cfg)
+    assert list(sd.keys()) == list(shapes.keys()) and len(sd) == 664
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    assert sd["encoders.3.27.norm1.weight"].shape == (512,) and sd["ups.0.0.weight"].shape == (2048, 1024, 1, 1)
+    assert sd["decoder0.0.beta"].shape == (1, 512, 1, 1)
+    names = [n for n, _ in net.named_modules() if "decoder" in n and n.count(".") == 0]
+    assert names == ["decoder0", "decoder1", "decoder2", "decoder3"]  # hook targets of DCPTModel
+    with pytest.raises(TypeError):
+        build_network(dict(type="NAFNetBaseline", bogus_kwarg=1))
+    from dcpt_amd._lib import DcptHipError
+
+    with pytest.raises(DcptHipError):  # no CPU fallback in the product arch
+        net(torch.zeros(1, 3, 16, 16))
+
+
+def test_pad_crop_and_tile_arithmetic():
+    from basicsr.models import build_model
+
+    m = build_model(_opt())
+    x = torch.rand(1, 3, 250, 253, generator=torch.Generator().manual_seed(1))
+    m.feed_data({"lq": x})
+    m.pre_test()
+    assert m.lq.shape == (1, 3, 256, 256) and (m.mod_pad_h, m.mod_pad_w) == (6, 3)
+    assert torch.equal(m.lq[..., :250, :253], x)
+    assert torch.equal(m.lq[..., 250:, :253], x[..., 243:249, :].flip(2))  # reflect (no edge repeat)
+    m.test()
+    m.post_test()
+    assert m.output.shape == x.shape
+    full = m.net_g(x)
+    # interior identical to the unpadded run; the last row/col see reflected instead of zero padding
+    assert torch.allclose(m.output[..., :249, :252], full[..., :249, :252], atol=1e-6)
+
+    mt = build_model(_opt(tile=dict(infer_size=512, tile_pad=16), network_g=dict(type="_TestConvArch")))
+    big = torch.rand(1, 3, 600, 700, generator=torch.Generator().manual_seed(2))
+    mt.feed_data({"lq": big})
+    mt.pre_test()
+    mt.test_tile()
+    mt.post_test()
+    assert torch.allclose(mt.output, mt.net_g(big), atol=1e-6)  # 3x3 receptive field < tile_pad: tiling is exact
+
+
+def test_metrics_match_independent_implementations():
+    from scipy.signal import correlate2d
+
+    from basicsr.metrics import calculate_psnr, calculate_ssim
+
+    rs = np.random.RandomState(0)
+    a = rs.randint(0, 256, (40, 37, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rs.randint(-9, 10, a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    assert abs(calculate_psnr(a, b, 0) - 10 * np.log10(255.0 ** 2 / mse)) < 1e-9
+    assert calculate_psnr(a, a, 0) == float("inf")
+    assert abs(calculate_ssim(a, a, 0) - 1.0) < 1e-12
+    # independent SSIM: 2-D 11x11 sigma-1.5 window, 'valid'
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    win = np.outer(g / g.sum(), g / g.sum())
+    vals = []
+    for c in range(3):
+        x, y = a[..., c].astype(np.float64), b[..., c].astype(np.float64)
+        f = lambda z: correlate2d(z, win, mode="valid")  # noqa: E731
+        mx, my = f(x), f(y)
+        sx, sy, sxy = f(x * x) - mx * mx, f(y * y) - my * my, f(x * y) - mx * my
+        c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        vals.append((((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sx + sy + c2))).mean())
+    assert abs(calculate_ssim(a, b, 0) - np.mean(vals)) < 1e-9
+    assert abs(calculate_psnr(a, b, 4) - calculate_psnr(a[4:-4, 4:-4], b[4:-4, 4:-4], 0)) < 1e-12
+
+
+def test_cli_end_to_end_with_cpu_test_arch(tmp_path):
+    import logging
+
+    from basicsr.test import test_pipeline
+
+    logging.getLogger("basicsr").handlers.clear()
+    yml = os.path.join(ROOT, "options", "all_in_one", "test", "test_NAFNet_5d.yml")
+    argv = ["-opt", yml, "--force_yml", "num_gpu=0", "network_g:type=_TestConvArch"]
+    for k in ("width", "enc_blk_nums", "middle_blk_num", "dec_blk_nums"):
+        argv.append(f"network_g:{k}=4" if k == "width" else f"network_g:{k}=~")
+    # the test arch ignores the NAFNet kwargs that remain: give it a forgiving ctor
+    orig = _TestConvArch.__init__
+
+    def lenient(self, img_channel=3, window_size=8, width=4, **_):
+        orig(self, img_channel, window_size, width)
+
+    _TestConvArch.__init__ = lenient
+    try:
+        res = test_pipeline(str(tmp_path), argv=argv)
+    finally:
+        _TestConvArch.__init__ = orig
+    assert set(res.keys()) == {"Rain100L", "CBSD68"}
+    for r in res.values():
+        assert 5.0 < r["psnr"] < 60.0 and 0.0 < r["ssim"] <= 1.0
+
+
+def test_cli_refuses_cpu_for_product_arch(tmp_path):
+    import logging
+
+    from basicsr.test import test_pipeline
+    from dcpt_amd._lib import DcptHipError
+
+    logging.getLogger("basicsr").handlers.clear()
+    yml = os.path.join(ROOT, "options", "all_in_one", "test", "test_NAFNet_5d.yml")
+    with pytest.raises(DcptHipError):
+        test_pipeline(str(tmp_path), argv=["-opt", yml, "--force_yml", "num_gpu=0", "network_g:width=8",
+                                           "network_g:enc_blk_nums=[1,1]", "network_g:dec_blk_nums=[1,1]"])
+
+
+# ------------------------------------------------------------------------------------------------
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import tests.test_plumbing_cpu  # noqa: F401  (registers _TestConvArch in the spawned process)
+    from basicsr.models import build_model
+
+    opt = _opt(dist=True, rank=rank, world_size=world, is_train=True,
+               train=dict(pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"),
+                          optim_g=dict(type="SGD", lr=0.0)))
+    m = build_model(opt)
+    g = torch.Generator().manual_seed(100 + rank)
+    m.feed_data({"lq": torch.rand(2, 3, 16, 16, generator=g), "gt": torch.rand(2, 3, 16, 16, generator=g)})
+    m.optimize_parameters(1)
+    grads = torch.cat([p.grad.flatten() for p in m.net_g.parameters()])
+    torch.save({"grads": grads, "log": dict(m.get_current_log())}, os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_step_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"r{i}.pt")) for i in range(2))
+    assert torch.allclose(r0["grads"], r1["grads"], atol=1e-7)  # DDP averaged the gradients
+    # single-process reference: mean of the two ranks' local gradients
+    from basicsr.models import build_model
+
+    local = []
+    losses = []
+    for rank in range(2):
+        m = build_model(_opt(is_train=True, train=dict(pixel_opt=dict(type="L1Loss"), optim_g=dict(type="SGD", lr=0.0))))
+        g = torch.Generator().manual_seed(100 + rank)
+        m.feed_data({"lq": torch.rand(2, 3, 16, 16, generator=g), "gt": torch.rand(2, 3, 16, 16, generator=g)})
+        m.optimize_parameters(1)
+        local.append(torch.cat([p.grad.flatten() for p in m.net_g.parameters()]))
+        losses.append(m.get_current_log()["l_pix"])
+    assert torch.allclose(r0["grads"], (local[0] + local[1]) / 2, atol=1e-6)
+    assert abs(r0["log"]["l_pix"] - (losses[0] + losses[1]) / 2) < 1e-6  # reduce(dst=0) / world
