@@ -1,0 +1,102 @@
+"""Degradation-classifier head of DCPT, MI355X-native.
+
+Same registry name, constructor kwargs, ``forward(lq, features)`` contract and ``state_dict`` keys/shapes as
+the reference's ``PromptIR_NoImg_DC`` (basicsr/archs/degrad_classify_arch.py:558-641; 97 keys for
+feature_dims of length 4 with 2 blocks).  Every conv -> LayerNorm(channels) -> (+shortcut) -> ReLU group is one
+autograd node backed by ``dcpt_conv_ln_fwd/bwd`` (1x1 and dense 3x3 convolutions run as fp32 MFMA GEMMs, the 3x3
+as an implicit GEMM), the downsample layers by ``dcpt_conv1x1_pool_relu_*``, the softmax feature mixing by
+``dcpt_mix_*`` and the head by ``dcpt_meanpool_fc_*``.  Child modules only own the parameters.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from basicsr.utils.registry import ARCH_REGISTRY
+from dcpt_amd import functional as DF
+
+
+class LayerNorm(nn.Module):
+    """channels_first LayerNorm parameters (reference :17-44, eps 1e-6); applied inside the fused conv op."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_first"):
+        super().__init__()
+        if data_format != "channels_first":
+            raise NotImplementedError("only channels_first is on the DCPT path")
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.normalized_shape = (normalized_shape,)
+
+
+class Conv2d(nn.Conv2d):
+    """conv + norm (+ activation) holder (reference :69-103); ``fused`` runs conv -> LN -> [+res] -> [ReLU]."""
+
+    def __init__(self, *args, norm=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+
+    def fused(self, x, res=None, relu=True):
+        return DF.conv_ln(x, self.weight, self.norm.weight, self.norm.bias, res, relu)
+
+
+class BottleneckBlock(nn.Module):
+    """reference :132-243 restricted to what the DCPT head instantiates: in == out channels (identity shortcut),
+    stride 1, norm "LN", bias-free convs."""
+
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, norm="LN"):
+        super().__init__()
+        if in_channels != out_channels or norm != "LN":
+            raise NotImplementedError("the DCPT head uses identity-shortcut LN bottlenecks only")
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, 1
+        self.shortcut = None
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, bias=False, norm=LayerNorm(bottleneck_channels))
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, padding=1, bias=False,
+                            norm=LayerNorm(bottleneck_channels))
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False, norm=LayerNorm(out_channels))
+        for layer in (self.conv1, self.conv2, self.conv3):  # c2_msra_fill (fvcore): kaiming_normal fan_out / relu
+            nn.init.kaiming_normal_(layer.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        out = self.conv1.fused(x, relu=True)
+        out = self.conv2.fused(out, relu=True)
+        return self.conv3.fused(out, res=x, relu=True)  # relu(LN(conv3) + shortcut)
+
+
+class _Downsample(nn.Sequential):
+    """Conv2d(1x1, bias=False) -> MaxPool2d(2,2) -> ReLU as one op (reference :596-602)."""
+
+    def forward(self, x):
+        return DF.conv1x1_pool_relu(x, self[0].weight)
+
+
+@ARCH_REGISTRY.register()
+class PromptIR_NoImg_DC(nn.Module):
+    def __init__(self, feature_dims, num_res_blocks=2, num_classes=3, downsample=False):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("downsample=True (token inputs) is not on the DCPT path")
+        self.feature_dims = list(feature_dims)
+        self.downsample = downsample
+        self.bottleneck_layers = nn.ModuleList()
+        self.downsample_layers = nn.ModuleList()
+        for l, dim in enumerate(self.feature_dims):
+            self.bottleneck_layers.append(nn.Sequential(*[
+                BottleneckBlock(dim, dim, bottleneck_channels=int(dim * 2), norm="LN") for _ in range(num_res_blocks)]))
+            nxt = self.feature_dims[l + 1] if l < len(self.feature_dims) - 1 else dim
+            self.downsample_layers.append(_Downsample(nn.Conv2d(dim, nxt, 1, bias=False), nn.MaxPool2d(2, 2), nn.ReLU()))
+        last = self.feature_dims[-1]
+        self.last_stage = nn.Sequential(*[
+            BottleneckBlock(last, last, bottleneck_channels=int(last * 2), norm="LN") for _ in range(num_res_blocks)])
+        self.mixing_weights = nn.Parameter(torch.ones(len(self.bottleneck_layers)), requires_grad=True)
+        self.fc = nn.Linear(last, num_classes)
+
+    def forward(self, lq, features):
+        """``lq`` is accepted and ignored, exactly like the reference (:621)."""
+        x = None
+        for i, feature in enumerate(features):
+            x = DF.mix(x, feature, self.mixing_weights, i)
+            x = self.bottleneck_layers[i](x)
+            x = self.downsample_layers[i](x)
+        x = self.last_stage(x)
+        return DF.meanpool_fc(x, self.fc.weight, self.fc.bias)

@@ -69,6 +69,21 @@ SIGNATURES = {
     "dcpt_up_ps_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_up_ps_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_fused_bias_act": (cint, [f32p, f32p, f32p, f32p, i64, cint, i64, cint, cint, C.c_float, C.c_float, stream_t]),
+    "dcpt_conv_ln_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint, cint]),
+    "dcpt_conv_ln_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, cint, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint,
+                                cint, cint, cint, stream_t]),
+    "dcpt_conv_ln_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz,
+                                cint, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv1x1_pool_relu_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
+    "dcpt_conv1x1_pool_relu_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv1x1_pool_relu_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,
+                                          stream_t]),
+    "dcpt_mix_fwd": (cint, [f32p, f32p, f32p, cint, cint, f32p, i64, stream_t]),
+    "dcpt_mix_bwd_ws_bytes": (sz, [i64]),
+    "dcpt_mix_bwd": (cint, [f32p, f32p, f32p, cint, cint, f32p, f32p, C.c_void_p, sz, i64, stream_t]),
+    "dcpt_meanpool_fc_ws_bytes": (sz, [cint, cint, cint]),
+    "dcpt_meanpool_fc_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_meanpool_fc_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_prof_enable": (cint, [cint]),
     "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
     "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),

@@ -8,7 +8,7 @@
 #pragma once
 #include "dcpt_common.h"
 
-enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4 };
+enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5 };
 enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5 };
 
 struct GemmNT {
@@ -28,6 +28,8 @@ struct GemmNT {
     int P;
     // A_GATHER / E_SCATTER*: coarse grid gH x gW per image, fine image is 2gH x 2gW with gC channels;
     // column index = (2*i + j) * gC + ch  <->  fine pixel (2h+i, 2w+j), channel ch
+    // A_CONV3 (implicit GEMM of a dense 3x3, zero pad 1): image gH x gW with gC channels, K = 9*gC,
+    // column index = tap * gC + ch, tap = 3*ky + kx  <->  pixel (h+ky-1, w+kx-1)
     int gH, gW, gC;
     // epilogues
     const float* bias;    // [N]

@@ -232,6 +232,7 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
     DCPT_CHECK_ARG(p.K % 4 == 0, "gemm_nt: K=%d must be a multiple of 4", p.K);
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 64) < (1ll << 31), "gemm_nt: grid too large");
     if (aload == A_GATHER) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 4 * p.gC, "gemm_nt: gather needs K == 4*gC, gC %% 4 == 0");
+    if (aload == A_CONV3) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 9 * p.gC, "gemm_nt: conv3 needs K == 9*gC, gC %% 4 == 0");
     // algorithmic work of this launch (for the live roofline in bench.py)
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : 1) + (double)p.N * p.K;
@@ -249,6 +250,7 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_SCATTER)
     CASE(A_PLAIN, E_SCATTER_ADD)
     CASE(A_GATHER, E_PLAIN)
+    CASE(A_CONV3, E_PLAIN)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

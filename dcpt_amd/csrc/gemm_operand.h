@@ -21,6 +21,7 @@ struct RowCtx {
     int64_t off;
     float mu, rstd;
     int img;
+    int h, w;  // A_CONV3: pixel coordinates of the row
     bool valid;
 };
 
@@ -31,12 +32,18 @@ __device__ __forceinline__ void make_row(const Operand& o, int64_t m, RowCtx& rc
     rc.mu = 0.f;
     rc.rstd = 0.f;
     rc.img = 0;
+    rc.h = 0;
+    rc.w = 0;
     if constexpr (KIND == A_GATHER) {
         const int w = (int)(mm % o.gW);
         const int64_t t = mm / o.gW;
         const int h = (int)(t % o.gH);
         const int64_t b = t / o.gH;
         rc.off = ((b * (2 * o.gH) + 2 * h) * (int64_t)(2 * o.gW) + 2 * w) * o.gC;
+    } else if constexpr (KIND == A_CONV3) {
+        rc.w = (int)(mm % o.gW);
+        rc.h = (int)((mm / o.gW) % o.gH);
+        rc.off = mm * (int64_t)o.gC;
     } else {
         rc.off = mm * (int64_t)o.ld;
     }
@@ -69,6 +76,16 @@ __device__ __forceinline__ void load_raw(const Operand& o, const RowCtx& rc, int
     } else if constexpr (KIND == A_SG) {
         r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
         r.b = ok ? ldg4(o.ptr + rc.off + o.ncols + c) : f4_zero();
+    } else if constexpr (KIND == A_CONV3) {
+        r.a = f4_zero();
+        if (ok) {
+            const int tap = c / o.gC;
+            const int ch = c - tap * o.gC;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int hh = rc.h + ky - 1, ww = rc.w + kx - 1;
+            if (hh >= 0 && hh < o.gH && ww >= 0 && ww < o.gW)
+                r.a = ldg4(o.ptr + rc.off + ((int64_t)(ky - 1) * o.gW + (kx - 1)) * o.gC + ch);
+        }
     } else {  // A_GATHER
         if (ok) {
             const int ij = c / o.gC;

@@ -204,6 +204,7 @@ int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t s) {
     CASE(A_PLAIN, A_SG)
     CASE(A_PLAIN, A_GATHER)
     CASE(A_GATHER, A_PLAIN)
+    CASE(A_PLAIN, A_CONV3)
 #undef CASE
     dcpt_set_error("gemm_tn: unsupported loader combination %d/%d", xload, yload);
     return DCPT_ERR_ARG;

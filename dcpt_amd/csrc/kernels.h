@@ -7,6 +7,12 @@
 int launch_ln_stats(const float* x, float* mu, float* rstd, int64_t M, int C, float eps, hipStream_t s);
 int launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* mu, float* rstd, int64_t M, int C,
                   float eps, hipStream_t s);
+// y = [relu]( LN(x)*w + b [+ res] )   (channels-first LayerNorm of the classifier head, fused tail)
+int launch_ln_act_fwd(const float* x, const float* w, const float* b, const float* res, int relu, float* y, float* mu,
+                      float* rstd, int64_t M, int C, float eps, hipStream_t s);
+// as launch_ln_bwd, with the incoming gradient first masked by (ymask > 0) and optionally copied to gmasked
+int launch_ln_act_bwd(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
+                      const float* ymask, float* gmasked, float* dx, float* part, int nblk, int64_t M, int C, hipStream_t s);
 // dx = LN-backward(gy; x, mu, rstd, w) (+ dres if non-null).  Column sums go to part[nblk][3][C]
 // (0: sum gy*xhat, 1: sum gy, 2: sum dx_total); returns nblk through *nblk_out.
 int ln_bwd_num_blocks(int64_t M, int C);
@@ -50,11 +56,13 @@ enum WPackMode {
     WP_DOWN = 1,        // out[oc][ij*C + ic] = in[oc][ic][ij]                  in: [N=2C][C][2][2]  (K = 4C)
     WP_DOWN_T = 2,      // out[ij*C + ic][oc] = in[oc][ic][ij]
     WP_UP = 3,          // out[ij*G + kk][ic] = in[4kk+ij][ic]                  in: [N=4G][K]
-    WP_UP_T = 4         // out[ic][ij*G + kk] = in[4kk+ij][ic]
+    WP_UP_T = 4,        // out[ic][ij*G + kk] = in[4kk+ij][ic]
+    WP_CONV3 = 5,       // out[oc][tap*Ci + ic] = in[oc][ic][tap]              in: [N=Co][Ci][3][3]  (K = 9*Ci)
+    WP_CONV3_T = 6      // out[ic][tap*Co + oc] = in[oc][ic][8-tap]            (dgrad: N' = Ci rows, K' = 9*Co)
 };
 int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int mode, hipStream_t s);
 
-enum WReduceMode { WR_PLAIN = 0, WR_DOWN = 1, WR_UP = 2 };
+enum WReduceMode { WR_PLAIN = 0, WR_DOWN = 1, WR_UP = 2, WR_CONV3 = 3 };
 // dW = rowscale[n] * sum_s slab[s][n][k] (layout per mode)
 // optional: dgain[n] = sum_k W[n][k]*G[n][k] + wbias[n]*cs[n];  dbias[n] = rowscale[n]*cs[n]
 //           (cs = sum over the cs_rows partial rows colsum[r][n])

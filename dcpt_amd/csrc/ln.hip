@@ -17,7 +17,7 @@ __host__ __device__ inline int ln_group(int C) {
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ mu,
                                                        float* __restrict__ rstd, int64_t M, int C, float eps, int G,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       float* __restrict__ y) {
+                                                       float* __restrict__ y, const float* __restrict__ res, int relu) {
     const int tid = threadIdx.x;
     const int gpb = 256 / G;
     const int64_t row = (int64_t)blockIdx.x * gpb + tid / G;
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
             o.y = fmaf((v.y - mean) * rs, ww.y, bb.y);
             o.z = fmaf((v.z - mean) * rs, ww.z, bb.z);
             o.w = fmaf((v.w - mean) * rs, ww.w, bb.w);
+            if (res) o = f4_add(o, ldg4(res + row * (int64_t)C + 4 * q));
+            if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             stg4(yr + 4 * q, o);
         }
     }
@@ -65,6 +67,8 @@ struct LnBwdP {
     const float* rstd;
     const float* w;
     const float* dres;
+    const float* ymask;  // optional: zero the incoming gradient where this (post-ReLU) tensor is <= 0
+    float* gmasked;      // optional: the masked incoming gradient is also written here (residual branch)
     float* dx;
     float* part;  // [nblk][3][C]
     int64_t M;
@@ -99,6 +103,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
             const int q = lig + j * G;
             if (valid && q < nq) {
                 g[j] = ldg4(p.gy + ro + 4 * q);
+                if (p.ymask) {
+                    const float4 ym = ldg4(p.ymask + ro + 4 * q);
+                    g[j] = make_float4(ym.x > 0.f ? g[j].x : 0.f, ym.y > 0.f ? g[j].y : 0.f, ym.z > 0.f ? g[j].z : 0.f,
+                                       ym.w > 0.f ? g[j].w : 0.f);
+                }
+                if (p.gmasked) stg4(p.gmasked + ro + 4 * q, g[j]);
                 const float4 xv = ldg4(p.x + ro + 4 * q);
                 xh[j] = make_float4((xv.x - mean) * rs, (xv.y - mean) * rs, (xv.z - mean) * rs, (xv.w - mean) * rs);
             } else {
@@ -177,18 +187,24 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
 int launch_ln_stats(const float* x, float* mu, float* rstd, int64_t M, int C, float eps, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && M > 0, "ln_stats: C=%d must be a positive multiple of 4", C);
     const int G = ln_group(C), gpb = 256 / G;
-    ln_stats_kernel<<<dim3((unsigned)cdiv64(M, gpb)), dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, nullptr, nullptr, nullptr);
+    ln_stats_kernel<<<dim3((unsigned)cdiv64(M, gpb)), dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, nullptr, nullptr, nullptr,
+                                                                          nullptr, 0);
     DCPT_CHECK_LAUNCH("ln_stats");
+    return DCPT_OK;
+}
+
+int launch_ln_act_fwd(const float* x, const float* w, const float* b, const float* res, int relu, float* y, float* mu,
+                      float* rstd, int64_t M, int C, float eps, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && M > 0, "ln_fwd: C=%d must be a positive multiple of 4", C);
+    const int G = ln_group(C), gpb = 256 / G;
+    ln_stats_kernel<<<dim3((unsigned)cdiv64(M, gpb)), dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y, res, relu);
+    DCPT_CHECK_LAUNCH("ln_fwd");
     return DCPT_OK;
 }
 
 int launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* mu, float* rstd, int64_t M, int C,
                   float eps, hipStream_t s) {
-    DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && M > 0, "ln_fwd: C=%d must be a positive multiple of 4", C);
-    const int G = ln_group(C), gpb = 256 / G;
-    ln_stats_kernel<<<dim3((unsigned)cdiv64(M, gpb)), dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y);
-    DCPT_CHECK_LAUNCH("ln_fwd");
-    return DCPT_OK;
+    return launch_ln_act_fwd(x, w, b, nullptr, 0, y, mu, rstd, M, C, eps, s);
 }
 
 int ln_bwd_num_blocks(int64_t M, int C) {
@@ -200,8 +216,14 @@ int ln_bwd_num_blocks(int64_t M, int C) {
 
 int launch_ln_bwd(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
                   float* dx, float* part, int nblk, int64_t M, int C, hipStream_t s) {
+    return launch_ln_act_bwd(gy, x, mu, rstd, w, dres, nullptr, nullptr, dx, part, nblk, M, C, s);
+}
+
+int launch_ln_act_bwd(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
+                      const float* ymask, float* gmasked, float* dx, float* part, int nblk, int64_t M, int C, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of 4, <= 2048", C);
     LnBwdP p;
+    p.ymask = ymask; p.gmasked = gmasked;
     p.gy = gy; p.x = x; p.mu = mu; p.rstd = rstd; p.w = w; p.dres = dres; p.dx = dx; p.part = part;
     p.M = M; p.C = C; p.G = ln_group(C);
     const int gpb = 256 / p.G;

@@ -137,11 +137,21 @@ __global__ void wpack_kernel(const float* __restrict__ in, float* __restrict__ o
         const int r = (int)(i / K), ic = (int)(i % K);
         const int ij = r / G, kk = r % G;
         out[i] = in[(int64_t)(4 * kk + ij) * K + ic];
-    } else {  // WP_UP_T: out[ic][ij*G + kk] = in[4kk+ij][ic]
+    } else if (mode == WP_UP_T) {  // out[ic][ij*G + kk] = in[4kk+ij][ic]
         const int G = N / 4;
         const int ic = (int)(i / N), r = (int)(i % N);
         const int ij = r / G, kk = r % G;
         out[i] = in[(int64_t)(4 * kk + ij) * K + ic];
+    } else if (mode == WP_CONV3) {  // N = Co, K = 9*Ci: out[oc][tap*Ci + ic] = in[(oc*Ci + ic)*9 + tap]
+        const int Ci = K / 9;
+        const int oc = (int)(i / K), r = (int)(i % K);
+        const int tap = r / Ci, ic = r % Ci;
+        out[i] = in[((int64_t)oc * Ci + ic) * 9 + tap];
+    } else {  // WP_CONV3_T: N = Co, K = 9*Ci (of the forward conv); out[ic][tap*Co + oc] = in[(oc*Ci+ic)*9 + 8-tap]
+        const int Ci = K / 9, Co = N;
+        const int ic = (int)(i / (9 * Co)), r = (int)(i % (9 * Co));
+        const int tap = r / Co, oc = r % Co;
+        out[i] = in[((int64_t)oc * Ci + ic) * 9 + (8 - tap)];
     }
 }
 
@@ -181,10 +191,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             const int ij = k / C, ic = k % C;
             float* d = dW + ((int64_t)n * C + ic) * 4 + ij;
             d[0] = o.x; d[4] = o.y; d[8] = o.z; d[12] = o.w;
-        } else {  // WR_UP: packed row n = ij*G + kk -> dW[4kk+ij][k]
+        } else if (mode == WR_UP) {  // packed row n = ij*G + kk -> dW[4kk+ij][k]
             const int G = N / 4;
             const int ij = n / G, kk = n % G;
             stg4(dW + (int64_t)(4 * kk + ij) * K + k, o);
+        } else {  // WR_CONV3: packed k = tap*Ci + ic -> dW[n][ic][tap]
+            const int Ci = K / 9;
+            const int tap = k / Ci, ic = k % Ci;
+            float* d = dW + ((int64_t)n * Ci + ic) * 9 + tap;
+            d[0] = o.x; d[9] = o.y; d[18] = o.z; d[27] = o.w;
         }
     }
     if (dgain == nullptr && dbias == nullptr) return;

@@ -384,3 +384,173 @@ class _FusedLeakyReLUFn(torch.autograd.Function):
 
 def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     return _FusedLeakyReLUFn.apply(x, bias, negative_slope, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# degradation-classifier head (reference basicsr/archs/degrad_classify_arch.py)
+class _ConvLNFn(torch.autograd.Function):
+    """conv(1x1 | 3x3, no bias) -> channels-first LayerNorm -> [+res] -> [ReLU]
+    (Conv2d wrapper :69-103 with norm=LN; BottleneckBlock tail :227-243)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, lnw, lnb, res, relu):
+        lib = _lib.load()
+        _require_gpu(x, weight, lnw, lnb, res)
+        x = _nhwc(x)
+        res_ = None if res is None else _nhwc(res)
+        w_, lw, lb = _contig(weight.detach()), _contig(lnw.detach()), _contig(lnb.detach())
+        B, Cin, H, W = x.shape
+        Cout, ks = w_.shape[0], w_.shape[2]
+        dev = x.device
+        z = _empty_nhwc(B, Cout, H, W, dev)
+        y = _empty_nhwc(B, Cout, H, W, dev)
+        stats = torch.empty((2, B * H * W), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.dcpt_conv_ln_ws_bytes(B, H, W, Cin, Cout, ks, 0))
+        check(lib.dcpt_conv_ln_fwd(x.data_ptr(), w_.data_ptr(), lw.data_ptr(), lb.data_ptr(), _p(res_), int(bool(relu)),
+                                   z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                                   ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)), "dcpt_conv_ln_fwd")
+        ctx.save_for_backward(x, w_, lw, z, y, stats)
+        ctx.relu, ctx.has_res = bool(relu), res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_, lw, z, y, stats = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cin, H, W = x.shape
+        Cout, ks = w_.shape[0], w_.shape[2]
+        dev = x.device
+        dx = _empty_nhwc(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        dlw, dlb = torch.empty_like(lw), torch.empty_like(lw)
+        dres = _empty_nhwc(B, Cout, H, W, dev) if ctx.has_res else None
+        ws = _workspace(dev, lib.dcpt_conv_ln_ws_bytes(B, H, W, Cin, Cout, ks, 1))
+        check(lib.dcpt_conv_ln_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), lw.data_ptr(), z.data_ptr(), y.data_ptr(),
+                                   stats[0].data_ptr(), stats[1].data_ptr(), dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(),
+                                   dlb.data_ptr(), _p(dres), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks,
+                                   int(ctx.relu), _stream(dev)), "dcpt_conv_ln_bwd")
+        return dx, dw, dlw, dlb, dres, None
+
+
+def conv_ln(x, weight, lnw, lnb, res=None, relu=True):
+    return _ConvLNFn.apply(x, weight, lnw, lnb, res, relu)
+
+
+class _ConvPoolReluFn(torch.autograd.Function):
+    """Conv2d(1x1, bias=False) -> MaxPool2d(2,2) -> ReLU (degrad_classify_arch.py:596-602)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        _require_gpu(x, weight)
+        x = _nhwc(x)
+        w_ = _contig(weight.detach())
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        z = _empty_nhwc(B, Cout, H, W, dev)
+        y = _empty_nhwc(B, Cout, H // 2, W // 2, dev)
+        ws = _workspace(dev, lib.dcpt_conv1x1_pool_relu_ws_bytes(B, H, W, Cin, Cout, 0))
+        check(lib.dcpt_conv1x1_pool_relu_fwd(x.data_ptr(), w_.data_ptr(), z.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv1x1_pool_relu_fwd")
+        ctx.save_for_backward(x, w_, z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_, z = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        dx = _empty_nhwc(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        ws = _workspace(dev, lib.dcpt_conv1x1_pool_relu_ws_bytes(B, H, W, Cin, Cout, 1))
+        check(lib.dcpt_conv1x1_pool_relu_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), z.data_ptr(), dx.data_ptr(),
+                                             dw.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, _stream(dev)),
+              "dcpt_conv1x1_pool_relu_bwd")
+        return dx, dw
+
+
+def conv1x1_pool_relu(x, weight):
+    return _ConvPoolReluFn.apply(x, weight)
+
+
+class _MixFn(torch.autograd.Function):
+    """prev + softmax(mixing_weights)[idx] * feat (degrad_classify_arch.py:632-637)."""
+
+    @staticmethod
+    def forward(ctx, prev, feat, mixing_weights, idx):
+        lib = _lib.load()
+        _require_gpu(prev, feat, mixing_weights)
+        feat = _nhwc(feat)
+        prev_ = None if prev is None else _nhwc(prev)
+        mw = _contig(mixing_weights.detach())
+        out = _empty_nhwc(*feat.shape, feat.device)
+        check(lib.dcpt_mix_fwd(_p(prev_), feat.data_ptr(), mw.data_ptr(), mw.numel(), int(idx), out.data_ptr(), feat.numel(),
+                               _stream(feat.device)), "dcpt_mix_fwd")
+        ctx.save_for_backward(feat, mw)
+        ctx.idx, ctx.has_prev = int(idx), prev is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        feat, mw = ctx.saved_tensors
+        dout = _nhwc(dout)
+        dev = feat.device
+        dfeat = _empty_nhwc(*feat.shape, dev)
+        dmix = torch.empty_like(mw)
+        ws = _workspace(dev, lib.dcpt_mix_bwd_ws_bytes(feat.numel()))
+        check(lib.dcpt_mix_bwd(dout.data_ptr(), feat.data_ptr(), mw.data_ptr(), mw.numel(), ctx.idx, dfeat.data_ptr(),
+                               dmix.data_ptr(), ws.data_ptr(), ws.numel(), feat.numel(), _stream(dev)), "dcpt_mix_bwd")
+        return (dout if ctx.has_prev else None), dfeat, dmix, None
+
+
+def mix(prev, feat, mixing_weights, idx):
+    return _MixFn.apply(prev, feat, mixing_weights, idx)
+
+
+class _MeanPoolFCFn(torch.autograd.Function):
+    """x.mean(dim=[-1,-2]) -> Linear (degrad_classify_arch.py:639-640)."""
+
+    @staticmethod
+    def forward(ctx, x, fw, fb):
+        lib = _lib.load()
+        _require_gpu(x, fw, fb)
+        x = _nhwc(x)
+        fw_, fb_ = _contig(fw.detach()), (None if fb is None else _contig(fb.detach()))
+        B, Cc, H, W = x.shape
+        NC = fw_.shape[0]
+        dev = x.device
+        pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, NC), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.dcpt_meanpool_fc_ws_bytes(B, H * W, Cc))
+        check(lib.dcpt_meanpool_fc_fwd(x.data_ptr(), fw_.data_ptr(), _p(fb_), pooled.data_ptr(), logits.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), B, H * W, Cc, NC, _stream(dev)), "dcpt_meanpool_fc_fwd")
+        ctx.save_for_backward(pooled, fw_)
+        ctx.shape, ctx.has_bias = (B, Cc, H, W), fb is not None
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.load()
+        pooled, fw_ = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        NC = fw_.shape[0]
+        dev = pooled.device
+        dl = _contig(dlogits)
+        dx = _empty_nhwc(B, Cc, H, W, dev)
+        dfw = torch.empty_like(fw_)
+        dfb = torch.empty((NC,), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.dcpt_meanpool_fc_ws_bytes(B, H * W, Cc))
+        check(lib.dcpt_meanpool_fc_bwd(dl.data_ptr(), pooled.data_ptr(), fw_.data_ptr(), dx.data_ptr(), dfw.data_ptr(),
+                                       dfb.data_ptr(), ws.data_ptr(), ws.numel(), B, H * W, Cc, NC, _stream(dev)),
+              "dcpt_meanpool_fc_bwd")
+        return dx, dfw, (dfb if ctx.has_bias else None)
+
+
+def meanpool_fc(x, fw, fb):
+    return _MeanPoolFCFn.apply(x, fw, fb)

@@ -121,6 +121,37 @@ int dcpt_up_ps_fwd(const float* x, const float* w, const float* skip, float* y, 
 int dcpt_up_ps_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, void* ws, size_t ws_bytes,
                    int B, int H, int W, int C, dcpt_stream_t stream);
 
+/* ---- degradation-classifier head (basicsr/archs/degrad_classify_arch.py) -------------------------
+ * conv (ksize 1 or dense 3x3 / pad 1, no bias, weight [Cout][Cin][k][k]) -> channels-first LayerNorm (eps 1e-6,
+ * :17-44) -> [+ res] -> [ReLU]: the `Conv2d` wrapper :69-103 with norm="LN" and the BottleneckBlock tail :227-243.
+ * z = conv output (saved for backward), y = result; x,z,y,res NHWC. */
+size_t dcpt_conv_ln_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int backward);
+int dcpt_conv_ln_fwd(const float* x, const float* w, const float* lnw, const float* lnb, const float* res, int relu, float* z,
+                     float* y, float* mu, float* rstd, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
+                     int ksize, dcpt_stream_t stream);
+/* dres (may be NULL) receives the gradient of the residual input; dx may be NULL */
+int dcpt_conv_ln_bwd(const float* dy, const float* x, const float* w, const float* lnw, const float* z, const float* y,
+                     const float* mu, const float* rstd, float* dx, float* dw, float* dlnw, float* dlnb, float* dres, void* ws,
+                     size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream);
+/* downsample layer :596-602: Conv2d(Cin, Cout, 1, bias=False) -> MaxPool2d(2,2) -> ReLU; y [B][H/2][W/2][Cout] */
+size_t dcpt_conv1x1_pool_relu_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward);
+int dcpt_conv1x1_pool_relu_fwd(const float* x, const float* w, float* z, float* y, void* ws, size_t ws_bytes, int B, int H, int W,
+                               int Cin, int Cout, dcpt_stream_t stream);
+int dcpt_conv1x1_pool_relu_bwd(const float* dy, const float* x, const float* w, const float* z, float* dx, float* dw, void* ws,
+                               size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+/* :632-637: out = prev + softmax(mixing_weights)[idx] * feat  (prev may be NULL); the gradient of prev equals dout */
+int dcpt_mix_fwd(const float* prev, const float* feat, const float* mixing_weights, int n, int idx, float* out, int64_t numel,
+                 dcpt_stream_t stream);
+size_t dcpt_mix_bwd_ws_bytes(int64_t numel);
+int dcpt_mix_bwd(const float* dout, const float* feat, const float* mixing_weights, int n, int idx, float* dfeat, float* dmix,
+                 void* ws, size_t ws_bytes, int64_t numel, dcpt_stream_t stream);
+/* :639-640: mean over the P pixels of each image, then Linear(C, NC).  x [B][P][C] */
+size_t dcpt_meanpool_fc_ws_bytes(int B, int P, int C);
+int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float* fb, float* pooled, float* logits, void* ws, size_t ws_bytes,
+                         int B, int P, int C, int NC, dcpt_stream_t stream);
+int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, const float* fw, float* dx, float* dfw, float* dfb, void* ws,
+                         size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream);
+
 /* ---- fused bias + leaky-ReLU (API parity with basicsr/ops/fused_act/src/fused_bias_act.cpp:14-26,
  * kernel fused_bias_act_kernel.cu:20-50): y = act(x + bias[(i / step_b) % size_b]) * scale, act in
  * {1: linear, 3: leaky relu(alpha)}; grad 0: forward, 1: first derivative w.r.t. x using `ref` sign. */

@@ -1,0 +1,65 @@
+"""ORACLE (test infrastructure, not product code) -- CPU restatement of the degradation-classifier head
+``PromptIR_NoImg_DC`` (reference basicsr/archs/degrad_classify_arch.py:558-641) in plain PyTorch fp32.
+Pinned by tests/golden/dc_head.npz (oracle/make_golden.py imports the real reference).
+Functional: parameters come as a flat dict keyed by the reference's state-dict names."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def layernorm_cf(x, w, b, eps=1e-6):
+    """channels_first LayerNorm (degrad_classify_arch.py:39-44)."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return w[:, None, None] * x + b[:, None, None]
+
+
+def bottleneck(x, P, pre):
+    """BottleneckBlock.forward (:227-243) with in==out channels (identity shortcut), norm=LN, no conv bias."""
+    g = lambda n: P[pre + n]
+    out = F.relu(layernorm_cf(F.conv2d(x, g("conv1.weight")), g("conv1.norm.weight"), g("conv1.norm.bias")))
+    out = F.relu(layernorm_cf(F.conv2d(out, g("conv2.weight"), padding=1), g("conv2.norm.weight"), g("conv2.norm.bias")))
+    out = layernorm_cf(F.conv2d(out, g("conv3.weight")), g("conv3.norm.weight"), g("conv3.norm.bias"))
+    return F.relu(out + x)
+
+
+def dc_forward(features, P):
+    """PromptIR_NoImg_DC.forward (:621-641) with downsample=False; ``lq`` is ignored by the reference.
+    features: list of NCHW maps, highest resolution first."""
+    n = len(features)
+    mix = torch.softmax(P["mixing_weights"], dim=0)  # F.softmax without dim on a 1-D tensor -> dim 0 (:633)
+    nblk = len({k.split(".")[2] for k in P if k.startswith("bottleneck_layers.0.")})
+    x = 0
+    for i, f in enumerate(features):
+        x = x + mix[i] * f
+        for b in range(nblk):
+            x = bottleneck(x, P, f"bottleneck_layers.{i}.{b}.")
+        x = F.relu(F.max_pool2d(F.conv2d(x, P[f"downsample_layers.{i}.0.weight"]), 2, 2))
+    for b in range(len({k.split(".")[1] for k in P if k.startswith("last_stage.")})):
+        x = bottleneck(x, P, f"last_stage.{b}.")
+    x = x.mean(dim=[-1, -2])
+    return F.linear(x, P["fc.weight"], P["fc.bias"])
+
+
+def dc_param_shapes(feature_dims, num_res_blocks=2, num_classes=3):
+    shapes = {"mixing_weights": (len(feature_dims),)}
+
+    def block(pre, c):
+        for name, (co, ci, k) in (("conv1", (2 * c, c, 1)), ("conv2", (2 * c, 2 * c, 3)), ("conv3", (c, 2 * c, 1))):
+            shapes[f"{pre}{name}.weight"] = (co, ci, k, k)
+            shapes[f"{pre}{name}.norm.weight"] = (co,)
+            shapes[f"{pre}{name}.norm.bias"] = (co,)
+
+    for l, c in enumerate(feature_dims):
+        for b in range(num_res_blocks):
+            block(f"bottleneck_layers.{l}.{b}.", c)
+    for l, c in enumerate(feature_dims):
+        nxt = feature_dims[l + 1] if l < len(feature_dims) - 1 else c
+        shapes[f"downsample_layers.{l}.0.weight"] = (nxt, c, 1, 1)
+    for b in range(num_res_blocks):
+        block(f"last_stage.{b}.", feature_dims[-1])
+    shapes["fc.weight"] = (num_classes, feature_dims[-1])
+    shapes["fc.bias"] = (num_classes,)
+    return shapes

@@ -143,6 +143,31 @@ def gen_tlsc(ref):
     np.savez_compressed(os.path.join(OUT, "nafnet_local_tiny.npz"), y=_np(yo))
 
 
+DC_CFG = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+
+
+def gen_dc_head(ref):
+    """PromptIR_NoImg_DC (degrad_classify_arch.py:558-641) on four feature maps, CE loss, all gradients."""
+    net = ref.dc.PromptIR_NoImg_DC(**DC_CFG)
+    fill_module_(net, seed=0)
+    feats = [keyed_input(f"dc.f{i}", (3, c, 32 >> i, 32 >> i), lo=-1.0, hi=1.0).requires_grad_(True)
+             for i, c in enumerate(DC_CFG["feature_dims"])]
+    labels = torch.tensor([1, 7, 4])
+    logits = net(None, list(feats))
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out = {"logits": _np(logits), "loss": np.float64(loss.item())}
+    for i, f in enumerate(feats):
+        out[f"df{i}"] = _np(f.grad)
+    names, l2, sm, ab = _grad_summary(net)
+    out["g_names"], out["g_l2"], out["g_sum"], out["g_abs"] = names, l2, sm, ab
+    for k, p in net.named_parameters():  # full gradients for the small tensors and the first / last blocks
+        if p.numel() <= 4096 or k.startswith("bottleneck_layers.0.0.") or k.startswith("last_stage.1.conv1"):
+            out["g." + k] = _np(p.grad)
+    out["keys"] = np.array(list(net.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "dc_head.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -155,6 +180,7 @@ def main():
     gen_nafnet_tiny(ref)
     gen_nafnet_full(ref)
     gen_tlsc(ref)
+    gen_dc_head(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

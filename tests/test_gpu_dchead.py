@@ -1,0 +1,142 @@
+"""GPU parity: degradation-classifier head (PromptIR_NoImg_DC) and its building blocks vs the oracle and
+the golden vectors of the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dcpt_amd.keyed_init import keyed_input, keyed_state_dict, keyed_tensor
+from oracle import dc_oracle as D
+
+pytestmark = pytest.mark.gpu
+DC_CFG = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from dcpt_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def check(name, a, b, tol):
+    e = relerr(a, b)
+    assert np.isfinite(e) and e <= tol, f"{name}: scale-relative max error {e:.3e} > {tol:.1e}"
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,relu,res", [
+    (2, 8, 16, 6, 10, 1, True, False), (1, 16, 16, 9, 7, 3, True, False), (2, 16, 8, 8, 8, 1, True, True),
+    (1, 128, 128, 16, 16, 3, True, False), (2, 64, 32, 5, 5, 1, False, False), (1, 24, 40, 4, 6, 3, True, True)])
+def test_conv_ln(dev, B, Cin, Cout, H, W, ks, relu, res):
+    from dcpt_amd import functional as DF
+
+    x = keyed_input("cl.x", (B, Cin, H, W), lo=-1, hi=1)
+    w = keyed_tensor("cl.conv.weight", (Cout, Cin, ks, ks))
+    lw = keyed_tensor("cl.norm.weight", (Cout,))
+    lb = keyed_tensor("cl.norm.bias", (Cout,))
+    r = keyed_input("cl.res", (B, Cout, H, W), lo=-1, hi=1) if res else None
+    go = keyed_input("cl.go", (B, Cout, H, W), lo=-1, hi=1)
+    ts = [x, w, lw, lb] + ([r] if res else [])
+    ref = [t.clone().requires_grad_(True) for t in ts]
+    y = D.layernorm_cf(F.conv2d(ref[0], ref[1], padding=ks // 2), ref[2], ref[3])
+    if res:
+        y = y + ref[4]
+    if relu:
+        y = F.relu(y)
+    y.backward(go)
+    gpu = [t.to(dev).requires_grad_(True) for t in ts]
+    yg = DF.conv_ln(gpu[0], gpu[1], gpu[2], gpu[3], gpu[4] if res else None, relu)
+    yg.backward(go.to(dev))
+    check("y", yg, y, 2e-5)
+    for n, a, b in zip(["dx", "dw", "dlnw", "dlnb", "dres"], gpu, ref):
+        check(n, a.grad, b.grad, 1e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 8, 16, 6, 10), (1, 64, 128, 16, 16), (3, 16, 16, 2, 2)])
+def test_conv_pool_relu(dev, B, Cin, Cout, H, W):
+    from dcpt_amd import functional as DF
+
+    x = keyed_input("cp.x", (B, Cin, H, W), lo=-1, hi=1)
+    w = keyed_tensor("cp.conv.weight", (Cout, Cin, 1, 1))
+    go = keyed_input("cp.go", (B, Cout, H // 2, W // 2), lo=-1, hi=1)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.relu(F.max_pool2d(F.conv2d(xr, wr), 2, 2))
+    yr.backward(go)
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = DF.conv1x1_pool_relu(xg, wg)
+    y.backward(go.to(dev))
+    check("y", y, yr, 1e-5)
+    check("dx", xg.grad, xr.grad, 1e-4)
+    check("dw", wg.grad, wr.grad, 1e-4)
+
+
+def test_mix_and_head(dev):
+    from dcpt_amd import functional as DF
+
+    prev = keyed_input("mx.p", (2, 16, 6, 6), lo=-1, hi=1)
+    feat = keyed_input("mx.f", (2, 16, 6, 6), lo=-1, hi=1)
+    mw = keyed_tensor("mx.mixing_weights", (4,))
+    go = keyed_input("mx.go", (2, 16, 6, 6), lo=-1, hi=1)
+    for use_prev in (True, False):
+        pr, fr, mr = prev.clone().requires_grad_(True), feat.clone().requires_grad_(True), mw.clone().requires_grad_(True)
+        yr = (pr if use_prev else 0) + torch.softmax(mr, 0)[2] * fr
+        yr.backward(go)
+        pg, fg, mg = (t.to(dev).requires_grad_(True) for t in (prev, feat, mw))
+        y = DF.mix(pg if use_prev else None, fg, mg, 2)
+        y.backward(go.to(dev))
+        check("mix y", y, yr, 1e-6)
+        check("mix df", fg.grad, fr.grad, 1e-6)
+        check("mix dw", mg.grad, mr.grad, 1e-5)
+        if use_prev:
+            check("mix dprev", pg.grad, pr.grad, 1e-7)
+    x = keyed_input("hd.x", (3, 64, 5, 7), lo=-1, hi=1)
+    fw, fb = keyed_tensor("hd.fc.weight", (10, 64)), keyed_tensor("hd.fc.bias", (10,))
+    gl = keyed_input("hd.go", (3, 10), lo=-1, hi=1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, fw, fb))
+    lr = F.linear(xr.mean(dim=[-1, -2]), wr, br)
+    lr.backward(gl)
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, fw, fb))
+    lg = DF.meanpool_fc(xg, wg, bg)
+    lg.backward(gl.to(dev))
+    check("logits", lg, lr, 1e-5)
+    check("dx", xg.grad, xr.grad, 1e-5)
+    check("dfw", wg.grad, wr.grad, 1e-5)
+    check("dfb", bg.grad, br.grad, 1e-5)
+
+
+def test_dc_head_golden(dev, golden_dir):
+    from basicsr.archs import build_network
+
+    g = np.load(os.path.join(golden_dir, "dc_head.npz"))
+    net = build_network(dict(type="PromptIR_NoImg_DC", **DC_CFG))
+    sd = keyed_state_dict(D.dc_param_shapes(**DC_CFG), seed=0)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    feats = [keyed_input(f"dc.f{i}", (3, c, 32 >> i, 32 >> i), lo=-1.0, hi=1.0).to(dev).requires_grad_(True)
+             for i, c in enumerate(DC_CFG["feature_dims"])]
+    logits = net(None, feats)
+    loss = F.cross_entropy(logits, torch.tensor([1, 7, 4], device=dev))
+    loss.backward()
+    check("logits", logits, g["logits"], 1e-4)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for i, f in enumerate(feats):
+        check(f"df{i}", f.grad, g[f"df{i}"], 1e-3)
+    params = dict(net.named_parameters())
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(params[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 1e-3 * max(1e-9, l2), (n, mine, l2)
+    for k in g.files:
+        if k.startswith("g.") and k != "g_names":
+            check("grad " + k[2:], params[k[2:]].grad, g[k], 1e-3)

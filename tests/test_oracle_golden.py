@@ -106,3 +106,30 @@ def test_tlsc(golden_dir):
     x = keyed_input("tlsc.x", (2, 8, 48, 40), lo=-1.0, hi=1.0)
     y = O.tlsc_avgpool(x, tuple(int(k) for k in g["kernel"]))
     _close(y, g["y"], rtol=1e-5, atol=1e-6)
+
+
+def test_dc_head(golden_dir):
+    from oracle import dc_oracle as D
+
+    g = np.load(os.path.join(golden_dir, "dc_head.npz"))
+    cfg = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+    shapes = D.dc_param_shapes(**cfg)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]] and len(shapes) == 97
+    P = _req(keyed_state_dict(shapes, seed=0))
+    feats = [keyed_input(f"dc.f{i}", (3, c, 32 >> i, 32 >> i), lo=-1.0, hi=1.0).requires_grad_(True)
+             for i, c in enumerate(cfg["feature_dims"])]
+    logits = D.dc_forward(feats, P)
+    loss = torch.nn.functional.cross_entropy(logits, torch.tensor([1, 7, 4]))
+    loss.backward()
+    _close(logits, g["logits"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for i, f in enumerate(feats):
+        ref = g[f"df{i}"]
+        assert np.abs(f.grad.numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), i
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(P[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 1e-4 * max(1e-6, l2), (n, mine, l2)
+    for k in g.files:
+        if k.startswith("g.") and k != "g_names":
+            ref = g[k]
+            assert np.abs(P[k[2:]].grad.numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), k
