@@ -1,0 +1,177 @@
+"""DCPT pre-training step and its variants (reference
+basicsr/models/degradation_classification_pretrain_model.py:16-169 ``DCPTModel``,
+..._direct_train_model.py ``DCTModel`` (reconstruction forward on ``lq``, :140) and
+..._model.py ``DCModel`` (frozen encoder under no_grad, detached taps, :94-97,:122-148)).
+
+One step = encoder forward on the clean image (pixel loss), encoder forward on the degraded image with
+forward hooks on the decoder groups, classifier head on the tapped features (classification loss), ONE
+backward through head -> taps -> encoder (twice), two optimizer steps.  Under DDP every fused block returns
+all its gradients at once, so the bucketed RCCL all-reduce overlaps the remaining backward kernels; a
+bucket is only complete after BOTH uses of each encoder weight have back-propagated."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from basicsr.archs import build_network
+from basicsr.losses import build_loss
+from basicsr.utils import get_root_logger
+from basicsr.utils.registry import MODEL_REGISTRY
+
+from .base_model import BaseModel
+
+
+def top1_accuracy(logits: torch.Tensor, target: torch.Tensor) -> float:
+    """timm.utils.metrics.accuracy(..., topk=(1,)) restated: percentage of argmax hits."""
+    return float((logits.argmax(dim=1) == target).float().mean().item() * 100.0)
+
+
+@MODEL_REGISTRY.register()
+class DCPTModel(BaseModel):
+    recon_on_lq = False       # DCTModel: True
+    freeze_encoder = False    # DCModel: True
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.net_g = self.model_to_device(build_network(opt["network_g"]))
+        self.net_dc = self.model_to_device(build_network(opt["network_dc"]))
+        for net, tag in ((self.net_g, "g"), (self.net_dc, "dc")):
+            path = self.opt["path"].get(f"pretrain_network_{tag}", None)
+            if path is not None:
+                self.load_network(net, path, self.opt["path"].get(f"strict_load_{tag}", True),
+                                  self.opt["path"].get(f"param_key_{tag}", "params"), self.opt.get("remove_norm", False))
+        self.hook_outputs = []
+        self.hooks = []
+        if self.is_train:
+            self.init_training_settings()
+
+    # -- hooks -------------------------------------------------------------------------------
+    def hook_forward_fn(self, module, input, output):  # noqa: A002
+        if isinstance(output, tuple):
+            output = output[-1]
+        self.hook_outputs.append(output.detach() if self.freeze_encoder else output)
+
+    def install_hooks(self):
+        hook_names = self.opt.get("hook_names", None)
+        if hook_names is None:
+            raise ValueError("hook_names is required (e.g. 'decoder' for NAFNet, 'decoder_level' for Restormer)")
+        for name, module in self.net_g.named_modules():
+            if hook_names in name and name.count(".") == 1:  # reference :65-68
+                self.hooks.append(module.register_forward_hook(self.hook_forward_fn))
+        if not self.hooks:
+            raise ValueError(f"no module of net_g matches hook_names={hook_names!r}")
+
+    def init_training_settings(self):
+        self.net_g.train()
+        self.net_dc.train()
+        train_opt = self.opt["train"]
+        self.install_hooks()
+        self.cri_classify = build_loss(train_opt["classify_opt"]).to(self.device) if train_opt.get("classify_opt") else None
+        self.cri_pixel = build_loss(train_opt["pixel_opt"]).to(self.device) if train_opt.get("pixel_opt") else None
+        if self.cri_classify is None:
+            raise ValueError("Classify loss is None.")
+        self.setup_optimizers()
+        if train_opt.get("scheduler"):
+            self.setup_schedulers()
+
+    def setup_optimizers(self):
+        train_opt = self.opt["train"]
+        self.optimizer_g = None
+        nets = [("dc", self.net_dc)] if self.freeze_encoder else [("g", self.net_g), ("dc", self.net_dc)]
+        for tag, net in nets:
+            params = []
+            for k, v in net.named_parameters():
+                if v.requires_grad:
+                    params.append(v)
+                else:
+                    get_root_logger().warning(f"Params {k} will not be optimized.")
+            cfg = dict(train_opt[f"optim_{tag}"])
+            opt = self.get_optimizer(cfg.pop("type"), params, **cfg)
+            setattr(self, f"optimizer_{tag}", opt)
+            self.optimizers.append(opt)
+
+    def feed_data(self, data):
+        self.lq = data["lq"].to(self.device, non_blocking=True)
+        self.dataset_idx = data["dataset_idx"].to(self.device, non_blocking=True)
+        if "gt" in data:
+            self.gt = data["gt"].to(self.device, non_blocking=True)
+
+    # -- the step ----------------------------------------------------------------------------------
+    def optimize_parameters(self, current_iter):
+        loss_dict = OrderedDict()
+        l_total = 0
+        if not self.freeze_encoder:
+            self.net_g.train()
+            self.net_dc.eval()
+            self.optimizer_g.zero_grad()
+            recon_in = self.lq if self.recon_on_lq else self.gt
+            pix_output = self.net_g(recon_in, hook=False)
+            self.hook_outputs = []  # drop the taps recorded by the reconstruction forward
+            if self.cri_pixel:
+                l_pix = self.cri_pixel(pix_output, self.gt)
+                l_total = l_total + l_pix
+                loss_dict["l_pix"] = l_pix
+        self.net_dc.train()
+        self.optimizer_dc.zero_grad()
+        if self.freeze_encoder:
+            self.net_g.eval()
+            self.hook_outputs = []
+            with torch.no_grad():
+                self.net_g(self.lq, hook=True)
+        else:
+            self.net_g(self.lq, hook=True)  # returns None; the hooks collect decoder0..3
+        cls_output = self.net_dc(self.lq, self.hook_outputs[::-1])
+        l_classify = self.cri_classify(cls_output, self.dataset_idx)
+        l_total = l_total + l_classify
+        loss_dict["l_classify"] = l_classify
+        l_total.backward()
+        if self.optimizer_g is not None:
+            self.optimizer_g.step()
+        self.optimizer_dc.step()
+        self.hook_outputs = []
+        self.cls_output = cls_output.detach()
+        self.log_dict = self.reduce_loss_dict(loss_dict)
+
+    def test(self):
+        if not self.hooks:
+            self.install_hooks()
+        self.net_g.eval()
+        self.net_dc.eval()
+        self.hook_outputs = []
+        with torch.no_grad():
+            self.net_g(self.lq, hook=True)
+            self.cls_output = self.net_dc(self.lq, self.hook_outputs[::-1])
+        self.hook_outputs = []
+
+    def dist_validation(self, dataloader, current_iter, tb_logger, save_img, clamp=True):
+        if self.opt["rank"] == 0:
+            return self.nondist_validation(dataloader, current_iter, tb_logger, save_img, clamp)
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img, clamp=True):
+        hits, n = 0.0, 0
+        for val_data in dataloader:
+            self.feed_data(val_data)
+            self.test()
+            hits += top1_accuracy(self.cls_output, self.dataset_idx) * self.lq.shape[0]
+            n += self.lq.shape[0]
+        acc = hits / max(1, n)
+        self.metric_results = {"top1": acc}
+        get_root_logger().info(f"Validation {dataloader.dataset.opt['name']}\n\t # top1: {acc:.4f}\n")
+        return self.metric_results
+
+    def save(self, epoch, current_iter):
+        self.save_network(self.net_g, "net_g", current_iter)
+        self.save_network(self.net_dc, "net_dc", current_iter)
+
+
+@MODEL_REGISTRY.register()
+class DCTModel(DCPTModel):
+    """direct-train variant: the reconstruction forward sees ``lq`` (reference ..._direct_train_model.py:140)."""
+    recon_on_lq = True
+
+
+@MODEL_REGISTRY.register()
+class DCModel(DCPTModel):
+    """classifier-only variant: frozen encoder under no_grad, detached taps (reference ..._model.py:94-97,:122-148)."""
+    freeze_encoder = True

@@ -168,6 +168,41 @@ def gen_dc_head(ref):
     np.savez_compressed(os.path.join(OUT, "dc_head.npz"), **out)
 
 
+def gen_dcpt_step(ref):
+    """Re-enact DCPTModel.optimize_parameters (degradation_classification_pretrain_model.py:133-169) with the
+    reference archs: net_g(gt) -> L1; net_g(lq, hook=True) with hooks on decoder{i}.0; net_dc(taps[::-1]) -> CE;
+    one backward.  Stores both losses and every parameter-gradient norm of both nets."""
+    net_g = ref.nafnet.NAFNetBaseline(**TINY)
+    net_dc = ref.dc.PromptIR_NoImg_DC(**DC_CFG)
+    fill_module_(net_g, seed=0)
+    fill_module_(net_dc, seed=0)
+    gt = keyed_input("dcpt.gt", (2, 3, 32, 32))
+    lq = keyed_input("dcpt.lq", (2, 3, 32, 32))
+    labels = torch.tensor([3, 8])
+    taps = []
+    for name, module in net_g.named_modules():
+        if "decoder" in name and name.count(".") == 1:
+            module.register_forward_hook(lambda m, i, o: taps.append(o))
+    pix = net_g(gt, hook=False)
+    taps.clear()
+    l_pix = (pix - gt).abs().mean()
+    assert net_g(lq, hook=True) is None
+    assert len(taps) == 4
+    cls = net_dc(lq, taps[::-1])
+    l_cls = torch.nn.functional.cross_entropy(cls, labels)
+    (l_pix + l_cls).backward()
+    out = {"l_pix": np.float64(l_pix.item()), "l_classify": np.float64(l_cls.item()), "logits": _np(cls)}
+    for tag, net in (("g", net_g), ("dc", net_dc)):
+        names, l2, sm, ab = _grad_summary(net)
+        out[f"{tag}_names"], out[f"{tag}_l2"], out[f"{tag}_sum"] = names, l2, sm
+    out["g.intro.weight"] = _np(net_g.intro.weight.grad)
+    out["g.ending.weight"] = _np(net_g.ending.weight.grad)
+    out["g.decoder3.0.conv5.weight"] = _np(dict(net_g.named_parameters())["decoder3.0.conv5.weight"].grad)
+    out["dc.fc.weight"] = _np(net_dc.fc.weight.grad)
+    out["dc.mixing_weights"] = _np(net_dc.mixing_weights.grad)
+    np.savez_compressed(os.path.join(OUT, "dcpt_step.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -181,6 +216,7 @@ def main():
     gen_nafnet_full(ref)
     gen_tlsc(ref)
     gen_dc_head(ref)
+    gen_dcpt_step(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -133,3 +133,26 @@ def test_dc_head(golden_dir):
         if k.startswith("g.") and k != "g_names":
             ref = g[k]
             assert np.abs(P[k[2:]].grad.numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), k
+
+
+def test_dcpt_step(golden_dir):
+    """oracle re-enactment of DCPTModel.optimize_parameters == the reference's (losses + all grad norms)."""
+    from oracle import dc_oracle as D
+
+    g = np.load(os.path.join(golden_dir, "dcpt_step.npz"))
+    Pg = _req(keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0))
+    Pd = _req(keyed_state_dict(D.dc_param_shapes(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10), seed=0))
+    gt = keyed_input("dcpt.gt", (2, 3, 32, 32))
+    lq = keyed_input("dcpt.lq", (2, 3, 32, 32))
+    pix, _ = O.nafnet_forward(gt, Pg)
+    l_pix = O.l1_loss(pix, gt)
+    none, taps = O.nafnet_forward(lq, Pg, hook=True)
+    assert none is None
+    logits = D.dc_forward(taps[::-1], Pd)
+    l_cls = torch.nn.functional.cross_entropy(logits, torch.tensor([3, 8]))
+    (l_pix + l_cls).backward()
+    assert abs(float(l_pix) - float(g["l_pix"])) < 1e-6 and abs(float(l_cls) - float(g["l_classify"])) < 1e-5
+    for tag, P in (("g", Pg), ("dc", Pd)):
+        for n, l2 in zip([str(s) for s in g[f"{tag}_names"]], g[f"{tag}_l2"]):
+            mine = float(P[n].grad.double().pow(2).sum().sqrt())
+            assert abs(mine - l2) <= 2e-4 * max(1e-7, l2), (tag, n, mine, l2)
