@@ -40,6 +40,28 @@ class NafBlockSaved(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _SAVED_FIELDS]
 
 
+MDTA_PARAM_FIELDS = ("norm_w", "norm_b", "qkv_w", "dw_w", "proj_w", "temperature")
+MDTA_SAVED_FIELDS = ("mu", "rstd", "qkv1", "qkv", "nrm", "ghat", "attn", "attnT", "out_att")
+GDFN_PARAM_FIELDS = ("norm_w", "norm_b", "in_w", "dw_w", "out_w")
+GDFN_SAVED_FIELDS = ("mu", "rstd", "u", "t")
+
+
+class MdtaParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in MDTA_PARAM_FIELDS]
+
+
+class MdtaSaved(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in MDTA_SAVED_FIELDS]
+
+
+class GdfnParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GDFN_PARAM_FIELDS]
+
+
+class GdfnSaved(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GDFN_SAVED_FIELDS]
+
+
 PARAM_FIELDS = tuple(_PARAM_FIELDS)
 SAVED_FIELDS = tuple(_SAVED_FIELDS)
 
@@ -84,6 +106,23 @@ SIGNATURES = {
     "dcpt_meanpool_fc_ws_bytes": (sz, [cint, cint, cint]),
     "dcpt_meanpool_fc_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_meanpool_fc_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint, cint]),
+    "dcpt_conv_fwd": (cint, [f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_mdta_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
+    "dcpt_mdta_fwd": (cint, [C.POINTER(MdtaParams), f32p, f32p, C.POINTER(MdtaSaved), C.c_void_p, sz, cint, cint, cint, cint,
+                             cint, cint, stream_t]),
+    "dcpt_mdta_bwd": (cint, [C.POINTER(MdtaParams), C.POINTER(MdtaParams), f32p, C.POINTER(MdtaSaved), f32p, f32p, C.c_void_p,
+                             sz, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_gdfn_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
+    "dcpt_gdfn_fwd": (cint, [C.POINTER(GdfnParams), f32p, f32p, C.POINTER(GdfnSaved), C.c_void_p, sz, cint, cint, cint, cint,
+                             cint, cint, stream_t]),
+    "dcpt_gdfn_bwd": (cint, [C.POINTER(GdfnParams), C.POINTER(GdfnParams), f32p, C.POINTER(GdfnSaved), f32p, f32p, C.c_void_p,
+                             sz, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_pixel_unshuffle": (cint, [f32p, f32p, cint, cint, cint, cint, stream_t]),
+    "dcpt_pixel_shuffle": (cint, [f32p, f32p, cint, cint, cint, cint, stream_t]),
+    "dcpt_concat_channels": (cint, [f32p, f32p, f32p, i64, cint, cint, stream_t]),
+    "dcpt_split_channels": (cint, [f32p, f32p, f32p, i64, cint, cint, stream_t]),
     "dcpt_prof_enable": (cint, [cint]),
     "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
     "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),

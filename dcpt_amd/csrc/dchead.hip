@@ -348,6 +348,36 @@ extern "C" int dcpt_conv_ln_bwd(const float* dy, const float* x, const float* w,
     return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s);
 }
 
+extern "C" size_t dcpt_conv_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int backward) {
+    return conv_layout(B, H, W, Cin, Cout, ksize, backward, false, nullptr, 0, nullptr);
+}
+
+extern "C" int dcpt_conv_fwd(const float* x, const float* w, float* y, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
+                             int Cout, int ksize, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(x && w && y, "conv_fwd: null argument");
+    DCPT_CHECK_ARG((ksize == 1 || ksize == 3) && Cin % 4 == 0 && Cout % 4 == 0, "conv_fwd: ksize=%d Cin=%d Cout=%d", ksize, Cin, Cout);
+    ConvWs cw;
+    const size_t need = conv_layout(B, H, W, Cin, Cout, ksize, 0, false, ws, ws_bytes, &cw);
+    if (ws == nullptr || need > ws_bytes) {
+        dcpt_set_error("conv_fwd: workspace too small");
+        return DCPT_ERR_WS;
+    }
+    return conv_fwd(x, w, y, cw, B, H, W, Cin, Cout, ksize, (hipStream_t)stream);
+}
+
+extern "C" int dcpt_conv_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, void* ws, size_t ws_bytes,
+                             int B, int H, int W, int Cin, int Cout, int ksize, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(dy && x && w && dw, "conv_bwd: null argument");
+    DCPT_CHECK_ARG((ksize == 1 || ksize == 3) && Cin % 4 == 0 && Cout % 4 == 0, "conv_bwd: bad shape");
+    ConvWs cw;
+    const size_t need = conv_layout(B, H, W, Cin, Cout, ksize, 1, false, ws, ws_bytes, &cw);
+    if (ws == nullptr || need > ws_bytes) {
+        dcpt_set_error("conv_bwd: workspace too small");
+        return DCPT_ERR_WS;
+    }
+    return conv_bwd(dy, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, (hipStream_t)stream);
+}
+
 extern "C" size_t dcpt_conv1x1_pool_relu_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward) {
     return conv_layout(B, H, W, Cin, Cout, 1, backward, false, nullptr, 0, nullptr);
 }

@@ -50,12 +50,21 @@ struct DwP {
     float* out;         // fwd: t2 [M][C]; bwd_a: da [M][2C]; bwd_b: dt1 [M][2C]
     float* part;        // fwd: pool_part [B][NBLK][C]; bwd_b: wpart [B*NBLK][10][2C]
     int B, H, W, C;
+    int Ctot;  // bwd_b / plain: total channel count of the depthwise conv
 };
+
+__device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float a) {
+    return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.39894228040143268f * expf(-0.5f * a * a);
+}
+__device__ __forceinline__ float4 gelu4(float4 a) { return make_float4(gelu_f(a.x), gelu_f(a.y), gelu_f(a.z), gelu_f(a.w)); }
+__device__ __forceinline__ float4 gelu_d4(float4 a) { return make_float4(gelu_df(a.x), gelu_df(a.y), gelu_df(a.z), gelu_df(a.w)); }
 
 __device__ __forceinline__ float4 ld_or_zero(const float* p, bool ok) { return ok ? ldg4(p) : f4_zero(); }
 
 // MODE 0: forward (t2 + pool partials);  MODE 1: backward-a (da)
-template <int MODE>
+// GATE 0: SimpleGate g1*g2 (NAFNet);  GATE 1: gelu(g1)*g2 (Restormer GDFN, exact erf GELU)
+template <int MODE, int GATE>
 __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
     __shared__ float4 red[256];
     const DwMap mp = dw_map(p.H, p.W, p.C / 4);
@@ -73,12 +82,12 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
         w1[t] = ld_or_zero(p.w2p + t * C2 + c1, qok);
         w2[t] = ld_or_zero(p.w2p + t * C2 + c2, qok);
     }
-    if (qok) {
+    if (qok && p.b2) {
         bias1 = ldg4(p.b2 + c1);
         bias2 = ldg4(p.b2 + c2);
     }
-    float4 sv = f4_zero(), dpv = f4_zero();
-    if (MODE == 1 && qok) {
+    float4 sv = make_float4(1.f, 1.f, 1.f, 1.f), dpv = f4_zero();
+    if (MODE == 1 && qok && p.simg) {
         sv = ldg4(p.simg + (int64_t)b * C + c1);
         dpv = ldg4(p.dpool + (int64_t)b * C + c1);
     }
@@ -119,21 +128,26 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
                 const float4 g1 = f4_add(a0_1, bias1), g2 = f4_add(a0_2, bias2);
                 const int64_t pix = ((int64_t)b * p.H + y) * p.W + x;
                 if (MODE == 0) {
-                    const float4 t = f4_mul(g1, g2);
+                    const float4 t = f4_mul(GATE == 0 ? g1 : gelu4(g1), g2);
                     stg4(p.out + pix * C + c1, t);
                     pool = f4_add(pool, t);
                 } else {
                     const float4 dts = ldg4(p.in1 + pix * C + c1);
                     const float4 dt2 = f4_fma(dts, sv, dpv);
-                    stg4(p.out + pix * C2 + c1, f4_mul(dt2, g2));
-                    stg4(p.out + pix * C2 + c2, f4_mul(dt2, g1));
+                    if (GATE == 0) {
+                        stg4(p.out + pix * C2 + c1, f4_mul(dt2, g2));
+                        stg4(p.out + pix * C2 + c2, f4_mul(dt2, g1));
+                    } else {
+                        stg4(p.out + pix * C2 + c1, f4_mul(f4_mul(dt2, g2), gelu_d4(g1)));
+                        stg4(p.out + pix * C2 + c2, f4_mul(dt2, gelu4(g1)));
+                    }
                 }
             }
             a0_1 = a1_1; a0_2 = a1_2;
             a1_1 = a2_1; a1_2 = a2_2;
         }
     }
-    if (MODE == 0) {
+    if (MODE == 0 && p.part != nullptr) {
         red[tid] = pool;
         __syncthreads();
         if (pl == 0 && qok) {
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
 // Thread = one quad of the 2C channels.
 __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
     __shared__ float4 red[256];
-    const int C2 = 2 * p.C;
+    const int C2 = p.Ctot;
     const DwMap mp = dw_map(p.H, p.W, C2 / 4);
     const int tid = threadIdx.x;
     const int ql = tid % mp.QB, pl = tid / mp.QB;
@@ -225,6 +239,58 @@ __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
     }
 }
 
+// Plain depthwise 3x3 (no bias, no gate) over Ctot channels (Restormer MDTA qkv_dwconv), plus per-block partial
+// sums of out^2 for the first nsq channels (the L2 norms of q and k over the pixels).
+__global__ __launch_bounds__(256) void dw_plain_kernel(const DwP p, int nsq) {
+    __shared__ float4 red[256];
+    const int C = p.Ctot;
+    const DwMap mp = dw_map(p.H, p.W, C / 4);
+    const int tid = threadIdx.x;
+    const int ql = tid % mp.QB, pl = tid / mp.QB;
+    const int q = blockIdx.x * mp.QB + ql;
+    const int b = blockIdx.z;
+    const bool qok = q < mp.QW;
+    const int c0 = 4 * q;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = ld_or_zero(p.w2p + t * C + c0, qok);
+    float4 sq = f4_zero();
+    for (int item = blockIdx.y; item < mp.items; item += gridDim.y) {
+        const int band = item / mp.nwc, wc = item % mp.nwc;
+        const int x = wc * mp.PB + pl;
+        const bool ok = qok && x < p.W;
+        const int h0 = band * RH;
+        const int h1 = (h0 + RH < p.H) ? h0 + RH : p.H;
+        float4 a0 = f4_zero(), a1 = f4_zero();
+        for (int r = h0 - 1; r <= h1; ++r) {
+            const bool rin = ok && r >= 0 && r < p.H;
+            const float* pc = p.in0 + (((int64_t)b * p.H + r) * p.W + x) * C + c0;
+            const float4 xl = ld_or_zero(pc - C, rin && x > 0);
+            const float4 xc = ld_or_zero(pc, rin);
+            const float4 xr = ld_or_zero(pc + C, rin && x + 1 < p.W);
+            a0 = f4_fma(w[6], xl, f4_fma(w[7], xc, f4_fma(w[8], xr, a0)));
+            a1 = f4_fma(w[3], xl, f4_fma(w[4], xc, f4_fma(w[5], xr, a1)));
+            const float4 a2 = f4_fma(w[0], xl, f4_fma(w[1], xc, f4_mul(w[2], xr)));
+            const int y = r - 1;
+            if (ok && y >= h0) {
+                stg4(p.out + (((int64_t)b * p.H + y) * p.W + x) * C + c0, a0);
+                sq = f4_fma(a0, a0, sq);
+            }
+            a0 = a1;
+            a1 = a2;
+        }
+    }
+    if (p.part != nullptr) {
+        red[tid] = sq;
+        __syncthreads();
+        if (pl == 0 && qok && c0 < nsq) {
+            float4 s = red[ql];
+            for (int j = 1; j < mp.PB; ++j) s = f4_add(s, red[j * mp.QB + ql]);
+            stg4(p.part + ((int64_t)b * gridDim.y + blockIdx.y) * nsq + c0, s);
+        }
+    }
+}
+
 __global__ void dw_pack_kernel(const float* __restrict__ w2, float* __restrict__ w2p, int C2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C2 * 9) {
@@ -280,7 +346,7 @@ int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2,
     p.in0 = t1; p.w2p = w2p; p.b2 = b2; p.out = t2; p.part = pool_part;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
     const DwMap mp = dw_map(g.H, g.W, g.C / 4);
-    dw_gate_kernel<0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p);
+    dw_gate_kernel<0, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("dw_fwd");
     return DCPT_OK;
 }
@@ -292,7 +358,7 @@ int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const f
     p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = da;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
     const DwMap mp = dw_map(g.H, g.W, g.C / 4);
-    dw_gate_kernel<1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p);
+    dw_gate_kernel<1, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("dw_bwd_a");
     return DCPT_OK;
 }
@@ -302,10 +368,61 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd_b: C=%d must be a multiple of 4", g.C);
     DwP p{};
     p.in0 = da; p.in1 = t1; p.w2p = w2p; p.out = dt1; p.part = wpart;
-    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
+    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.Ctot = 2 * g.C;
     const DwMap mp = dw_map(g.H, g.W, g.C / 2);
     dw_bwd_b_kernel<<<dim3(mp.nqc, dw_num_blocks_per_image_b(g), g.B), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("dw_bwd_b");
+    return DCPT_OK;
+}
+
+// ---- generic entry points used by the Restormer blocks ---------------------------------------------
+int dw_num_blocks_generic(int B, int H, int W, int Ctot) {
+    DwGeom g{B, H, W, Ctot};
+    return nblk_for(g, Ctot / 4);
+}
+
+int launch_dw_gelu_fwd(const float* u, const float* w2p, float* t, int B, int H, int W, int Ch, hipStream_t s) {
+    DCPT_CHECK_ARG(Ch % 4 == 0 && B <= 65535, "dw_gelu_fwd: Ch=%d must be a multiple of 4", Ch);
+    DwP p{};
+    p.in0 = u; p.w2p = w2p; p.out = t; p.B = B; p.H = H; p.W = W; p.C = Ch;
+    DwGeom g{B, H, W, Ch};
+    const DwMap mp = dw_map(H, W, Ch / 4);
+    dw_gate_kernel<0, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("dw_gelu_fwd");
+    return DCPT_OK;
+}
+
+int launch_dw_gelu_bwd_a(const float* dt, const float* u, const float* w2p, float* da, int B, int H, int W, int Ch, hipStream_t s) {
+    DCPT_CHECK_ARG(Ch % 4 == 0 && B <= 65535, "dw_gelu_bwd_a: Ch=%d must be a multiple of 4", Ch);
+    DwP p{};
+    p.in0 = u; p.in1 = dt; p.w2p = w2p; p.out = da; p.B = B; p.H = H; p.W = W; p.C = Ch;
+    DwGeom g{B, H, W, Ch};
+    const DwMap mp = dw_map(H, W, Ch / 4);
+    dw_gate_kernel<1, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("dw_gelu_bwd_a");
+    return DCPT_OK;
+}
+
+int launch_dw_plain_fwd(const float* x, const float* w2p, float* y, float* sq_part, int nsq, int B, int H, int W, int Ctot,
+                        hipStream_t s) {
+    DCPT_CHECK_ARG(Ctot % 4 == 0 && nsq % 4 == 0 && B <= 65535, "dw_plain_fwd: Ctot=%d", Ctot);
+    DwP p{};
+    p.in0 = x; p.w2p = w2p; p.out = y; p.part = sq_part; p.B = B; p.H = H; p.W = W; p.Ctot = Ctot;
+    const DwMap mp = dw_map(H, W, Ctot / 4);
+    dw_plain_kernel<<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p, nsq);
+    DCPT_CHECK_LAUNCH("dw_plain_fwd");
+    return DCPT_OK;
+}
+
+// dx = dw^T(dy) over Ctot channels, wpart[B*nblk][10][Ctot] (nblk = dw_num_blocks_generic)
+int launch_dw_generic_bwd(const float* dy, const float* x, const float* w2p, float* dx, float* wpart, int B, int H, int W, int Ctot,
+                          hipStream_t s) {
+    DCPT_CHECK_ARG(Ctot % 4 == 0 && B <= 65535, "dw_generic_bwd: Ctot=%d", Ctot);
+    DwP p{};
+    p.in0 = dy; p.in1 = x; p.w2p = w2p; p.out = dx; p.part = wpart; p.B = B; p.H = H; p.W = W; p.Ctot = Ctot;
+    const DwMap mp = dw_map(H, W, Ctot / 4);
+    dw_bwd_b_kernel<<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("dw_generic_bwd");
     return DCPT_OK;
 }
 

@@ -8,8 +8,8 @@
 #pragma once
 #include "dcpt_common.h"
 
-enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5 };
-enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5 };
+enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5, A_LNBF = 6 };
+enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6 };
 
 struct GemmNT {
     const float* A;   // [M][lda]   (A_SG: 2K columns; A_GATHER: fine NHWC image, see g*)
@@ -18,7 +18,7 @@ struct GemmNT {
     int64_t M;
     int N, K;
     int lda, ldc;
-    // A_LN: a = (x - mu[m]) * rstd[m] * lnw[k] + lnb[k]
+    // A_LN: a = (x - mu[m]) * rstd[m] * lnw[k] + lnb[k];   A_LNBF (Restormer BiasFree): a = x * rstd[m] * lnw[k]
     const float* mu;
     const float* rstd;
     const float* lnw;
@@ -32,10 +32,14 @@ struct GemmNT {
     // column index = tap * gC + ch, tap = 3*ky + kx  <->  pixel (h+ky-1, w+kx-1)
     int gH, gW, gC;
     // epilogues
-    const float* bias;    // [N]
-    const float* res;     // E_RESID: [M][ldc]; E_SCATTER_ADD: fine image like C
-    const float* cscale;  // E_RESID: [N]
+    const float* bias;    // [N] (may be null)
+    const float* res;     // E_RESID / E_ADDSCALED: [M][ldres]; E_SCATTER_ADD: fine image like C
+    const float* cscale;  // E_RESID: C = res + (acc+bias)*cscale[n] (null = 1); E_ADDSCALED: C = acc + cscale[n]*res
     const float* aux;     // E_SGBWD: v [M][2N]
+    int ldres;            // row stride of res (0 = ldc)
+    // batching: grid.y = nb1*nb2 problems; pointer offsets b1*s?1 + b2*s?2 (elements)
+    int nb1, nb2;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sS1, sS2;
 };
 
 int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t stream);
@@ -43,7 +47,7 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t stream);
 struct GemmTN {
     const float* X;  // [M][ldx]  -> rows of G (n index)
     const float* Y;  // [M][ldy]  -> cols of G (k index)
-    float* slab;     // [splits][N][K]
+    float* slab;     // [batch][splits][N][K]
     float* colsum;   // [splits * gemm_tn_tiles_k(N, K)][N] partial column sums of X' (may be null)
     int64_t M;
     int N, K;
@@ -58,6 +62,9 @@ struct GemmTN {
     const float* simg;
     int P;
     int gH, gW, gC;  // gather geometry for whichever operand is gathered
+    // batching: grid.y = nb1*nb2 problems; X/Y offsets b1*s?1 + b2*s?2; slab of batch z at z*splits*N*K
+    int nb1, nb2;
+    int64_t sX1, sX2, sY1, sY2;
 };
 
 // xload in {A_PLAIN, A_GATHER}; yload any GemmALoad kind

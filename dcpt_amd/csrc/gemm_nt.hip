@@ -24,6 +24,7 @@ constexpr int LDS_LD = BK + 4;
 // issued before the LDS round trip so their latency overlaps it.
 template <int EK, int BM, int BN>
 __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0, int tid) {
+    const int ldres = p.ldres ? p.ldres : p.ldc;
     constexpr int LDC = BN + 4;
     constexpr int Q = BN / 4;          // float4 groups per row
     constexpr int RPP = 256 / Q;       // rows per pass
@@ -35,7 +36,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     if constexpr (EK == E_BIAS || EK == E_RESID) {
         if (p.bias) bias = ldg4(p.bias + n);
     }
-    if constexpr (EK == E_RESID) cs = ldg4(p.cscale + n);
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
+        if (p.cscale) cs = ldg4(p.cscale + n);
+    }
     int si = 0, sj = 0, ch = 0;
     if constexpr (EK == E_SCATTER || EK == E_SCATTER_ADD) {
         const int ij = n / p.gC;
@@ -55,9 +58,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
             const bool ok = m < p.M;
             pre1[it] = f4_zero();
             pre2[it] = f4_zero();
-            if constexpr (EK == E_RESID) {
+            if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
                 addr[it] = m * p.ldc + n;
-                if (ok) pre1[it] = ldg4(p.res + addr[it]);
+                if (ok) pre1[it] = ldg4(p.res + m * ldres + n);
             } else if constexpr (EK == E_SGBWD) {
                 addr[it] = m * p.ldc + n;
                 if (ok) {
@@ -90,6 +93,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 stg4(p.C + addr[it], f4_add(v, bias));
             } else if constexpr (EK == E_RESID) {
                 stg4(p.C + addr[it], f4_fma(f4_add(v, bias), cs, pre1[it]));
+            } else if constexpr (EK == E_ADDSCALED) {
+                stg4(p.C + addr[it], f4_fma(cs, pre1[it], v));
             } else if constexpr (EK == E_SGBWD) {
                 stg4(p.C + addr[it], f4_mul(v, pre2[it]));
                 stg4(p.C + addr[it] + p.N, f4_mul(v, pre1[it]));
@@ -101,8 +106,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
 }
 
 template <int BM, int BN, int WM, int WN, int AK, int EK>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT pin) {
     static_assert(WM * WN == 4, "4 waves");
+    GemmNT p = pin;
+    if (gridDim.y > 1) {  // batched: shift the base pointers of this problem
+        const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
+        p.A += b1 * p.sA1 + b2 * p.sA2;
+        p.Bw += b1 * p.sB1 + b2 * p.sB2;
+        p.C += b1 * p.sC1 + b2 * p.sC2;
+        if (p.res) p.res += b1 * p.sR1 + b2 * p.sR2;
+        if (p.cscale) p.cscale += b1 * p.sS1 + b2 * p.sS2;
+    }
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD;
@@ -212,14 +226,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 
 template <int AK, int EK>
 int launch_cfg(const GemmNT& p, hipStream_t s) {
+    const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     if (p.N <= 64) {
         constexpr int BM = 128, BN = 64;
         const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
-        gemm_nt_kernel<BM, BN, 4, 1, AK, EK><<<dim3((unsigned)tiles), dim3(256), 0, s>>>(p);
+        gemm_nt_kernel<BM, BN, 4, 1, AK, EK><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
     } else {
         constexpr int BM = 128, BN = 128;
         const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
-        gemm_nt_kernel<BM, BN, 2, 2, AK, EK><<<dim3((unsigned)tiles), dim3(256), 0, s>>>(p);
+        gemm_nt_kernel<BM, BN, 2, 2, AK, EK><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
     }
     DCPT_CHECK_LAUNCH("gemm_nt");
     return DCPT_OK;
@@ -227,7 +242,10 @@ int launch_cfg(const GemmNT& p, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
+int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
+    GemmNT p = pin;
+    if (p.nb1 < 1) p.nb1 = 1;
+    if (p.nb2 < 1) p.nb2 = 1;
     DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)p.M, p.N, p.K);
     DCPT_CHECK_ARG(p.K % 4 == 0, "gemm_nt: K=%d must be a multiple of 4", p.K);
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 64) < (1ll << 31), "gemm_nt: grid too large");
@@ -237,7 +255,8 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : 1) + (double)p.N * p.K;
     if (epi == E_RESID || epi == E_SCATTER_ADD) bytes += mn;
-    ProfScope prof(s, PROF_NT + aload * 8 + epi, p.M, p.N, p.K, 2.0 * mn * p.K, bytes * 4.0);
+    const double nbat = (double)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
+    ProfScope prof(s, PROF_NT + aload * 8 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
 #define CASE(AK, EK) \
     if (aload == AK && epi == EK) return launch_cfg<AK, EK>(p, s);
     CASE(A_LN, E_BIAS)
@@ -251,6 +270,10 @@ int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_SCATTER_ADD)
     CASE(A_GATHER, E_PLAIN)
     CASE(A_CONV3, E_PLAIN)
+    CASE(A_LNBF, E_PLAIN)
+    CASE(A_LN, E_PLAIN)
+    CASE(A_PLAIN, E_RESID)
+    CASE(A_PLAIN, E_ADDSCALED)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

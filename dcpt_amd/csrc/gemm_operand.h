@@ -51,6 +51,7 @@ __device__ __forceinline__ void make_row(const Operand& o, int64_t m, RowCtx& rc
         rc.mu = o.mu[mm];
         rc.rstd = o.rstd[mm];
     }
+    if constexpr (KIND == A_LNBF) rc.rstd = o.rstd[mm];
     if constexpr (KIND == A_SCALE) rc.img = (int)(mm / o.P);
 }
 
@@ -70,6 +71,9 @@ __device__ __forceinline__ void load_raw(const Operand& o, const RowCtx& rc, int
         r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
         r.b = ok ? ldg4(o.lnw + c) : f4_zero();
         r.c = ok ? ldg4(o.lnb + c) : f4_zero();
+    } else if constexpr (KIND == A_LNBF) {
+        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
+        r.b = ok ? ldg4(o.lnw + c) : f4_zero();
     } else if constexpr (KIND == A_SCALE) {
         r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
         r.b = ok ? ldg4(o.simg + (int64_t)rc.img * o.ncols + c) : f4_zero();
@@ -108,6 +112,8 @@ __device__ __forceinline__ float4 finish(const RowCtx& rc, const RawVec& r) {
         o.z = fmaf((r.a.z - rc.mu) * rc.rstd, r.b.z, r.c.z);
         o.w = fmaf((r.a.w - rc.mu) * rc.rstd, r.b.w, r.c.w);
         return o;
+    } else if constexpr (KIND == A_LNBF) {
+        return make_float4(r.a.x * rc.rstd * r.b.x, r.a.y * rc.rstd * r.b.y, r.a.z * rc.rstd * r.b.z, r.a.w * rc.rstd * r.b.w);
     } else if constexpr (KIND == A_SCALE || KIND == A_SG) {
         return f4_mul(r.a, r.b);
     } else {

@@ -14,8 +14,15 @@ namespace {
 constexpr int BR = 32;  // reduction rows per LDS tile
 
 template <int BN, int BKo, int WN, int WK, int XK, int YK>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     static_assert(WN * WK == 4, "4 waves");
+    GemmTN p = pin;
+    if (gridDim.y > 1) {
+        const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
+        p.X += b1 * p.sX1 + b2 * p.sX2;
+        p.Y += b1 * p.sY1 + b2 * p.sY2;
+        p.slab += (int64_t)blockIdx.y * p.splits * p.N * p.K;
+    }
     constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
     constexpr int LDX = BN + 4, LDY = BKo + 4;
     constexpr int XQ = BN / 4, YQ = BKo / 4;           // float4 per tile row
@@ -150,18 +157,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 
 template <int XK, int YK>
 int launch_cfg(const GemmTN& p, hipStream_t s) {
+    const unsigned nbatch = (unsigned)(p.nb1 * p.nb2);
     if (p.N <= 64 && p.K <= 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 64);
-        gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
     } else if (p.K <= 64) {
         const int tiles = cdiv(p.N, 128) * cdiv(p.K, 64);
-        gemm_tn_kernel<128, 64, 4, 1, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<128, 64, 4, 1, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
     } else if (p.N <= 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 128);
-        gemm_tn_kernel<64, 128, 1, 4, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<64, 128, 1, 4, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
     } else {
         const int tiles = cdiv(p.N, 128) * cdiv(p.K, 128);
-        gemm_tn_kernel<128, 128, 2, 2, XK, YK><<<dim3(tiles * p.splits), dim3(256), 0, s>>>(p);
+        gemm_tn_kernel<128, 128, 2, 2, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
     }
     DCPT_CHECK_LAUNCH("gemm_tn");
     return DCPT_OK;
@@ -190,12 +198,17 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
     *splits = (int)cdiv64(M, rps);
 }
 
-int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t s) {
+int launch_gemm_tn(const GemmTN& pin, int xload, int yload, hipStream_t s) {
+    GemmTN p = pin;
+    if (p.nb1 < 1) p.nb1 = 1;
+    if (p.nb2 < 1) p.nb2 = 1;
+    DCPT_CHECK_ARG(p.nb1 * p.nb2 == 1 || p.colsum == nullptr, "gemm_tn: column sums are not supported for batched problems");
     DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_tn: empty problem");
     DCPT_CHECK_ARG(p.N % 4 == 0 && p.K % 4 == 0, "gemm_tn: N=%d, K=%d must be multiples of 4", p.N, p.K);
     DCPT_CHECK_ARG(p.splits >= 1 && p.splits <= 65535 && p.rows_per_split % 32 == 0, "gemm_tn: bad split plan");
     const double bytes = (double)p.M * p.N + (double)p.M * p.K * (yload == A_SG ? 2 : 1) + (double)p.splits * p.N * p.K;
-    ProfScope prof(s, PROF_TN + xload * 8 + yload, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K, bytes * 4.0);
+    ProfScope prof(s, PROF_TN + xload * 8 + yload, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K * p.nb1 * p.nb2,
+                   bytes * 4.0 * p.nb1 * p.nb2);
 #define CASE(XK, YK) \
     if (xload == XK && yload == YK) return launch_cfg<XK, YK>(p, s);
     CASE(A_PLAIN, A_PLAIN)
@@ -205,6 +218,7 @@ int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t s) {
     CASE(A_PLAIN, A_GATHER)
     CASE(A_GATHER, A_PLAIN)
     CASE(A_PLAIN, A_CONV3)
+    CASE(A_PLAIN, A_LNBF)
 #undef CASE
     dcpt_set_error("gemm_tn: unsupported loader combination %d/%d", xload, yload);
     return DCPT_ERR_ARG;

@@ -13,6 +13,10 @@ int launch_ln_act_fwd(const float* x, const float* w, const float* b, const floa
 // as launch_ln_bwd, with the incoming gradient first masked by (ymask > 0) and optionally copied to gmasked
 int launch_ln_act_bwd(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
                       const float* ymask, float* gmasked, float* dx, float* part, int nblk, int64_t M, int C, hipStream_t s);
+// general form: biasfree = 1 selects Restormer's BiasFree_LayerNorm backward (part row 1 is then meaningless)
+int launch_ln_bwd_ex(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
+                     const float* ymask, float* gmasked, int biasfree, float* dx, float* part, int nblk, int64_t M, int C,
+                     hipStream_t s);
 // dx = LN-backward(gy; x, mu, rstd, w) (+ dres if non-null).  Column sums go to part[nblk][3][C]
 // (0: sum gy*xhat, 1: sum gy, 2: sum dx_total); returns nblk through *nblk_out.
 int ln_bwd_num_blocks(int64_t M, int C);
@@ -39,6 +43,18 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
                     hipStream_t s);
 // dw2[ch*9+tap] and db2[ch] from wpart[R][10][C2]
 int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float* db2, hipStream_t s);
+
+// generic depthwise pieces (Restormer): w2p is the [9][Ctot] packed weight (launch_dw_pack_weights)
+int dw_num_blocks_generic(int B, int H, int W, int Ctot);
+// t[M][Ch] = gelu(dw(u)[:, :Ch]) * dw(u)[:, Ch:]   (u has 2*Ch channels, no bias)
+int launch_dw_gelu_fwd(const float* u, const float* w2p, float* t, int B, int H, int W, int Ch, hipStream_t s);
+int launch_dw_gelu_bwd_a(const float* dt, const float* u, const float* w2p, float* da, int B, int H, int W, int Ch, hipStream_t s);
+// y = dw(x) over Ctot channels; sq_part[B][nblk][nsq] partial sums of y^2 for the first nsq channels (may be null)
+int launch_dw_plain_fwd(const float* x, const float* w2p, float* y, float* sq_part, int nsq, int B, int H, int W, int Ctot,
+                        hipStream_t s);
+// dx = dw^T(dy); wpart[B*nblk][10][Ctot] partials of the tap gradients (rows 0..8) -- reduce with launch_dw_wgrad_reduce
+int launch_dw_generic_bwd(const float* dy, const float* x, const float* w2p, float* dx, float* wpart, int B, int H, int W, int Ctot,
+                          hipStream_t s);
 
 // ---- misc.hip -----------------------------------------------------------------------------
 // pooled[b][k] = (sum_blk pool_part[b][blk][k]) / P ;  s[b][n] = sum_k Wsca[n][k]*pooled[b][k] + bsca[n]

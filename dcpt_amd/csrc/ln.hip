@@ -74,6 +74,7 @@ struct LnBwdP {
     int64_t M;
     int C, G;
     int64_t iters;
+    int biasfree;  // Restormer BiasFree_LayerNorm: y = x * rstd * w (variance about the mean, numerator not centred)
 };
 
 template <int NQ>
@@ -116,11 +117,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
                 xh[j] = f4_zero();
             }
             const float4 gw = f4_mul(g[j], w[j]);
-            s1 += f4_sum(gw);
-            s2 += f4_sum(f4_mul(gw, xh[j]));
+            if (p.biasfree) {
+                // s2 = mean_c(gw * x * rstd);  x*rstd = xhat + mu*rstd
+                const float mr = mean * rs;
+                const float4 xr = make_float4(xh[j].x + mr, xh[j].y + mr, xh[j].z + mr, xh[j].w + mr);
+                s2 += (valid && q < nq) ? f4_sum(f4_mul(gw, xr)) : 0.f;
+            } else {
+                s1 += f4_sum(gw);
+                s2 += f4_sum(f4_mul(gw, xh[j]));
+            }
         }
-        s1 = group_sum(s1, G) * invC;  // mean_c(g)
-        s2 = group_sum(s2, G) * invC;  // mean_c(g * xhat)
+        s1 = group_sum(s1, G) * invC;  // mean_c(g)            (0 for BiasFree)
+        s2 = group_sum(s2, G) * invC;  // mean_c(g * xhat)     (BiasFree: mean_c(g * x * rstd))
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int q = lig + j * G;
@@ -133,7 +141,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
                 d.w = rs * (gw.w - xh[j].w * s2 - s1);
                 if (p.dres) d = f4_add(d, ldg4(p.dres + ro + 4 * q));
                 stg4(p.dx + ro + 4 * q, d);
-                aw[j] = f4_fma(g[j], xh[j], aw[j]);
+                if (p.biasfree) {
+                    const float mr = mean * rs;
+                    aw[j] = f4_fma(g[j], make_float4(xh[j].x + mr, xh[j].y + mr, xh[j].z + mr, xh[j].w + mr), aw[j]);
+                } else {
+                    aw[j] = f4_fma(g[j], xh[j], aw[j]);
+                }
                 ab[j] = f4_add(ab[j], g[j]);
                 ad[j] = f4_add(ad[j], d);
             }
@@ -221,8 +234,15 @@ int launch_ln_bwd(const float* gy, const float* x, const float* mu, const float*
 
 int launch_ln_act_bwd(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
                       const float* ymask, float* gmasked, float* dx, float* part, int nblk, int64_t M, int C, hipStream_t s) {
+    return launch_ln_bwd_ex(gy, x, mu, rstd, w, dres, ymask, gmasked, 0, dx, part, nblk, M, C, s);
+}
+
+int launch_ln_bwd_ex(const float* gy, const float* x, const float* mu, const float* rstd, const float* w, const float* dres,
+                     const float* ymask, float* gmasked, int biasfree, float* dx, float* part, int nblk, int64_t M, int C,
+                     hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of 4, <= 2048", C);
     LnBwdP p;
+    p.biasfree = biasfree;
     p.ymask = ymask; p.gmasked = gmasked;
     p.gy = gy; p.x = x; p.mu = mu; p.rstd = rstd; p.w = w; p.dres = dres; p.dx = dx; p.part = part;
     p.M = M; p.C = C; p.G = ln_group(C);

@@ -554,3 +554,243 @@ class _MeanPoolFCFn(torch.autograd.Function):
 
 def meanpool_fc(x, fw, fb):
     return _MeanPoolFCFn.apply(x, fw, fb)
+
+
+# ------------------------------------------------------------------------------------------------
+# Restormer pieces (reference basicsr/archs/restormer_arch.py)
+from ._lib import GdfnParams, GdfnSaved, MdtaParams, MdtaSaved  # noqa: E402
+
+
+class _ConvFn(torch.autograd.Function):
+    """bias-free conv (1x1 or dense 3x3 / pad 1), NHWC -> NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        _require_gpu(x, weight)
+        x = _nhwc(x)
+        w_ = _contig(weight.detach())
+        B, Cin, H, W = x.shape
+        Cout, ks = w_.shape[0], w_.shape[2]
+        dev = x.device
+        y = _empty_nhwc(B, Cout, H, W, dev)
+        ws = _workspace(dev, lib.dcpt_conv_ws_bytes(B, H, W, Cin, Cout, ks, 0))
+        check(lib.dcpt_conv_fwd(x.data_ptr(), w_.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks,
+                                _stream(dev)), "dcpt_conv_fwd")
+        ctx.save_for_backward(x, w_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        dy = _nhwc(dy)
+        B, Cin, H, W = x.shape
+        Cout, ks = w_.shape[0], w_.shape[2]
+        dev = x.device
+        dx = _empty_nhwc(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        ws = _workspace(dev, lib.dcpt_conv_ws_bytes(B, H, W, Cin, Cout, ks, 1))
+        check(lib.dcpt_conv_bwd(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)), "dcpt_conv_bwd")
+        return dx, dw
+
+
+def conv_nobias(x, weight):
+    return _ConvFn.apply(x, weight)
+
+
+class _PixelUnshuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        _require_gpu(x)
+        x = _nhwc(x)
+        B, Cc, H, W = x.shape
+        y = _empty_nhwc(B, 4 * Cc, H // 2, W // 2, x.device)
+        check(lib.dcpt_pixel_unshuffle(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _stream(x.device)), "dcpt_pixel_unshuffle")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _nhwc(dy)
+        B, C4, H, W = dy.shape
+        dx = _empty_nhwc(B, C4 // 4, 2 * H, 2 * W, dy.device)
+        check(lib.dcpt_pixel_shuffle(dy.data_ptr(), dx.data_ptr(), B, H, W, C4, _stream(dy.device)), "dcpt_pixel_shuffle")
+        return dx
+
+
+class _PixelShuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        _require_gpu(x)
+        x = _nhwc(x)
+        B, C4, H, W = x.shape
+        y = _empty_nhwc(B, C4 // 4, 2 * H, 2 * W, x.device)
+        check(lib.dcpt_pixel_shuffle(x.data_ptr(), y.data_ptr(), B, H, W, C4, _stream(x.device)), "dcpt_pixel_shuffle")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _nhwc(dy)
+        B, Cc, H, W = dy.shape
+        dx = _empty_nhwc(B, 4 * Cc, H // 2, W // 2, dy.device)
+        check(lib.dcpt_pixel_unshuffle(dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _stream(dy.device)), "dcpt_pixel_unshuffle")
+        return dx
+
+
+def pixel_unshuffle2(x):
+    return _PixelUnshuffleFn.apply(x)
+
+
+def pixel_shuffle2(x):
+    return _PixelShuffleFn.apply(x)
+
+
+class _ConcatFn(torch.autograd.Function):
+    """torch.cat([a, b], 1) on NHWC maps."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        _require_gpu(a, b)
+        a, b = _nhwc(a), _nhwc(b)
+        B, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        out = _empty_nhwc(B, Ca + Cb, H, W, a.device)
+        check(lib.dcpt_concat_channels(a.data_ptr(), b.data_ptr(), out.data_ptr(), B * H * W, Ca, Cb, _stream(a.device)),
+              "dcpt_concat_channels")
+        ctx.dims = (Ca, Cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        dout = _nhwc(dout)
+        Ca, Cb = ctx.dims
+        B, _, H, W = dout.shape
+        da, db = _empty_nhwc(B, Ca, H, W, dout.device), _empty_nhwc(B, Cb, H, W, dout.device)
+        check(lib.dcpt_split_channels(dout.data_ptr(), da.data_ptr(), db.data_ptr(), B * H * W, Ca, Cb, _stream(dout.device)),
+              "dcpt_split_channels")
+        return da, db
+
+
+def concat_channels(a, b):
+    return _ConcatFn.apply(a, b)
+
+
+class _MDTAFn(torch.autograd.Function):
+    """x + project_out(attn(LN(x)))  (restormer_arch.py:103-145, :156-157)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree):
+        lib = _lib.load()
+        _require_gpu(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature)
+        x = _nhwc(x)
+        ps = [None if t is None else _contig(t.detach()) for t in (norm_w, norm_b, qkv_w, dw_w, proj_w, temperature)]
+        B, Cc, H, W = x.shape
+        dev = x.device
+        M, ch = B * H * W, Cc // heads
+        y = _empty_nhwc(B, Cc, H, W, dev)
+        stats = torch.empty((2, M), dtype=torch.float32, device=dev)
+        qkv1 = _empty_nhwc(B, 3 * Cc, H, W, dev)
+        qkv = _empty_nhwc(B, 3 * Cc, H, W, dev)
+        nrm = torch.empty((B, 2 * Cc), dtype=torch.float32, device=dev)
+        att = torch.empty((3, B, heads, ch, ch), dtype=torch.float32, device=dev)
+        out_att = _empty_nhwc(B, Cc, H, W, dev)
+        sv = MdtaSaved(stats[0].data_ptr(), stats[1].data_ptr(), qkv1.data_ptr(), qkv.data_ptr(), nrm.data_ptr(),
+                       att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), out_att.data_ptr())
+        pp = MdtaParams(*[_p(t) for t in ps])
+        ws = _workspace(dev, lib.dcpt_mdta_ws_bytes(B, H, W, Cc, heads, 0))
+        check(lib.dcpt_mdta_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
+                                heads, int(biasfree), _stream(dev)), "dcpt_mdta_fwd")
+        ctx.save_for_backward(x, stats, qkv1, qkv, nrm, att, out_att, *[t for t in ps if t is not None])
+        ctx.has_bias = ps[1] is not None
+        ctx.heads, ctx.biasfree = heads, bool(biasfree)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, qkv1, qkv, nrm, att, out_att, *ps = ctx.saved_tensors
+        if ctx.has_bias:
+            norm_w, norm_b, qkv_w, dw_w, proj_w, temp = ps
+        else:
+            norm_w, qkv_w, dw_w, proj_w, temp = ps
+            norm_b = None
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = _empty_nhwc(B, Cc, H, W, dev)
+        plist = [norm_w, norm_b, qkv_w, dw_w, proj_w, temp]
+        grads = [None if t is None else torch.empty_like(t) for t in plist]
+        sv = MdtaSaved(stats[0].data_ptr(), stats[1].data_ptr(), qkv1.data_ptr(), qkv.data_ptr(), nrm.data_ptr(),
+                       att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), out_att.data_ptr())
+        pp = MdtaParams(*[_p(t) for t in plist])
+        gg = MdtaParams(*[_p(t) for t in grads])
+        ws = _workspace(dev, lib.dcpt_mdta_ws_bytes(B, H, W, Cc, ctx.heads, 1))
+        check(lib.dcpt_mdta_bwd(C.byref(pp), C.byref(gg), x.data_ptr(), C.byref(sv), dy.data_ptr(), dx.data_ptr(), ws.data_ptr(),
+                                ws.numel(), B, H, W, Cc, ctx.heads, int(ctx.biasfree), _stream(dev)), "dcpt_mdta_bwd")
+        return (dx, *grads, None, None)
+
+
+def mdta(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree):
+    return _MDTAFn.apply(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree)
+
+
+class _GDFNFn(torch.autograd.Function):
+    """x + project_out(gelu(x1) * x2)  (restormer_arch.py:75-100, :158)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, in_w, dw_w, out_w, biasfree):
+        lib = _lib.load()
+        _require_gpu(x, norm_w, norm_b, in_w, dw_w, out_w)
+        x = _nhwc(x)
+        ps = [None if t is None else _contig(t.detach()) for t in (norm_w, norm_b, in_w, dw_w, out_w)]
+        B, Cc, H, W = x.shape
+        dev = x.device
+        M = B * H * W
+        hidden = ps[4].shape[1]
+        hp = (hidden + 3) // 4 * 4
+        y = _empty_nhwc(B, Cc, H, W, dev)
+        stats = torch.empty((2, M), dtype=torch.float32, device=dev)
+        u = _empty_nhwc(B, 2 * hp, H, W, dev)
+        t = _empty_nhwc(B, hp, H, W, dev)
+        sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), t.data_ptr())
+        pp = GdfnParams(*[_p(q) for q in ps])
+        ws = _workspace(dev, lib.dcpt_gdfn_ws_bytes(B, H, W, Cc, hidden, 0))
+        check(lib.dcpt_gdfn_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
+                                hidden, int(biasfree), _stream(dev)), "dcpt_gdfn_fwd")
+        ctx.save_for_backward(x, stats, u, t, *[q for q in ps if q is not None])
+        ctx.has_bias, ctx.biasfree, ctx.hidden = ps[1] is not None, bool(biasfree), hidden
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, u, t, *ps = ctx.saved_tensors
+        if ctx.has_bias:
+            norm_w, norm_b, in_w, dw_w, out_w = ps
+        else:
+            norm_w, in_w, dw_w, out_w = ps
+            norm_b = None
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = _empty_nhwc(B, Cc, H, W, dev)
+        plist = [norm_w, norm_b, in_w, dw_w, out_w]
+        grads = [None if q is None else torch.empty_like(q) for q in plist]
+        sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), t.data_ptr())
+        pp = GdfnParams(*[_p(q) for q in plist])
+        gg = GdfnParams(*[_p(q) for q in grads])
+        ws = _workspace(dev, lib.dcpt_gdfn_ws_bytes(B, H, W, Cc, ctx.hidden, 1))
+        check(lib.dcpt_gdfn_bwd(C.byref(pp), C.byref(gg), x.data_ptr(), C.byref(sv), dy.data_ptr(), dx.data_ptr(), ws.data_ptr(),
+                                ws.numel(), B, H, W, Cc, ctx.hidden, int(ctx.biasfree), _stream(dev)), "dcpt_gdfn_bwd")
+        return (dx, *grads, None)
+
+
+def gdfn(x, norm_w, norm_b, in_w, dw_w, out_w, biasfree):
+    return _GDFNFn.apply(x, norm_w, norm_b, in_w, dw_w, out_w, biasfree)

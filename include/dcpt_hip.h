@@ -152,6 +152,69 @@ int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float* fb, float
 int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, const float* fw, float* dx, float* dfw, float* dfb, void* ws,
                          size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream);
 
+/* plain conv (ksize 1 or dense 3x3 / pad 1, no bias), NHWC -> NHWC: Restormer Downsample/Upsample convs
+ * (restormer_arch.py:179-185,194-200) and reduce_chan_level{2,3} (:300-302,:315-317) */
+size_t dcpt_conv_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int backward);
+int dcpt_conv_fwd(const float* x, const float* w, float* y, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
+                  int ksize, dcpt_stream_t stream);
+int dcpt_conv_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, void* ws, size_t ws_bytes, int B, int H,
+                  int W, int Cin, int Cout, int ksize, dcpt_stream_t stream);
+
+/* ---- Restormer blocks (basicsr/archs/restormer_arch.py) -------------------------------------------------
+ * MDTA half of a TransformerBlock (:148-159 with Attention :103-145):  y = x + project_out(attn(LN(x))).
+ * biasfree = 1: BiasFree_LayerNorm (:26-40, norm_b ignored), 0: WithBias_LayerNorm (:43-59).  heads: C % heads == 0 and
+ * (C / heads) % 4 == 0.  ReLU attention (:134-136), F.normalize over the pixels (eps 1e-12). */
+typedef struct {
+    const float* norm_w; const float* norm_b;   /* [C] */
+    const float* qkv_w;                         /* [3C][C][1][1] */
+    const float* dw_w;                          /* [3C][1][3][3] */
+    const float* proj_w;                        /* [C][C][1][1] */
+    const float* temperature;                   /* [heads][1][1] */
+} dcpt_mdta_params;
+typedef struct {
+    float* norm_w; float* norm_b; float* qkv_w; float* dw_w; float* proj_w; float* temperature;
+} dcpt_mdta_params_grads;
+typedef struct {   /* saved for backward; M = B*H*W, ch = C/heads */
+    float* mu; float* rstd;       /* [M] */
+    float* qkv1;                  /* [M][3C] conv1x1(LN(x)) */
+    float* qkv;                   /* [M][3C] after the depthwise 3x3 */
+    float* nrm;                   /* [B][2C] L2 norms of q and k over the pixels */
+    float* ghat; float* attn; float* attnT;   /* [B][heads][ch][ch] */
+    float* out_att;               /* [M][C] attn @ v */
+} dcpt_mdta_saved;
+size_t dcpt_mdta_ws_bytes(int B, int H, int W, int C, int heads, int backward);
+int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y, const dcpt_mdta_saved* saved, void* ws, size_t ws_bytes,
+                  int B, int H, int W, int C, int heads, int biasfree, dcpt_stream_t stream);
+int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_grads* g, const float* x, const dcpt_mdta_saved* saved,
+                  const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int heads, int biasfree,
+                  dcpt_stream_t stream);
+/* GDFN half (:75-100):  y = x + project_out(gelu(x1) * x2), (x1,x2) = dwconv(project_in(LN(x))).chunk(2); exact erf GELU.
+ * hidden = int(C * ffn_expansion_factor) may be any positive integer (padded to a multiple of 4 internally). */
+typedef struct {
+    const float* norm_w; const float* norm_b;   /* [C] */
+    const float* in_w;                          /* [2*hidden][C][1][1] */
+    const float* dw_w;                          /* [2*hidden][1][3][3] */
+    const float* out_w;                         /* [C][hidden][1][1] */
+} dcpt_gdfn_params;
+typedef struct { float* norm_w; float* norm_b; float* in_w; float* dw_w; float* out_w; } dcpt_gdfn_params_grads;
+typedef struct {   /* hp = hidden rounded up to a multiple of 4 */
+    float* mu; float* rstd;   /* [M] */
+    float* u;                 /* [M][2hp] project_in(LN(x)) */
+    float* t;                 /* [M][hp]  gelu(x1)*x2 */
+} dcpt_gdfn_saved;
+size_t dcpt_gdfn_ws_bytes(int B, int H, int W, int C, int hidden, int backward);
+int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y, const dcpt_gdfn_saved* saved, void* ws, size_t ws_bytes,
+                  int B, int H, int W, int C, int hidden, int biasfree, dcpt_stream_t stream);
+int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_grads* g, const float* x, const dcpt_gdfn_saved* saved,
+                  const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int hidden, int biasfree,
+                  dcpt_stream_t stream);
+/* NHWC PixelUnshuffle(2): x [B][H][W][C] -> y [B][H/2][W/2][4C];  PixelShuffle(2): x [B][H][W][C4] -> y [B][2H][2W][C4/4] */
+int dcpt_pixel_unshuffle(const float* x, float* y, int B, int H, int W, int C, dcpt_stream_t stream);
+int dcpt_pixel_shuffle(const float* x, float* y, int B, int H, int W, int C4, dcpt_stream_t stream);
+/* channel concat of two NHWC maps ([M][Ca], [M][Cb] -> [M][Ca+Cb]) and its inverse */
+int dcpt_concat_channels(const float* a, const float* b, float* out, int64_t M, int Ca, int Cb, dcpt_stream_t stream);
+int dcpt_split_channels(const float* cat, float* a, float* b, int64_t M, int Ca, int Cb, dcpt_stream_t stream);
+
 /* ---- fused bias + leaky-ReLU (API parity with basicsr/ops/fused_act/src/fused_bias_act.cpp:14-26,
  * kernel fused_bias_act_kernel.cu:20-50): y = act(x + bias[(i / step_b) % size_b]) * scale, act in
  * {1: linear, 3: leaky relu(alpha)}; grad 0: forward, 1: first derivative w.r.t. x using `ref` sign. */

@@ -203,6 +203,42 @@ def gen_dcpt_step(ref):
     np.savez_compressed(os.path.join(OUT, "dcpt_step.npz"), **out)
 
 
+R_CFG = dict(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
+
+
+def gen_restormer(ref):
+    """tiny Restormer (BiasFree LN, hook support) and Restormer_origin (WithBias LN): output, taps, dL/dinput, grad norms;
+    plus a single TransformerBlock (dim 48, 1 head, hidden 127 = int(48*2.66)) with every gradient."""
+    for tag, cls in (("restormer", ref.restormer.Restormer), ("restormer_origin", ref.restormer.Restormer_origin)):
+        net = cls(**R_CFG)
+        fill_module_(net, seed=0)
+        x = keyed_input(f"{tag}.x", (2, 3, 32, 32)).requires_grad_(True)
+        gw = keyed_input(f"{tag}.gw", (2, 3, 32, 32), lo=-1.0, hi=1.0)
+        y = net(x)
+        (y * gw).sum().backward()
+        out = {"y": _np(y), "dx": _np(x.grad), "keys": np.array(list(net.state_dict().keys()))}
+        names, l2, sm, ab = _grad_summary(net)
+        out["g_names"], out["g_l2"], out["g_sum"] = names, l2, sm
+        for k, p in net.named_parameters():
+            if p.numel() <= 2048 and ("encoder_level1" in k or "latent" in k or "refinement" in k or k.startswith("output")):
+                out["g." + k] = _np(p.grad)
+        if tag == "restormer":
+            assert net(x.detach(), hook=True) is None
+        np.savez_compressed(os.path.join(OUT, f"{tag}_tiny.npz"), **out)
+    for lnt in ("BiasFree", "WithBias"):
+        blk = ref.restormer.TransformerBlock(dim=48, num_heads=1, ffn_expansion_factor=2.66, bias=False, LayerNorm_type=lnt)
+        sd = {k: keyed_tensor(f"tb{lnt}." + k, tuple(v.shape)) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd, strict=True)
+        x = keyed_input(f"tb{lnt}.x", (2, 48, 12, 10), lo=-1.0, hi=1.0).requires_grad_(True)
+        go = keyed_input(f"tb{lnt}.go", (2, 48, 12, 10), lo=-1.0, hi=1.0)
+        y = blk(x)
+        y.backward(go)
+        out = {"y": _np(y), "dx": _np(x.grad)}
+        for k, p in blk.named_parameters():
+            out["g." + k] = _np(p.grad)
+        np.savez_compressed(os.path.join(OUT, f"restormer_block_{lnt}.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -217,6 +253,7 @@ def main():
     gen_tlsc(ref)
     gen_dc_head(ref)
     gen_dcpt_step(ref)
+    gen_restormer(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

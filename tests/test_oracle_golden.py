@@ -156,3 +156,50 @@ def test_dcpt_step(golden_dir):
         for n, l2 in zip([str(s) for s in g[f"{tag}_names"]], g[f"{tag}_l2"]):
             mine = float(P[n].grad.double().pow(2).sum().sqrt())
             assert abs(mine - l2) <= 2e-4 * max(1e-7, l2), (tag, n, mine, l2)
+
+
+R_CFG = dict(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
+
+
+def _restormer_shapes(name):
+    """state-dict shapes of the product arch (checked key-by-key against the reference's own key list in the fixture)"""
+    from basicsr.archs import build_network
+
+    return {k: tuple(v.shape) for k, v in build_network(dict(type=name, **R_CFG)).state_dict().items()}
+
+
+@pytest.mark.parametrize("tag,origin", [("restormer", False), ("restormer_origin", True)])
+def test_restormer_tiny(golden_dir, tag, origin):
+    from oracle import restormer_oracle as R
+
+    g = np.load(os.path.join(golden_dir, f"{tag}_tiny.npz"))
+    shapes = _restormer_shapes("Restormer_origin" if origin else "Restormer")
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    P = _req(keyed_state_dict(shapes, seed=0))
+    x = keyed_input(f"{tag}.x", (2, 3, 32, 32)).requires_grad_(True)
+    gw = keyed_input(f"{tag}.gw", (2, 3, 32, 32), lo=-1.0, hi=1.0)
+    y, taps = R.restormer_forward(x, P, origin=origin)
+    (y * gw).sum().backward()
+    _close(y, g["y"], rtol=1e-4, atol=1e-5)
+    assert np.abs(x.grad.numpy() - g["dx"]).max() <= 1e-4 * np.abs(g["dx"]).max()
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(P[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 2e-4 * max(1e-7, l2), (n, mine, l2)
+    assert len(taps) == 3 and R.restormer_forward(x.detach(), P, hook=True, origin=origin)[0] is None
+
+
+@pytest.mark.parametrize("lnt", ["BiasFree", "WithBias"])
+def test_restormer_block(golden_dir, lnt):
+    from oracle import restormer_oracle as R
+
+    g = np.load(os.path.join(golden_dir, f"restormer_block_{lnt}.npz"))
+    P = _req({k[2:]: keyed_tensor(f"tb{lnt}." + k[2:], g[k].shape) for k in g.files if k.startswith("g.")})
+    x = keyed_input(f"tb{lnt}.x", (2, 48, 12, 10), lo=-1.0, hi=1.0).requires_grad_(True)
+    go = keyed_input(f"tb{lnt}.go", (2, 48, 12, 10), lo=-1.0, hi=1.0)
+    y = R.transformer_block(x, P, "")
+    y.backward(go)
+    _close(y, g["y"], rtol=1e-4, atol=1e-5)
+    assert np.abs(x.grad.numpy() - g["dx"]).max() <= 1e-4 * np.abs(g["dx"]).max()
+    for k in P:
+        ref = g["g." + k]
+        assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-4 * max(1e-7, np.abs(ref).max()), k
