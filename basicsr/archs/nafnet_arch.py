@@ -19,6 +19,8 @@ import torch.nn as nn
 from basicsr.utils.registry import ARCH_REGISTRY
 from dcpt_amd import functional as DF
 
+from .arch_util import AvgPool2d, Local_Base
+
 
 class LayerNorm2d(nn.Module):
     """Per-pixel channel LayerNorm (reference nafnet_arch.py:56-64); weight/bias shape (C,)."""
@@ -82,6 +84,11 @@ class NAFBlock(nn.Module):
         }
 
     def forward(self, inp):
+        pool = self.sca[0]
+        if isinstance(pool, AvgPool2d) and pool.kernel_size is not None:
+            k1, k2 = int(pool.kernel_size[0]), int(pool.kernel_size[1])
+            if not (k1 >= inp.shape[-2] and k2 >= inp.shape[-1]):  # arch_util.py:352-353: window covers the map -> global mean
+                return DF.nafblock_local(inp, self.fused_params(), k1, k2)
         return DF.nafblock(inp, self.fused_params())
 
 
@@ -134,3 +141,27 @@ class NAFNetBaseline(nn.Module):
         if not hook:
             return DF.conv3x3_out(x, self.ending.weight, self.ending.bias, inp)
         return None
+
+
+@ARCH_REGISTRY.register()
+class NAFNet(Local_Base, NAFNetBaseline):
+    """TLSC test-time variant (reference nafnet_arch.py:277-288): every SCA global mean becomes a local box mean of
+    1.5 x the training patch size (scaled per level); inference only."""
+
+    def __init__(self, *args, train_size=(1, 3, 128, 128), fast_imp=False, **kwargs):
+        Local_Base.__init__(self)
+        NAFNetBaseline.__init__(self, *args, **kwargs)
+        N, C, H, W = train_size
+        base_size = (int(H * 1.5), int(W * 1.5))
+        self.eval()
+        with torch.no_grad():
+            self.convert(base_size=base_size, train_size=train_size, fast_imp=fast_imp)
+
+    def _assign_local_kernels(self, train_size):
+        h, w = train_size[-2], train_size[-1]
+        n_enc = len(self.encoders)
+        groups = [(enc, i) for i, enc in enumerate(self.encoders)] + [(self.middle_blks, n_enc)]
+        groups += [(getattr(self, f"decoder{i}"), n_enc - 1 - i) for i in range(self._n_dec)]
+        for seq, level in groups:
+            for blk in seq:
+                blk.sca[0].set_kernel_from_feature(h >> level, w >> level)

@@ -78,6 +78,9 @@ SIGNATURES = {
                                  cint, cint, cint, cint, stream_t]),
     "dcpt_nafblock_bwd": (cint, [C.POINTER(NafBlockParams), C.POINTER(NafBlockGrads), f32p, C.POINTER(NafBlockSaved),
                                  f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_nafblock_local_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
+    "dcpt_nafblock_local_fwd": (cint, [C.POINTER(NafBlockParams), f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint,
+                                       stream_t]),
     "dcpt_conv3x3_in_fwd": (cint, [f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv3x3_in_bwd_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
     "dcpt_conv3x3_in_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),

@@ -9,7 +9,7 @@
 #include "dcpt_common.h"
 
 enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5, A_LNBF = 6 };
-enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6 };
+enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7 };
 
 struct GemmNT {
     const float* A;   // [M][lda]   (A_SG: 2K columns; A_GATHER: fine NHWC image, see g*)
@@ -35,6 +35,7 @@ struct GemmNT {
     const float* bias;    // [N] (may be null)
     const float* res;     // E_RESID / E_ADDSCALED: [M][ldres]; E_SCATTER_ADD: fine image like C
     const float* cscale;  // E_RESID: C = res + (acc+bias)*cscale[n] (null = 1); E_ADDSCALED: C = acc + cscale[n]*res
+                          // E_MUL: C = (acc+bias)*res
     const float* aux;     // E_SGBWD: v [M][2N]
     int ldres;            // row stride of res (0 = ldc)
     // batching: grid.y = nb1*nb2 problems; pointer offsets b1*s?1 + b2*s?2 (elements)

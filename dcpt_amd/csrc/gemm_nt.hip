@@ -33,7 +33,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     const int n = n0 + 4 * q;
     if (n >= p.N) return;
     float4 bias = f4_zero(), cs = make_float4(1.f, 1.f, 1.f, 1.f);
-    if constexpr (EK == E_BIAS || EK == E_RESID) {
+    if constexpr (EK == E_BIAS || EK == E_RESID || EK == E_MUL) {
         if (p.bias) bias = ldg4(p.bias + n);
     }
     if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
             const bool ok = m < p.M;
             pre1[it] = f4_zero();
             pre2[it] = f4_zero();
-            if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
+            if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL) {
                 addr[it] = m * p.ldc + n;
                 if (ok) pre1[it] = ldg4(p.res + m * ldres + n);
             } else if constexpr (EK == E_SGBWD) {
@@ -95,6 +95,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 stg4(p.C + addr[it], f4_fma(f4_add(v, bias), cs, pre1[it]));
             } else if constexpr (EK == E_ADDSCALED) {
                 stg4(p.C + addr[it], f4_fma(cs, pre1[it], v));
+            } else if constexpr (EK == E_MUL) {
+                stg4(p.C + addr[it], f4_mul(f4_add(v, bias), pre1[it]));
             } else if constexpr (EK == E_SGBWD) {
                 stg4(p.C + addr[it], f4_mul(v, pre2[it]));
                 stg4(p.C + addr[it] + p.N, f4_mul(v, pre1[it]));
@@ -274,6 +276,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     CASE(A_LN, E_PLAIN)
     CASE(A_PLAIN, E_RESID)
     CASE(A_PLAIN, E_ADDSCALED)
+    CASE(A_PLAIN, E_MUL)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

@@ -67,6 +67,9 @@ int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, 
 int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, float* dpool, float* dWsca, float* dbsca,
                    int B, int C, int P, hipStream_t s);
 
+// TLSC box mean (arch_util.py:378-396): out[M][C] local k1 x k2 mean of in, replicate-padded; rowsum: [B][H][W-k2+1][C] scratch
+int launch_box_mean(const float* in, float* rowsum, float* out, int B, int H, int W, int C, int k1, int k2, hipStream_t s);
+
 enum WPackMode {
     WP_TRANSPOSE = 0,   // out[k][n] = in[n][k] * (rs ? rs[n] : 1)             in: [N][K]
     WP_DOWN = 1,        // out[oc][ij*C + ic] = in[oc][ic][ij]                  in: [N=2C][C][2][2]  (K = 4C)

@@ -216,7 +216,75 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (dbias && tid == 0) dbias[n] = rsc * cs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// TLSC local average pooling (reference basicsr/archs/arch_util.py:378-396): box mean with a k1 x k2 window, the
+// (H-k1+1) x (W-k2+1) result replicate-padded back to H x W.  Separable running sums, exact window sums (no prefix-sum
+// cancellation): pass 1 along W, pass 2 along H (+ divide).
+// pass 1: rs[b][h][j][c] = sum_{x=j}^{j+k2-1} in[b][h][x][c], j in [0, W-k2]   thread = (b, h, channel quad)
+__global__ __launch_bounds__(256) void box_rows_kernel(const float* __restrict__ in, float* __restrict__ rs, int B, int H, int W,
+                                                       int C, int k2) {
+    const int nq = C / 4, Wo = W - k2 + 1;
+    const int64_t total = (int64_t)B * H * nq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i % nq);
+    const int64_t bh = i / nq;
+    const float* src = in + bh * W * (int64_t)C + 4 * q;
+    float* dst = rs + bh * Wo * (int64_t)C + 4 * q;
+    float4 acc = f4_zero();
+    for (int x = 0; x < k2; ++x) acc = f4_add(acc, ldg4(src + (int64_t)x * C));
+    stg4(dst, acc);
+    for (int j = 1; j < Wo; ++j) {
+        acc = f4_add(acc, ldg4(src + (int64_t)(j + k2 - 1) * C));
+        const float4 o = ldg4(src + (int64_t)(j - 1) * C);
+        acc = make_float4(acc.x - o.x, acc.y - o.y, acc.z - o.z, acc.w - o.w);
+        stg4(dst + (int64_t)j * C, acc);
+    }
+}
+// pass 2: out[b][h][w][c] = (sum_{y=r}^{r+k1-1} rs[b][y][cw][c]) / (k1*k2), r = clamp(h - pt, 0, H-k1), cw = clamp(w - pl, 0, W-k2)
+// thread = (b, output column w, channel quad): walks h with a running column sum over the distinct r values
+__global__ __launch_bounds__(256) void box_cols_kernel(const float* __restrict__ rs, float* __restrict__ out, int B, int H, int W,
+                                                       int C, int k1, int k2) {
+    const int nq = C / 4, Wo = W - k2 + 1, Ho = H - k1 + 1;
+    const int pl = (W - Wo) / 2, pt = (H - Ho) / 2;
+    const int64_t total = (int64_t)B * W * nq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i % nq);
+    const int64_t bw = i / nq;
+    const int w = (int)(bw % W);
+    const int64_t b = bw / W;
+    int cw = w - pl;
+    cw = cw < 0 ? 0 : (cw > Wo - 1 ? Wo - 1 : cw);
+    const float* src = rs + (b * H * (int64_t)Wo + cw) * C + 4 * q;   // row y at src + y*Wo*C
+    const int64_t rstride = (int64_t)Wo * C;
+    const float inv = 1.0f / (float)(k1 * k2);
+    float4 acc = f4_zero();
+    for (int y = 0; y < k1; ++y) acc = f4_add(acc, ldg4(src + y * rstride));
+    int r = 0;
+    for (int h = 0; h < H; ++h) {
+        int want = h - pt;
+        want = want < 0 ? 0 : (want > Ho - 1 ? Ho - 1 : want);
+        while (r < want) {
+            acc = f4_add(acc, ldg4(src + (int64_t)(r + k1) * rstride));
+            const float4 o = ldg4(src + (int64_t)r * rstride);
+            acc = make_float4(acc.x - o.x, acc.y - o.y, acc.z - o.z, acc.w - o.w);
+            ++r;
+        }
+        stg4(out + ((b * H + h) * (int64_t)W + w) * C + 4 * q, f4_scale(acc, inv));
+    }
+}
+
 }  // namespace
+
+int launch_box_mean(const float* in, float* rowsum, float* out, int B, int H, int W, int C, int k1, int k2, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 4 == 0 && k1 >= 1 && k2 >= 1 && k1 <= H && k2 <= W, "box_mean: bad window %dx%d for %dx%d", k1, k2, H, W);
+    box_rows_kernel<<<dim3((unsigned)cdiv64((int64_t)B * H * (C / 4), 256)), dim3(256), 0, s>>>(in, rowsum, B, H, W, C, k2);
+    DCPT_CHECK_LAUNCH("box_rows");
+    box_cols_kernel<<<dim3((unsigned)cdiv64((int64_t)B * W * (C / 4), 256)), dim3(256), 0, s>>>(rowsum, out, B, H, W, C, k1, k2);
+    DCPT_CHECK_LAUNCH("box_cols");
+    return DCPT_OK;
+}
 
 int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const float* bsca, float* pooled, float* simg,
                    int B, int C, int P, hipStream_t s) {

@@ -234,3 +234,81 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, s));
     return DCPT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// TLSC variant (reference nafnet_arch.py:277-288 NAFNet(Local_Base) + arch_util.py:313-455): inference-only forward in
+// which SCA's global mean is a local k1 x k2 box mean, so the channel-attention scale is a per-pixel map:
+//   smap = Wsca * boxmean(t2) + bsca (1x1 conv = MFMA GEMM),  x = t2 * smap  (GEMM epilogue E_MUL)
+namespace {
+struct LocalWs {
+    float *w2p, *pool_part, *t1, *t2, *rowsum, *mmap, *t2s, *y, *v, *stats;
+    int nblk_pool;
+};
+size_t local_layout(int B, int H, int W, int C, int k2, void* base, size_t bytes, LocalWs* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    const int64_t M = (int64_t)B * H * W;
+    DwGeom g{B, H, W, C};
+    LocalWs w{};
+    w.nblk_pool = dw_num_blocks_per_image(g);
+    w.w2p = a.get<float>((size_t)18 * C);
+    w.pool_part = a.get<float>((size_t)B * w.nblk_pool * C);
+    w.t1 = a.get<float>((size_t)M * 2 * C);
+    w.t2 = a.get<float>((size_t)M * C);
+    w.rowsum = a.get<float>((size_t)B * H * (W - k2 + 1) * C);
+    w.mmap = a.get<float>((size_t)M * C);
+    w.t2s = a.get<float>((size_t)M * C);
+    w.y = a.get<float>((size_t)M * C);
+    w.v = w.t1;  // t1 is dead once t2 exists
+    w.stats = a.get<float>((size_t)2 * M);
+    if (out) *out = w;
+    return a.off;
+}
+}  // namespace
+
+extern "C" size_t dcpt_nafblock_local_ws_bytes(int B, int H, int W, int C, int k1, int k2) {
+    (void)k1;
+    return local_layout(B, H, W, C, k2 < W ? k2 : W, nullptr, 0, nullptr);
+}
+
+extern "C" int dcpt_nafblock_local_fwd(const dcpt_nafblock_params* p, const float* inp, float* out, void* ws, size_t ws_bytes, int B,
+                                       int H, int W, int C, int k1, int k2, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(p && inp && out, "nafblock_local_fwd: null argument");
+    DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k1 >= 1 && k2 >= 1, "nafblock_local_fwd: bad shape");
+    if (k1 > H) k1 = H;   // arch_util.py:381 k = min(size, kernel)
+    if (k2 > W) k2 = W;
+    LocalWs w;
+    const size_t need = local_layout(B, H, W, C, k2, ws, ws_bytes, &w);
+    if (ws == nullptr || need > ws_bytes) {
+        dcpt_set_error("nafblock_local_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DCPT_ERR_WS;
+    }
+    const int64_t M = (int64_t)B * H * W;
+    float* mu = w.stats;
+    float* rstd = w.stats + M;
+    DCPT_TRY(launch_ln_stats(inp, mu, rstd, M, C, 1e-6f, s));
+    GemmNT g{};
+    g.M = M; g.A = inp; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = w.t1; g.ldc = 2 * C;
+    g.mu = mu; g.rstd = rstd; g.lnw = p->norm1_w; g.lnb = p->norm1_b; g.bias = p->conv1_b;
+    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    DwGeom dg{B, H, W, C};
+    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
+    DCPT_TRY(launch_dw_fwd(w.t1, w.w2p, p->conv2_b, w.t2, w.pool_part, dg, s));
+    DCPT_TRY(launch_box_mean(w.t2, w.rowsum, w.mmap, B, H, W, C, k1, k2, s));
+    g = GemmNT{};
+    g.M = M; g.A = w.mmap; g.lda = C; g.K = C; g.Bw = p->sca_w; g.N = C; g.C = w.t2s; g.ldc = C; g.bias = p->sca_b; g.res = w.t2;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_MUL, s));
+    g = GemmNT{};
+    g.M = M; g.A = w.t2s; g.lda = C; g.K = C; g.Bw = p->conv3_w; g.N = C; g.C = w.y; g.ldc = C;
+    g.bias = p->conv3_b; g.res = inp; g.cscale = p->beta;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_RESID, s));
+    DCPT_TRY(launch_ln_stats(w.y, mu, rstd, M, C, 1e-6f, s));
+    g = GemmNT{};
+    g.M = M; g.A = w.y; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = w.v; g.ldc = 2 * C;
+    g.mu = mu; g.rstd = rstd; g.lnw = p->norm2_w; g.lnb = p->norm2_b; g.bias = p->conv4_b;
+    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    g = GemmNT{};
+    g.M = M; g.A = w.v; g.lda = 2 * C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
+    g.bias = p->conv5_b; g.res = w.y; g.cscale = p->gamma;
+    return launch_gemm_nt(g, A_SG, E_RESID, s);
+}

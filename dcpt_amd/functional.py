@@ -136,6 +136,23 @@ def nafblock(inp: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor
     return _NAFBlockFn.apply(inp, *[params[k] for k in PARAM_FIELDS])
 
 
+def nafblock_local(inp: torch.Tensor, params: Dict[str, torch.Tensor], k1: int, k2: int) -> torch.Tensor:
+    """TLSC inference forward (reference nafnet_arch.py:277-288 + arch_util.py:313-455): SCA with a k1 x k2 local mean."""
+    if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params.values())):
+        raise NotImplementedError("the TLSC NAFNet variant is inference-only: call it under torch.no_grad()")
+    lib = _lib.load()
+    ps = [_contig(params[k].detach()) for k in PARAM_FIELDS]
+    _require_gpu(inp, *ps)
+    inp = _nhwc(inp)
+    B, Cc, H, W = inp.shape
+    out = _empty_nhwc(B, Cc, H, W, inp.device)
+    pp = NafBlockParams(*[p.data_ptr() for p in ps])
+    ws = _workspace(inp.device, lib.dcpt_nafblock_local_ws_bytes(B, H, W, Cc, k1, k2))
+    check(lib.dcpt_nafblock_local_fwd(C.byref(pp), inp.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc,
+                                      int(k1), int(k2), _stream(inp.device)), "dcpt_nafblock_local_fwd")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 class _LayerNorm2dFn(torch.autograd.Function):
     """reference nafnet_arch.py:25-53 (LayerNormFunction)."""

@@ -90,6 +90,13 @@ int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* 
                       const dcpt_nafblock_saved* saved, const float* dout, float* dinp, void* ws, size_t ws_bytes,
                       int B, int H, int W, int C, dcpt_stream_t stream);
 
+/* TLSC variant (nafnet_arch.py:277-288 `NAFNet`, arch_util.py:313-455): inference-only forward where SCA's global
+ * mean is a k1 x k2 local box mean (replicate-padded), i.e. a per-pixel attention map.  Callers use the plain
+ * dcpt_nafblock_fwd when the window covers the whole map (arch_util.py:352-353). */
+size_t dcpt_nafblock_local_ws_bytes(int B, int H, int W, int C, int k1, int k2);
+int dcpt_nafblock_local_fwd(const dcpt_nafblock_params* p, const float* inp, float* out, void* ws, size_t ws_bytes, int B, int H,
+                            int W, int C, int k1, int k2, dcpt_stream_t stream);
+
 /* ---- network-edge 3x3 convs ------------------------------------------------------------------
  * intro: nafnet_arch.py:202-210,252  x NCHW [B][Cin][H][W] -> y NHWC [B][H][W][Cout]
  * ending: nafnet_arch.py:211-219,271-272  x NHWC -> y NCHW [B][Cout][H][W] (+ res NCHW, may be NULL) */

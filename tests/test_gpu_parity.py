@@ -310,3 +310,21 @@ def test_batch_consistency_full_size(dev):
         y2 = net(torch.cat([x1, x1], 0))
     assert torch.equal(y2[0], y2[1])
     check("batch vs single", y2[0:1], y1, 1e-6)
+
+
+def test_nafnet_local_tlsc_golden(dev, golden_dir):
+    """TLSC `NAFNet` (N10): local-window SCA at inference, vs the real reference's output."""
+    from basicsr.archs import build_network
+
+    g = np.load(os.path.join(golden_dir, "nafnet_local_tiny.npz"))
+    net = build_network(dict(type="NAFNet", train_size=(1, 3, 16, 16), **TINY))
+    ks = [tuple(b.sca[0].kernel_size) for b in net.encoders[0]] + [tuple(net.middle_blks[0].sca[0].kernel_size)]
+    assert ks == [(24, 24), (1, 1)]
+    net.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0), strict=True)
+    net = net.to(dev).eval()
+    x = keyed_input("tlsc.img", (1, 3, 48, 32)).to(dev)
+    with torch.no_grad():
+        y = net(x)
+    check("y", y, g["y"], 2e-4)
+    with pytest.raises(NotImplementedError):
+        net(x.requires_grad_(True))
