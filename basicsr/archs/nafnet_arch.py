@@ -126,8 +126,36 @@ class NAFNetBaseline(nn.Module):
             chan //= 2
             setattr(self, f"decoder{i}", nn.Sequential(*[NAFBlock(chan) for _ in range(num)]))
         self._n_dec = len(dec_blk_nums)
+        # >1: the batch is processed as that many sub-batches on separate HIP streams, so the HBM-bound kernels of one
+        # sub-batch (LayerNorm, depthwise conv, reductions) overlap the MFMA-bound GEMMs of the other (same arithmetic,
+        # same results; autograd replays each sub-batch's backward on its own stream)
+        self.stream_chunks = 1
+        self._side_streams = []
+
+    def _streams(self, n, device):
+        while len(self._side_streams) < n:
+            self._side_streams.append(torch.cuda.Stream(device=device))
+        return self._side_streams[:n]
 
     def forward(self, inp, hook=False):
+        n = int(getattr(self, "stream_chunks", 1))
+        if n > 1 and not hook and inp.is_cuda and inp.shape[0] >= n:
+            cur = torch.cuda.current_stream(inp.device)
+            streams = self._streams(n, inp.device)
+            outs = []
+            for ch, st in zip(inp.chunk(n, 0), streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    ch.record_stream(st)
+                    o = self._forward_impl(ch, False)
+                o.record_stream(cur)
+                outs.append(o)
+            for st in streams:
+                cur.wait_stream(st)
+            return torch.cat(outs, 0)
+        return self._forward_impl(inp, hook)
+
+    def _forward_impl(self, inp, hook=False):
         x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias)
         encs = []
         for encoder, down in zip(self.encoders, self.downs):

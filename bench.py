@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (the metric is quoted at 32)")
+    ap.add_argument("--chunks", type=int, default=1, help="sub-batches on separate HIP streams inside the model forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -116,6 +117,7 @@ def main():
     net = build_network(dict(type="NAFNetBaseline", **CFG))
     fill_module_(net, seed=0)
     net = net.to(dev)
+    net.stream_chunks = args.chunks
     model = net
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -191,7 +193,7 @@ def main():
                 "workload": "NAFNet-width64 enc[1,1,1,28] mid1 dec[1,1,1,1] fwd+L1+bwd(+all-reduce)+AdamW, 256x256, fp32 "
                             "(BASELINE.json configs[1])",
                 "per_gpu_batch": args.batch, "global_batch": world * args.batch, "image": [SIZE, SIZE],
-                "parallelism": f"dp{world}", "loss": round(loss_val, 6),
+                "parallelism": f"dp{world}", "loss": round(loss_val, 6), "stream_chunks": args.chunks,
             },
         }
         step_s = dt / args.steps

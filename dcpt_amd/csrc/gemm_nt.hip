@@ -12,11 +12,10 @@
 // one M panel so an A panel is fetched from HBM once per XCD and re-read from that XCD's L2.
 #include "gemm_operand.h"
 #include "prof.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
 
 // Epilogue: the accumulators are first parked in LDS ([BM][BN+4] floats, reusing the operand tiles'
 // space), then every thread owns one float4 column group of 16 rows: global loads (residual / gate
@@ -107,8 +106,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AK, int EK>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT pin) {
+template <int BM, int BN, int WM, int WN, int AK, int EK, int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_nt_kernel(const GemmNT pin) {
+    constexpr int LDS_LD = BK + 4;
+    constexpr int TPR = BK / 4;        // threads per tile row (one float4 each)
+    constexpr int RPP = 256 / TPR;     // rows per pass
     static_assert(WM * WN == 4, "4 waves");
     GemmNT p = pin;
     if (gridDim.y > 1) {  // batched: shift the base pointers of this problem
@@ -120,10 +122,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT pin) {
         if (p.cscale) p.cscale += b1 * p.sS1 + b2 * p.sS2;
     }
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD;
-    constexpr int OP_SZ = 2 * (A_SZ + B_SZ), C_SZ = BM * (BN + 4);
-    __shared__ __attribute__((aligned(16))) float smem[OP_SZ > C_SZ ? OP_SZ : C_SZ];
+    constexpr int OP_SZ = 2 * (A_SZ + B_SZ);
+    // the accumulators are parked in the operand area for the epilogue; if it is too small for the whole tile
+    // (16-deep k-tiles) the epilogue runs in two row halves
+    constexpr int C_ROWS = (OP_SZ >= BM * (BN + 4)) ? BM : BM / 2;
+    static_assert(OP_SZ >= C_ROWS * (BN + 4), "epilogue staging does not fit");
+    __shared__ __attribute__((aligned(16))) float smem[OP_SZ];
     float* const As0 = smem;               // [2][A_SZ]
     float* const Bs0 = smem + 2 * A_SZ;    // [2][B_SZ]
 
@@ -139,34 +145,49 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT pin) {
     oa.mu = p.mu; oa.rstd = p.rstd; oa.lnw = p.lnw; oa.lnb = p.lnb;
     oa.simg = p.simg; oa.P = p.P; oa.gH = p.gH; oa.gW = p.gW; oa.gC = p.gC;
 
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const int lrow = tid / TPR, lk = (tid % TPR) * 4;
     RowCtx rca[A_IT];
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) make_row<AK>(oa, m0 + lrow + 32 * i, rca[i]);
+    for (int i = 0; i < A_IT; ++i) make_row<AK>(oa, m0 + lrow + RPP * i, rca[i]);
     const float* brow[B_IT];
     bool bval[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + lrow + 32 * i;
+        const int n = n0 + lrow + RPP * i;
         bval[i] = n < p.N;
         brow[i] = p.Bw + (int64_t)(bval[i] ? n : 0) * p.K;
     }
 
     RawVec ra[A_IT];
     float4 rb[B_IT];
+    float4 kw = f4_zero(), kb = f4_zero();  // A_LN / A_LNBF: per-column weight/bias of this thread's k quad (same for all its rows)
     auto gload = [&](int kt) {
         const int k = kt * BK + lk;
+        if constexpr (AK == A_LN || AK == A_LNBF) {
+            kw = (k < p.K) ? ldg4(p.lnw + k) : f4_zero();
+            if constexpr (AK == A_LN) kb = (k < p.K) ? ldg4(p.lnb + k) : f4_zero();
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) load_raw<AK>(oa, rca[i], k, ra[i]);
+            for (int i = 0; i < A_IT; ++i) ra[i].a = (rca[i].valid && k < p.K) ? ldg4(p.A + rca[i].off + k) : f4_zero();
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) load_raw<AK>(oa, rca[i], k, ra[i]);
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[i] = (bval[i] && k < p.K) ? ldg4(brow[i] + k) : f4_zero();
     };
     auto lstore = [&](int buf) {
+        if constexpr (AK == A_LN || AK == A_LNBF) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                ra[i].b = kw;
+                ra[i].c = kb;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            *reinterpret_cast<float4*>(&As0[buf * A_SZ + (lrow + 32 * i) * LDS_LD + lk]) = finish<AK>(rca[i], ra[i]);
+            *reinterpret_cast<float4*>(&As0[buf * A_SZ + (lrow + RPP * i) * LDS_LD + lk]) = finish<AK>(rca[i], ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs0[buf * B_SZ + (lrow + 32 * i) * LDS_LD + lk]) = rb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs0[buf * B_SZ + (lrow + RPP * i) * LDS_LD + lk]) = rb[i];
     };
 
     floatx16 acc[TM][TN];
@@ -212,18 +233,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT pin) {
     // park the accumulators in LDS (the last k-tile's barrier already separates us from the MFMA reads)
     constexpr int LDC = BN + 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int ps = 0; ps < BM / C_ROWS; ++ps) {
+        if (ps > 0) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = (wn * TN + j) * 32 + (lane & 31);
+        for (int i = 0; i < TM; ++i) {
+            const int rb = (wm * TM + i) * 32;   // first row of this MFMA tile inside the block tile
+            if (rb / C_ROWS != ps) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                smem[ml * LDC + nl] = acc[i][j][r];
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = rb - ps * C_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    smem[ml * LDC + nl] = acc[i][j][r];
+                }
             }
         }
-    __syncthreads();
-    epilogue_rows<EK, BM, BN>(p, smem, m0, n0, tid);
+        __syncthreads();
+        epilogue_rows<EK, C_ROWS, BN>(p, smem, m0 + ps * C_ROWS, n0, tid);
+    }
 }
 
 template <int AK, int EK>
@@ -232,11 +260,11 @@ int launch_cfg(const GemmNT& p, hipStream_t s) {
     if (p.N <= 64) {
         constexpr int BM = 128, BN = 64;
         const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
-        gemm_nt_kernel<BM, BN, 4, 1, AK, EK><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
+        gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
     } else {
         constexpr int BM = 128, BN = 128;
         const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
-        gemm_nt_kernel<BM, BN, 2, 2, AK, EK><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
+        gemm_nt_kernel<BM, BN, 2, 2, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
     }
     DCPT_CHECK_LAUNCH("gemm_nt");
     return DCPT_OK;
@@ -248,6 +276,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     GemmNT p = pin;
     if (p.nb1 < 1) p.nb1 = 1;
     if (p.nb2 < 1) p.nb2 = 1;
+
     DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)p.M, p.N, p.K);
     DCPT_CHECK_ARG(p.K % 4 == 0, "gemm_nt: K=%d must be a multiple of 4", p.K);
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 64) < (1ll << 31), "gemm_nt: grid too large");
@@ -281,3 +310,4 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;
 }
+

@@ -59,6 +59,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     const int yrow = tid / YQ, yc = (tid % YQ) * 4;
     RawVec rx[X_IT], ry[Y_IT];
     RowCtx rcx[X_IT], rcy[Y_IT];
+    // A_LN / A_LNBF on Y: this thread always handles the same 4 columns, so weight/bias are loaded once
+    float4 kw = f4_zero(), kb = f4_zero();
+    if constexpr (YK == A_LN || YK == A_LNBF) {
+        if (k0 + yc < p.K) {
+            kw = ldg4(p.lnw + k0 + yc);
+            if constexpr (YK == A_LN) kb = ldg4(p.lnb + k0 + yc);
+        }
+    }
     auto gload = [&](int64_t mt) {
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
@@ -68,7 +76,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
 #pragma unroll
         for (int i = 0; i < Y_IT; ++i) {
             make_row<YK>(oy, mt + yrow + YR * i, rcy[i]);
-            load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
+            if constexpr (YK == A_LN || YK == A_LNBF) {
+                ry[i].a = (rcy[i].valid && k0 + yc < p.K) ? ldg4(p.Y + rcy[i].off + k0 + yc) : f4_zero();
+                ry[i].b = kw;
+                ry[i].c = kb;
+            } else {
+                load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
+            }
         }
     };
     auto lstore = [&](int buf) {
