@@ -130,22 +130,33 @@ class SRModel(BaseModel):
         self.output = self.output[:, :, 0:h - self.mod_pad_h * self.scale, 0:w - self.mod_pad_w * self.scale]
 
     def test_tile(self):
-        """independent ``infer_size`` tiles with ``tile_pad`` context, centre pasted back (sr_model.py:273-361)"""
+        """independent ``infer_size`` tiles with ``tile_pad`` context, centre pasted back (sr_model.py:273-361).
+        Same tiles, same arithmetic as the reference's loop; tiles of equal padded shape (interior / edge / corner
+        classes) are stacked into one batch per class so the GPU sees a few large launches instead of many 1-image ones."""
         net = self._net()
         net.eval()
         size, pad, sc = self.opt["tile"]["infer_size"], self.opt["tile"]["tile_pad"], self.opt.get("scale", 1)
+        max_batch = int(self.opt["tile"].get("max_batch", 16))
         b, c, height, width = self.lq.shape
         self.output = self.lq.new_zeros((b, c, height * sc, width * sc))
+        groups = {}
         for ty in range(math.ceil(height / size)):
             for tx in range(math.ceil(width / size)):
                 x0, y0 = tx * size, ty * size
                 x1, y1 = min(x0 + size, width), min(y0 + size, height)
                 xp0, yp0 = max(x0 - pad, 0), max(y0 - pad, 0)
                 xp1, yp1 = min(x1 + pad, width), min(y1 + pad, height)
+                groups.setdefault((yp1 - yp0, xp1 - xp0), []).append((x0, y0, x1, y1, xp0, yp0, xp1, yp1))
+        for tiles in groups.values():
+            for i in range(0, len(tiles), max(1, max_batch // b)):
+                chunk = tiles[i:i + max(1, max_batch // b)]
+                inp = torch.cat([self.lq[:, :, t[5]:t[7], t[4]:t[6]] for t in chunk], 0)
                 with torch.no_grad():
-                    out = net(self.lq[:, :, yp0:yp1, xp0:xp1])
-                ox, oy = (x0 - xp0) * sc, (y0 - yp0) * sc
-                self.output[:, :, y0 * sc:y1 * sc, x0 * sc:x1 * sc] = out[:, :, oy:oy + (y1 - y0) * sc, ox:ox + (x1 - x0) * sc]
+                    out = net(inp)
+                for j, (x0, y0, x1, y1, xp0, yp0, xp1, yp1) in enumerate(chunk):
+                    ox, oy = (x0 - xp0) * sc, (y0 - yp0) * sc
+                    self.output[:, :, y0 * sc:y1 * sc, x0 * sc:x1 * sc] = \
+                        out[j * b:(j + 1) * b, :, oy:oy + (y1 - y0) * sc, ox:ox + (x1 - x0) * sc]
         if net is self.net_g:
             net.train()
 

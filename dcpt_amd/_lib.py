@@ -150,10 +150,17 @@ def load():
         if _lib is not None:
             return _lib
         if not os.path.exists(LIB_PATH):
-            raise DcptHipError(
-                f"{LIB_PATH} not found: build it with `python -m dcpt_amd.build` (hipcc, gfx950). "
-                "dcpt_amd has no CPU/eager fallback."
-            )
+            # the library is built in-tree; if this checkout has no binary yet, compile it now (hipcc, gfx950).
+            # There is still no CPU / eager fallback: without hipcc this raises.
+            try:
+                from . import build as _build
+
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                raise DcptHipError(
+                    f"{LIB_PATH} not found and could not be built ({e}); run `python -m dcpt_amd.build` (hipcc, gfx950). "
+                    "dcpt_amd has no CPU/eager fallback."
+                ) from e
         # One HIP runtime per process: make sure torch's bundled libamdhip64 is the one already
         # loaded before our library's DT_NEEDED libamdhip64.so.7 is resolved (loading ours first would
         # bring in /opt/rocm's copy and torch's streams/pointers would belong to another runtime).

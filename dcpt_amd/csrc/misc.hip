@@ -171,8 +171,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int kb = 0; kb < K; kb += 4 * tpr) {
         const int k = kb + 4 * ql;
         float4 g = f4_zero();
-        if (k < K)
-            for (int s = sgi; s < splits; s += sg) g = f4_add(g, ldg4(slab + ((int64_t)s * N + n) * K + k));
+        if (k < K) {
+            // 4 independent partial sums keep 4 loads in flight per thread (fixed order -> still deterministic)
+            float4 g1 = f4_zero(), g2 = f4_zero(), g3 = f4_zero();
+            const float* base = slab + (int64_t)n * K + k;
+            const int64_t sstride = (int64_t)N * K;
+            int s = sgi;
+            for (; s + 3 * sg < splits; s += 4 * sg) {
+                g = f4_add(g, ldg4(base + (int64_t)s * sstride));
+                g1 = f4_add(g1, ldg4(base + (int64_t)(s + sg) * sstride));
+                g2 = f4_add(g2, ldg4(base + (int64_t)(s + 2 * sg) * sstride));
+                g3 = f4_add(g3, ldg4(base + (int64_t)(s + 3 * sg) * sstride));
+            }
+            for (; s < splits; s += sg) g = f4_add(g, ldg4(base + (int64_t)s * sstride));
+            g = f4_add(f4_add(g, g1), f4_add(g2, g3));
+        }
         if (sg > 1) {
             __syncthreads();
             red4[tid] = g;

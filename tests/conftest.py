@@ -17,3 +17,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """(re)build libdcpt_hip.so if the sources changed -- a digest check, seconds when up to date"""
+    from dcpt_amd import build
+
+    build.build()
