@@ -354,7 +354,7 @@ def test_tiled_inference_matches_per_tile_loop(dev):
     from basicsr.models import build_model
 
     opt = dict(name="t", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
-               network_g=dict(type="NAFNetBaseline", window_size=16, **TINY), path=dict(), tile=dict(infer_size=32, tile_pad=8),
+               network_g=dict(type="NAFNetBaseline", window_size=16, **TINY), path=dict(), tile=dict(infer_size=32, tile_pad=16),
                val=dict(save_img=False))
     m = build_model(opt)
     m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0), strict=True)
@@ -371,7 +371,7 @@ def test_tiled_inference_matches_per_tile_loop(dev):
         for y0 in range(0, 80, 32):
             for x0 in range(0, 96, 32):
                 x1, y1 = min(x0 + 32, 96), min(y0 + 32, 80)
-                xp0, yp0, xp1, yp1 = max(x0 - 8, 0), max(y0 - 8, 0), min(x1 + 8, 96), min(y1 + 8, 80)
+                xp0, yp0, xp1, yp1 = max(x0 - 16, 0), max(y0 - 16, 0), min(x1 + 16, 96), min(y1 + 16, 80)
                 out = m.net_g(lq[:, :, yp0:yp1, xp0:xp1].contiguous())
                 ref[:, :, y0:y1, x0:x1] = out[:, :, y0 - yp0:y0 - yp0 + (y1 - y0), x0 - xp0:x0 - xp0 + (x1 - x0)]
     check("tiled", got, ref[:, :, :75, :88].cpu(), 1e-5)
