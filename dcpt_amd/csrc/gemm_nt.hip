@@ -12,7 +12,6 @@
 // one M panel so an A panel is fetched from HBM once per XCD and re-read from that XCD's L2.
 #include "gemm_operand.h"
 #include "prof.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -21,12 +20,13 @@ namespace {
 // space), then every thread owns one float4 column group of 16 rows: global loads (residual / gate
 // inputs) and stores are 16 B per lane and 512 B contiguous per row, and all the loads of a thread are
 // issued before the LDS round trip so their latency overlaps it.
-template <int EK, int BM, int BN>
+template <int EK, int BM, int BN, int NT_>
 __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0, int tid) {
+    constexpr int NTHR = NT_;
     const int ldres = p.ldres ? p.ldres : p.ldc;
     constexpr int LDC = BN + 4;
     constexpr int Q = BN / 4;          // float4 groups per row
-    constexpr int RPP = 256 / Q;       // rows per pass
+    constexpr int RPP = NTHR / Q;      // rows per pass
     constexpr int IT = BM / RPP;
     const int q = tid % Q, r0 = tid / Q;
     const int n = n0 + 4 * q;
@@ -107,11 +107,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
 }
 
 template <int BM, int BN, int WM, int WN, int AK, int EK, int BK>
-__global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_nt_kernel(const GemmNT pin) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin) {
+    constexpr int NTHR = WM * WN * 64;
     constexpr int LDS_LD = BK + 4;
     constexpr int TPR = BK / 4;        // threads per tile row (one float4 each)
-    constexpr int RPP = 256 / TPR;     // rows per pass
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int RPP = NTHR / TPR;    // rows per pass
     GemmNT p = pin;
     if (gridDim.y > 1) {  // batched: shift the base pointers of this problem
         const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm_nt_kernel(const Ge
             }
         }
         __syncthreads();
-        epilogue_rows<EK, C_ROWS, BN>(p, smem, m0 + ps * C_ROWS, n0, tid);
+        epilogue_rows<EK, C_ROWS, BN, NTHR>(p, smem, m0 + ps * C_ROWS, n0, tid);
     }
 }
 
