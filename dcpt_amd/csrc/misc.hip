@@ -216,17 +216,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
     }
     if (dgain == nullptr && dbias == nullptr) return;
+    // column sum of this row: cs_rows partial rows, one load per thread + a fixed-order block reduction
     float cs = 0.f;
     if (colsum)
-        for (int s = 0; s < cs_rows; ++s) cs += colsum[(int64_t)s * N + n];
-    if (dgain) {
-        dot = group_sum(dot, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = dot;
-        __syncthreads();
-        if (tid == 0) dgain[n] = ((red[0] + red[1]) + (red[2] + red[3])) + (wbias ? wbias[n] * cs : 0.f);
+        for (int r = tid; r < cs_rows; r += 256) cs += colsum[(int64_t)r * N + n];
+    cs = group_sum(cs, 64);
+    dot = group_sum(dot, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = cs;
+        red4[tid >> 6].x = dot;
     }
-    if (dbias && tid == 0) dbias[n] = rsc * cs;
+    __syncthreads();
+    if (tid == 0) {
+        cs = (red[0] + red[1]) + (red[2] + red[3]);
+        dot = (red4[0].x + red4[1].x) + (red4[2].x + red4[3].x);
+        if (dgain) dgain[n] = dot + (wbias ? wbias[n] * cs : 0.f);
+        if (dbias) dbias[n] = rsc * cs;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
