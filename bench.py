@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (the metric is quoted at 32)")
     ap.add_argument("--chunks", type=int, default=1, help="sub-batches on separate HIP streams inside the model forward")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even with one rank (path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -105,8 +106,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    use_ddp = world > 1 or args.force_ddp
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
 
     from basicsr.archs import build_network
@@ -119,7 +124,7 @@ def main():
     net = net.to(dev)
     net.stream_chunks = args.chunks
     model = net
-    if world > 1:
+    if use_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
         # reference base_model.py:108-115; buckets all-reduce on RCCL's stream while backward continues
@@ -143,7 +148,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -156,7 +161,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     prof_rows = []
     if use_prof:
         buf = (ctypes.c_double * (8 * 512))()
@@ -167,7 +172,7 @@ def main():
             prof_rows.append(dict(kernel=prof_class_name(int(cls)), M=int(M), N=int(N), K=int(K), launches=int(cnt), ms=ms,
                                   flops=fl, bytes=by))
         prof_rows.sort(key=lambda r: -r["ms"])
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -204,11 +209,21 @@ def main():
         if prof_rows:
             top = prof_rows[0]
             ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the committed PMC passes (cannot be read live): see the file's "source"
+            traffic, traffic_src = None, None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                    pmc = json.load(fh)
+                if top["kernel"] in pmc["kernels"]:
+                    traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 PMC passes of an earlier run of this command)"
+            except (OSError, ValueError, KeyError):
+                pass
             gemm_ms = sum(r["ms"] for r in prof_rows)
             res["roofline"] = {
                 "bound": "mfma", "kernel": top["kernel"], "MNK": [top["M"], top["N"], top["K"]],
                 "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches": top["launches"], "avg_launch_us": round(top["ms"] * 1e3 / max(1, top["launches"]), 2),
                 "alg_flops_per_launch": round(top["flops"] / max(1, top["launches"])),
                 "alg_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
@@ -227,7 +242,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 
