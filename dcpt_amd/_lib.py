@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")
+LIB_PATH = os.environ.get("DCPT_HIP_LIB") or os.path.join(_HERE, "lib", "libdcpt_hip.so")  # env override: diagnostic builds (tools/)
 
 _lib = None
 _lock = threading.Lock()

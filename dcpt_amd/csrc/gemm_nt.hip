@@ -1,106 +1,150 @@
 // NT GEMM on fp32 MFMA:  C[m][n] = sum_k A'(m,k) * Bw[n][k]  with fused operand loader + epilogue.
 //
 // Tile: BM x BN x 32, 256 threads = 4 waves (64 lanes each), every wave owns TM x TN MFMA tiles of
-// 32x32 (v_mfma_f32_32x32x2_f32).  A and Bw tiles are staged through LDS ([rows][32+4] floats, the
-// +4 keeps ds_read_b128 conflict-free for 32 consecutive rows), double buffered: the next tile's
-// global loads are issued into registers before the current tile's MFMAs and written to the other
-// LDS buffer after them, one barrier per k-tile.  Lane (i = lane&31, h = lane>>5) reads 4
-// consecutive k of row i at k-offset 4h as one ds_read_b128 and feeds four MFMAs (the k order inside
-// a block of 8 is {0,4},{1,5},{2,6},{3,7}; A and B use the same order so the sum is unchanged).
+// 32x32 (v_mfma_f32_32x32x2_f32).  A and Bw tiles live in LDS as [rows][32] floats, UNPADDED, with the
+// eight 16-byte k-quads of row r stored at slot q ^ ((r >> 1) & 7): ds_read_b128 of 32 consecutive rows at
+// one k-quad is conflict-free, and a wave's 64 lanes (8 rows x 8 quads) cover 1 KiB of contiguous LDS.
+// That is exactly the image an LDS-DMA (buffer_load_dwordx4 ... lds) writes, so operands that need no math
+// (weights, plain / gathered / implicit-conv activations) go global -> LDS without touching VGPRs, the swizzle
+// being applied on the SOURCE side (each lane fetches k-quad slot ^ f(row)).  Operands with a fused transform
+// (LayerNorm, SimpleGate, SCA scale) are loaded to registers before the current tile's MFMAs and written
+// (transformed) to the same image after them.  Double buffered, one barrier per k-tile.
+// Lane (i = lane&31, h = lane>>5) reads the 4 consecutive k at quad 2j+h of row i as one ds_read_b128 and feeds
+// four MFMAs (k order inside a block of 8 is {0,4},{1,5},{2,6},{3,7}; A and B use the same order).
 //
 // Block id -> tile: XCD-aware (dcpt_common.h xcd_remap); consecutive logical ids walk the N tiles of
 // one M panel so an A panel is fetched from HBM once per XCD and re-read from that XCD's L2.
 #include "gemm_operand.h"
 #include "prof.h"
 
+#ifdef DCPT_TIMELINE
+// Diagnostic build only (tools/timeline.py): per-block phase stamps, 100 MHz wall clock + HW id.
+__device__ unsigned long long g_tl[1 << 15][12];
+extern "C" int dcpt_timeline_read(unsigned long long* host, int nblk) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * 12 * (size_t)nblk);
+}
+#define TL_STAMP(i) if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < (1 << 15)) { g_tl[blockIdx.x][i] = wall_clock64(); if (i == 1) g_tl[blockIdx.x][6] = clock64(); if (i == 2) g_tl[blockIdx.x][7] = clock64(); }
+#define TL_HWID() if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < (1 << 15)) { unsigned hw, xcc; \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+    g_tl[blockIdx.x][4] = hw; g_tl[blockIdx.x][5] = xcc; }
+#if DCPT_TIMELINE >= 2
+#define TL_LOOP_DECL unsigned long long tl_c = 0, tl_v = 0, tl_b = 0, tl_1, tl_2, tl_3, tl_4;
+#define TL_T(n) tl_##n = __builtin_readcyclecounter();
+#define TL_ACC() tl_c += tl_2 - tl_1; tl_v += tl_3 - tl_2; tl_b += tl_4 - tl_3;
+#define TL_LOOP_END() if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < (1 << 15)) { g_tl[blockIdx.x][8] = tl_c; g_tl[blockIdx.x][9] = tl_v; g_tl[blockIdx.x][10] = tl_b; }
+#else
+#define TL_LOOP_DECL
+#define TL_T(n)
+#define TL_ACC()
+#define TL_LOOP_END()
+#endif
+#else
+#define TL_STAMP(i)
+#define TL_HWID()
+#define TL_LOOP_DECL
+#define TL_T(n)
+#define TL_ACC()
+#define TL_LOOP_END()
+#endif
+
 namespace {
 
+// element index of output row m in the fine NHWC image of the scatter epilogues (i = j = ch = 0)
+__device__ __forceinline__ int64_t scatter_elem(const GemmNT& p, int64_t m) {
+    const int w = (int)(m % p.gW);
+    const int64_t t = m / p.gW;
+    const int h = (int)(t % p.gH);
+    const int64_t b = t / p.gH;
+    return ((b * (2 * p.gH) + 2 * h) * (int64_t)(2 * p.gW) + 2 * w) * p.gC;
+}
 
-// Epilogue: the accumulators are first parked in LDS ([BM][BN+4] floats, reusing the operand tiles'
-// space), then every thread owns one float4 column group of 16 rows: global loads (residual / gate
-// inputs) and stores are 16 B per lane and 512 B contiguous per row, and all the loads of a thread are
-// issued before the LDS round trip so their latency overlaps it.
-template <int EK, int BM, int BN, int NT_>
+// Epilogue: the accumulators are first parked in LDS ([ROWS][BN] floats, reusing the operand tiles'
+// space), then every thread owns one float4 column group of ROWS / RPP rows: global loads (residual / gate
+// inputs) and stores are 16 B per lane and BN*4 B contiguous per row, all through buffer windows opened at
+// the tile's first row (rows past M / columns past N are dropped by the range check), and all the loads
+// of a thread are issued before the LDS round trip so their latency overlaps it.
+template <int EK, int ROWS, int BN, int NT_>
 __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0, int tid) {
-    constexpr int NTHR = NT_;
-    const int ldres = p.ldres ? p.ldres : p.ldc;
-    constexpr int LDC = BN + 4;
     constexpr int Q = BN / 4;          // float4 groups per row
-    constexpr int RPP = NTHR / Q;      // rows per pass
-    constexpr int IT = BM / RPP;
+    constexpr int RPP = NT_ / Q;       // rows per pass
+    constexpr int IT = ROWS / RPP;
+    const int ldres = p.ldres ? p.ldres : p.ldc;
     const int q = tid % Q, r0 = tid / Q;
     const int n = n0 + 4 * q;
-    if (n >= p.N) return;
+    const bool nok = n < p.N;
     float4 bias = f4_zero(), cs = make_float4(1.f, 1.f, 1.f, 1.f);
     if constexpr (EK == E_BIAS || EK == E_RESID || EK == E_MUL) {
-        if (p.bias) bias = ldg4(p.bias + n);
+        if (p.bias && nok) bias = ldg4(p.bias + n);
     }
     if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
-        if (p.cscale) cs = ldg4(p.cscale + n);
+        if (p.cscale && nok) cs = ldg4(p.cscale + n);
     }
-    int si = 0, sj = 0, ch = 0;
-    if constexpr (EK == E_SCATTER || EK == E_SCATTER_ADD) {
-        const int ij = n / p.gC;
-        ch = n - ij * p.gC;
-        si = ij >> 1;
-        sj = ij & 1;
+    constexpr bool SCAT = (EK == E_SCATTER || EK == E_SCATTER_ADD);
+    // windows
+    int64_t cbase;
+    uint32_t coladd;  // byte offset of this thread's column group inside a row
+    if constexpr (SCAT) {
+        const int64_t mf = (m0 < p.M) ? m0 : 0;
+        cbase = scatter_elem(p, mf);
+        const int nn = nok ? n : 0;
+        const int ij = nn / p.gC;
+        const int ch = nn - ij * p.gC;
+        coladd = (uint32_t)((((ij >> 1) * (2 * p.gW) + (ij & 1)) * p.gC + ch) * 4);
+    } else {
+        cbase = m0 * (int64_t)p.ldc;
+        coladd = 4u * (uint32_t)n;
     }
+    const rsrc_t rsC = make_rsrc(p.C + cbase);
+    rsrc_t rsR = rsC, rsX = rsC;
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
+    if constexpr (EK == E_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
     constexpr int HALF = (EK == E_SGBWD) ? 2 : 1;   // SGBWD needs two loads per row: do it in two halves
     constexpr int ITH = IT / HALF;
 #pragma unroll
     for (int hh = 0; hh < HALF; ++hh) {
         float4 pre1[ITH], pre2[ITH];
-        int64_t addr[ITH];
+        uint32_t addr[ITH];
 #pragma unroll
         for (int it = 0; it < ITH; ++it) {
-            const int64_t m = m0 + r0 + (int64_t)(hh * ITH + it) * RPP;
-            const bool ok = m < p.M;
+            const int rl = r0 + (hh * ITH + it) * RPP;
+            const int64_t m = m0 + rl;
+            const bool ok = (m < p.M) && nok;
             pre1[it] = f4_zero();
             pre2[it] = f4_zero();
-            if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL) {
-                addr[it] = m * p.ldc + n;
-                if (ok) pre1[it] = ldg4(p.res + m * ldres + n);
-            } else if constexpr (EK == E_SGBWD) {
-                addr[it] = m * p.ldc + n;
-                if (ok) {
-                    pre1[it] = ldg4(p.aux + m * (2 * (int64_t)p.N) + n);
-                    pre2[it] = ldg4(p.aux + m * (2 * (int64_t)p.N) + p.N + n);
-                }
-            } else if constexpr (EK == E_SCATTER || EK == E_SCATTER_ADD) {
-                const int64_t mm = ok ? m : 0;
-                const int w = (int)(mm % p.gW);
-                const int64_t t = mm / p.gW;
-                const int h = (int)(t % p.gH);
-                const int64_t b = t / p.gH;
-                addr[it] = ((b * (2 * p.gH) + 2 * h + si) * (int64_t)(2 * p.gW) + 2 * w + sj) * p.gC + ch;
-                if constexpr (EK == E_SCATTER_ADD) {
-                    if (ok) pre1[it] = ldg4(p.res + addr[it]);
-                }
+            if constexpr (SCAT) {
+                addr[it] = ok ? (uint32_t)((scatter_elem(p, m) - cbase) * 4) + coladd : ROW_SENT;
+                if constexpr (EK == E_SCATTER_ADD) pre1[it] = buf_ld4(rsR, addr[it]);
             } else {
-                addr[it] = m * p.ldc + n;
+                addr[it] = ok ? (uint32_t)rl * (uint32_t)p.ldc * 4u + coladd : ROW_SENT;
+                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL)
+                    pre1[it] = buf_ld4(rsR, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
+                if constexpr (EK == E_SGBWD) {
+                    const uint32_t xo = ok ? (uint32_t)rl * (uint32_t)p.N * 8u + coladd : ROW_SENT;
+                    pre1[it] = buf_ld4(rsX, xo);
+                    pre2[it] = buf_ld4(rsX, xo + 4u * (uint32_t)p.N);
+                }
             }
         }
 #pragma unroll
         for (int it = 0; it < ITH; ++it) {
             const int rl = r0 + (hh * ITH + it) * RPP;
-            const int64_t m = m0 + rl;
-            if (m >= p.M) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * LDC + 4 * q]);
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * BN + 4 * q]);
             if constexpr (EK == E_PLAIN || EK == E_SCATTER) {
-                stg4(p.C + addr[it], v);
+                buf_st4(rsC, addr[it], v);
             } else if constexpr (EK == E_BIAS) {
-                stg4(p.C + addr[it], f4_add(v, bias));
+                buf_st4(rsC, addr[it], f4_add(v, bias));
             } else if constexpr (EK == E_RESID) {
-                stg4(p.C + addr[it], f4_fma(f4_add(v, bias), cs, pre1[it]));
+                buf_st4(rsC, addr[it], f4_fma(f4_add(v, bias), cs, pre1[it]));
             } else if constexpr (EK == E_ADDSCALED) {
-                stg4(p.C + addr[it], f4_fma(cs, pre1[it], v));
+                buf_st4(rsC, addr[it], f4_fma(cs, pre1[it], v));
             } else if constexpr (EK == E_MUL) {
-                stg4(p.C + addr[it], f4_mul(f4_add(v, bias), pre1[it]));
+                buf_st4(rsC, addr[it], f4_mul(f4_add(v, bias), pre1[it]));
             } else if constexpr (EK == E_SGBWD) {
-                stg4(p.C + addr[it], f4_mul(v, pre2[it]));
-                stg4(p.C + addr[it] + p.N, f4_mul(v, pre1[it]));
+                buf_st4(rsC, addr[it], f4_mul(v, pre2[it]));
+                buf_st4(rsC, addr[it] + 4u * (uint32_t)p.N, f4_mul(v, pre1[it]));
             } else {  // E_SCATTER_ADD
-                stg4(p.C + addr[it], f4_add(v, pre1[it]));
+                buf_st4(rsC, addr[it], f4_add(v, pre1[it]));
             }
         }
     }
@@ -108,11 +152,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
 
 template <int BM, int BN, int WM, int WN, int AK, int EK, int BK>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin) {
-    constexpr int NTHR = WM * WN * 64;
-    constexpr int LDS_LD = BK + 4;
-    constexpr int TPR = BK / 4;        // threads per tile row (one float4 each)
-    constexpr int RPP = NTHR / TPR;    // rows per pass
+    static_assert(BK == 32 && WM * WN == 4, "32-deep k-tiles, 4 waves");
+    constexpr int NTHR = 256;
+    constexpr bool A_DMA = (AK == A_PLAIN || AK == A_GATHER || AK == A_CONV3);  // pure data movement
     GemmNT p = pin;
+    TL_STAMP(0) TL_HWID()
     if (gridDim.y > 1) {  // batched: shift the base pointers of this problem
         const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
         p.A += b1 * p.sA1 + b2 * p.sA2;
@@ -122,18 +166,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
         if (p.cscale) p.cscale += b1 * p.sS1 + b2 * p.sS2;
     }
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
-    constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;      // 256 threads cover 32 rows x 8 quads per pass
+    constexpr int A_SZ = BM * 32, B_SZ = BN * 32;
     constexpr int OP_SZ = 2 * (A_SZ + B_SZ);
-    // the accumulators are parked in the operand area for the epilogue; if it is too small for the whole tile
-    // (16-deep k-tiles) the epilogue runs in two row halves
-    constexpr int C_ROWS = (OP_SZ >= BM * (BN + 4)) ? BM : BM / 2;
-    static_assert(OP_SZ >= C_ROWS * (BN + 4), "epilogue staging does not fit");
+    static_assert(OP_SZ >= BM * BN, "epilogue staging does not fit");
     __shared__ __attribute__((aligned(16))) float smem[OP_SZ];
     float* const As0 = smem;               // [2][A_SZ]
     float* const Bs0 = smem + 2 * A_SZ;    // [2][B_SZ]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tilesN = (p.N + BN - 1) / BN;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -144,50 +186,58 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
     oa.ptr = p.A; oa.M = p.M; oa.ncols = p.K; oa.ld = p.lda;
     oa.mu = p.mu; oa.rstd = p.rstd; oa.lnw = p.lnw; oa.lnb = p.lnb;
     oa.simg = p.simg; oa.P = p.P; oa.gH = p.gH; oa.gW = p.gW; oa.gC = p.gC;
+    open_window<AK>(oa, m0 < p.M ? m0 : 0);
+    const i32x4 rsB = make_rsrc_dma(p.Bw + (int64_t)n0 * p.K);
+    rsrc_t rsW = oa.rs, rsWb = oa.rs;
+    if constexpr (AK == A_LN || AK == A_LNBF) rsW = make_rsrc(p.lnw, (uint32_t)p.K * 4u);
+    if constexpr (AK == A_LN) rsWb = make_rsrc(p.lnb, (uint32_t)p.K * 4u);
 
-    const int lrow = tid / TPR, lk = (tid % TPR) * 4;
+    // staging map: thread -> row (tid >> 3) + 32 * pass, LDS slot tid & 7, i.e. logical k-quad slot ^ f(row)
+    const int lrow = tid >> 3;
+    const int lk = 4 * ((tid & 7) ^ ((tid >> 4) & 7));
     RowCtx rca[A_IT];
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) make_row<AK>(oa, m0 + lrow + RPP * i, rca[i]);
-    const float* brow[B_IT];
-    bool bval[B_IT];
+    for (int i = 0; i < A_IT; ++i) make_row<AK>(oa, m0 + lrow + 32 * i, rca[i]);
+    uint32_t boff[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + lrow + RPP * i;
-        bval[i] = n < p.N;
-        brow[i] = p.Bw + (int64_t)(bval[i] ? n : 0) * p.K;
+        const int nl = lrow + 32 * i;
+        boff[i] = (n0 + nl < p.N) ? (uint32_t)nl * (uint32_t)p.K * 4u + 4u * (uint32_t)lk : ROW_SENT;
     }
+    const uint32_t lds_a = lds_addr(As0) + wave * 1024, lds_b = lds_addr(Bs0) + wave * 1024;   // this wave's 8 rows inside a 32-row pass
+    const int lds_t = tid * 4;          // this thread's quad inside a 32-row pass (floats)
 
     RawVec ra[A_IT];
-    float4 rb[B_IT];
     float4 kw = f4_zero(), kb = f4_zero();  // A_LN / A_LNBF: per-column weight/bias of this thread's k quad (same for all its rows)
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, int buf) {
         const int k = kt * BK + lk;
-        if constexpr (AK == A_LN || AK == A_LNBF) {
-            kw = (k < p.K) ? ldg4(p.lnw + k) : f4_zero();
-            if constexpr (AK == A_LN) kb = (k < p.K) ? ldg4(p.lnb + k) : f4_zero();
+        const uint32_t ksent = (k < p.K) ? 0u : COL_SENT;   // only the last k-tile of a ragged K
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) ra[i].a = (rca[i].valid && k < p.K) ? ldg4(p.A + rca[i].off + k) : f4_zero();
+        for (int i = 0; i < B_IT; ++i) dma16(rsB, lds_b + (buf * B_SZ + i * 1024) * 4, boff[i] + ksent, (uint32_t)kt * (BK * 4));
+        if constexpr (A_DMA) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) dma16(oa.rsd, lds_a + (buf * A_SZ + i * 1024) * 4, elem_voff<AK>(oa, rca[i], k), 0);
         } else {
+            if constexpr (AK == A_LN || AK == A_LNBF) {
+                kw = buf_ld4(rsW, 4u * (uint32_t)k);
+                if constexpr (AK == A_LN) kb = buf_ld4(rsWb, 4u * (uint32_t)k);
+            }
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) load_raw<AK>(oa, rca[i], k, ra[i]);
         }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = (bval[i] && k < p.K) ? ldg4(brow[i] + k) : f4_zero();
     };
     auto lstore = [&](int buf) {
-        if constexpr (AK == A_LN || AK == A_LNBF) {
+        if constexpr (!A_DMA) {
+            if constexpr (AK == A_LN || AK == A_LNBF) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                ra[i].b = kw;
-                ra[i].c = kb;
+                for (int i = 0; i < A_IT; ++i) {
+                    ra[i].b = kw;
+                    ra[i].c = kb;
+                }
             }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As0[buf * A_SZ + i * 1024 + lds_t]) = finish<AK>(rca[i], ra[i]);
         }
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            *reinterpret_cast<float4*>(&As0[buf * A_SZ + (lrow + RPP * i) * LDS_LD + lk]) = finish<AK>(rca[i], ra[i]);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs0[buf * B_SZ + (lrow + RPP * i) * LDS_LD + lk]) = rb[i];
     };
 
     floatx16 acc[TM][TN];
@@ -199,59 +249,69 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (p.K + BK - 1) / BK;
-    gload(0);
+    gload(0, 0);
     lstore(0);
+    dma_wait_all();
     __syncthreads();
-    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-    const int b_off = (wn * TN * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    TL_STAMP(1)
+    // fragment addresses: row (lane & 31) of the wave's tile, slot (2j + h) ^ f(row) for k-group j
+    const int fi = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    const int a_row = (wm * TM * 32 + (lane & 31)) * 32;
+    const int b_row = (wn * TN * 32 + (lane & 31)) * 32;
+    int slot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot[j] = ((2 * j + fh) ^ fi) * 4;
+    TL_LOOP_DECL
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
-        const float* as = As0 + buf * A_SZ + a_off;
-        const float* bs = Bs0 + buf * B_SZ + b_off;
+        TL_T(1)
+        if (kt + 1 < nkt) gload(kt + 1, buf ^ 1);
+        const float* as = As0 + buf * A_SZ + a_row;
+        const float* bs = Bs0 + buf * B_SZ + b_row;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
+        for (int j = 0; j < 4; ++j) {
             float4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 1024 + slot[j]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk);
+            for (int jn = 0; jn < TN; ++jn) bf[jn] = *reinterpret_cast<const float4*>(bs + jn * 1024 + slot[j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
                 }
         }
         if (kt + 1 < nkt) lstore(buf ^ 1);
+        TL_T(2)
+        dma_wait_all();   // this wave's LDS-DMA pieces of tile kt+1 have landed; the barrier publishes them
+        TL_T(3)
         __syncthreads();
+        TL_T(4) TL_ACC()
     }
+    TL_LOOP_END()
 
+    TL_STAMP(2)
     // park the accumulators in LDS (the last k-tile's barrier already separates us from the MFMA reads)
-    constexpr int LDC = BN + 4;
 #pragma unroll
-    for (int ps = 0; ps < BM / C_ROWS; ++ps) {
-        if (ps > 0) __syncthreads();
+    for (int i = 0; i < TM; ++i) {
+        const int rb = (wm * TM + i) * 32;   // first row of this MFMA tile inside the block tile
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rb = (wm * TM + i) * 32;   // first row of this MFMA tile inside the block tile
-            if (rb / C_ROWS != ps) continue;
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wn * TN + j) * 32 + (lane & 31);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = (wn * TN + j) * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = rb - ps * C_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    smem[ml * LDC + nl] = acc[i][j][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int ml = rb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                smem[ml * BN + nl] = acc[i][j][r];
             }
         }
-        __syncthreads();
-        epilogue_rows<EK, C_ROWS, BN, NTHR>(p, smem, m0 + ps * C_ROWS, n0, tid);
     }
+    __syncthreads();
+    epilogue_rows<EK, BM, BN, NTHR>(p, smem, m0, n0, tid);
+    TL_STAMP(3)
 }
 
 template <int AK, int EK>
@@ -280,6 +340,9 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)p.M, p.N, p.K);
     DCPT_CHECK_ARG(p.K % 4 == 0, "gemm_nt: K=%d must be a multiple of 4", p.K);
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 64) < (1ll << 31), "gemm_nt: grid too large");
+    // 32-bit offsets inside a tile's buffer window (gemm_operand.h)
+    DCPT_CHECK_ARG(p.K < (1 << 20) && p.N < (1 << 20) && p.lda < (1 << 20) && p.ldc < (1 << 20) && p.ldres < (1 << 20),
+                   "gemm_nt: K/N/row strides must be below 2^20");
     if (aload == A_GATHER) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 4 * p.gC, "gemm_nt: gather needs K == 4*gC, gC %% 4 == 0");
     if (aload == A_CONV3) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 9 * p.gC, "gemm_nt: conv3 needs K == 9*gC, gC %% 4 == 0");
     // algorithmic work of this launch (for the live roofline in bench.py)

@@ -1,7 +1,66 @@
 // Fused operand loaders shared by the NT and TN MFMA GEMMs.
 // An operand is a logical [M][ncols] fp32 matrix derived on the fly from NHWC activations.
+//
+// All global accesses of the GEMMs go through buffer resources (buffer_load/store_dwordx4 ... offen):
+// a block opens a WINDOW at the first element its tile can touch (64-bit, wave-uniform base in SGPRs)
+// and addresses everything with 32-bit byte offsets relative to it.  Rows past M, columns past ncols
+// and zero-padding taps get an offset above the window size (ROW_SENT / COL_SENT), which the hardware
+// range check turns into "load returns 0 / store is dropped" -- no exec-mask branches around the
+// memory instructions, so the compiler is free to interleave them with the MFMAs.
 #pragma once
 #include "gemm.h"
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t WIN_BYTES = 0x3FFFFFFFu;  // every real offset of a tile is far below this (checked at launch)
+constexpr uint32_t ROW_SENT = 0x80000000u;   // row past M
+constexpr uint32_t COL_SENT = 0x40000000u;   // column past ncols / padding tap
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes = WIN_BYTES) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    // (bit-cast the whole vector: __builtin_bit_cast of a single ext-vector element reads element 0 on this hipcc)
+    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_st4(rsrc_t r, uint32_t voff, float4 f) {
+    floatx4 v;
+    v.x = f.x;
+    v.y = f.y;
+    v.z = f.z;
+    v.w = f.w;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_st1(rsrc_t r, uint32_t voff, float f) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, voff, 0, 0);
+}
+// LDS-DMA: 16 B per lane straight into LDS at (wave-uniform LDS byte address) + lane * 16, no VGPR staging.
+// Issued as inline asm on purpose: hipcc would otherwise order every later ds_read behind the pending LDS
+// write with an s_waitcnt vmcnt(0) right after the issue, exposing the whole HBM/L2 latency.  hipcc does not
+// count these loads, so the kernels wait for them themselves (dma_wait_all) before the barrier that
+// publishes the tile.  The resource is passed as four SGPR words (same content as rsrc_t).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc_dma(const void* base, uint32_t bytes = WIN_BYTES) {
+    const uint64_t a = (uint64_t)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));  // stride 0, 48-bit address
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)((__attribute__((address_space(3))) const void*)p));
+}
+__device__ __forceinline__ void dma16(i32x4 rs, uint32_t lds_byte, uint32_t voff, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(lds_byte), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct Operand {
     const float* ptr;
@@ -15,91 +74,107 @@ struct Operand {
     const float* simg;
     int P;
     int gH, gW, gC;
+    // window, set by open_window()
+    rsrc_t rs;
+    i32x4 rsd;     // the same window for LDS-DMA
+    int64_t base;  // element index of the window start
+    rsrc_t rs_s;   // A_SCALE: the per-image scale table
 };
 
 struct RowCtx {
-    int64_t off;
+    uint32_t off;   // byte offset of the row's first element inside the window, or ROW_SENT
+    uint32_t soff;  // A_SCALE: byte offset of the row's image inside simg
     float mu, rstd;
-    int img;
     int h, w;  // A_CONV3: pixel coordinates of the row
-    bool valid;
 };
 
 template <int KIND>
-__device__ __forceinline__ void make_row(const Operand& o, int64_t m, RowCtx& rc) {
-    rc.valid = m < o.M;
-    const int64_t mm = rc.valid ? m : 0;
-    rc.mu = 0.f;
-    rc.rstd = 0.f;
-    rc.img = 0;
-    rc.h = 0;
-    rc.w = 0;
+__device__ __forceinline__ int64_t row_elem(const Operand& o, int64_t m) {
     if constexpr (KIND == A_GATHER) {
-        const int w = (int)(mm % o.gW);
-        const int64_t t = mm / o.gW;
+        const int w = (int)(m % o.gW);
+        const int64_t t = m / o.gW;
         const int h = (int)(t % o.gH);
         const int64_t b = t / o.gH;
-        rc.off = ((b * (2 * o.gH) + 2 * h) * (int64_t)(2 * o.gW) + 2 * w) * o.gC;
+        return ((b * (2 * o.gH) + 2 * h) * (int64_t)(2 * o.gW) + 2 * w) * o.gC;
     } else if constexpr (KIND == A_CONV3) {
+        return m * (int64_t)o.gC;
+    } else {
+        return m * (int64_t)o.ld;
+    }
+}
+
+// m_first: first row this block will touch (wave-uniform)
+template <int KIND>
+__device__ __forceinline__ void open_window(Operand& o, int64_t m_first) {
+    int64_t base = row_elem<KIND>(o, m_first);
+    if constexpr (KIND == A_CONV3) {  // taps reach one image row + one pixel back
+        base -= (int64_t)(o.gW + 1) * o.gC;
+        if (base < 0) base = 0;
+    }
+    o.base = base;
+    o.rs = make_rsrc(o.ptr + base);
+    o.rsd = make_rsrc_dma(o.ptr + base);
+    if constexpr (KIND == A_SCALE) o.rs_s = make_rsrc(o.simg);
+}
+
+template <int KIND>
+__device__ __forceinline__ void make_row(const Operand& o, int64_t m, RowCtx& rc) {
+    const bool valid = m < o.M;
+    const int64_t mm = valid ? m : 0;
+    rc.mu = 0.f;
+    rc.rstd = 0.f;
+    rc.soff = 0;
+    rc.h = 0;
+    rc.w = 0;
+    rc.off = valid ? (uint32_t)((row_elem<KIND>(o, mm) - o.base) * 4) : ROW_SENT;
+    if constexpr (KIND == A_CONV3) {
         rc.w = (int)(mm % o.gW);
         rc.h = (int)((mm / o.gW) % o.gH);
-        rc.off = mm * (int64_t)o.gC;
-    } else {
-        rc.off = mm * (int64_t)o.ld;
     }
     if constexpr (KIND == A_LN) {
         rc.mu = o.mu[mm];
         rc.rstd = o.rstd[mm];
     }
     if constexpr (KIND == A_LNBF) rc.rstd = o.rstd[mm];
-    if constexpr (KIND == A_SCALE) rc.img = (int)(mm / o.P);
+    if constexpr (KIND == A_SCALE) rc.soff = (uint32_t)(mm / o.P) * (uint32_t)o.ncols * 4u;
+}
+
+// byte offset (inside the window) of the 4 floats at logical column c of the row, or a sentinel
+template <int KIND>
+__device__ __forceinline__ uint32_t elem_voff(const Operand& o, const RowCtx& rc, int c) {
+    bool ok = c < o.ncols;
+    uint32_t v;
+    if constexpr (KIND == A_CONV3) {
+        const int tap = c / o.gC;
+        const int ch = c - tap * o.gC;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int hh = rc.h + ky - 1, ww = rc.w + kx - 1;
+        ok = ok && hh >= 0 && hh < o.gH && ww >= 0 && ww < o.gW;
+        v = rc.off + (uint32_t)((((ky - 1) * o.gW + (kx - 1)) * o.gC + ch) * 4);
+    } else if constexpr (KIND == A_GATHER) {
+        const int ij = c / o.gC;
+        const int ch = c - ij * o.gC;
+        v = rc.off + (uint32_t)((((ij >> 1) * (2 * o.gW) + (ij & 1)) * o.gC + ch) * 4);
+    } else {
+        v = rc.off + 4u * (uint32_t)c;
+    }
+    return ok ? v : COL_SENT;
 }
 
 // Operand access is split in two so that the global loads of the NEXT tile can stay in flight
 // across the current tile's MFMAs: load_raw() only issues loads (no dependent math), finish() applies
-// the fused transform right before the value is written to LDS.
+// the fused transform right before the value is written to LDS.  (A_LN / A_LNBF: the per-column
+// weight/bias in b/c are filled by the kernels, which load them once per k-tile.)
 struct RawVec {
     float4 a, b, c;
 };
 
 template <int KIND>
 __device__ __forceinline__ void load_raw(const Operand& o, const RowCtx& rc, int c, RawVec& r) {
-    const bool ok = rc.valid && c < o.ncols;
-    if constexpr (KIND == A_PLAIN) {
-        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
-    } else if constexpr (KIND == A_LN) {
-        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
-        r.b = ok ? ldg4(o.lnw + c) : f4_zero();
-        r.c = ok ? ldg4(o.lnb + c) : f4_zero();
-    } else if constexpr (KIND == A_LNBF) {
-        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
-        r.b = ok ? ldg4(o.lnw + c) : f4_zero();
-    } else if constexpr (KIND == A_SCALE) {
-        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
-        r.b = ok ? ldg4(o.simg + (int64_t)rc.img * o.ncols + c) : f4_zero();
-    } else if constexpr (KIND == A_SG) {
-        r.a = ok ? ldg4(o.ptr + rc.off + c) : f4_zero();
-        r.b = ok ? ldg4(o.ptr + rc.off + o.ncols + c) : f4_zero();
-    } else if constexpr (KIND == A_CONV3) {
-        r.a = f4_zero();
-        if (ok) {
-            const int tap = c / o.gC;
-            const int ch = c - tap * o.gC;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int hh = rc.h + ky - 1, ww = rc.w + kx - 1;
-            if (hh >= 0 && hh < o.gH && ww >= 0 && ww < o.gW)
-                r.a = ldg4(o.ptr + rc.off + ((int64_t)(ky - 1) * o.gW + (kx - 1)) * o.gC + ch);
-        }
-    } else {  // A_GATHER
-        if (ok) {
-            const int ij = c / o.gC;
-            const int ch = c - ij * o.gC;
-            const int64_t a = rc.off + ((int64_t)(ij >> 1) * (2 * o.gW) + (ij & 1)) * o.gC + ch;
-            r.a = ldg4(o.ptr + a);
-        } else {
-            r.a = f4_zero();
-        }
-    }
+    const uint32_t v = elem_voff<KIND>(o, rc, c);
+    r.a = buf_ld4(o.rs, v);
+    if constexpr (KIND == A_SCALE) r.b = buf_ld4(o.rs_s, c < o.ncols ? rc.soff + 4u * (uint32_t)c : COL_SENT);
+    if constexpr (KIND == A_SG) r.b = buf_ld4(o.rs, v + 4u * (uint32_t)o.ncols);
 }
 
 template <int KIND>

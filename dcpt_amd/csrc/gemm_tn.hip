@@ -2,10 +2,12 @@
 //
 // Both operands are NHWC activations/gradients: the reduction index m (pixels) is the slow axis,
 // so MFMA operand fragments are plain ds_read_b32 of consecutive floats (lane i reads column i of
-// row mm + lane>>5): no transposition anywhere.  The pixel range is split into `splits` chunks
-// (grid.y); every chunk writes its own [N][K] slab and a deterministic reduce kernel (misc.hip)
-// sums the slabs -- no float atomics.  Blocks of the first k-tile column also emit the column sums
-// of X' (bias gradients) from the LDS tile they already hold.
+// row mm + lane>>5): no transposition anywhere, and the LDS tiles are plain row-major [32][BN] images --
+// which is what an LDS-DMA writes, so operands without a fused transform (dO always; plain / gathered /
+// implicit-conv activations) go global -> LDS without touching VGPRs (buffer_load_dwordx4 ... lds).
+// The pixel range is split into `splits` chunks (grid.y); every chunk writes its own [N][K] slab and a
+// deterministic reduce kernel (misc.hip) sums the slabs -- no float atomics.  Blocks of the first k-tile
+// column also emit the column sums of X' (bias gradients) from the LDS tile they already hold.
 #include "gemm_operand.h"
 #include "prof.h"
 
@@ -13,9 +15,13 @@ namespace {
 
 constexpr int BR = 32;  // reduction rows per LDS tile
 
+template <int KIND>
+constexpr bool is_dma() { return KIND == A_PLAIN || KIND == A_GATHER || KIND == A_CONV3; }
+
 template <int BN, int BKo, int WN, int WK, int XK, int YK>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     static_assert(WN * WK == 4, "4 waves");
+    static_assert(is_dma<XK>(), "X (the output gradient) is never transformed");
     GemmTN p = pin;
     if (gridDim.y > 1) {
         const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
@@ -24,14 +30,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
         p.slab += (int64_t)blockIdx.y * p.splits * p.N * p.K;
     }
     constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
-    constexpr int LDX = BN + 4, LDY = BKo + 4;
     constexpr int XQ = BN / 4, YQ = BKo / 4;           // float4 per tile row
     constexpr int XR = 256 / XQ, YR = 256 / YQ;        // rows covered per pass
     constexpr int X_IT = BR / XR, Y_IT = BR / YR;
-    __shared__ __attribute__((aligned(16))) float Xs[2][BR * LDX];
-    __shared__ __attribute__((aligned(16))) float Ys[2][BR * LDY];
+    constexpr bool Y_DMA = is_dma<YK>();
+    __shared__ __attribute__((aligned(16))) float Xs[2][BR * BN];
+    __shared__ __attribute__((aligned(16))) float Ys[2][BR * BKo];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WK, wk = wave % WK;
     // 1-D grid, XCD-aware: the tiles of one pixel chunk (split) get consecutive logical ids, i.e. run
     // on one XCD at about the same time, so its X/Y row panels are fetched from HBM once and re-read
@@ -54,11 +61,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     oy.ptr = p.Y; oy.M = mend; oy.ncols = p.K; oy.ld = p.ldy;
     oy.mu = p.mu; oy.rstd = p.rstd; oy.lnw = p.lnw; oy.lnb = p.lnb; oy.simg = p.simg; oy.P = p.P;
     oy.gH = p.gH; oy.gW = p.gW; oy.gC = p.gC;
+    open_window<XK>(ox, mbeg < p.M ? mbeg : 0);
+    open_window<YK>(oy, mbeg < p.M ? mbeg : 0);
 
     const int xrow = tid / XQ, xc = (tid % XQ) * 4;
     const int yrow = tid / YQ, yc = (tid % YQ) * 4;
-    RawVec rx[X_IT], ry[Y_IT];
-    RowCtx rcx[X_IT], rcy[Y_IT];
+    RawVec ry[Y_IT];
+    RowCtx rcy[Y_IT];
     // A_LN / A_LNBF on Y: this thread always handles the same 4 columns, so weight/bias are loaded once
     float4 kw = f4_zero(), kb = f4_zero();
     if constexpr (YK == A_LN || YK == A_LNBF) {
@@ -67,31 +76,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
             if constexpr (YK == A_LN) kb = ldg4(p.lnb + k0 + yc);
         }
     }
-    auto gload = [&](int64_t mt) {
+    // LDS-DMA: a wave's 64 lanes write 1 KiB of consecutive tile floats
+    const uint32_t lds_x = lds_addr(&Xs[0][0]) + wave * 1024, lds_y = lds_addr(&Ys[0][0]) + wave * 1024;
+    auto gload = [&](int64_t mt, int buf) {
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
-            make_row<XK>(ox, mt + xrow + XR * i, rcx[i]);
-            load_raw<XK>(ox, rcx[i], n0 + xc, rx[i]);
+            RowCtx rc;
+            make_row<XK>(ox, mt + xrow + XR * i, rc);
+            dma16(ox.rsd, lds_x + (buf * BR * BN + i * XR * BN) * 4, elem_voff<XK>(ox, rc, n0 + xc), 0);
         }
 #pragma unroll
         for (int i = 0; i < Y_IT; ++i) {
             make_row<YK>(oy, mt + yrow + YR * i, rcy[i]);
-            if constexpr (YK == A_LN || YK == A_LNBF) {
-                ry[i].a = (rcy[i].valid && k0 + yc < p.K) ? ldg4(p.Y + rcy[i].off + k0 + yc) : f4_zero();
-                ry[i].b = kw;
-                ry[i].c = kb;
+            if constexpr (Y_DMA) {
+                dma16(oy.rsd, lds_y + (buf * BR * BKo + i * YR * BKo) * 4, elem_voff<YK>(oy, rcy[i], k0 + yc), 0);
             } else {
                 load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
+                if constexpr (YK == A_LN || YK == A_LNBF) {
+                    ry[i].b = kw;
+                    ry[i].c = kb;
+                }
             }
         }
     };
     auto lstore = [&](int buf) {
+        if constexpr (!Y_DMA) {
 #pragma unroll
-        for (int i = 0; i < X_IT; ++i)
-            *reinterpret_cast<float4*>(&Xs[buf][(xrow + XR * i) * LDX + xc]) = finish<XK>(rcx[i], rx[i]);
-#pragma unroll
-        for (int i = 0; i < Y_IT; ++i)
-            *reinterpret_cast<float4*>(&Ys[buf][(yrow + YR * i) * LDY + yc]) = finish<YK>(rcy[i], ry[i]);
+            for (int i = 0; i < Y_IT; ++i)
+                *reinterpret_cast<float4*>(&Ys[buf][(yrow + YR * i) * BKo + yc]) = finish<YK>(rcy[i], ry[i]);
+        }
     };
 
     floatx16 acc[TN][TK];
@@ -109,15 +122,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
 
     const int64_t nmt = (mend - mbeg + BR - 1) / BR;
     if (nmt > 0) {
-        gload(mbeg);
+        gload(mbeg, 0);
         lstore(0);
     }
+    dma_wait_all();
     __syncthreads();
-    const int x_off = (lane >> 5) * LDX + wn * TN * 32 + (lane & 31);
-    const int y_off = (lane >> 5) * LDY + wk * TK * 32 + (lane & 31);
+    const int x_off = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+    const int y_off = (lane >> 5) * BKo + wk * TK * 32 + (lane & 31);
     for (int64_t t = 0; t < nmt; ++t) {
         const int buf = (int)(t & 1);
-        if (t + 1 < nmt) gload(mbeg + (t + 1) * BR);
+        if (t + 1 < nmt) gload(mbeg + (t + 1) * BR, buf ^ 1);
         const float* xs = &Xs[buf][x_off];
         const float* ys = &Ys[buf][y_off];
         // software-pipelined fragments: the ds_reads of step s+1 are issued before the MFMAs of step s
@@ -131,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
             const int cur = st & 1, nxt = cur ^ 1;
             if (st + 1 < BR / 2) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) a[nxt][i] = xs[(2 * st + 2) * LDX + i * 32];
+                for (int i = 0; i < TN; ++i) a[nxt][i] = xs[(2 * st + 2) * BN + i * 32];
 #pragma unroll
-                for (int j = 0; j < TK; ++j) b[nxt][j] = ys[(2 * st + 2) * LDY + j * 32];
+                for (int j = 0; j < TK; ++j) b[nxt][j] = ys[(2 * st + 2) * BKo + j * 32];
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads ahead of this step's MFMAs
 #pragma unroll
@@ -146,24 +160,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
         if (do_cs && (int)(t % tilesK) == tile_k) {
             float s = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < BR; ++r) s += Xs[buf][r * LDX + tid];
+            for (int r = 0; r < BR; ++r) s += Xs[buf][r * BN + tid];
             cs += s;
         }
         if (t + 1 < nmt) lstore(buf ^ 1);
+        dma_wait_all();   // this wave's LDS-DMA pieces of the next tile have landed; the barrier publishes them
         __syncthreads();
     }
 
-    float* slab = p.slab + (int64_t)split * p.N * p.K;
+    // slab stores through a buffer window at the tile's first element; rows past N / columns past K are dropped
+    const rsrc_t rsS = make_rsrc(p.slab + (int64_t)split * p.N * p.K + (int64_t)n0 * p.K + k0);
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TK; ++j) {
-            const int k = k0 + (wk * TK + j) * 32 + (lane & 31);
-            if (k >= p.K) continue;
+            const int kl = (wk * TK + j) * 32 + (lane & 31);
+            const bool kok = k0 + kl < p.K;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + (wn * TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < p.N) slab[(int64_t)n * p.K + k] = acc[i][j][r];
+                const int nl = (wn * TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t o = (kok && n0 + nl < p.N) ? ((uint32_t)nl * (uint32_t)p.K + (uint32_t)kl) * 4u : ROW_SENT;
+                buf_st1(rsS, o, acc[i][j][r]);
             }
         }
     if (do_cs && n0 + tid < p.N) p.colsum[((int64_t)split * tilesK + tile_k) * p.N + n0 + tid] = cs;
@@ -220,6 +237,9 @@ int launch_gemm_tn(const GemmTN& pin, int xload, int yload, hipStream_t s) {
     DCPT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_tn: empty problem");
     DCPT_CHECK_ARG(p.N % 4 == 0 && p.K % 4 == 0, "gemm_tn: N=%d, K=%d must be multiples of 4", p.N, p.K);
     DCPT_CHECK_ARG(p.splits >= 1 && p.splits <= 65535 && p.rows_per_split % 32 == 0, "gemm_tn: bad split plan");
+    // 32-bit offsets inside a block's buffer windows (gemm_operand.h): one pixel chunk of either operand, one slab tile
+    DCPT_CHECK_ARG((double)(p.rows_per_split + 64) * (double)(p.ldx > p.ldy ? p.ldx : p.ldy) * 4.0 < 1.0e9 && (double)p.N * p.K < 2.0e8,
+                   "gemm_tn: pixel chunk or slab too large for 32-bit window offsets");
     const double bytes = (double)p.M * p.N + (double)p.M * p.K * (yload == A_SG ? 2 : 1) + (double)p.splits * p.N * p.K;
     ProfScope prof(s, PROF_TN + xload * 8 + yload, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K * p.nb1 * p.nb2,
                    bytes * 4.0 * p.nb1 * p.nb2);
