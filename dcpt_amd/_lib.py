@@ -25,7 +25,7 @@ _PARAM_FIELDS = [
     "norm1_w", "norm1_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b",
     "sca_w", "sca_b", "norm2_w", "norm2_b", "conv4_w", "conv4_b", "conv5_w", "conv5_b", "beta", "gamma",
 ]
-_SAVED_FIELDS = ["t1", "t2", "y", "v", "mu1", "rstd1", "mu2", "rstd2", "pooled", "s"]
+_SAVED_FIELDS = ["t1", "t2", "y", "v", "mu1", "rstd1", "mu2", "rstd2", "pooled", "s", "xn1", "xn2"]
 
 
 class NafBlockParams(C.Structure):
@@ -128,6 +128,7 @@ SIGNATURES = {
     "dcpt_split_channels": (cint, [f32p, f32p, f32p, i64, cint, cint, stream_t]),
     "dcpt_prof_enable": (cint, [cint]),
     "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
+    "dcpt_set_side_stream": (cint, [cint]),
     "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
     "dcpt_nhwc_to_nchw": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
 }

@@ -60,6 +60,14 @@ __device__ __forceinline__ void dma16(i32x4 rs, uint32_t lds_byte, uint32_t voff
                  : "v"(voff), "s"(rs), "s"(lds_byte), "s"(soff)
                  : "memory");
 }
+// 4 B per lane: (wave-uniform LDS byte address) + lane * 4
+__device__ __forceinline__ void dma4(i32x4 rs, uint32_t lds_byte, uint32_t voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(lds_byte)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct Operand {

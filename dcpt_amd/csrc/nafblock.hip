@@ -1,19 +1,24 @@
 // NAFBlock forward / backward composition (reference basicsr/archs/nafnet_arch.py:165-186).
 //
 // Forward (NHWC, M = B*H*W pixels):
-//   stats1 = LN-stats(inp)                                   ln_stats
-//   t1  = conv1(LN1(inp))            LN fused into the A loader   gemm_nt<A_LN, E_BIAS>
+//   xn1 = LN1(inp), stats1                                   ln_fwd (kept for conv1's weight gradient)
+//   t1  = conv1(xn1)                                         gemm_nt<A_PLAIN, E_BIAS>  (operands by LDS-DMA)
 //   t2  = SG(dw3x3(t1)+b2), pool partial sums                dw_fwd
 //   s   = Wsca * mean(t2) + bsca                             sca_fwd
 //   y   = inp + (conv3(t2*s)+b3)*beta                        gemm_nt<A_SCALE, E_RESID>
-//   stats2 = LN-stats(y)
-//   v   = conv4(LN2(y))                                      gemm_nt<A_LN, E_BIAS>
+//   xn2 = LN2(y), stats2                                     ln_fwd
+//   v   = conv4(xn2)                                         gemm_nt<A_PLAIN, E_BIAS>
 //   out = y + (conv5(SG(v))+b5)*gamma                        gemm_nt<A_SG, E_RESID>
 //
 // Backward never materialises the conv3/conv5 outputs: with G[n][k] = sum_m dO[m][n]*A'[m][k]
 // (the un-scaled weight gradient) one has  dW = gain[n]*G,  dgain[n] = sum_k W[n][k]*G[n][k] +
 // b[n]*sum_m dO[m][n],  db = gain[n]*sum_m dO[m][n]   (gain = beta or gamma), which also stays exact
 // for the reference's zero-initialised beta/gamma.
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+
 #include "gemm.h"
 #include "kernels.h"
 #include "../../include/dcpt_hip.h"
@@ -42,7 +47,7 @@ size_t fwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWs
 
 struct BwdWs {
     float *wT5, *wT4, *wT3, *wT1, *w2p;
-    float *b2a, *b2b;       // [M][2C]
+    float *b2a, *b2b, *b2c; // [M][2C]
     float *bca, *bcb, *bcc; // [M][C]
     float* slab;
     float* colsum;
@@ -65,6 +70,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.w2p = a.get<float>((size_t)18 * C);
     w.b2a = a.get<float>((size_t)M * 2 * C);
     w.b2b = a.get<float>((size_t)M * 2 * C);
+    w.b2c = a.get<float>((size_t)M * 2 * C);
     w.bca = a.get<float>((size_t)M * C);
     w.bcb = a.get<float>((size_t)M * C);
     w.bcc = a.get<float>((size_t)M * C);
@@ -101,7 +107,78 @@ int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yl
     return DCPT_OK;
 }
 
+// Weight-gradient side stream.  In the backward pass the four wgrad GEMMs (+ their slab reductions) are off the
+// critical path dout -> dinp: they run on a second, low-priority HIP stream, forked/joined with events inside one
+// dcpt_nafblock_bwd call, so that the HBM-bound kernels of the main chain (LayerNorm / depthwise / SCA backward) and the
+// launch ramps and tails of its GEMMs overlap MFMA-bound wgrad work instead of leaving the matrix cores idle.
+// DCPT_SIDE_STREAM=0 in the environment keeps everything on the caller's stream.
+struct Side {
+    hipStream_t ss = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+std::mutex g_side_mu;
+std::map<hipStream_t, Side*> g_sides;
+int g_side_enabled = -1;
+
+void side_init_locked() {
+    if (g_side_enabled < 0) {
+        const char* e = getenv("DCPT_SIDE_STREAM");
+        g_side_enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+}
+
+Side* side_for(hipStream_t main) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    side_init_locked();
+    if (!g_side_enabled) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;   // keep graph captures single-stream
+    }
+    auto it = g_sides.find(main);
+    if (it != g_sides.end()) return it->second;
+    Side* sd = new Side();
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    bool ok = hipStreamCreateWithPriority(&sd->ss, hipStreamNonBlocking, least) == hipSuccess;
+    for (int i = 0; ok && i < 5; ++i) ok = hipEventCreateWithFlags(&sd->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        delete sd;
+        sd = nullptr;
+    }
+    g_sides[main] = sd;
+    return sd;
+}
+
+// main-stream work up to here is visible to the side stream's next launches
+int side_fork(Side* sd, int i, hipStream_t main) {
+    if (!sd) return DCPT_OK;
+    if (hipEventRecord(sd->ev[i], main) != hipSuccess || hipStreamWaitEvent(sd->ss, sd->ev[i], 0) != hipSuccess) {
+        dcpt_set_error("nafblock_bwd: side-stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        return DCPT_ERR_HIP;
+    }
+    return DCPT_OK;
+}
+int side_join(Side* sd, int i, hipStream_t main) {
+    if (!sd) return DCPT_OK;
+    if (hipEventRecord(sd->ev[i], sd->ss) != hipSuccess || hipStreamWaitEvent(main, sd->ev[i], 0) != hipSuccess) {
+        dcpt_set_error("nafblock_bwd: side-stream join failed: %s", hipGetErrorString(hipGetLastError()));
+        return DCPT_ERR_HIP;
+    }
+    return DCPT_OK;
+}
+
 }  // namespace
+
+extern "C" int dcpt_set_side_stream(int on) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    side_init_locked();
+    const int prev = g_side_enabled;
+    g_side_enabled = on ? 1 : 0;
+    return prev;
+}
 
 extern "C" size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C) { return fwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
 extern "C" size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C) { return bwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
@@ -121,13 +198,15 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     const int P = H * W;
     const float eps = 1e-6f;  // nafnet_arch.py:57
 
-    DCPT_TRY(launch_ln_stats(inp, sv->mu1, sv->rstd1, M, C, eps, s));
+    DCPT_CHECK_ARG(sv->xn1 && sv->xn2, "nafblock_fwd: saved.xn1 / saved.xn2 missing");
+    // the normalised activations are materialised once: conv1's forward GEMM and (in backward) its weight-gradient GEMM
+    // then take them as plain operands, i.e. straight global -> LDS by DMA
+    DCPT_TRY(launch_ln_fwd(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
     GemmNT g{};
     g.M = M;
     // t1 = conv1(LN1(inp))
-    g.A = inp; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C;
-    g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.lnb = p->norm1_b; g.bias = p->conv1_b;
-    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
     // t2 = SG(dw(t1)+b2) and pooling partials
     DwGeom dg{B, H, W, C};
     DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
@@ -138,12 +217,11 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     g.M = M; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = p->conv3_w; g.N = C; g.C = sv->y; g.ldc = C;
     g.simg = sv->s; g.P = P; g.bias = p->conv3_b; g.res = inp; g.cscale = p->beta;
     DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESID, s));
-    DCPT_TRY(launch_ln_stats(sv->y, sv->mu2, sv->rstd2, M, C, eps, s));
+    DCPT_TRY(launch_ln_fwd(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
     // v = conv4(LN2(y))
     g = GemmNT{};
-    g.M = M; g.A = sv->y; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C;
-    g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.lnb = p->norm2_b; g.bias = p->conv4_b;
-    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    g.M = M; g.A = sv->xn2; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
     // out = y + (conv5(SG(v))+b5)*gamma
     g = GemmNT{};
     g.M = M; g.A = sv->v; g.lda = 2 * C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
@@ -157,6 +235,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
                                  int B, int H, int W, int C, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && gr && inp && sv && dout && dinp, "nafblock_bwd: null argument");
+    DCPT_CHECK_ARG(sv->xn1 && sv->xn2, "nafblock_bwd: saved.xn1 / saved.xn2 missing");
     DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nafblock_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     BwdWs w;
     const size_t need = bwd_ws_layout(B, H, W, C, ws, ws_bytes, &w);
@@ -180,8 +259,11 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     float* gln = w.bca;
     float* dy = w.bcb;
     float* dts = w.bcc;
-    float* da = w.b2a;   // dv is dead once B4 is done
+    float* da = w.b2c;
     float* dt1 = w.b2b;
+    Side* sd = side_for(s);
+    hipStream_t sw = sd ? sd->ss : s;   // stream of the weight-gradient GEMMs
+    DCPT_TRY(side_fork(sd, 0, s));      // dout / saved activations / packed weights are ready
 
     GemmNT g{};
     GemmTN tp{};
@@ -191,19 +273,20 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     // B2: conv5 / gamma gradients
     tp = GemmTN{};
     DCPT_TRY(wgrad(dout, C, C, sv->v, C2, C, A_SG, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w,
-                   gr->gamma, gr->conv5_b, s));
+                   gr->gamma, gr->conv5_b, sw));
+    DCPT_TRY(side_fork(sd, 1, s));      // dv
     // B3: grad w.r.t. LN2 output
     g = GemmNT{};
     g.M = M; g.A = dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = gln; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    // B4: conv4 gradients (Y = LN2(y))
+    // B4: conv4 gradients (Y = LN2(y), kept by the forward pass)
     tp = GemmTN{};
-    tp.mu = sv->mu2; tp.rstd = sv->rstd2; tp.lnw = p->norm2_w; tp.lnb = p->norm2_b;
-    DCPT_TRY(wgrad(dv, C2, C2, sv->y, C, C, A_LN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
-                   gr->conv4_b, s));
+    DCPT_TRY(wgrad(dv, C2, C2, sv->xn2, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
+                   gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
     DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, s));
+    DCPT_TRY(side_fork(sd, 2, s));      // dy
     // B6: dts = d(t2*s)
     g = GemmNT{};
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = dts; g.ldc = C;
@@ -212,7 +295,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     tp = GemmTN{};
     tp.simg = sv->s; tp.P = P;
     DCPT_TRY(wgrad(dy, C, C, sv->t2, C, C, A_SCALE, tp, M, w.slab, w.colsum, p->beta, p->conv3_w, p->conv3_b, gr->conv3_w,
-                   gr->beta, gr->conv3_b, s));
+                   gr->beta, gr->conv3_b, sw));
     // B8: SCA backward
     DCPT_TRY(launch_sca_ds(dts, sv->t2, w.ds_part, w.ds, B, C, P, s));
     DCPT_TRY(launch_sca_bwd(w.ds, sv->pooled, p->sca_w, w.dpool, gr->sca_w, gr->sca_b, B, C, P, s));
@@ -220,18 +303,19 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_dw_bwd_a(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, da, dg, s));
     DCPT_TRY(launch_dw_bwd_b(da, sv->t1, w.w2p, dt1, w.wpart, dg, s));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, s));
+    DCPT_TRY(side_fork(sd, 3, s));      // dt1
     // B11: grad w.r.t. LN1 output
     g = GemmNT{};
     g.M = M; g.A = dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = gln; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    // B12: conv1 gradients (Y = LN1(inp))
+    // B12: conv1 gradients (Y = LN1(inp), kept by the forward pass)
     tp = GemmTN{};
-    tp.mu = sv->mu1; tp.rstd = sv->rstd1; tp.lnw = p->norm1_w; tp.lnb = p->norm1_b;
-    DCPT_TRY(wgrad(dt1, C2, C2, inp, C, C, A_LN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
-                   gr->conv1_b, s));
+    DCPT_TRY(wgrad(dt1, C2, C2, sv->xn1, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
+                   gr->conv1_b, sw));
     // B13: dinp = dy + LN1-backward
     DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, s));
+    DCPT_TRY(side_join(sd, 4, s));      // the caller's stream continues only after every weight gradient is written
     return DCPT_OK;
 }
 
@@ -241,7 +325,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
 //   smap = Wsca * boxmean(t2) + bsca (1x1 conv = MFMA GEMM),  x = t2 * smap  (GEMM epilogue E_MUL)
 namespace {
 struct LocalWs {
-    float *w2p, *pool_part, *t1, *t2, *rowsum, *mmap, *t2s, *y, *v, *stats;
+    float *w2p, *pool_part, *t1, *t2, *rowsum, *mmap, *t2s, *y, *v, *stats, *xn;
     int nblk_pool;
 };
 size_t local_layout(int B, int H, int W, int C, int k2, void* base, size_t bytes, LocalWs* out) {
@@ -260,6 +344,7 @@ size_t local_layout(int B, int H, int W, int C, int k2, void* base, size_t bytes
     w.y = a.get<float>((size_t)M * C);
     w.v = w.t1;  // t1 is dead once t2 exists
     w.stats = a.get<float>((size_t)2 * M);
+    w.xn = w.mmap;  // LN1(inp) is dead before the box mean is written, LN2(y) is formed after it was consumed
     if (out) *out = w;
     return a.off;
 }
@@ -286,11 +371,10 @@ extern "C" int dcpt_nafblock_local_fwd(const dcpt_nafblock_params* p, const floa
     const int64_t M = (int64_t)B * H * W;
     float* mu = w.stats;
     float* rstd = w.stats + M;
-    DCPT_TRY(launch_ln_stats(inp, mu, rstd, M, C, 1e-6f, s));
+    DCPT_TRY(launch_ln_fwd(inp, p->norm1_w, p->norm1_b, w.xn, mu, rstd, M, C, 1e-6f, s));
     GemmNT g{};
-    g.M = M; g.A = inp; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = w.t1; g.ldc = 2 * C;
-    g.mu = mu; g.rstd = rstd; g.lnw = p->norm1_w; g.lnb = p->norm1_b; g.bias = p->conv1_b;
-    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    g.M = M; g.A = w.xn; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = w.t1; g.ldc = 2 * C; g.bias = p->conv1_b;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
     DwGeom dg{B, H, W, C};
     DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
     DCPT_TRY(launch_dw_fwd(w.t1, w.w2p, p->conv2_b, w.t2, w.pool_part, dg, s));
@@ -302,11 +386,10 @@ extern "C" int dcpt_nafblock_local_fwd(const dcpt_nafblock_params* p, const floa
     g.M = M; g.A = w.t2s; g.lda = C; g.K = C; g.Bw = p->conv3_w; g.N = C; g.C = w.y; g.ldc = C;
     g.bias = p->conv3_b; g.res = inp; g.cscale = p->beta;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_RESID, s));
-    DCPT_TRY(launch_ln_stats(w.y, mu, rstd, M, C, 1e-6f, s));
+    DCPT_TRY(launch_ln_fwd(w.y, p->norm2_w, p->norm2_b, w.xn, mu, rstd, M, C, 1e-6f, s));
     g = GemmNT{};
-    g.M = M; g.A = w.y; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = w.v; g.ldc = 2 * C;
-    g.mu = mu; g.rstd = rstd; g.lnw = p->norm2_w; g.lnb = p->norm2_b; g.bias = p->conv4_b;
-    DCPT_TRY(launch_gemm_nt(g, A_LN, E_BIAS, s));
+    g.M = M; g.A = w.xn; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = w.v; g.ldc = 2 * C; g.bias = p->conv4_b;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
     g = GemmNT{};
     g.M = M; g.A = w.v; g.lda = 2 * C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
     g.bias = p->conv5_b; g.res = w.y; g.cscale = p->gamma;

@@ -97,23 +97,25 @@ class _NAFBlockFn(torch.autograd.Function):
         t2 = _empty_nhwc(B, Cc, H, W, dev)
         y = _empty_nhwc(B, Cc, H, W, dev)
         v = _empty_nhwc(B, 2 * Cc, H, W, dev)
+        xn = torch.empty((2, B, H, W, Cc), dtype=torch.float32, device=dev)   # LN1(inp), LN2(y)
         stats = torch.empty((4, M), dtype=torch.float32, device=dev)
         pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         s = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr())
+                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr(),
+                           xn[0].data_ptr(), xn[1].data_ptr())
         nws = lib.dcpt_nafblock_fwd_ws_bytes(B, H, W, Cc)
         ws = _workspace(dev, nws)
         check(lib.dcpt_nafblock_fwd(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
                                     B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd")
-        ctx.save_for_backward(inp, t1, t2, y, v, stats, pooled, s, *params)
+        ctx.save_for_backward(inp, t1, t2, y, v, stats, pooled, s, xn, *params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        inp, t1, t2, y, v, stats, pooled, s, *params = ctx.saved_tensors
+        inp, t1, t2, y, v, stats, pooled, s, xn, *params = ctx.saved_tensors
         dout = _nhwc(dout)
         B, Cc, H, W = inp.shape
         dev = inp.device
@@ -122,7 +124,8 @@ class _NAFBlockFn(torch.autograd.Function):
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         gs = NafBlockGrads(*[g.data_ptr() for g in grads])
         sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr())
+                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr(),
+                           xn[0].data_ptr(), xn[1].data_ptr())
         nws = lib.dcpt_nafblock_bwd_ws_bytes(B, H, W, Cc)
         ws = _workspace(dev, nws)
         check(lib.dcpt_nafblock_bwd(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(),

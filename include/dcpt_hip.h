@@ -78,6 +78,8 @@ typedef struct {   /* activations kept for backward (M = B*H*W pixels) */
     float* mu1; float* rstd1; float* mu2; float* rstd2;   /* [M] */
     float* pooled;  /* [B][C]   mean_{h,w} t2 */
     float* s;       /* [B][C]   SCA scale */
+    float* xn1;     /* [M][C]   LN1(inp): read back by conv1's forward and weight-gradient GEMMs as a plain operand */
+    float* xn2;     /* [M][C]   LN2(y) */
 } dcpt_nafblock_saved;
 
 size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C);
@@ -239,6 +241,13 @@ int dcpt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, dcpt_strea
  * 8*loaderA + epilogue/loaderB. */
 int dcpt_prof_enable(int on);
 int dcpt_prof_read(double* out, int max_rows);
+
+/* ---- weight-gradient side stream ------------------------------------------------------------------
+ * dcpt_nafblock_bwd enqueues its four weight-gradient GEMMs (+ slab reductions) on an internal low-priority
+ * HIP stream, forked from and joined back into `stream` with events inside the call (callers see ordinary
+ * stream semantics).  on = 0 keeps everything on the caller's stream (also: DCPT_SIDE_STREAM=0 in the
+ * environment, and automatically while `stream` is being captured into a graph).  Returns the previous setting. */
+int dcpt_set_side_stream(int on);
 
 #ifdef __cplusplus
 }
