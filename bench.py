@@ -33,15 +33,15 @@ BYTES_PER_IMAGE = 3.50e9
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
 PEAK_HBM_TBS = 8.0
 
-ALOAD = {0: "plain", 1: "ln", 2: "scale", 3: "sg", 4: "gather"}
-EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_add"}
+ALOAD = {0: "plain", 1: "ln", 2: "scale", 3: "sg", 4: "gather", 5: "conv3", 6: "lnbf"}
+EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_add", 6: "addscaled", 7: "mul", 8: "biasgate"}
 
 
 def prof_class_name(cls: int) -> str:
     if cls >= 512:
         c = cls - 512
         return f"gemm_tn<x={ALOAD.get(c // 8, c // 8)},y={ALOAD.get(c % 8, c % 8)}>"
-    return f"gemm_nt<a={ALOAD.get(cls // 8, cls // 8)},epi={EPI.get(cls % 8, cls % 8)}>"
+    return f"gemm_nt<a={ALOAD.get(cls // 16, cls // 16)},epi={EPI.get(cls % 16, cls % 16)}>"
 
 
 def cpu_baseline(seconds_budget: float = 25.0):

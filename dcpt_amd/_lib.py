@@ -25,7 +25,7 @@ _PARAM_FIELDS = [
     "norm1_w", "norm1_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b",
     "sca_w", "sca_b", "norm2_w", "norm2_b", "conv4_w", "conv4_b", "conv5_w", "conv5_b", "beta", "gamma",
 ]
-_SAVED_FIELDS = ["t1", "t2", "y", "v", "mu1", "rstd1", "mu2", "rstd2", "pooled", "s", "xn1", "xn2"]
+_SAVED_FIELDS = ["t1", "t2", "y", "v", "mu1", "rstd1", "mu2", "rstd2", "pooled", "s", "xn1", "xn2", "g"]
 
 
 class NafBlockParams(C.Structure):

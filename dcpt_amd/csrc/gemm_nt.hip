@@ -63,6 +63,38 @@ __device__ __forceinline__ int64_t scatter_elem(const GemmNT& p, int64_t m) {
 // inputs) and stores are 16 B per lane and BN*4 B contiguous per row, all through buffer windows opened at
 // the tile's first row (rows past M / columns past N are dropped by the range check), and all the loads
 // of a thread are issued before the LDS round trip so their latency overlaps it.
+// E_BIASGATE: the tile's columns are [BN/2 of the first half | the matching BN/2 of the second half]; a thread owns the
+// float4 group q of both halves, writes C = acc + bias for both and their product to `gate`.
+template <int ROWS, int BN, int NT_>
+__device__ __forceinline__ void epilogue_gate(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0h, int tid) {
+    constexpr int HB = BN / 2;
+    constexpr int Q = HB / 4;          // float4 groups per half row
+    constexpr int RPP = NT_ / Q;
+    constexpr int IT = ROWS / RPP;
+    const int Ch = p.N / 2;
+    const int q = tid % Q, r0 = tid / Q;
+    const int n = n0h + 4 * q;
+    const bool nok = n < Ch;
+    float4 b1 = f4_zero(), b2 = f4_zero();
+    if (p.bias && nok) {
+        b1 = ldg4(p.bias + n);
+        b2 = ldg4(p.bias + Ch + n);
+    }
+    const rsrc_t rsC = make_rsrc(p.C + m0 * (int64_t)p.ldc);
+    const rsrc_t rsG = make_rsrc(p.gate + m0 * (int64_t)Ch);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int rl = r0 + it * RPP;
+        const bool ok = (m0 + rl < p.M) && nok;
+        const float4 v1 = f4_add(*reinterpret_cast<const float4*>(&Cs[rl * BN + 4 * q]), b1);
+        const float4 v2 = f4_add(*reinterpret_cast<const float4*>(&Cs[rl * BN + HB + 4 * q]), b2);
+        const uint32_t o = ok ? ((uint32_t)rl * (uint32_t)p.ldc + (uint32_t)n) * 4u : ROW_SENT;
+        buf_st4(rsC, o, v1);
+        buf_st4(rsC, o + 4u * (uint32_t)Ch, v2);
+        buf_st4(rsG, ok ? ((uint32_t)rl * (uint32_t)Ch + (uint32_t)n) * 4u : ROW_SENT, f4_mul(v1, v2));
+    }
+}
+
 template <int EK, int ROWS, int BN, int NT_>
 __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0, int tid) {
     constexpr int Q = BN / 4;          // float4 groups per row
@@ -177,17 +209,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tilesN = (p.N + BN - 1) / BN;
+    constexpr bool GATE = (EK == E_BIASGATE);
+    const int tilesN = GATE ? (p.N / 2 + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(lin / tilesN) * BM;
-    const int n0 = (lin % tilesN) * BN;
+    const int n0 = (lin % tilesN) * (GATE ? BN / 2 : BN);   // GATE: first column of the tile inside each half
 
     Operand oa;
     oa.ptr = p.A; oa.M = p.M; oa.ncols = p.K; oa.ld = p.lda;
     oa.mu = p.mu; oa.rstd = p.rstd; oa.lnw = p.lnw; oa.lnb = p.lnb;
     oa.simg = p.simg; oa.P = p.P; oa.gH = p.gH; oa.gW = p.gW; oa.gC = p.gC;
     open_window<AK>(oa, m0 < p.M ? m0 : 0);
-    const i32x4 rsB = make_rsrc_dma(p.Bw + (int64_t)n0 * p.K);
+    const i32x4 rsB = make_rsrc_dma(p.Bw + (GATE ? 0 : (int64_t)n0 * p.K));
     rsrc_t rsW = oa.rs, rsWb = oa.rs;
     if constexpr (AK == A_LN || AK == A_LNBF) rsW = make_rsrc(p.lnw, (uint32_t)p.K * 4u);
     if constexpr (AK == A_LN) rsWb = make_rsrc(p.lnb, (uint32_t)p.K * 4u);
@@ -202,7 +235,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int nl = lrow + 32 * i;
-        boff[i] = (n0 + nl < p.N) ? (uint32_t)nl * (uint32_t)p.K * 4u + 4u * (uint32_t)lk : ROW_SENT;
+        if constexpr (GATE) {  // tile row nl < BN/2: column n0 + nl of the first half, else the partner column of the second half
+            const int hl = nl % (BN / 2), Ch = p.N / 2;
+            const int n = (nl < BN / 2 ? 0 : Ch) + n0 + hl;
+            boff[i] = (n0 + hl < Ch) ? (uint32_t)n * (uint32_t)p.K * 4u + 4u * (uint32_t)lk : ROW_SENT;
+        } else {
+            boff[i] = (n0 + nl < p.N) ? (uint32_t)nl * (uint32_t)p.K * 4u + 4u * (uint32_t)lk : ROW_SENT;
+        }
     }
     const uint32_t lds_a = lds_addr(As0) + wave * 1024, lds_b = lds_addr(Bs0) + wave * 1024;   // this wave's 8 rows inside a 32-row pass
     const int lds_t = tid * 4;          // this thread's quad inside a 32-row pass (floats)
@@ -310,20 +349,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
         }
     }
     __syncthreads();
-    epilogue_rows<EK, BM, BN, NTHR>(p, smem, m0, n0, tid);
+    if constexpr (GATE) epilogue_gate<BM, BN, NTHR>(p, smem, m0, n0, tid);
+    else epilogue_rows<EK, BM, BN, NTHR>(p, smem, m0, n0, tid);
     TL_STAMP(3)
 }
 
 template <int AK, int EK>
 int launch_cfg(const GemmNT& p, hipStream_t s) {
     const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
+    constexpr bool GATE = (EK == E_BIASGATE);
     if (p.N <= 64) {
         constexpr int BM = 128, BN = 64;
-        const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
+        const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
         gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
     } else {
         constexpr int BM = 128, BN = 128;
-        const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
+        const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
         gemm_nt_kernel<BM, BN, 2, 2, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
     }
     DCPT_CHECK_LAUNCH("gemm_nt");
@@ -344,13 +385,15 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     DCPT_CHECK_ARG(p.K < (1 << 20) && p.N < (1 << 20) && p.lda < (1 << 20) && p.ldc < (1 << 20) && p.ldres < (1 << 20),
                    "gemm_nt: K/N/row strides must be below 2^20");
     if (aload == A_GATHER) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 4 * p.gC, "gemm_nt: gather needs K == 4*gC, gC %% 4 == 0");
+    if (epi == E_BIASGATE)
+        DCPT_CHECK_ARG(p.gate && p.N % 8 == 0 && (double)p.N * p.K * 4.0 < 1.0e9, "gemm_nt: gate epilogue needs gate != null, N %% 8 == 0");
     if (aload == A_CONV3) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 9 * p.gC, "gemm_nt: conv3 needs K == 9*gC, gC %% 4 == 0");
     // algorithmic work of this launch (for the live roofline in bench.py)
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
-    double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : 1) + (double)p.N * p.K;
+    double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : epi == E_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
     if (epi == E_RESID || epi == E_SCATTER_ADD) bytes += mn;
     const double nbat = (double)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
-    ProfScope prof(s, PROF_NT + aload * 8 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
+    ProfScope prof(s, PROF_NT + aload * 16 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
 #define CASE(AK, EK) \
     if (aload == AK && epi == EK) return launch_cfg<AK, EK>(p, s);
     CASE(A_LN, E_BIAS)
@@ -369,6 +412,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_RESID)
     CASE(A_PLAIN, E_ADDSCALED)
     CASE(A_PLAIN, E_MUL)
+    CASE(A_PLAIN, E_BIASGATE)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

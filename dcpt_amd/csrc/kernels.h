@@ -80,6 +80,16 @@ enum WPackMode {
     WP_CONV3_T = 6      // out[ic][tap*Co + oc] = in[oc][ic][8-tap]            (dgrad: N' = Ci rows, K' = 9*Co)
 };
 int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int mode, hipStream_t s);
+// up to WPACK_MAX_JOBS WP_TRANSPOSE jobs (out[k][n] = in[n][k] * rs[n]) in one launch
+constexpr int WPACK_MAX_JOBS = 6;
+struct WpackJobs {
+    const float* in[WPACK_MAX_JOBS];
+    float* out[WPACK_MAX_JOBS];
+    const float* rs[WPACK_MAX_JOBS];
+    int N[WPACK_MAX_JOBS], K[WPACK_MAX_JOBS];
+    int n;
+};
+int launch_wpack_multi(const WpackJobs& jobs, hipStream_t s);
 
 enum WReduceMode { WR_PLAIN = 0, WR_DOWN = 1, WR_UP = 2, WR_CONV3 = 3 };
 // dW = rowscale[n] * sum_s slab[s][n][k] (layout per mode)

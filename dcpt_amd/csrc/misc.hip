@@ -345,6 +345,27 @@ int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, floa
     return DCPT_OK;
 }
 
+// several row-scaled transposes in one launch: out_j[k][n] = in_j[n][k] * (rs_j ? rs_j[n] : 1)
+__global__ void wpack_multi_kernel(const WpackJobs jobs) {
+    const int y = blockIdx.y;
+    const int N = jobs.N[y], K = jobs.K[y];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int k = (int)(i / N), n = (int)(i % N);
+    const float v = jobs.in[y][(int64_t)n * K + k];
+    const float* rs = jobs.rs[y];
+    jobs.out[y][i] = rs ? v * rs[n] : v;
+}
+
+int launch_wpack_multi(const WpackJobs& jobs, hipStream_t s) {
+    DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= WPACK_MAX_JOBS, "wpack_multi: %d jobs", jobs.n);
+    int64_t mx = 0;
+    for (int j = 0; j < jobs.n; ++j) mx = (int64_t)jobs.N[j] * jobs.K[j] > mx ? (int64_t)jobs.N[j] * jobs.K[j] : mx;
+    wpack_multi_kernel<<<dim3((unsigned)cdiv64(mx, 256), jobs.n), dim3(256), 0, s>>>(jobs);
+    DCPT_CHECK_LAUNCH("wpack_multi");
+    return DCPT_OK;
+}
+
 int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int mode, hipStream_t s) {
     wpack_kernel<<<dim3((unsigned)cdiv64((int64_t)N * K, 256)), dim3(256), 0, s>>>(in, out, rs, N, K, mode);
     DCPT_CHECK_LAUNCH("wpack");

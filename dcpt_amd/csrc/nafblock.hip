@@ -8,7 +8,8 @@
 //   y   = inp + (conv3(t2*s)+b3)*beta                        gemm_nt<A_SCALE, E_RESID>
 //   xn2 = LN2(y), stats2                                     ln_fwd
 //   v   = conv4(xn2)                                         gemm_nt<A_PLAIN, E_BIAS>
-//   out = y + (conv5(SG(v))+b5)*gamma                        gemm_nt<A_SG, E_RESID>
+//   (v's GEMM epilogue also writes g = SG(v))                gemm_nt<A_PLAIN, E_BIASGATE>
+//   out = y + (conv5(g)+b5)*gamma                            gemm_nt<A_PLAIN, E_RESID>
 //
 // Backward never materialises the conv3/conv5 outputs: with G[n][k] = sum_m dO[m][n]*A'[m][k]
 // (the un-scaled weight gradient) one has  dW = gain[n]*G,  dgain[n] = sum_k W[n][k]*G[n][k] +
@@ -51,7 +52,7 @@ struct BwdWs {
     float *bca, *bcb, *bcc; // [M][C]
     float* slab;
     float* colsum;
-    float* lnpart;
+    float *lnpart, *lnpart2;
     float *ds_part, *ds, *dpool;
     float* wpart;
     int ln_nblk, nblk_b;
@@ -85,6 +86,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.colsum = a.get<float>(cs1 > cs2 ? cs1 : cs2);
     w.ln_nblk = ln_bwd_num_blocks(M, C);
     w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * C);
+    w.lnpart2 = a.get<float>((size_t)w.ln_nblk * 3 * C);
     w.ds_part = a.get<float>((size_t)B * sca_ds_num_blocks(P) * C);
     w.ds = a.get<float>((size_t)B * C);
     w.dpool = a.get<float>((size_t)B * C);
@@ -107,14 +109,15 @@ int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yl
     return DCPT_OK;
 }
 
-// Weight-gradient side stream.  In the backward pass the four wgrad GEMMs (+ their slab reductions) are off the
+// Weight-gradient side stream.  In the backward pass the four wgrad GEMMs (+ their slab reductions) and the small
+// parameter-gradient reductions of LayerNorm / depthwise conv are off the
 // critical path dout -> dinp: they run on a second, low-priority HIP stream, forked/joined with events inside one
 // dcpt_nafblock_bwd call, so that the HBM-bound kernels of the main chain (LayerNorm / depthwise / SCA backward) and the
 // launch ramps and tails of its GEMMs overlap MFMA-bound wgrad work instead of leaving the matrix cores idle.
 // DCPT_SIDE_STREAM=0 in the environment keeps everything on the caller's stream.
 struct Side {
     hipStream_t ss = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 std::mutex g_side_mu;
 std::map<hipStream_t, Side*> g_sides;
@@ -142,7 +145,7 @@ Side* side_for(hipStream_t main) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     bool ok = hipStreamCreateWithPriority(&sd->ss, hipStreamNonBlocking, least) == hipSuccess;
-    for (int i = 0; ok && i < 5; ++i) ok = hipEventCreateWithFlags(&sd->ev[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&sd->ev[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         delete sd;
@@ -198,7 +201,7 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     const int P = H * W;
     const float eps = 1e-6f;  // nafnet_arch.py:57
 
-    DCPT_CHECK_ARG(sv->xn1 && sv->xn2, "nafblock_fwd: saved.xn1 / saved.xn2 missing");
+    DCPT_CHECK_ARG(sv->xn1 && sv->xn2 && sv->g, "nafblock_fwd: saved.xn1 / saved.xn2 / saved.g missing");
     // the normalised activations are materialised once: conv1's forward GEMM and (in backward) its weight-gradient GEMM
     // then take them as plain operands, i.e. straight global -> LDS by DMA
     DCPT_TRY(launch_ln_fwd(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
@@ -221,12 +224,13 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     // v = conv4(LN2(y))
     g = GemmNT{};
     g.M = M; g.A = sv->xn2; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
+    g.gate = sv->g;   // the epilogue also emits SimpleGate(v), so conv5 (and its weight gradient) read a plain [M][C] operand
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIASGATE, s));
     // out = y + (conv5(SG(v))+b5)*gamma
     g = GemmNT{};
-    g.M = M; g.A = sv->v; g.lda = 2 * C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
+    g.M = M; g.A = sv->g; g.lda = C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
     g.bias = p->conv5_b; g.res = sv->y; g.cscale = p->gamma;
-    DCPT_TRY(launch_gemm_nt(g, A_SG, E_RESID, s));
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_RESID, s));
     return DCPT_OK;
 }
 
@@ -235,7 +239,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
                                  int B, int H, int W, int C, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && gr && inp && sv && dout && dinp, "nafblock_bwd: null argument");
-    DCPT_CHECK_ARG(sv->xn1 && sv->xn2, "nafblock_bwd: saved.xn1 / saved.xn2 missing");
+    DCPT_CHECK_ARG(sv->xn1 && sv->xn2 && sv->g, "nafblock_bwd: saved.xn1 / saved.xn2 / saved.g missing");
     DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nafblock_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     BwdWs w;
     const size_t need = bwd_ws_layout(B, H, W, C, ws, ws_bytes, &w);
@@ -249,11 +253,15 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DwGeom dg{B, H, W, C};
 
     // transposed (and gain-scaled) weights for the dgrad GEMMs
-    DCPT_TRY(launch_wpack(p->conv5_w, w.wT5, p->gamma, C, C, WP_TRANSPOSE, s));
-    DCPT_TRY(launch_wpack(p->conv4_w, w.wT4, nullptr, C2, C, WP_TRANSPOSE, s));
-    DCPT_TRY(launch_wpack(p->conv3_w, w.wT3, p->beta, C, C, WP_TRANSPOSE, s));
-    DCPT_TRY(launch_wpack(p->conv1_w, w.wT1, nullptr, C2, C, WP_TRANSPOSE, s));
-    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, C2, s));
+    // (one launch; the depthwise [2C][9] -> [9][2C] packing is a transpose as well)
+    WpackJobs jobs{};
+    jobs.n = 5;
+    jobs.in[0] = p->conv5_w; jobs.out[0] = w.wT5; jobs.rs[0] = p->gamma; jobs.N[0] = C;  jobs.K[0] = C;
+    jobs.in[1] = p->conv4_w; jobs.out[1] = w.wT4; jobs.rs[1] = nullptr;  jobs.N[1] = C2; jobs.K[1] = C;
+    jobs.in[2] = p->conv3_w; jobs.out[2] = w.wT3; jobs.rs[2] = p->beta;  jobs.N[2] = C;  jobs.K[2] = C;
+    jobs.in[3] = p->conv1_w; jobs.out[3] = w.wT1; jobs.rs[3] = nullptr;  jobs.N[3] = C2; jobs.K[3] = C;
+    jobs.in[4] = p->conv2_w; jobs.out[4] = w.w2p; jobs.rs[4] = nullptr;  jobs.N[4] = C2; jobs.K[4] = 9;
+    DCPT_TRY(launch_wpack_multi(jobs, s));
 
     float* dv = w.b2a;
     float* gln = w.bca;
@@ -272,7 +280,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SGBWD, s));
     // B2: conv5 / gamma gradients
     tp = GemmTN{};
-    DCPT_TRY(wgrad(dout, C, C, sv->v, C2, C, A_SG, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w,
+    DCPT_TRY(wgrad(dout, C, C, sv->g, C, C, A_PLAIN, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w,
                    gr->gamma, gr->conv5_b, sw));
     DCPT_TRY(side_fork(sd, 1, s));      // dv
     // B3: grad w.r.t. LN2 output
@@ -285,8 +293,8 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
                    gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
     DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
-    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, s));
-    DCPT_TRY(side_fork(sd, 2, s));      // dy
+    DCPT_TRY(side_fork(sd, 2, s));      // dy, LN2 partial sums
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2*s)
     g = GemmNT{};
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = dts; g.ldc = C;
@@ -302,8 +310,8 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     // B9/B10: SimpleGate + depthwise conv backward
     DCPT_TRY(launch_dw_bwd_a(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, da, dg, s));
     DCPT_TRY(launch_dw_bwd_b(da, sv->t1, w.w2p, dt1, w.wpart, dg, s));
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, s));
-    DCPT_TRY(side_fork(sd, 3, s));      // dt1
+    DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise partial sums
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
     // B11: grad w.r.t. LN1 output
     g = GemmNT{};
     g.M = M; g.A = dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = gln; g.ldc = C;
@@ -313,8 +321,9 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(wgrad(dt1, C2, C2, sv->xn1, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
                    gr->conv1_b, sw));
     // B13: dinp = dy + LN1-backward
-    DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart, w.ln_nblk, M, C, s));
-    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, s));
+    DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
+    DCPT_TRY(side_fork(sd, 5, s));      // LN1 partial sums
+    DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     DCPT_TRY(side_join(sd, 4, s));      // the caller's stream continues only after every weight gradient is written
     return DCPT_OK;
 }
@@ -389,9 +398,10 @@ extern "C" int dcpt_nafblock_local_fwd(const dcpt_nafblock_params* p, const floa
     DCPT_TRY(launch_ln_fwd(w.y, p->norm2_w, p->norm2_b, w.xn, mu, rstd, M, C, 1e-6f, s));
     g = GemmNT{};
     g.M = M; g.A = w.xn; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = w.v; g.ldc = 2 * C; g.bias = p->conv4_b;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
+    g.gate = w.t2s;   // t2*smap is dead once y exists
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIASGATE, s));
     g = GemmNT{};
-    g.M = M; g.A = w.v; g.lda = 2 * C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
+    g.M = M; g.A = w.t2s; g.lda = C; g.K = C; g.Bw = p->conv5_w; g.N = C; g.C = out; g.ldc = C;
     g.bias = p->conv5_b; g.res = w.y; g.cscale = p->gamma;
-    return launch_gemm_nt(g, A_SG, E_RESID, s);
+    return launch_gemm_nt(g, A_PLAIN, E_RESID, s);
 }

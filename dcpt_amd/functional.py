@@ -97,14 +97,14 @@ class _NAFBlockFn(torch.autograd.Function):
         t2 = _empty_nhwc(B, Cc, H, W, dev)
         y = _empty_nhwc(B, Cc, H, W, dev)
         v = _empty_nhwc(B, 2 * Cc, H, W, dev)
-        xn = torch.empty((2, B, H, W, Cc), dtype=torch.float32, device=dev)   # LN1(inp), LN2(y)
+        xn = torch.empty((3, B, H, W, Cc), dtype=torch.float32, device=dev)   # LN1(inp), LN2(y), SimpleGate(v)
         stats = torch.empty((4, M), dtype=torch.float32, device=dev)
         pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         s = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
                            stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr(),
-                           xn[0].data_ptr(), xn[1].data_ptr())
+                           xn[0].data_ptr(), xn[1].data_ptr(), xn[2].data_ptr())
         nws = lib.dcpt_nafblock_fwd_ws_bytes(B, H, W, Cc)
         ws = _workspace(dev, nws)
         check(lib.dcpt_nafblock_fwd(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
@@ -125,7 +125,7 @@ class _NAFBlockFn(torch.autograd.Function):
         gs = NafBlockGrads(*[g.data_ptr() for g in grads])
         sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
                            stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr(),
-                           xn[0].data_ptr(), xn[1].data_ptr())
+                           xn[0].data_ptr(), xn[1].data_ptr(), xn[2].data_ptr())
         nws = lib.dcpt_nafblock_bwd_ws_bytes(B, H, W, Cc)
         ws = _workspace(dev, nws)
         check(lib.dcpt_nafblock_bwd(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(),

@@ -80,6 +80,7 @@ typedef struct {   /* activations kept for backward (M = B*H*W pixels) */
     float* s;       /* [B][C]   SCA scale */
     float* xn1;     /* [M][C]   LN1(inp): read back by conv1's forward and weight-gradient GEMMs as a plain operand */
     float* xn2;     /* [M][C]   LN2(y) */
+    float* g;       /* [M][C]   SimpleGate(v), written by conv4's GEMM epilogue; conv5's operand in forward and weight gradient */
 } dcpt_nafblock_saved;
 
 size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C);
@@ -237,8 +238,8 @@ int dcpt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, dcpt_strea
 /* ---- optional launch profiling (bench.py) -------------------------------------------------------
  * While enabled, every MFMA GEMM launch is bracketed by HIP events on its own stream.
  * dcpt_prof_read waits for them and writes rows of 8 doubles {class id, M, N, K, launches, total ms,
- * algorithmic flops, algorithmic bytes}, one per (class, shape); class id = (0: NT | 512: TN) +
- * 8*loaderA + epilogue/loaderB. */
+ * algorithmic flops, algorithmic bytes}, one per (class, shape); class id = 16*loaderA + epilogue (NT) or
+ * 512 + 8*loaderX + loaderY (TN). */
 int dcpt_prof_enable(int on);
 int dcpt_prof_read(double* out, int max_rows);
 
