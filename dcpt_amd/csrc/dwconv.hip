@@ -8,36 +8,94 @@
 // (band, column-chunk) items of one image so that per-channel sums (pooling for SCA, depthwise
 // weight gradients) are reduced in registers, then once per block in LDS in a fixed order, and
 // written as per-block partials: deterministic, no float atomics.
+#include <stdlib.h>
+
+#include "bufops.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int RH = 8;  // rows per band
 
+// A thread owns VW channels (4 by default; VW = 2 keeps the 9 (x2) taps, the running rows and the loads at ~80 VGPRs
+// -> 5-7 waves per SIMD instead of 2-3, which measured no faster on MI355X), and every global access is a range-checked
+// buffer access relative to the image, so halo rows / columns are ordinary loads that return 0 (no exec-mask
+// branches: the loads of a row are all in flight together).
+template <int VW>
+struct vf {
+    float v[VW];
+};
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define VFOR for (int i_ = 0; i_ < VW; ++i_)
+template <int VW> __device__ __forceinline__ vf<VW> vz() { vf<VW> r; _Pragma("unroll") VFOR r.v[i_] = 0.f; return r; }
+template <int VW> __device__ __forceinline__ vf<VW> vfma(vf<VW> a, vf<VW> b, vf<VW> c) { vf<VW> r; _Pragma("unroll") VFOR r.v[i_] = fmaf(a.v[i_], b.v[i_], c.v[i_]); return r; }
+template <int VW> __device__ __forceinline__ vf<VW> vmul(vf<VW> a, vf<VW> b) { vf<VW> r; _Pragma("unroll") VFOR r.v[i_] = a.v[i_] * b.v[i_]; return r; }
+template <int VW> __device__ __forceinline__ vf<VW> vadd(vf<VW> a, vf<VW> b) { vf<VW> r; _Pragma("unroll") VFOR r.v[i_] = a.v[i_] + b.v[i_]; return r; }
+template <int VW> __device__ __forceinline__ vf<VW> bld(rsrc_t rs, uint32_t off) {
+    vf<VW> r;
+    if constexpr (VW == 4) {
+        const floatx4 t = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        const floatx2 t = __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+        r.v[0] = t.x; r.v[1] = t.y;
+    }
+    return r;
+}
+template <int VW> __device__ __forceinline__ void bst(rsrc_t rs, uint32_t off, vf<VW> a) {
+    if constexpr (VW == 4) {
+        floatx4 t; t.x = a.v[0]; t.y = a.v[1]; t.z = a.v[2]; t.w = a.v[3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs, off, 0, 0);
+    } else {
+        floatx2 t; t.x = a.v[0]; t.y = a.v[1];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), rs, off, 0, 0);
+    }
+}
+template <int VW> __device__ __forceinline__ vf<VW> gld(const float* p, bool ok) {   // small per-channel vectors
+    vf<VW> r = vz<VW>();
+    if (ok) { _Pragma("unroll") VFOR r.v[i_] = p[i_]; }
+    return r;
+}
+template <int VW> __device__ __forceinline__ void gst(float* p, vf<VW> a) { _Pragma("unroll") VFOR p[i_] = a.v[i_]; }
+
 struct DwMap {
-    int QW;   // quads handled per pixel
-    int QB;   // quads per block (power of two)
+    int QW;   // channel groups (of VW channels) handled per pixel
+    int QB;   // groups per block (power of two)
     int PB;   // columns per block
-    int nqc;  // quad chunks
+    int nqc;  // group chunks
     int nwc;  // column chunks
-    int nbands;
-    int items;  // per image
 };
 
-__host__ __device__ inline DwMap dw_map(int H, int W, int quads) {
+__host__ __device__ inline DwMap dw_map(int H, int W, int groups) {
     DwMap m;
-    m.QW = quads;
-    // at most 32 quads (512 B of channels) per block row, so a block spans >= 8 pixel columns and the
-    // left/right halo columns are mostly served by the same CU's L1 instead of another XCD's HBM fetch
+    m.QW = groups;
+    // at most 32 groups per block row, so a block spans >= 8 pixel columns and the left/right halo columns are
+    // mostly served by the same CU's L1 instead of another XCD's HBM fetch
     int qb = 1;
-    while (qb < quads && qb < 32) qb <<= 1;
+    while (qb < groups && qb < 32) qb <<= 1;
     m.QB = qb;
     m.PB = 256 / qb;
-    m.nqc = (quads + qb - 1) / qb;
+    m.nqc = (groups + qb - 1) / qb;
     m.nwc = (W + m.PB - 1) / m.PB;
-    m.nbands = (H + RH - 1) / RH;
-    m.items = m.nwc * m.nbands;
     return m;
+}
+
+// Block -> (channel chunk, y, image), XCD-aware: the blocks of one (image, channel chunk) get consecutive logical ids, i.e.
+// run on ONE XCD.  Block y owns column chunk y % nwc and the y / nwc-th of gridDim.y / nwc equal row ranges, which it walks
+// top to bottom in one pass: only the two rows around a range and the two columns around a chunk are read twice.
+struct DwBlk {
+    int x, y, z;      // channel chunk, (column chunk, row part), image
+};
+__device__ __forceinline__ DwBlk dw_block(const DwMap& mp) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int total = nx * ny * gridDim.z;
+    const int lin = xcd_remap(blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), total);
+    DwBlk k;
+    k.y = lin % ny;
+    k.x = (lin / ny) % nx;
+    k.z = lin / (ny * nx);
+    return k;
 }
 
 struct DwP {
@@ -57,238 +115,234 @@ __device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff
 __device__ __forceinline__ float gelu_df(float a) {
     return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.39894228040143268f * expf(-0.5f * a * a);
 }
-__device__ __forceinline__ float4 gelu4(float4 a) { return make_float4(gelu_f(a.x), gelu_f(a.y), gelu_f(a.z), gelu_f(a.w)); }
-__device__ __forceinline__ float4 gelu_d4(float4 a) { return make_float4(gelu_df(a.x), gelu_df(a.y), gelu_df(a.z), gelu_df(a.w)); }
+template <int VW> __device__ __forceinline__ vf<VW> vgelu(vf<VW> a) { vf<VW> r; _Pragma("unroll") VFOR r.v[i_] = gelu_f(a.v[i_]); return r; }
+template <int VW> __device__ __forceinline__ vf<VW> vgelu_d(vf<VW> a) { vf<VW> r; _Pragma("unroll") VFOR r.v[i_] = gelu_df(a.v[i_]); return r; }
 
-__device__ __forceinline__ float4 ld_or_zero(const float* p, bool ok) { return ok ? ldg4(p) : f4_zero(); }
+// per-block reduction over the PB pixel columns of the per-thread partial `val` (fixed order), result to dst[group]
+template <int VW>
+__device__ __forceinline__ void dw_block_reduce(float* red, vf<VW> val, int tid, int ql, int pl, int QB, int PB, bool qok, float* dst) {
+    __syncthreads();
+#pragma unroll
+    VFOR red[tid * VW + i_] = val.v[i_];
+    __syncthreads();
+    if (pl == 0 && qok) {
+        vf<VW> s;
+#pragma unroll
+        VFOR s.v[i_] = red[ql * VW + i_];
+        for (int j = 1; j < PB; ++j) {
+#pragma unroll
+            VFOR s.v[i_] += red[(j * QB + ql) * VW + i_];
+        }
+        gst<VW>(dst, s);
+    }
+}
 
 // MODE 0: forward (t2 + pool partials);  MODE 1: backward-a (da)
 // GATE 0: SimpleGate g1*g2 (NAFNet);  GATE 1: gelu(g1)*g2 (Restormer GDFN, exact erf GELU)
-template <int MODE, int GATE>
+template <int VW, int MODE, int GATE>
 __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
-    __shared__ float4 red[256];
-    const DwMap mp = dw_map(p.H, p.W, p.C / 4);
+    __shared__ float red[256 * VW];
+    const DwMap mp = dw_map(p.H, p.W, p.C / VW);
+    const DwBlk bk = dw_block(mp);
     const int tid = threadIdx.x;
     const int ql = tid % mp.QB, pl = tid / mp.QB;
-    const int q = blockIdx.x * mp.QB + ql;
-    const int b = blockIdx.z;
+    const int q = bk.x * mp.QB + ql;
+    const int b = bk.z;
     const bool qok = q < mp.QW;
     const int C = p.C, C2 = 2 * p.C;
-    const int c1 = 4 * q, c2 = C + 4 * q;
+    const int c1 = VW * q, c2 = C + VW * q;
 
-    float4 w1[9], w2[9], bias1 = f4_zero(), bias2 = f4_zero();
+    vf<VW> w1[9], w2[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        w1[t] = ld_or_zero(p.w2p + t * C2 + c1, qok);
-        w2[t] = ld_or_zero(p.w2p + t * C2 + c2, qok);
+        w1[t] = gld<VW>(p.w2p + t * C2 + c1, qok);
+        w2[t] = gld<VW>(p.w2p + t * C2 + c2, qok);
     }
-    if (qok && p.b2) {
-        bias1 = ldg4(p.b2 + c1);
-        bias2 = ldg4(p.b2 + c2);
-    }
-    float4 sv = make_float4(1.f, 1.f, 1.f, 1.f), dpv = f4_zero();
+    const vf<VW> bias1 = gld<VW>(p.b2 + c1, qok && p.b2), bias2 = gld<VW>(p.b2 + c2, qok && p.b2);
+    vf<VW> sv, dpv = vz<VW>();
+#pragma unroll
+    VFOR sv.v[i_] = 1.f;
     if (MODE == 1 && qok && p.simg) {
-        sv = ldg4(p.simg + (int64_t)b * C + c1);
-        dpv = ldg4(p.dpool + (int64_t)b * C + c1);
+        sv = gld<VW>(p.simg + (int64_t)b * C + c1, true);
+        dpv = gld<VW>(p.dpool + (int64_t)b * C + c1, true);
     }
-    float4 pool = f4_zero();
+    vf<VW> pool = vz<VW>();
+    // windows over image b (offsets fit 32 bits: checked by the launchers)
+    const int64_t img = (int64_t)b * p.H * p.W;
+    const rsrc_t rs_in = make_rsrc(p.in0 + img * C2);
+    const rsrc_t rs_out = make_rsrc(p.out + img * (MODE == 0 ? C : C2));
+    const rsrc_t rs_d = make_rsrc(MODE == 1 ? p.in1 + img * C : p.in0);
+    const uint32_t st = 4u * (uint32_t)C2;
 
-    for (int item = blockIdx.y; item < mp.items; item += gridDim.y) {
-        const int band = item / mp.nwc, wc = item % mp.nwc;
+    {
+        const int wc = bk.y % mp.nwc, nrp = gridDim.y / mp.nwc, rpp = (p.H + nrp - 1) / nrp;
         const int x = wc * mp.PB + pl;
         const bool ok = qok && x < p.W;
-        const int h0 = band * RH;
-        const int h1 = (h0 + RH < p.H) ? h0 + RH : p.H;
-        float4 a0_1 = f4_zero(), a0_2 = f4_zero(), a1_1 = f4_zero(), a1_2 = f4_zero();
+        const int h0 = (bk.y / mp.nwc) * rpp;
+        const int h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
+        const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
+        vf<VW> a0_1 = vz<VW>(), a0_2 = vz<VW>(), a1_1 = vz<VW>(), a1_2 = vz<VW>();
         for (int r = h0 - 1; r <= h1; ++r) {
-            const bool rin = ok && r >= 0 && r < p.H;
-            const int64_t rowbase = ((int64_t)b * p.H + r) * p.W;
-            float4 xl1, xc1, xr1, xl2, xc2, xr2;
-            {
-                const float* pc = p.in0 + (rowbase + x) * C2;
-                const bool okl = rin && x > 0, okr = rin && x + 1 < p.W;
-                xl1 = ld_or_zero(pc - C2 + c1, okl);
-                xl2 = ld_or_zero(pc - C2 + c2, okl);
-                xc1 = ld_or_zero(pc + c1, rin);
-                xc2 = ld_or_zero(pc + c2, rin);
-                xr1 = ld_or_zero(pc + C2 + c1, okr);
-                xr2 = ld_or_zero(pc + C2 + c2, okr);
-            }
-            // kernel row 2 completes output row r-1
-            a0_1 = f4_fma(w1[6], xl1, f4_fma(w1[7], xc1, f4_fma(w1[8], xr1, a0_1)));
-            a0_2 = f4_fma(w2[6], xl2, f4_fma(w2[7], xc2, f4_fma(w2[8], xr2, a0_2)));
-            // kernel row 1 -> output row r
-            a1_1 = f4_fma(w1[3], xl1, f4_fma(w1[4], xc1, f4_fma(w1[5], xr1, a1_1)));
-            a1_2 = f4_fma(w2[3], xl2, f4_fma(w2[4], xc2, f4_fma(w2[5], xr2, a1_2)));
-            // kernel row 0 starts output row r+1
-            const float4 a2_1 = f4_fma(w1[0], xl1, f4_fma(w1[1], xc1, f4_mul(w1[2], xr1)));
-            const float4 a2_2 = f4_fma(w2[0], xl2, f4_fma(w2[1], xc2, f4_mul(w2[2], xr2)));
+            const uint32_t ro = (r >= 0 && r < p.H) ? (uint32_t)((r * p.W + x) * C2) * 4u : ROW_SENT;
+            const uint32_t o1 = ro + 4u * (uint32_t)c1, o2 = ro + 4u * (uint32_t)c2;
+            const vf<VW> xl1 = bld<VW>(rs_in, (o1 - st) | cl), xl2 = bld<VW>(rs_in, (o2 - st) | cl);
+            const vf<VW> xc1 = bld<VW>(rs_in, o1 | cc), xc2 = bld<VW>(rs_in, o2 | cc);
+            const vf<VW> xr1 = bld<VW>(rs_in, (o1 + st) | cr), xr2 = bld<VW>(rs_in, (o2 + st) | cr);
             const int y = r - 1;
-            if (ok && y >= h0) {
-                const float4 g1 = f4_add(a0_1, bias1), g2 = f4_add(a0_2, bias2);
-                const int64_t pix = ((int64_t)b * p.H + y) * p.W + x;
-                if (MODE == 0) {
-                    const float4 t = f4_mul(GATE == 0 ? g1 : gelu4(g1), g2);
-                    stg4(p.out + pix * C + c1, t);
-                    pool = f4_add(pool, t);
+            const bool yok = ok && y >= h0;
+            vf<VW> dts = vz<VW>();
+            if (MODE == 1) dts = bld<VW>(rs_d, yok ? (uint32_t)((y * p.W + x) * C + c1) * 4u : ROW_SENT);
+            // kernel row 2 completes output row r-1
+            a0_1 = vfma(w1[6], xl1, vfma(w1[7], xc1, vfma(w1[8], xr1, a0_1)));
+            a0_2 = vfma(w2[6], xl2, vfma(w2[7], xc2, vfma(w2[8], xr2, a0_2)));
+            // kernel row 1 -> output row r
+            a1_1 = vfma(w1[3], xl1, vfma(w1[4], xc1, vfma(w1[5], xr1, a1_1)));
+            a1_2 = vfma(w2[3], xl2, vfma(w2[4], xc2, vfma(w2[5], xr2, a1_2)));
+            // kernel row 0 starts output row r+1
+            const vf<VW> a2_1 = vfma(w1[0], xl1, vfma(w1[1], xc1, vmul(w1[2], xr1)));
+            const vf<VW> a2_2 = vfma(w2[0], xl2, vfma(w2[1], xc2, vmul(w2[2], xr2)));
+            const vf<VW> g1 = vadd(a0_1, bias1), g2 = vadd(a0_2, bias2);
+            if (MODE == 0) {
+                const vf<VW> t = vmul(GATE == 0 ? g1 : vgelu(g1), g2);
+                bst<VW>(rs_out, yok ? (uint32_t)((y * p.W + x) * C + c1) * 4u : ROW_SENT, t);
+                if (yok) pool = vadd(pool, t);
+            } else {
+                const vf<VW> dt2 = vfma(dts, sv, dpv);
+                const uint32_t oo = yok ? (uint32_t)((y * p.W + x) * C2) * 4u : ROW_SENT;
+                if (GATE == 0) {
+                    bst<VW>(rs_out, oo + 4u * (uint32_t)c1, vmul(dt2, g2));
+                    bst<VW>(rs_out, oo + 4u * (uint32_t)c2, vmul(dt2, g1));
                 } else {
-                    const float4 dts = ldg4(p.in1 + pix * C + c1);
-                    const float4 dt2 = f4_fma(dts, sv, dpv);
-                    if (GATE == 0) {
-                        stg4(p.out + pix * C2 + c1, f4_mul(dt2, g2));
-                        stg4(p.out + pix * C2 + c2, f4_mul(dt2, g1));
-                    } else {
-                        stg4(p.out + pix * C2 + c1, f4_mul(f4_mul(dt2, g2), gelu_d4(g1)));
-                        stg4(p.out + pix * C2 + c2, f4_mul(dt2, gelu4(g1)));
-                    }
+                    bst<VW>(rs_out, oo + 4u * (uint32_t)c1, vmul(vmul(dt2, g2), vgelu_d(g1)));
+                    bst<VW>(rs_out, oo + 4u * (uint32_t)c2, vmul(dt2, vgelu(g1)));
                 }
             }
             a0_1 = a1_1; a0_2 = a1_2;
             a1_1 = a2_1; a1_2 = a2_2;
         }
     }
-    if (MODE == 0 && p.part != nullptr) {
-        red[tid] = pool;
-        __syncthreads();
-        if (pl == 0 && qok) {
-            float4 s = red[ql];
-            for (int j = 1; j < mp.PB; ++j) s = f4_add(s, red[j * mp.QB + ql]);
-            stg4(p.part + ((int64_t)b * gridDim.y + blockIdx.y) * C + c1, s);
-        }
-    }
+    if (MODE == 0 && p.part != nullptr)
+        dw_block_reduce<VW>(red, pool, tid, ql, pl, mp.QB, mp.PB, qok, p.part + ((int64_t)b * gridDim.y + bk.y) * C + c1);
 }
 
 // backward-b: dt1 = dw3x3^T(da), plus per-block partial sums of dw2[ch][tap] and db2[ch].
-// Thread = one quad of the 2C channels.
+// Thread = VW of the Ctot channels.
+template <int VW>
 __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
-    __shared__ float4 red[256];
+    __shared__ float red[256 * VW];
     const int C2 = p.Ctot;
-    const DwMap mp = dw_map(p.H, p.W, C2 / 4);
+    const DwMap mp = dw_map(p.H, p.W, C2 / VW);
+    const DwBlk bk = dw_block(mp);
     const int tid = threadIdx.x;
     const int ql = tid % mp.QB, pl = tid / mp.QB;
-    const int q = blockIdx.x * mp.QB + ql;
-    const int b = blockIdx.z;
+    const int q = bk.x * mp.QB + ql;
+    const int b = bk.z;
     const bool qok = q < mp.QW;
-    const int c0 = 4 * q;
-    float4 w[9], wa[10];
+    const int c0 = VW * q;
+    vf<VW> w[9], wa[10];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) w[t] = ld_or_zero(p.w2p + t * C2 + c0, qok);
+    for (int t = 0; t < 9; ++t) w[t] = gld<VW>(p.w2p + t * C2 + c0, qok);
 #pragma unroll
-    for (int t = 0; t < 10; ++t) wa[t] = f4_zero();
+    for (int t = 0; t < 10; ++t) wa[t] = vz<VW>();
+    const int64_t img = (int64_t)b * p.H * p.W;
+    const rsrc_t rs_d = make_rsrc(p.in0 + img * C2);
+    const rsrc_t rs_t = make_rsrc(p.in1 + img * C2);
+    const rsrc_t rs_o = make_rsrc(p.out + img * C2);
+    const uint32_t st = 4u * (uint32_t)C2;
 
-    for (int item = blockIdx.y; item < mp.items; item += gridDim.y) {
-        const int band = item / mp.nwc, wc = item % mp.nwc;
+    {
+        const int wc = bk.y % mp.nwc, nrp = gridDim.y / mp.nwc, rpp = (p.H + nrp - 1) / nrp;
         const int x = wc * mp.PB + pl;
         const bool ok = qok && x < p.W;
-        const int h0 = band * RH;
-        const int h1 = (h0 + RH < p.H) ? h0 + RH : p.H;
-        float4 a0 = f4_zero(), a1 = f4_zero();
+        const int h0 = (bk.y / mp.nwc) * rpp;
+        const int h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
+        const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
+        auto rowoff = [&](int r) -> uint32_t { return (r >= 0 && r < p.H) ? ((uint32_t)((r * p.W + x) * C2) + (uint32_t)c0) * 4u : ROW_SENT; };
+        vf<VW> a0 = vz<VW>(), a1 = vz<VW>();
         // t1 rows r-1, r at column x (for the weight gradient); row r+1 is loaded in the loop
-        float4 tm = f4_zero(), tc = f4_zero();
-        {
-            const int r = h0 - 1;
-            if (ok && r - 1 >= 0) tm = ldg4(p.in1 + (((int64_t)b * p.H + r - 1) * p.W + x) * C2 + c0);
-            if (ok && r >= 0) tc = ldg4(p.in1 + (((int64_t)b * p.H + r) * p.W + x) * C2 + c0);
-        }
+        vf<VW> tm = bld<VW>(rs_t, rowoff(h0 - 2) | cc), tc = bld<VW>(rs_t, rowoff(h0 - 1) | cc);
         for (int r = h0 - 1; r <= h1; ++r) {
-            const bool rin = ok && r >= 0 && r < p.H;
-            const float* pc = p.in0 + (((int64_t)b * p.H + r) * p.W + x) * C2 + c0;
-            const float4 dl = ld_or_zero(pc - C2, rin && x > 0);
-            const float4 dc = ld_or_zero(pc, rin);
-            const float4 dr = ld_or_zero(pc + C2, rin && x + 1 < p.W);
-            const bool tpin = ok && r + 1 >= 0 && r + 1 < p.H;
-            const float4 tp = ld_or_zero(p.in1 + (((int64_t)b * p.H + r + 1) * p.W + x) * C2 + c0, tpin);
+            const uint32_t o = rowoff(r);
+            const vf<VW> dl = bld<VW>(rs_d, (o - st) | cl), dc = bld<VW>(rs_d, o | cc), dr = bld<VW>(rs_d, (o + st) | cr);
+            const vf<VW> tp = bld<VW>(rs_t, rowoff(r + 1) | cc);
             // dt1[y][x] = sum_{ky,kx} da[y+1-ky][x+1-kx] * w[ky][kx];  da row r feeds y = r-1+ky
             // d{l,c,r} = da[r][x-1+j], j=0,1,2  <->  kx = 2-j
-            a0 = f4_fma(w[0 * 3 + 2], dl, f4_fma(w[0 * 3 + 1], dc, f4_fma(w[0 * 3 + 0], dr, a0)));  // ky=0 -> y=r-1
-            a1 = f4_fma(w[1 * 3 + 2], dl, f4_fma(w[1 * 3 + 1], dc, f4_fma(w[1 * 3 + 0], dr, a1)));  // ky=1 -> y=r
-            const float4 a2 = f4_fma(w[2 * 3 + 2], dl, f4_fma(w[2 * 3 + 1], dc, f4_mul(w[2 * 3 + 0], dr)));  // ky=2 -> y=r+1
+            a0 = vfma(w[0 * 3 + 2], dl, vfma(w[0 * 3 + 1], dc, vfma(w[0 * 3 + 0], dr, a0)));  // ky=0 -> y=r-1
+            a1 = vfma(w[1 * 3 + 2], dl, vfma(w[1 * 3 + 1], dc, vfma(w[1 * 3 + 0], dr, a1)));  // ky=1 -> y=r
+            const vf<VW> a2 = vfma(w[2 * 3 + 2], dl, vfma(w[2 * 3 + 1], dc, vmul(w[2 * 3 + 0], dr)));  // ky=2 -> y=r+1
             const int y = r - 1;
-            if (ok && y >= h0) stg4(p.out + (((int64_t)b * p.H + y) * p.W + x) * C2 + c0, a0);
+            bst<VW>(rs_o, (ok && y >= h0) ? rowoff(y) : ROW_SENT, a0);
             a0 = a1;
             a1 = a2;
-            // weight gradient: each da row counted once (rows of this band only)
-            if (rin && r >= h0 && r < h1) {
+            // weight gradient: each da row counted once (rows of this band only; dl/dc/dr are 0 outside the image)
+            if (r >= h0 && r < h1) {
                 // dw[ky][kx=2-j] += da[r][x-1+j] * t1[r-1+ky][x]
-                wa[0 * 3 + 2] = f4_fma(dl, tm, wa[0 * 3 + 2]);
-                wa[0 * 3 + 1] = f4_fma(dc, tm, wa[0 * 3 + 1]);
-                wa[0 * 3 + 0] = f4_fma(dr, tm, wa[0 * 3 + 0]);
-                wa[1 * 3 + 2] = f4_fma(dl, tc, wa[1 * 3 + 2]);
-                wa[1 * 3 + 1] = f4_fma(dc, tc, wa[1 * 3 + 1]);
-                wa[1 * 3 + 0] = f4_fma(dr, tc, wa[1 * 3 + 0]);
-                wa[2 * 3 + 2] = f4_fma(dl, tp, wa[2 * 3 + 2]);
-                wa[2 * 3 + 1] = f4_fma(dc, tp, wa[2 * 3 + 1]);
-                wa[2 * 3 + 0] = f4_fma(dr, tp, wa[2 * 3 + 0]);
-                wa[9] = f4_add(wa[9], dc);
+                wa[0 * 3 + 2] = vfma(dl, tm, wa[0 * 3 + 2]);
+                wa[0 * 3 + 1] = vfma(dc, tm, wa[0 * 3 + 1]);
+                wa[0 * 3 + 0] = vfma(dr, tm, wa[0 * 3 + 0]);
+                wa[1 * 3 + 2] = vfma(dl, tc, wa[1 * 3 + 2]);
+                wa[1 * 3 + 1] = vfma(dc, tc, wa[1 * 3 + 1]);
+                wa[1 * 3 + 0] = vfma(dr, tc, wa[1 * 3 + 0]);
+                wa[2 * 3 + 2] = vfma(dl, tp, wa[2 * 3 + 2]);
+                wa[2 * 3 + 1] = vfma(dc, tp, wa[2 * 3 + 1]);
+                wa[2 * 3 + 0] = vfma(dr, tp, wa[2 * 3 + 0]);
+                wa[9] = vadd(wa[9], dc);
             }
             tm = tc;
             tc = tp;
         }
     }
-    float* part = p.part + ((int64_t)b * gridDim.y + blockIdx.y) * 10 * C2;
+    float* part = p.part + ((int64_t)b * gridDim.y + bk.y) * 10 * C2;
 #pragma unroll
-    for (int t = 0; t < 10; ++t) {
-        __syncthreads();
-        red[tid] = wa[t];
-        __syncthreads();
-        if (pl == 0 && qok) {
-            float4 s = red[ql];
-            for (int j = 1; j < mp.PB; ++j) s = f4_add(s, red[j * mp.QB + ql]);
-            stg4(part + t * C2 + c0, s);
-        }
-    }
+    for (int t = 0; t < 10; ++t) dw_block_reduce<VW>(red, wa[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + c0);
 }
 
 // Plain depthwise 3x3 (no bias, no gate) over Ctot channels (Restormer MDTA qkv_dwconv), plus per-block partial
 // sums of out^2 for the first nsq channels (the L2 norms of q and k over the pixels).
+template <int VW>
 __global__ __launch_bounds__(256) void dw_plain_kernel(const DwP p, int nsq) {
-    __shared__ float4 red[256];
+    __shared__ float red[256 * VW];
     const int C = p.Ctot;
-    const DwMap mp = dw_map(p.H, p.W, C / 4);
+    const DwMap mp = dw_map(p.H, p.W, C / VW);
+    const DwBlk bk = dw_block(mp);
     const int tid = threadIdx.x;
     const int ql = tid % mp.QB, pl = tid / mp.QB;
-    const int q = blockIdx.x * mp.QB + ql;
-    const int b = blockIdx.z;
+    const int q = bk.x * mp.QB + ql;
+    const int b = bk.z;
     const bool qok = q < mp.QW;
-    const int c0 = 4 * q;
-    float4 w[9];
+    const int c0 = VW * q;
+    vf<VW> w[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) w[t] = ld_or_zero(p.w2p + t * C + c0, qok);
-    float4 sq = f4_zero();
-    for (int item = blockIdx.y; item < mp.items; item += gridDim.y) {
-        const int band = item / mp.nwc, wc = item % mp.nwc;
+    for (int t = 0; t < 9; ++t) w[t] = gld<VW>(p.w2p + t * C + c0, qok);
+    vf<VW> sq = vz<VW>();
+    const int64_t img = (int64_t)b * p.H * p.W;
+    const rsrc_t rs_in = make_rsrc(p.in0 + img * C);
+    const rsrc_t rs_o = make_rsrc(p.out + img * C);
+    const uint32_t st = 4u * (uint32_t)C;
+    {
+        const int wc = bk.y % mp.nwc, nrp = gridDim.y / mp.nwc, rpp = (p.H + nrp - 1) / nrp;
         const int x = wc * mp.PB + pl;
         const bool ok = qok && x < p.W;
-        const int h0 = band * RH;
-        const int h1 = (h0 + RH < p.H) ? h0 + RH : p.H;
-        float4 a0 = f4_zero(), a1 = f4_zero();
+        const int h0 = (bk.y / mp.nwc) * rpp;
+        const int h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
+        const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
+        vf<VW> a0 = vz<VW>(), a1 = vz<VW>();
         for (int r = h0 - 1; r <= h1; ++r) {
-            const bool rin = ok && r >= 0 && r < p.H;
-            const float* pc = p.in0 + (((int64_t)b * p.H + r) * p.W + x) * C + c0;
-            const float4 xl = ld_or_zero(pc - C, rin && x > 0);
-            const float4 xc = ld_or_zero(pc, rin);
-            const float4 xr = ld_or_zero(pc + C, rin && x + 1 < p.W);
-            a0 = f4_fma(w[6], xl, f4_fma(w[7], xc, f4_fma(w[8], xr, a0)));
-            a1 = f4_fma(w[3], xl, f4_fma(w[4], xc, f4_fma(w[5], xr, a1)));
-            const float4 a2 = f4_fma(w[0], xl, f4_fma(w[1], xc, f4_mul(w[2], xr)));
+            const uint32_t o = (r >= 0 && r < p.H) ? ((uint32_t)((r * p.W + x) * C) + (uint32_t)c0) * 4u : ROW_SENT;
+            const vf<VW> xl = bld<VW>(rs_in, (o - st) | cl), xc = bld<VW>(rs_in, o | cc), xr = bld<VW>(rs_in, (o + st) | cr);
+            a0 = vfma(w[6], xl, vfma(w[7], xc, vfma(w[8], xr, a0)));
+            a1 = vfma(w[3], xl, vfma(w[4], xc, vfma(w[5], xr, a1)));
+            const vf<VW> a2 = vfma(w[0], xl, vfma(w[1], xc, vmul(w[2], xr)));
             const int y = r - 1;
-            if (ok && y >= h0) {
-                stg4(p.out + (((int64_t)b * p.H + y) * p.W + x) * C + c0, a0);
-                sq = f4_fma(a0, a0, sq);
-            }
+            const bool yok = ok && y >= h0;
+            bst<VW>(rs_o, yok ? ((uint32_t)((y * p.W + x) * C) + (uint32_t)c0) * 4u : ROW_SENT, a0);
+            if (yok) sq = vfma(a0, a0, sq);
             a0 = a1;
             a1 = a2;
         }
     }
-    if (p.part != nullptr) {
-        red[tid] = sq;
-        __syncthreads();
-        if (pl == 0 && qok && c0 < nsq) {
-            float4 s = red[ql];
-            for (int j = 1; j < mp.PB; ++j) s = f4_add(s, red[j * mp.QB + ql]);
-            stg4(p.part + ((int64_t)b * gridDim.y + blockIdx.y) * nsq + c0, s);
-        }
-    }
+    if (p.part != nullptr)
+        dw_block_reduce<VW>(red, sq, tid, ql, pl, mp.QB, mp.PB, qok && c0 < nsq, p.part + ((int64_t)b * gridDim.y + bk.y) * nsq + c0);
 }
 
 __global__ void dw_pack_kernel(const float* __restrict__ w2, float* __restrict__ w2p, int C2) {
@@ -320,18 +374,45 @@ __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __res
     }
 }
 
-int nblk_for(const DwGeom& g, int quads) {
-    const DwMap mp = dw_map(g.H, g.W, quads);
-    int64_t want = cdiv64(1024, (int64_t)g.B * mp.nqc);
-    if (want > mp.items) want = mp.items;
-    if (want < 1) want = 1;
-    return (int)want;
+// channels per thread (2 or 4) and grid target; DCPT_DW_VW / DCPT_DW_BLOCKS override them for experiments
+int dw_vw() {
+    static int v = 0;
+    if (v == 0) {
+        const char* e = getenv("DCPT_DW_VW");
+        v = (e && e[0] == '2') ? 2 : 4;
+    }
+    return v;
+}
+int dw_target_blocks() {
+    static int v = 0;
+    if (v == 0) {
+        const char* e = getenv("DCPT_DW_BLOCKS");
+        v = e ? atoi(e) : 0;
+        if (v <= 0) v = 1024;
+    }
+    return v;
 }
 
+int nblk_for(const DwGeom& g, int quads) {
+    const DwMap mp = dw_map(g.H, g.W, quads);
+    // column chunks x row parts; a part is at least RH rows so that the two halo rows stay a small fraction
+    int64_t nrp = cdiv64(cdiv64(dw_target_blocks(), (int64_t)g.B * mp.nqc), mp.nwc);
+    const int64_t maxp = g.H / RH > 0 ? g.H / RH : 1;
+    if (nrp > maxp) nrp = maxp;
+    if (nrp < 1) nrp = 1;
+    return (int)(nrp * mp.nwc);
+}
 }  // namespace
 
-int dw_num_blocks_per_image(const DwGeom& g) { return nblk_for(g, g.C / 4); }
-int dw_num_blocks_per_image_b(const DwGeom& g) { return nblk_for(g, g.C / 2); }
+int dw_num_blocks_per_image(const DwGeom& g) { return nblk_for(g, g.C / dw_vw()); }
+int dw_num_blocks_per_image_b(const DwGeom& g) { return nblk_for(g, 2 * g.C / dw_vw()); }
+
+#define DW_CHECK_RANGE(H, W, Ct) DCPT_CHECK_ARG((double)(H) * (W) * (Ct) * 4.0 < 1.0e9, "depthwise conv: image of %d x %d x %d floats exceeds the 32-bit window", H, W, Ct)
+#define DW_LAUNCH(KERNEL, ...)                                  \
+    do {                                                        \
+        if (dw_vw() == 2) KERNEL<2 __VA_ARGS__;                 \
+        else KERNEL<4 __VA_ARGS__;                              \
+    } while (0)
 
 int launch_dw_pack_weights(const float* w2, float* w2p, int C2, hipStream_t s) {
     dw_pack_kernel<<<dim3(cdiv(C2 * 9, 256)), dim3(256), 0, s>>>(w2, w2p, C2);
@@ -345,8 +426,9 @@ int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2,
     DwP p{};
     p.in0 = t1; p.w2p = w2p; p.b2 = b2; p.out = t2; p.part = pool_part;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
-    const DwMap mp = dw_map(g.H, g.W, g.C / 4);
-    dw_gate_kernel<0, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p);
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C);
+    const DwMap mp = dw_map(g.H, g.W, g.C / dw_vw());
+    DW_LAUNCH(dw_gate_kernel, , 0, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_fwd");
     return DCPT_OK;
 }
@@ -357,8 +439,9 @@ int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const f
     DwP p{};
     p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = da;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
-    const DwMap mp = dw_map(g.H, g.W, g.C / 4);
-    dw_gate_kernel<1, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p);
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C);
+    const DwMap mp = dw_map(g.H, g.W, g.C / dw_vw());
+    DW_LAUNCH(dw_gate_kernel, , 1, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_bwd_a");
     return DCPT_OK;
 }
@@ -369,8 +452,9 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
     DwP p{};
     p.in0 = da; p.in1 = t1; p.w2p = w2p; p.out = dt1; p.part = wpart;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.Ctot = 2 * g.C;
-    const DwMap mp = dw_map(g.H, g.W, g.C / 2);
-    dw_bwd_b_kernel<<<dim3(mp.nqc, dw_num_blocks_per_image_b(g), g.B), dim3(256), 0, s>>>(p);
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C);
+    const DwMap mp = dw_map(g.H, g.W, 2 * g.C / dw_vw());
+    DW_LAUNCH(dw_bwd_b_kernel, ><<<dim3(mp.nqc, dw_num_blocks_per_image_b(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_bwd_b");
     return DCPT_OK;
 }
@@ -378,7 +462,7 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
 // ---- generic entry points used by the Restormer blocks ---------------------------------------------
 int dw_num_blocks_generic(int B, int H, int W, int Ctot) {
     DwGeom g{B, H, W, Ctot};
-    return nblk_for(g, Ctot / 4);
+    return nblk_for(g, Ctot / dw_vw());
 }
 
 int launch_dw_gelu_fwd(const float* u, const float* w2p, float* t, int B, int H, int W, int Ch, hipStream_t s) {
@@ -386,8 +470,9 @@ int launch_dw_gelu_fwd(const float* u, const float* w2p, float* t, int B, int H,
     DwP p{};
     p.in0 = u; p.w2p = w2p; p.out = t; p.B = B; p.H = H; p.W = W; p.C = Ch;
     DwGeom g{B, H, W, Ch};
-    const DwMap mp = dw_map(H, W, Ch / 4);
-    dw_gate_kernel<0, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p);
+    DW_CHECK_RANGE(H, W, 2 * Ch);
+    const DwMap mp = dw_map(H, W, Ch / dw_vw());
+    DW_LAUNCH(dw_gate_kernel, , 0, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_gelu_fwd");
     return DCPT_OK;
 }
@@ -397,8 +482,9 @@ int launch_dw_gelu_bwd_a(const float* dt, const float* u, const float* w2p, floa
     DwP p{};
     p.in0 = u; p.in1 = dt; p.w2p = w2p; p.out = da; p.B = B; p.H = H; p.W = W; p.C = Ch;
     DwGeom g{B, H, W, Ch};
-    const DwMap mp = dw_map(H, W, Ch / 4);
-    dw_gate_kernel<1, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p);
+    DW_CHECK_RANGE(H, W, 2 * Ch);
+    const DwMap mp = dw_map(H, W, Ch / dw_vw());
+    DW_LAUNCH(dw_gate_kernel, , 1, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_gelu_bwd_a");
     return DCPT_OK;
 }
@@ -408,8 +494,9 @@ int launch_dw_plain_fwd(const float* x, const float* w2p, float* y, float* sq_pa
     DCPT_CHECK_ARG(Ctot % 4 == 0 && nsq % 4 == 0 && B <= 65535, "dw_plain_fwd: Ctot=%d", Ctot);
     DwP p{};
     p.in0 = x; p.w2p = w2p; p.out = y; p.part = sq_part; p.B = B; p.H = H; p.W = W; p.Ctot = Ctot;
-    const DwMap mp = dw_map(H, W, Ctot / 4);
-    dw_plain_kernel<<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p, nsq);
+    DW_CHECK_RANGE(H, W, Ctot);
+    const DwMap mp = dw_map(H, W, Ctot / dw_vw());
+    DW_LAUNCH(dw_plain_kernel, ><<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p, nsq));
     DCPT_CHECK_LAUNCH("dw_plain_fwd");
     return DCPT_OK;
 }
@@ -420,8 +507,9 @@ int launch_dw_generic_bwd(const float* dy, const float* x, const float* w2p, flo
     DCPT_CHECK_ARG(Ctot % 4 == 0 && B <= 65535, "dw_generic_bwd: Ctot=%d", Ctot);
     DwP p{};
     p.in0 = dy; p.in1 = x; p.w2p = w2p; p.out = dx; p.part = wpart; p.B = B; p.H = H; p.W = W; p.Ctot = Ctot;
-    const DwMap mp = dw_map(H, W, Ctot / 4);
-    dw_bwd_b_kernel<<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p);
+    DW_CHECK_RANGE(H, W, Ctot);
+    const DwMap mp = dw_map(H, W, Ctot / dw_vw());
+    DW_LAUNCH(dw_bwd_b_kernel, ><<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_generic_bwd");
     return DCPT_OK;
 }
