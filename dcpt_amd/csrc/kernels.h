@@ -62,10 +62,14 @@ int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const fl
                    int B, int C, int P, hipStream_t s);
 // ds[b][k] = sum_{m in image b} dts[m][k] * t2[m][k]   (two-stage, deterministic)
 int sca_ds_num_blocks(int P);
-int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, int B, int C, int P, hipStream_t s);
+// backward: part[b][j][k] = sum over the j-th pixel slice of image b of dts*t2  (j < sca_ds_num_blocks(P))
+int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B, int C, int P, hipStream_t s);
+// critical path: dpool[b][k] = (1/P) sum_n Wsca[n][k] * sum_j part[b][j][n]
+int launch_sca_dpool(const float* ds_part, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s);
+// parameter gradients (off the critical path): ds = sum_j part, dWsca = ds^T pooled, dbsca = sum_b ds
+int launch_sca_wgrad(const float* ds_part, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C, int P,
+                     hipStream_t s);
 // dpool[b][k] = (sum_n Wsca[n][k]*ds[b][n]) / P ; dWsca[n][k] = sum_b ds[b][n]*pooled[b][k] ; dbsca[n] = sum_b ds[b][n]
-int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, float* dpool, float* dWsca, float* dbsca,
-                   int B, int C, int P, hipStream_t s);
 
 // TLSC box mean (arch_util.py:378-396): out[M][C] local k1 x k2 mean of in, replicate-padded; rowsum: [B][H][W-k2+1][C] scratch
 int launch_box_mean(const float* in, float* rowsum, float* out, int B, int H, int W, int C, int k1, int k2, hipStream_t s);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ 
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int nbeg = blockIdx.y * 64;
+#pragma unroll 4
     for (int n = nbeg + wave; n < nbeg + 64 && n < C; n += 4) {
         float s = 0.f;
         for (int k = 4 * lane; k < C; k += 256) {
@@ -74,26 +75,52 @@ __global__ void sca_ds_final_kernel(const float* __restrict__ part, float* __res
     ds[i] = s;
 }
 
-// SCA backward (tiny)
-//   dpool[b][k] = invP * sum_n Wsca[n][k] * ds[b][n]        grid (C/32, B): 32 k-columns x 8 n-groups
-__global__ __launch_bounds__(256) void sca_bwd_dpool_kernel(const float* __restrict__ ds, const float* __restrict__ Wsca,
-                                                            float* __restrict__ dpool, int C, float invP) {
-    __shared__ float red[8][32];
-    const int b = blockIdx.y;
-    const int kl = threadIdx.x & 31, ng = threadIdx.x >> 5;
-    const int k = blockIdx.x * 32 + kl;
-    float s = 0.f;
-    if (k < C)
-        for (int n = ng; n < C; n += 8) s = fmaf(Wsca[(int64_t)n * C + k], ds[(int64_t)b * C + n], s);
-    red[ng][kl] = s;
+// SCA backward, critical-path part:  dpool[b][k] = invP * sum_n Wsca[n][k] * ds[b][n],  ds[b][n] = sum_j part[b][j][n].
+// grid (C/64, B/4): 64 k-columns x 4 n-groups, 4 images per block: every Wsca element is loaded once per block and used for
+// the 4 images (ds comes from LDS, where the slices were summed on the way in: no separate ds pass on this path).
+constexpr int SCA_IPB = 4;
+__global__ __launch_bounds__(256) void sca_dpool_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ Wsca,
+                                                        float* __restrict__ dpool, int B, int C, float invP) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // ds[SCA_IPB][C], then red[4][SCA_IPB][64]
+    float* dsl = sm;
+    float* red = sm + SCA_IPB * C;
+    const int b0 = blockIdx.y * SCA_IPB;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SCA_IPB * C; i += 256) {
+        const int bi = i / C, n = i % C;
+        float v = 0.f;
+        if (b0 + bi < B)
+            for (int j = 0; j < nslices; ++j) v += part[((int64_t)(b0 + bi) * nslices + j) * C + n];
+        dsl[i] = v;
+    }
+    __syncthreads();
+    const int kl = tid & 63, ng = tid >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    float acc[SCA_IPB];
+#pragma unroll
+    for (int i = 0; i < SCA_IPB; ++i) acc[i] = 0.f;
+    if (k < C) {
+#pragma unroll 8
+        for (int n = ng; n < C; n += 4) {
+            const float w = Wsca[(int64_t)n * C + k];
+#pragma unroll
+            for (int i = 0; i < SCA_IPB; ++i) acc[i] = fmaf(w, dsl[i * C + n], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SCA_IPB; ++i) red[(ng * SCA_IPB + i) * 64 + kl] = acc[i];
     __syncthreads();
     if (ng == 0 && k < C) {
-        float t = red[0][kl];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) t += red[i][kl];
-        dpool[(int64_t)b * C + k] = t * invP;
+        for (int i = 0; i < SCA_IPB; ++i) {
+            if (b0 + i >= B) break;
+            const float t = (red[(0 * SCA_IPB + i) * 64 + kl] + red[(1 * SCA_IPB + i) * 64 + kl]) +
+                            (red[(2 * SCA_IPB + i) * 64 + kl] + red[(3 * SCA_IPB + i) * 64 + kl]);
+            dpool[(int64_t)(b0 + i) * C + k] = t * invP;
+        }
     }
 }
+
 //   role 0: dWsca[n][k] = sum_b ds[b][n] * pooled[b][k]     role 1: dbsca[n] = sum_b ds[b][n]
 __global__ __launch_bounds__(256) void sca_bwd_w_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
                                                         float* __restrict__ dWsca, float* __restrict__ dbsca, int B, int C) {
@@ -322,7 +349,7 @@ int sca_ds_num_blocks(int P) {
     return n;
 }
 
-int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, int B, int C, int P, hipStream_t s) {
+int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B, int C, int P, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && B <= 65535, "sca_ds: C=%d", C);
     const int nsl = sca_ds_num_blocks(P);
     const int nq = C / 4;
@@ -330,16 +357,21 @@ int launch_sca_ds(const float* dts, const float* t2, float* ds_part, float* ds, 
     while (qb < nq && qb < 256) qb <<= 1;
     sca_ds_part_kernel<<<dim3(cdiv(nq, qb), nsl, B), dim3(256), 0, s>>>(dts, t2, ds_part, C, P, nsl);
     DCPT_CHECK_LAUNCH("sca_ds_part");
-    sca_ds_final_kernel<<<dim3(cdiv(B * C, 256)), dim3(256), 0, s>>>(ds_part, ds, B * C, C, nsl);
-    DCPT_CHECK_LAUNCH("sca_ds_final");
     return DCPT_OK;
 }
 
-int launch_sca_bwd(const float* ds, const float* pooled, const float* Wsca, float* dpool, float* dWsca, float* dbsca, int B,
-                   int C, int P, hipStream_t s) {
-    DCPT_CHECK_ARG(B <= 65535, "sca_bwd: B too large");
-    sca_bwd_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), 0, s>>>(ds, Wsca, dpool, C, 1.0f / (float)P);
-    DCPT_CHECK_LAUNCH("sca_bwd_dpool");
+int launch_sca_dpool(const float* ds_part, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s) {
+    DCPT_CHECK_ARG(B <= 65535 * SCA_IPB && (size_t)(SCA_IPB * C + 4 * SCA_IPB * 64) * sizeof(float) <= 160 * 1024, "sca_dpool: B=%d C=%d", B, C);
+    sca_dpool_kernel<<<dim3(cdiv(C, 64), cdiv(B, SCA_IPB)), dim3(256), (SCA_IPB * C + 4 * SCA_IPB * 64) * sizeof(float), s>>>(
+        ds_part, sca_ds_num_blocks(P), Wsca, dpool, B, C, 1.0f / (float)P);
+    DCPT_CHECK_LAUNCH("sca_dpool");
+    return DCPT_OK;
+}
+
+int launch_sca_wgrad(const float* ds_part, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C, int P,
+                     hipStream_t s) {
+    sca_ds_final_kernel<<<dim3(cdiv(B * C, 256)), dim3(256), 0, s>>>(ds_part, ds, B * C, C, sca_ds_num_blocks(P));
+    DCPT_CHECK_LAUNCH("sca_ds_final");
     sca_bwd_w_kernel<<<dim3((unsigned)cdiv64((int64_t)C * C, 256), 2), dim3(256), 0, s>>>(ds, pooled, dWsca, dbsca, B, C);
     DCPT_CHECK_LAUNCH("sca_bwd_w");
     return DCPT_OK;

@@ -305,12 +305,13 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(wgrad(dy, C, C, sv->t2, C, C, A_SCALE, tp, M, w.slab, w.colsum, p->beta, p->conv3_w, p->conv3_b, gr->conv3_w,
                    gr->beta, gr->conv3_b, sw));
     // B8: SCA backward
-    DCPT_TRY(launch_sca_ds(dts, sv->t2, w.ds_part, w.ds, B, C, P, s));
-    DCPT_TRY(launch_sca_bwd(w.ds, sv->pooled, p->sca_w, w.dpool, gr->sca_w, gr->sca_b, B, C, P, s));
+    DCPT_TRY(launch_sca_ds_part(dts, sv->t2, w.ds_part, B, C, P, s));
+    DCPT_TRY(launch_sca_dpool(w.ds_part, p->sca_w, w.dpool, B, C, P, s));
     // B9/B10: SimpleGate + depthwise conv backward
     DCPT_TRY(launch_dw_bwd_a(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, da, dg, s));
     DCPT_TRY(launch_dw_bwd_b(da, sv->t1, w.w2p, dt1, w.wpart, dg, s));
-    DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise partial sums
+    DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise and SCA partial sums
+    DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, P, sw));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
     // B11: grad w.r.t. LN1 output
     g = GemmNT{};
