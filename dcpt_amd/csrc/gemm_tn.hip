@@ -78,23 +78,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     }
     // LDS-DMA: a wave's 64 lanes write 1 KiB of consecutive tile floats
     const uint32_t lds_x = lds_addr(&Xs[0][0]) + wave * 1024, lds_y = lds_addr(&Ys[0][0]) + wave * 1024;
+    // Plain rows (the common case): the byte offset of this thread's quad inside the chunk window is fixed, the pixel tile
+    // advances through the scalar offset of the DMA instruction, and only rows past the chunk end need the sentinel --
+    // a few VALU per tile instead of 64-bit row arithmetic per piece.
+    uint32_t xfix[X_IT], yfix[Y_IT];
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) xfix[i] = (n0 + xc < p.N) ? ((uint32_t)(xrow + XR * i) * (uint32_t)p.ldx + (uint32_t)(n0 + xc)) * 4u : COL_SENT;
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) yfix[i] = (k0 + yc < p.K) ? ((uint32_t)(yrow + YR * i) * (uint32_t)p.ldy + (uint32_t)(k0 + yc)) * 4u : COL_SENT;
     auto gload = [&](int64_t mt, int buf) {
+        const int left = (int)(mend - mt);                    // rows of the chunk from this tile on (wave-uniform)
+        const uint32_t step = (uint32_t)(mt - mbeg);          // tile's first row inside the chunk
+        if constexpr (XK == A_PLAIN) {
 #pragma unroll
-        for (int i = 0; i < X_IT; ++i) {
-            RowCtx rc;
-            make_row<XK>(ox, mt + xrow + XR * i, rc);
-            dma16(ox.rsd, lds_x + (buf * BR * BN + i * XR * BN) * 4, elem_voff<XK>(ox, rc, n0 + xc), 0);
+            for (int i = 0; i < X_IT; ++i)
+                dma16(ox.rsd, lds_x + (buf * BR * BN + i * XR * BN) * 4, (xrow + XR * i < left) ? xfix[i] : ROW_SENT, step * (uint32_t)p.ldx * 4u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < X_IT; ++i) {
+                RowCtx rc;
+                make_row<XK>(ox, mt + xrow + XR * i, rc);
+                dma16(ox.rsd, lds_x + (buf * BR * BN + i * XR * BN) * 4, elem_voff<XK>(ox, rc, n0 + xc), 0);
+            }
         }
+        if constexpr (YK == A_PLAIN) {
 #pragma unroll
-        for (int i = 0; i < Y_IT; ++i) {
-            make_row<YK>(oy, mt + yrow + YR * i, rcy[i]);
-            if constexpr (Y_DMA) {
-                dma16(oy.rsd, lds_y + (buf * BR * BKo + i * YR * BKo) * 4, elem_voff<YK>(oy, rcy[i], k0 + yc), 0);
-            } else {
-                load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
-                if constexpr (YK == A_LN || YK == A_LNBF) {
-                    ry[i].b = kw;
-                    ry[i].c = kb;
+            for (int i = 0; i < Y_IT; ++i)
+                dma16(oy.rsd, lds_y + (buf * BR * BKo + i * YR * BKo) * 4, (yrow + YR * i < left) ? yfix[i] : ROW_SENT, step * (uint32_t)p.ldy * 4u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < Y_IT; ++i) {
+                make_row<YK>(oy, mt + yrow + YR * i, rcy[i]);
+                if constexpr (Y_DMA) {
+                    dma16(oy.rsd, lds_y + (buf * BR * BKo + i * YR * BKo) * 4, elem_voff<YK>(oy, rcy[i], k0 + yc), 0);
+                } else {
+                    load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
+                    if constexpr (YK == A_LN || YK == A_LNBF) {
+                        ry[i].b = kw;
+                        ry[i].c = kb;
+                    }
                 }
             }
         }
@@ -134,22 +156,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
         if (t + 1 < nmt) gload(mbeg + (t + 1) * BR, buf ^ 1);
         const float* xs = &Xs[buf][x_off];
         const float* ys = &Ys[buf][y_off];
-        // software-pipelined fragments: the ds_reads of step s+1 are issued before the MFMAs of step s
-        float a[2][TN], b[2][TK];
+        // software-pipelined fragments: the ds_reads of step s+2 are issued before the MFMAs of step s (a ring of three
+        // fragment sets), so an LDS round trip has two MFMA groups (512 cycles) to complete
+        float a[3][TN], b[3][TK];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) a[0][i] = xs[i * 32];
+        for (int pf = 0; pf < 2; ++pf) {
 #pragma unroll
-        for (int j = 0; j < TK; ++j) b[0][j] = ys[j * 32];
+            for (int i = 0; i < TN; ++i) a[pf][i] = xs[2 * pf * BN + i * 32];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[pf][j] = ys[2 * pf * BKo + j * 32];
+        }
 #pragma unroll
         for (int st = 0; st < BR / 2; ++st) {
-            const int cur = st & 1, nxt = cur ^ 1;
-            if (st + 1 < BR / 2) {
+            const int cur = st % 3, nxt = (st + 2) % 3;
+            if (st + 2 < BR / 2) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) a[nxt][i] = xs[(2 * st + 2) * BN + i * 32];
+                for (int i = 0; i < TN; ++i) a[nxt][i] = xs[(2 * st + 4) * BN + i * 32];
 #pragma unroll
-                for (int j = 0; j < TK; ++j) b[nxt][j] = ys[(2 * st + 2) * BKo + j * 32];
+                for (int j = 0; j < TK; ++j) b[nxt][j] = ys[(2 * st + 4) * BKo + j * 32];
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads ahead of this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);  // keep the later steps' ds_reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll

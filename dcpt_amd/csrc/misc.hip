@@ -76,51 +76,35 @@ __global__ void sca_ds_final_kernel(const float* __restrict__ part, float* __res
 }
 
 // SCA backward, critical-path part:  dpool[b][k] = invP * sum_n Wsca[n][k] * ds[b][n],  ds[b][n] = sum_j part[b][j][n].
-// grid (C/64, B/4): 64 k-columns x 4 n-groups, 4 images per block: every Wsca element is loaded once per block and used for
-// the 4 images (ds comes from LDS, where the slices were summed on the way in: no separate ds pass on this path).
-constexpr int SCA_IPB = 4;
+// grid (C/32, B): 32 k-columns x 8 n-groups; the block first sums the pixel slices of its image into LDS (so there is no
+// separate ds pass on this path), then every thread runs an 8-way unrolled dot over its n values.
 __global__ __launch_bounds__(256) void sca_dpool_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ Wsca,
-                                                        float* __restrict__ dpool, int B, int C, float invP) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // ds[SCA_IPB][C], then red[4][SCA_IPB][64]
-    float* dsl = sm;
-    float* red = sm + SCA_IPB * C;
-    const int b0 = blockIdx.y * SCA_IPB;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < SCA_IPB * C; i += 256) {
-        const int bi = i / C, n = i % C;
+                                                        float* __restrict__ dpool, int C, float invP) {
+    extern __shared__ __attribute__((aligned(16))) float dsl[];   // ds[C]
+    __shared__ float red[8][32];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int n = tid; n < C; n += 256) {
         float v = 0.f;
-        if (b0 + bi < B)
-            for (int j = 0; j < nslices; ++j) v += part[((int64_t)(b0 + bi) * nslices + j) * C + n];
-        dsl[i] = v;
+        for (int j = 0; j < nslices; ++j) v += part[((int64_t)b * nslices + j) * C + n];
+        dsl[n] = v;
     }
     __syncthreads();
-    const int kl = tid & 63, ng = tid >> 6;
-    const int k = blockIdx.x * 64 + kl;
-    float acc[SCA_IPB];
-#pragma unroll
-    for (int i = 0; i < SCA_IPB; ++i) acc[i] = 0.f;
+    const int kl = tid & 31, ng = tid >> 5;
+    const int k = blockIdx.x * 32 + kl;
+    float s = 0.f;
     if (k < C) {
 #pragma unroll 8
-        for (int n = ng; n < C; n += 4) {
-            const float w = Wsca[(int64_t)n * C + k];
-#pragma unroll
-            for (int i = 0; i < SCA_IPB; ++i) acc[i] = fmaf(w, dsl[i * C + n], acc[i]);
-        }
+        for (int n = ng; n < C; n += 8) s = fmaf(Wsca[(int64_t)n * C + k], dsl[n], s);
     }
-#pragma unroll
-    for (int i = 0; i < SCA_IPB; ++i) red[(ng * SCA_IPB + i) * 64 + kl] = acc[i];
+    red[ng][kl] = s;
     __syncthreads();
     if (ng == 0 && k < C) {
+        float t = red[0][kl];
 #pragma unroll
-        for (int i = 0; i < SCA_IPB; ++i) {
-            if (b0 + i >= B) break;
-            const float t = (red[(0 * SCA_IPB + i) * 64 + kl] + red[(1 * SCA_IPB + i) * 64 + kl]) +
-                            (red[(2 * SCA_IPB + i) * 64 + kl] + red[(3 * SCA_IPB + i) * 64 + kl]);
-            dpool[(int64_t)(b0 + i) * C + k] = t * invP;
-        }
+        for (int i = 1; i < 8; ++i) t += red[i][kl];
+        dpool[(int64_t)b * C + k] = t * invP;
     }
 }
-
 //   role 0: dWsca[n][k] = sum_b ds[b][n] * pooled[b][k]     role 1: dbsca[n] = sum_b ds[b][n]
 __global__ __launch_bounds__(256) void sca_bwd_w_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
                                                         float* __restrict__ dWsca, float* __restrict__ dbsca, int B, int C) {
@@ -361,9 +345,9 @@ int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B,
 }
 
 int launch_sca_dpool(const float* ds_part, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s) {
-    DCPT_CHECK_ARG(B <= 65535 * SCA_IPB && (size_t)(SCA_IPB * C + 4 * SCA_IPB * 64) * sizeof(float) <= 160 * 1024, "sca_dpool: B=%d C=%d", B, C);
-    sca_dpool_kernel<<<dim3(cdiv(C, 64), cdiv(B, SCA_IPB)), dim3(256), (SCA_IPB * C + 4 * SCA_IPB * 64) * sizeof(float), s>>>(
-        ds_part, sca_ds_num_blocks(P), Wsca, dpool, B, C, 1.0f / (float)P);
+    DCPT_CHECK_ARG(B <= 65535 && C * 4 <= 65536, "sca_dpool: B=%d C=%d", B, C);
+    sca_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), C * sizeof(float), s>>>(ds_part, sca_ds_num_blocks(P), Wsca, dpool, C,
+                                                                                 1.0f / (float)P);
     DCPT_CHECK_LAUNCH("sca_dpool");
     return DCPT_OK;
 }

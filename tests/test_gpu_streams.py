@@ -1,0 +1,91 @@
+"""GPU tests of the mechanisms around the kernels: the weight-gradient side stream must not change a single bit, the
+LDS-DMA GEMM tiles must be exact for ragged shapes (rows / columns / reduction depth that do not fill a tile -- the
+hardware range check supplies the zeros), and repeated calls must be bit-reproducible."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dcpt_amd.keyed_init import keyed_input, keyed_tensor
+from tests.test_gpu_parity import FUSED, block_params, check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from dcpt_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _block_grads(dev, c, shape, tag):
+    from dcpt_amd import functional as DF
+
+    P = block_params(c, tag)
+    x = keyed_input(tag + "x", shape, lo=-1.0, hi=1.0)
+    go = keyed_input(tag + "go", shape, lo=-1.0, hi=1.0)
+    Pg = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
+    xg = x.to(dev).requires_grad_(True)
+    y = DF.nafblock(xg, {fk: Pg[rk] for fk, rk in FUSED.items()})
+    y.backward(go.to(dev))
+    torch.cuda.synchronize()
+    return [y.detach().clone(), xg.grad.clone()] + [Pg[k].grad.clone() for k in sorted(Pg)]
+
+
+@pytest.mark.parametrize("c,shape", [(32, (2, 32, 24, 20)), (128, (2, 128, 32, 32))])
+def test_side_stream_is_bit_identical(dev, c, shape):
+    from dcpt_amd import _lib
+
+    lib = _lib.load()
+    prev = lib.dcpt_set_side_stream(1)
+    try:
+        on = _block_grads(dev, c, shape, f"ss{c}.")
+        on2 = _block_grads(dev, c, shape, f"ss{c}.")
+        lib.dcpt_set_side_stream(0)
+        off = _block_grads(dev, c, shape, f"ss{c}.")
+    finally:
+        lib.dcpt_set_side_stream(prev)
+    for a, b, c_ in zip(on, on2, off):
+        assert torch.equal(a, b), "two runs with the side stream differ (race?)"
+        assert torch.equal(a, c_), "side stream on/off must give identical bits"
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(1, 16, 16, 16, 32), (2, 12, 20, 16, 16), (1, 9, 7, 36, 40), (1, 16, 16, 48, 200),
+                                         (3, 5, 5, 132, 4), (1, 20, 13, 256, 260)])
+def test_conv1x1_ragged_shapes(dev, B, H, W, Ci, Co):
+    """forward (NT GEMM), input gradient (NT) and weight gradient (TN, split slabs) of a bias-free 1x1 conv"""
+    from dcpt_amd import functional as DF
+
+    x = keyed_input(f"rg{Ci}.{Co}.x", (B, Ci, H, W), lo=-1, hi=1)
+    w = keyed_tensor(f"rg{Ci}.{Co}.conv.weight", (Co, Ci, 1, 1))
+    go = keyed_input(f"rg{Ci}.{Co}.go", (B, Co, H, W), lo=-1, hi=1)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(go.double())
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = DF.conv_nobias(xg, wg)
+    y.backward(go.to(dev))
+    assert torch.isfinite(y).all()
+    check("y", y, yr.float(), 2e-6)
+    check("dx", xg.grad, xr.grad.float(), 2e-6)
+    check("dw", wg.grad, wr.grad.float(), 5e-6)
+
+
+def test_gemm_is_reproducible(dev):
+    from dcpt_amd import functional as DF
+
+    x = keyed_input("rep.x", (4, 96, 40, 24), lo=-1, hi=1).to(dev).requires_grad_(True)
+    w = keyed_tensor("rep.conv.weight", (160, 96, 1, 1)).to(dev).requires_grad_(True)
+    go = keyed_input("rep.go", (4, 160, 40, 24), lo=-1, hi=1).to(dev)
+    outs = []
+    for _ in range(3):
+        x.grad = None
+        w.grad = None
+        y = DF.conv_nobias(x, w)
+        y.backward(go)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
