@@ -33,6 +33,9 @@ __device__ __forceinline__ void buf_st4(rsrc_t r, uint32_t voff, float4 f) {
     v.w = f.w;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, DCPT_ST_AUX);
 }
+__device__ __forceinline__ float buf_ld1(rsrc_t r, uint32_t voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
 __device__ __forceinline__ void buf_st1(rsrc_t r, uint32_t voff, float f) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, voff, 0, 0);
 }

@@ -3,188 +3,258 @@
 // <= 4 channels, so these are bandwidth-bound direct convolutions on the VALU (K = 27 is far too
 // small for MFMA).  The image side stays NCHW-contiguous: the layout change to/from NHWC is fused
 // into these kernels, so no separate permute pass ever touches the big tensors.
+#include "bufops.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int MAXCS = 4;
+constexpr int WGRAD_BLOCKS = 768;   // weight-gradient kernel: one resident round (3 blocks/CU), few partial rows to reduce
 
-// y[p][c] = sum_{s,tap} x[p+off(tap)][s] * W(c,s,tap) (+bias[c]);  thread = (pixel, channel quad)
-__global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H,
-                                                          int W, int Cs, int Cb, int wmode) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cs*9][Cb]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < Cs * 9 * Cb; i += 256) {
-        const int st = i / Cb, c = i % Cb;
-        const int s = st / 9, tap = st % 9;
-        wl[i] = (wmode == 0) ? w[((int64_t)c * Cs + s) * 9 + tap] : w[((int64_t)s * Cb + c) * 9 + (8 - tap)];
-    }
-    __syncthreads();
+// All three kernels share one shape: a thread owns one channel quad of the big side and one pixel column, keeps its
+// CS*9 weight (or gradient) float4s in registers and streams down a strip of rows, carrying the three output rows that
+// an input row feeds as running accumulators -- so every input element is loaded once per thread, the small-side scalars
+// are 3*CS loads per row, and there is no LDS traffic in the loop (the previous version re-read every weight from LDS per
+// output and ran at < 1 TB/s).  Loads/stores are range-checked buffer accesses relative to image b: padding and strip
+// halos are sentinel offsets, not branches.
+struct EdgeMap {
+    int QB, PB;     // quads x pixel columns per block (QB * PB = 256)
+    int nqc, nwc;   // quad chunks, column chunks
+    int strips, RS; // row strips per image, rows per strip
+};
+inline __host__ __device__ EdgeMap edge_map(int B, int H, int W, int Cb, int target = 2048) {
+    EdgeMap m;
     const int nq = Cb / 4;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + tid;
-    const int64_t npix = (int64_t)B * H * W;
-    if (idx >= npix * nq) return;
-    const int q = (int)(idx % nq);
-    const int64_t pix = idx / nq;
-    const int xw = (int)(pix % W);
-    const int64_t t = pix / W;
-    const int yh = (int)(t % H);
-    const int64_t b = t / H;
-    float4 acc = bias ? ldg4(bias + 4 * q) : f4_zero();
-    for (int s = 0; s < Cs; ++s) {
-        const float* xs = x + ((b * Cs + s) * H) * (int64_t)W;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = yh - 1 + ky;
-            if (yy < 0 || yy >= H) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = xw - 1 + kx;
-                if (xx < 0 || xx >= W) continue;
-                const float v = xs[(int64_t)yy * W + xx];
-                const float4 wv = *reinterpret_cast<const float4*>(&wl[(s * 9 + ky * 3 + kx) * Cb + 4 * q]);
-                acc = f4_fma(make_float4(v, v, v, v), wv, acc);
-            }
-        }
-    }
-    stg4(y + pix * Cb + 4 * q, acc);
+    int qb = MAXCS;   // at least MAXCS lanes per pixel: lane s of a pixel's group writes small channel s in b2s
+    while (qb < nq && qb < 64) qb <<= 1;
+    m.QB = qb;
+    m.PB = 256 / qb;
+    m.nqc = (nq + qb - 1) / qb;
+    m.nwc = (W + m.PB - 1) / m.PB;
+    // about `target` blocks, strips of at least 8 rows
+    int64_t st = target / ((int64_t)B * m.nqc * m.nwc);
+    if (st > H / 8) st = H / 8;
+    if (st < 1) st = 1;
+    m.RS = (int)((H + st - 1) / st);
+    m.strips = (H + m.RS - 1) / m.RS;
+    return m;
 }
 
-// y[p][s] = sum_{c,tap} x[p+off(tap)][c] * W(s,c,tap) (+bias[s]) (+res[p][s]);  G lanes per pixel
+struct EdgeBlk {
+    int q, x, b, y0, y1;
+    bool qok, ok;
+};
+__device__ __forceinline__ EdgeBlk edge_block(const EdgeMap& m, int H, int W, int Cb) {
+    EdgeBlk k;
+    const int tid = threadIdx.x;
+    const int ql = tid % m.QB, pl = tid / m.QB;
+    const int qc = blockIdx.x % m.nqc, wc = blockIdx.x / m.nqc;
+    k.q = qc * m.QB + ql;
+    k.x = wc * m.PB + pl;
+    k.b = blockIdx.z;
+    k.y0 = blockIdx.y * m.RS;
+    k.y1 = (k.y0 + m.RS < H) ? k.y0 + m.RS : H;
+    k.qok = k.q < Cb / 4;
+    k.ok = k.qok && k.x < W;
+    return k;
+}
+
+// small -> big:  y[p][c] = sum_{s,tap} x[p+off(tap)][s] * W(c,s,tap) (+bias[c])      x NCHW [B][CS][H][W], y NHWC
+// wmode 0: W = w[c][s][tap] (intro forward);  wmode 1: W = w[s][c][8-tap] (ending dgrad)
+template <int CS>
+__global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                          int W, int Cb, int wmode) {
+    const EdgeMap m = edge_map(B, H, W, Cb);
+    const EdgeBlk k = edge_block(m, H, W, Cb);
+    float4 wv[CS * 9];
+#pragma unroll
+    for (int s = 0; s < CS; ++s)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float4 v = f4_zero();
+            if (k.qok) {
+                float* vp = &v.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * k.q + j;
+                    vp[j] = (wmode == 0) ? w[((int64_t)c * CS + s) * 9 + t] : w[((int64_t)s * Cb + c) * 9 + (8 - t)];
+                }
+            }
+            wv[s * 9 + t] = v;
+        }
+    const float4 bv = (bias && k.qok) ? ldg4(bias + 4 * k.q) : f4_zero();
+    const rsrc_t rs_x = make_rsrc(x + (int64_t)k.b * CS * H * W);
+    const rsrc_t rs_y = make_rsrc(y + (int64_t)k.b * H * W * Cb);
+    const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
+    float4 a0 = f4_zero(), a1 = f4_zero();
+    for (int r = k.y0 - 1; r <= k.y1; ++r) {
+        float4 a2 = f4_zero();
+        const bool rin = r >= 0 && r < H;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const uint32_t o = rin ? (uint32_t)((s * H + r) * W + k.x) * 4u : ROW_SENT;
+            const float vl = buf_ld1(rs_x, (o - 4u) | cl), vc = buf_ld1(rs_x, o | cc), vr = buf_ld1(rs_x, (o + 4u) | cr);
+            const float4 l4 = make_float4(vl, vl, vl, vl), c4 = make_float4(vc, vc, vc, vc), r4 = make_float4(vr, vr, vr, vr);
+            a0 = f4_fma(wv[s * 9 + 6], l4, f4_fma(wv[s * 9 + 7], c4, f4_fma(wv[s * 9 + 8], r4, a0)));   // ky = 2 -> row r-1
+            a1 = f4_fma(wv[s * 9 + 3], l4, f4_fma(wv[s * 9 + 4], c4, f4_fma(wv[s * 9 + 5], r4, a1)));   // ky = 1 -> row r
+            a2 = f4_fma(wv[s * 9 + 0], l4, f4_fma(wv[s * 9 + 1], c4, f4_fma(wv[s * 9 + 2], r4, a2)));   // ky = 0 -> row r+1
+        }
+        const int yo = r - 1;
+        buf_st4(rs_y, (k.ok && yo >= k.y0) ? ((uint32_t)(yo * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT, f4_add(a0, bv));
+        a0 = a1;
+        a1 = a2;
+    }
+}
+
+// big -> small:  y[p][s] = sum_{c,tap} x[p+off(tap)][c] * W(s,c,tap) (+bias[s]) (+res[p][s])     x NHWC, y/res NCHW [B][CS][H][W]
+// wmode 0: W = w[s][c][tap] (ending forward);  wmode 1: W = w[c][s][8-tap] (intro dgrad).  One wave holds all quads of a pixel.
 template <int CS>
 __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ res,
-                                                          float* __restrict__ y, int B, int H, int W, int Cb, int wmode, int G,
-                                                          int64_t iters) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [CS*9][Cb]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < CS * 9 * Cb; i += 256) {
-        const int st = i / Cb, c = i % Cb;
-        const int s = st / 9, tap = st % 9;
-        wl[i] = (wmode == 0) ? w[((int64_t)s * Cb + c) * 9 + tap] : w[((int64_t)c * CS + s) * 9 + (8 - tap)];
-    }
-    __syncthreads();
-    const int lig = tid % G, gid = tid / G, gpb = 256 / G;
-    const int nq = Cb / 4;
-    const int64_t npix = (int64_t)B * H * W;
-    float out_acc[CS];
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t pix = (it * gridDim.x + blockIdx.x) * gpb + gid;
-        const bool valid = pix < npix;
-        const int64_t pp = valid ? pix : 0;
-        const int xw = (int)(pp % W);
-        const int64_t t = pp / W;
-        const int yh = (int)(t % H);
-        const int64_t b = t / H;
+                                                          float* __restrict__ y, int B, int H, int W, int Cb, int wmode) {
+    const EdgeMap m = edge_map(B, H, W, Cb);
+    const EdgeBlk k = edge_block(m, H, W, Cb);
+    float4 wv[CS * 9];
 #pragma unroll
-        for (int s = 0; s < CS; ++s) out_acc[s] = 0.f;
-        for (int q = lig; q < nq; q += G) {
+    for (int s = 0; s < CS; ++s)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = yh - 1 + ky;
+        for (int t = 0; t < 9; ++t) {
+            float4 v = f4_zero();
+            if (k.qok) {
+                float* vp = &v.x;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = xw - 1 + kx;
-                    if (!valid || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                    const float4 v = ldg4(x + ((b * H + yy) * (int64_t)W + xx) * Cb + 4 * q);
-                    const int tap = ky * 3 + kx;
-#pragma unroll
-                    for (int s = 0; s < CS; ++s) {
-                        const float4 wv = *reinterpret_cast<const float4*>(&wl[(s * 9 + tap) * Cb + 4 * q]);
-                        out_acc[s] += f4_sum(f4_mul(v, wv));
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * k.q + j;
+                    vp[j] = (wmode == 0) ? w[((int64_t)s * Cb + c) * 9 + t] : w[((int64_t)c * CS + s) * 9 + (8 - t)];
                 }
             }
+            wv[s * 9 + t] = v;
+        }
+    const rsrc_t rs_x = make_rsrc(x + (int64_t)k.b * H * W * Cb);
+    const rsrc_t rs_y = make_rsrc(y + (int64_t)k.b * CS * H * W);
+    const rsrc_t rs_r = make_rsrc(res ? res + (int64_t)k.b * CS * H * W : y);
+    const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
+    const uint32_t st = 4u * (uint32_t)Cb;
+    const int ql = threadIdx.x % m.QB;
+    float a0[CS], a1[CS];
+#pragma unroll
+    for (int s = 0; s < CS; ++s) a0[s] = a1[s] = 0.f;
+    for (int r = k.y0 - 1; r <= k.y1; ++r) {
+        const uint32_t o = (r >= 0 && r < H) ? ((uint32_t)(r * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT;
+        const float4 xl = buf_ld4(rs_x, (o - st) | cl), xc = buf_ld4(rs_x, o | cc), xr = buf_ld4(rs_x, (o + st) | cr);
+        float a2[CS];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            a0[s] += f4_sum(f4_fma(wv[s * 9 + 6], xl, f4_fma(wv[s * 9 + 7], xc, f4_mul(wv[s * 9 + 8], xr))));
+            a1[s] += f4_sum(f4_fma(wv[s * 9 + 3], xl, f4_fma(wv[s * 9 + 4], xc, f4_mul(wv[s * 9 + 5], xr))));
+            a2[s] = f4_sum(f4_fma(wv[s * 9 + 0], xl, f4_fma(wv[s * 9 + 1], xc, f4_mul(wv[s * 9 + 2], xr))));
+        }
+        const int yo = r - 1;
+        float mine = 0.f;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const float t = group_sum(a0[s], m.QB);   // over the channel quads of this pixel (consecutive lanes)
+            if (ql == s) mine = t;
+        }
+        if (ql < CS) {
+            const uint32_t oo = (k.x < W && yo >= k.y0) ? (uint32_t)((ql * H + yo) * W + k.x) * 4u : ROW_SENT;
+            if (bias) mine += bias[ql];
+            if (res) mine += buf_ld1(rs_r, oo);
+            buf_st1(rs_y, oo, mine);
         }
 #pragma unroll
-        for (int s = 0; s < CS; ++s) out_acc[s] = group_sum(out_acc[s], G);
-        if (valid && lig < CS) {
-            float v = 0.f;
-#pragma unroll
-            for (int s = 0; s < CS; ++s)
-                if (s == lig) v = out_acc[s];
-            const int64_t o = ((b * CS + lig) * H + yh) * (int64_t)W + xw;
-            if (bias) v += bias[lig];
-            if (res) v += res[o];
-            y[o] = v;
+        for (int s = 0; s < CS; ++s) {
+            a0[s] = a1[s];
+            a1[s] = a2[s];
         }
     }
 }
 
 // Weight gradient partials: acc[s*9+tap] (float4 over 4 big channels) += big[p][4q..] * small[p+off][s]
-// thread = (pixel-slot, channel quad); block partials [nblk][Cs*9+1][Cb] (last row: column sum of big)
+// block partials [nblk][CS*9+1][Cb] (last row: column sum of big), nblk = conv3x3_wgrad_num_blocks()
 template <int CS>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ big, const float* __restrict__ small,
-                                                            float* __restrict__ part, int B, int H, int W, int Cb,
-                                                            int64_t iters) {
+                                                            float* __restrict__ part, int B, int H, int W, int Cb) {
     __shared__ float4 red[256];
-    const int nq = Cb / 4;
-    int qb = 1;
-    while (qb < nq && qb < 256) qb <<= 1;
-    const int pb = 256 / qb;
-    const int tid = threadIdx.x, ql = tid % qb, pl = tid / qb;
-    const int q = blockIdx.y * qb + ql;
-    const bool qok = q < nq;
-    const int64_t npix = (int64_t)B * H * W;
+    const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
+    const EdgeBlk k = edge_block(m, H, W, Cb);
+    const int tid = threadIdx.x, ql = tid % m.QB, pl = tid / m.QB;
     float4 acc[CS * 9 + 1];
 #pragma unroll
     for (int i = 0; i < CS * 9 + 1; ++i) acc[i] = f4_zero();
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t pix = (it * gridDim.x + blockIdx.x) * pb + pl;
-        if (!qok || pix >= npix) continue;
-        const int xw = (int)(pix % W);
-        const int64_t t = pix / W;
-        const int yh = (int)(t % H);
-        const int64_t b = t / H;
-        const float4 g = ldg4(big + pix * Cb + 4 * q);
-        acc[CS * 9] = f4_add(acc[CS * 9], g);
+    const rsrc_t rs_g = make_rsrc(big + (int64_t)k.b * H * W * Cb);
+    const rsrc_t rs_s = make_rsrc(small + (int64_t)k.b * CS * H * W);
+    const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
+    // small-side window: rows r-1, r, r+1 x columns x-1, x, x+1 per small channel, shifted down one row per step
+    float sm[CS][3][3];
+    auto load_row = [&](int r, int slot) {
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
-            const float* xs = small + ((b * CS + s) * H) * (int64_t)W;
+            const uint32_t o = (r >= 0 && r < H) ? (uint32_t)((s * H + r) * W + k.x) * 4u : ROW_SENT;
+            sm[s][slot][0] = buf_ld1(rs_s, (o - 4u) | cl);
+            sm[s][slot][1] = buf_ld1(rs_s, o | cc);
+            sm[s][slot][2] = buf_ld1(rs_s, (o + 4u) | cr);
+        }
+    };
+    load_row(k.y0 - 1, 0);
+    load_row(k.y0, 1);
+    for (int r = k.y0; r < k.y1; ++r) {
+        load_row(r + 1, 2);
+        const float4 g = buf_ld4(rs_g, k.ok ? ((uint32_t)(r * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT);
+        acc[CS * 9] = f4_add(acc[CS * 9], g);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = yh - 1 + ky;
+        for (int s = 0; s < CS; ++s)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = xw - 1 + kx;
-                    float v = 0.f;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = xs[(int64_t)yy * W + xx];
+                    const float v = sm[s][ky][kx];
                     acc[s * 9 + ky * 3 + kx] = f4_fma(g, make_float4(v, v, v, v), acc[s * 9 + ky * 3 + kx]);
                 }
+#pragma unroll
+        for (int s = 0; s < CS; ++s)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                sm[s][0][kx] = sm[s][1][kx];
+                sm[s][1][kx] = sm[s][2][kx];
             }
-        }
     }
-    float* pp = part + (int64_t)blockIdx.x * (CS * 9 + 1) * Cb;
+    const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * m.nwc + blockIdx.x / m.nqc;
+    float* pp = part + blk * (CS * 9 + 1) * Cb;
 #pragma unroll
     for (int i = 0; i < CS * 9 + 1; ++i) {
         __syncthreads();
         red[tid] = acc[i];
         __syncthreads();
-        if (pl == 0 && qok) {
+        if (pl == 0 && k.qok) {
             float4 s = red[ql];
-            for (int j = 1; j < pb; ++j) s = f4_add(s, red[j * qb + ql]);
-            stg4(pp + (int64_t)i * Cb + 4 * q, s);
+            for (int j = 1; j < m.PB; ++j) s = f4_add(s, red[j * m.QB + ql]);
+            stg4(pp + (int64_t)i * Cb + 4 * k.q, s);
         }
     }
 }
 
-// G[c][s][tap] = sum_r part[r][s*9+tap][c]; row Cs*9 is the column sum of big
+// G[c][s][tap] = sum_r part[r][s*9+tap][c]; row Cs*9 is the column sum of big.  block = 16 columns x 16 row groups (fixed order)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ part, int R, int Cs, int Cb,
                                                                    float* __restrict__ dW, float* __restrict__ bsum,
                                                                    int omode) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][16];
     const int j = blockIdx.y;  // 0 .. Cs*9
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const int nj = Cs * 9 + 1;
     float sacc = 0.f;
-    if (c < Cb)
-        for (int r = rg; r < R; r += 4) sacc += part[((int64_t)r * nj + j) * Cb + c];
+    if (c < Cb) {
+#pragma unroll 8
+        for (int r = rg; r < R; r += 16) sacc += part[((int64_t)r * nj + j) * Cb + c];
+    }
     red[rg][cl] = sacc;
     __syncthreads();
     if (rg == 0 && c < Cb) {
-        const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float v = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += red[i][cl];
         if (j == Cs * 9) {
             if (bsum) bsum[c] = v;
         } else {
@@ -244,70 +314,57 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float* __re
     }
 }
 
-inline int pow2_group(int nq) {
-    int g = 1;
-    while (g < nq && g < 64) g <<= 1;
-    return g;
-}
-
 }  // namespace
+
+#define EDGE_CHECK(name)                                                                                                     \
+    DCPT_CHECK_ARG(Cb % 4 == 0 && Cs >= 1 && Cs <= MAXCS && B <= 65535 && (double)H * W * (Cb > Cs ? Cb : Cs) * 4.0 < 1.0e9, \
+                   name ": Cs=%d (1..4), Cb=%d (%%4), image %dx%d", Cs, Cb, H, W)
+#define EDGE_GO(KERNEL, ...)                                                     \
+    do {                                                                         \
+        const EdgeMap m = edge_map(B, H, W, Cb);                                 \
+        const dim3 grid(m.nqc * m.nwc, m.strips, B);                             \
+        if (Cs == 1) KERNEL<1><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);          \
+        else if (Cs == 2) KERNEL<2><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);     \
+        else if (Cs == 3) KERNEL<3><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);     \
+        else KERNEL<4><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);                  \
+    } while (0)
 
 int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cs, int Cb,
                        int wmode, hipStream_t s) {
-    DCPT_CHECK_ARG(Cb % 4 == 0 && Cs >= 1 && Cs * 9 * Cb * 4 <= 65536, "conv3x3_s2b: Cs=%d Cb=%d unsupported", Cs, Cb);
-    const int64_t n = (int64_t)B * H * W * (Cb / 4);
-    conv3x3_s2b_kernel<<<dim3((unsigned)cdiv64(n, 256)), dim3(256), Cs * 9 * Cb * sizeof(float), s>>>(x, w, bias, y, B, H, W,
-                                                                                                       Cs, Cb, wmode);
+    EDGE_CHECK("conv3x3_s2b");
+    EDGE_GO(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_s2b");
     return DCPT_OK;
 }
 
 int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W,
                        int Cs, int Cb, int wmode, hipStream_t s) {
-    DCPT_CHECK_ARG(Cb % 4 == 0 && Cs >= 1 && Cs <= MAXCS && Cs * 9 * Cb * 4 <= 65536, "conv3x3_b2s: Cs=%d (<=4) Cb=%d (%%4)", Cs, Cb);
-    const int G = pow2_group(Cb / 4) < MAXCS ? MAXCS : pow2_group(Cb / 4);
-    const int gpb = 256 / G;
-    const int64_t npix = (int64_t)B * H * W;
-    int64_t nblk = cdiv64(npix, gpb);
-    if (nblk > 8192) nblk = 8192;
-    const int64_t iters = cdiv64(npix, nblk * gpb);
-#define GO(CS) conv3x3_b2s_kernel<CS><<<dim3((unsigned)nblk), dim3(256), CS * 9 * Cb * sizeof(float), s>>>(x, w, bias, res, y, B, H, W, Cb, wmode, G, iters)
-    if (Cs == 1) GO(1);
-    else if (Cs == 2) GO(2);
-    else if (Cs == 3) GO(3);
-    else GO(4);
-#undef GO
+    EDGE_CHECK("conv3x3_b2s");
+    DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
+    EDGE_GO(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_b2s");
     return DCPT_OK;
 }
 
 int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb) {
-    const int nq = Cb / 4;
-    int qb = 1;
-    while (qb < nq && qb < 256) qb <<= 1;
-    const int pb = 256 / qb;
-    int64_t nblk = cdiv64((int64_t)B * H * W, (int64_t)pb * 64);
-    if (nblk > 1024) nblk = 1024;
-    if (nblk < 1) nblk = 1;
-    return (int)nblk;
+    const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
+    return B * m.strips * m.nwc;
 }
 
 int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H,
                          int W, int Cs, int Cb, int omode, hipStream_t s) {
-    DCPT_CHECK_ARG(Cb % 4 == 0 && Cs >= 1 && Cs <= MAXCS, "conv3x3_wgrad: Cs=%d (<=4) Cb=%d (%%4)", Cs, Cb);
-    const int nq = Cb / 4;
-    int qb = 1;
-    while (qb < nq && qb < 256) qb <<= 1;
-    const int pb = 256 / qb;
-    const int64_t iters = cdiv64((int64_t)B * H * W, (int64_t)nblk * pb);
-#define GO(CS) conv3x3_wgrad_kernel<CS><<<dim3(nblk, cdiv(nq, qb)), dim3(256), 0, s>>>(big, small, part, B, H, W, Cb, iters)
-    if (Cs == 1) GO(1);
-    else if (Cs == 2) GO(2);
-    else if (Cs == 3) GO(3);
-    else GO(4);
-#undef GO
+    EDGE_CHECK("conv3x3_wgrad");
+    DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad: nblk mismatch");
+    {
+        const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
+        const dim3 grid(m.nqc * m.nwc, m.strips, B);
+        if (Cs == 1) conv3x3_wgrad_kernel<1><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+        else if (Cs == 2) conv3x3_wgrad_kernel<2><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+        else if (Cs == 3) conv3x3_wgrad_kernel<3><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+        else conv3x3_wgrad_kernel<4><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+    }
     DCPT_CHECK_LAUNCH("conv3x3_wgrad");
-    conv3x3_wgrad_reduce_kernel<<<dim3(cdiv(Cb, 64), Cs * 9 + 1), dim3(256), 0, s>>>(part, nblk, Cs, Cb, dW, bsum, omode);
+    conv3x3_wgrad_reduce_kernel<<<dim3(cdiv(Cb, 16), Cs * 9 + 1), dim3(256), 0, s>>>(part, nblk, Cs, Cb, dW, bsum, omode);
     DCPT_CHECK_LAUNCH("conv3x3_wgrad_reduce");
     return DCPT_OK;
 }

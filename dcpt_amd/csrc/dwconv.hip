@@ -361,8 +361,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __res
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    if (c < C2)
+    if (c < C2) {
+#pragma unroll 8
         for (int r = rg; r < R; r += 8) s += wpart[((int64_t)r * 10 + t) * C2 + c];
+    }
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < C2) {

@@ -183,8 +183,10 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int r = rg; r < R; r += 16) s += part[((int64_t)r * nj + j) * C + c];
+    }
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < C) {
