@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ 
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int k = tid; k < C; k += 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int j = 0; j < nblk; ++j) s += pool_part[((int64_t)b * nblk + j) * C + k];
         s *= invP;
         pl[k] = s;
@@ -71,6 +72,7 @@ __global__ void sca_ds_final_kernel(const float* __restrict__ part, float* __res
     if (i >= BC) return;
     const int b = i / C, k = i % C;
     float s = 0.f;
+#pragma unroll 8
     for (int j = 0; j < nslices; ++j) s += part[((int64_t)b * nslices + j) * C + k];
     ds[i] = s;
 }
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void sca_dpool_kernel(const float* __restrict_
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int n = tid; n < C; n += 256) {
         float v = 0.f;
+#pragma unroll 8
         for (int j = 0; j < nslices; ++j) v += part[((int64_t)b * nslices + j) * C + n];
         dsl[n] = v;
     }
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void sca_bwd_w_kernel(const float* __restrict_
         if (i >= (int64_t)C * C) return;
         const int n = (int)(i / C), k = (int)(i % C);
         float s = 0.f;
+#pragma unroll 8
         for (int b = 0; b < B; ++b) s = fmaf(ds[(int64_t)b * C + n], pooled[(int64_t)b * C + k], s);
         dWsca[i] = s;
     } else {
