@@ -41,9 +41,9 @@ class NafBlockSaved(C.Structure):
 
 
 MDTA_PARAM_FIELDS = ("norm_w", "norm_b", "qkv_w", "dw_w", "proj_w", "temperature")
-MDTA_SAVED_FIELDS = ("mu", "rstd", "qkv1", "qkv", "nrm", "ghat", "attn", "attnT", "out_att")
+MDTA_SAVED_FIELDS = ("mu", "rstd", "qkv1", "qkv", "nrm", "ghat", "attn", "attnT", "out_att", "xn")
 GDFN_PARAM_FIELDS = ("norm_w", "norm_b", "in_w", "dw_w", "out_w")
-GDFN_SAVED_FIELDS = ("mu", "rstd", "u", "t")
+GDFN_SAVED_FIELDS = ("mu", "rstd", "u", "t", "xn")
 
 
 class MdtaParams(C.Structure):

@@ -47,12 +47,17 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     if (y != nullptr && valid) {
         float* yr = y + row * (int64_t)C;
         for (int q = lig; q < nq; q += G) {
-            const float4 v = ldg4(xr + 4 * q), ww = ldg4(w + 4 * q), bb = ldg4(b + 4 * q);
+            const float4 v = ldg4(xr + 4 * q), ww = ldg4(w + 4 * q);
             float4 o;
-            o.x = fmaf((v.x - mean) * rs, ww.x, bb.x);
-            o.y = fmaf((v.y - mean) * rs, ww.y, bb.y);
-            o.z = fmaf((v.z - mean) * rs, ww.z, bb.z);
-            o.w = fmaf((v.w - mean) * rs, ww.w, bb.w);
+            if (b != nullptr) {
+                const float4 bb = ldg4(b + 4 * q);
+                o.x = fmaf((v.x - mean) * rs, ww.x, bb.x);
+                o.y = fmaf((v.y - mean) * rs, ww.y, bb.y);
+                o.z = fmaf((v.z - mean) * rs, ww.z, bb.z);
+                o.w = fmaf((v.w - mean) * rs, ww.w, bb.w);
+            } else {  // Restormer BiasFree_LayerNorm (restormer_arch.py:36-40): x / sqrt(var + eps) * w, numerator not centred
+                o = make_float4(v.x * rs * ww.x, v.y * rs * ww.y, v.z * rs * ww.z, v.w * rs * ww.w);
+            }
             if (res) o = f4_add(o, ldg4(res + row * (int64_t)C + 4 * q));
             if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             stg4(yr + 4 * q, o);

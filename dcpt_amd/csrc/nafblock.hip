@@ -15,13 +15,9 @@
 // (the un-scaled weight gradient) one has  dW = gain[n]*G,  dgain[n] = sum_k W[n][k]*G[n][k] +
 // b[n]*sum_m dO[m][n],  db = gain[n]*sum_m dO[m][n]   (gain = beta or gamma), which also stays exact
 // for the reference's zero-initialised beta/gamma.
-#include <stdlib.h>
-
-#include <map>
-#include <mutex>
-
 #include "gemm.h"
 #include "kernels.h"
+#include "side.h"
 #include "../../include/dcpt_hip.h"
 
 namespace {
@@ -109,79 +105,7 @@ int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yl
     return DCPT_OK;
 }
 
-// Weight-gradient side stream.  In the backward pass the four wgrad GEMMs (+ their slab reductions) and the small
-// parameter-gradient reductions of LayerNorm / depthwise conv are off the
-// critical path dout -> dinp: they run on a second, low-priority HIP stream, forked/joined with events inside one
-// dcpt_nafblock_bwd call, so that the HBM-bound kernels of the main chain (LayerNorm / depthwise / SCA backward) and the
-// launch ramps and tails of its GEMMs overlap MFMA-bound wgrad work instead of leaving the matrix cores idle.
-// DCPT_SIDE_STREAM=0 in the environment keeps everything on the caller's stream.
-struct Side {
-    hipStream_t ss = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-};
-std::mutex g_side_mu;
-std::map<hipStream_t, Side*> g_sides;
-int g_side_enabled = -1;
-
-void side_init_locked() {
-    if (g_side_enabled < 0) {
-        const char* e = getenv("DCPT_SIDE_STREAM");
-        g_side_enabled = (e && e[0] == '0') ? 0 : 1;
-    }
-}
-
-Side* side_for(hipStream_t main) {
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    side_init_locked();
-    if (!g_side_enabled) return nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;   // keep graph captures single-stream
-    }
-    auto it = g_sides.find(main);
-    if (it != g_sides.end()) return it->second;
-    Side* sd = new Side();
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    bool ok = hipStreamCreateWithPriority(&sd->ss, hipStreamNonBlocking, least) == hipSuccess;
-    for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&sd->ev[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError();
-        delete sd;
-        sd = nullptr;
-    }
-    g_sides[main] = sd;
-    return sd;
-}
-
-// main-stream work up to here is visible to the side stream's next launches
-int side_fork(Side* sd, int i, hipStream_t main) {
-    if (!sd) return DCPT_OK;
-    if (hipEventRecord(sd->ev[i], main) != hipSuccess || hipStreamWaitEvent(sd->ss, sd->ev[i], 0) != hipSuccess) {
-        dcpt_set_error("nafblock_bwd: side-stream fork failed: %s", hipGetErrorString(hipGetLastError()));
-        return DCPT_ERR_HIP;
-    }
-    return DCPT_OK;
-}
-int side_join(Side* sd, int i, hipStream_t main) {
-    if (!sd) return DCPT_OK;
-    if (hipEventRecord(sd->ev[i], sd->ss) != hipSuccess || hipStreamWaitEvent(main, sd->ev[i], 0) != hipSuccess) {
-        dcpt_set_error("nafblock_bwd: side-stream join failed: %s", hipGetErrorString(hipGetLastError()));
-        return DCPT_ERR_HIP;
-    }
-    return DCPT_OK;
-}
-
 }  // namespace
-
-extern "C" int dcpt_set_side_stream(int on) {
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    side_init_locked();
-    const int prev = g_side_enabled;
-    g_side_enabled = on ? 1 : 0;
-    return prev;
-}
 
 extern "C" size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C) { return fwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
 extern "C" size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C) { return bwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
@@ -270,7 +194,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     float* da = w.b2c;
     float* dt1 = w.b2b;
     Side* sd = side_for(s);
-    hipStream_t sw = sd ? sd->ss : s;   // stream of the weight-gradient GEMMs
+    hipStream_t sw = side_stream(sd, s);   // stream of the weight-gradient GEMMs
     DCPT_TRY(side_fork(sd, 0, s));      // dout / saved activations / packed weights are ready
 
     GemmNT g{};
@@ -325,7 +249,7 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 5, s));      // LN1 partial sums
     DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
-    DCPT_TRY(side_join(sd, 4, s));      // the caller's stream continues only after every weight gradient is written
+    DCPT_TRY(side_join(sd, s));      // the caller's stream continues only after every weight gradient is written
     return DCPT_OK;
 }
 

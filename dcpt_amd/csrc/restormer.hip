@@ -12,6 +12,7 @@
 // The L2 norms over the pixels come for free as per-block partial sums of squares from the depthwise kernel.
 #include "gemm.h"
 #include "kernels.h"
+#include "side.h"
 #include "../../include/dcpt_hip.h"
 
 namespace {
@@ -222,6 +223,7 @@ struct MdtaWs {
     float *dqkv, *dqkv1;              // [M][3c]
     float *dxn;                       // [M][c]
     float *dG, *dGT, *scr;            // [B*heads][ch][ch]
+    float *scr2;                      // [3c] sink of the (non-existent) depthwise bias gradient
     float *cqk;                       // [B][2c]
     float *dtpart;                    // [B*heads]
     float *slab;                      // weight-gradient slabs
@@ -251,6 +253,7 @@ size_t mdta_layout(int B, int H, int W, int c, int heads, int backward, void* ba
         w.dG = a.get<float>((size_t)B * heads * ch * ch);
         w.dGT = a.get<float>((size_t)B * heads * ch * ch);
         w.scr = a.get<float>((size_t)B * heads * ch * ch);
+        w.scr2 = a.get<float>((size_t)3 * c);
         w.cqk = a.get<float>((size_t)B * 2 * c);
         w.dtpart = a.get<float>((size_t)B * heads);
         int sp1, sp2;
@@ -341,11 +344,13 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
     }
     const int64_t M = (int64_t)B * H * W;
     const int P = H * W, ch = C / heads, C3 = 3 * C;
-    DCPT_TRY(launch_ln_stats(x, sv->mu, sv->rstd, M, C, 1e-6f, s));  // restormer_arch.py:40,59
+    DCPT_CHECK_ARG(sv->xn != nullptr, "mdta_fwd: saved.xn missing");
+    // the normalised activations are materialised once (restormer_arch.py:40,59); the qkv conv and, in backward, its weight
+    // gradient then take them as plain operands (global -> LDS by DMA)
+    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, 1e-6f, s));
     GemmNT g{};
-    g.M = M; g.A = x; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = sv->qkv1; g.ldc = C3;
-    g.mu = sv->mu; g.rstd = sv->rstd; g.lnw = p->norm_w; g.lnb = p->norm_b;
-    DCPT_TRY(launch_gemm_nt(g, biasfree ? A_LNBF : A_LN, E_PLAIN, s));
+    g.M = M; g.A = sv->xn; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = sv->qkv1; g.ldc = C3;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     DCPT_TRY(launch_dw_pack_weights(p->dw_w, w.w2p, C3, s));
     DCPT_TRY(launch_dw_plain_fwd(sv->qkv1, w.w2p, sv->qkv, w.sqpart, 2 * C, B, H, W, C3, s));
     sq_norm_kernel<<<dim3(cdiv(B * 2 * C, 256)), dim3(256), 0, s>>>(w.sqpart, w.nblk_dw, sv->nrm, B, 2 * C);
@@ -386,14 +391,18 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     }
     const int64_t M = (int64_t)B * H * W;
     const int P = H * W, ch = C / heads, C3 = 3 * C;
-    const int yl = biasfree ? A_LNBF : A_LN;
     GemmNT g{};
     GemmTN tp{};
+    // (the weight-gradient side stream of side.hip measured 1.7 % SLOWER on Restormer -- its depthwise kernels lose more to
+    // the co-running GEMMs than the GEMMs gain -- so these blocks keep everything on the caller's stream)
+    Side* sd = nullptr;
+    hipStream_t sw = side_stream(sd, s);
+    DCPT_TRY(side_fork(sd, 0, s));          // dy and the saved activations are ready
     // B1: d_att = dy * Wproj ; dWproj = dy^T out_att
     DCPT_TRY(launch_wpack(p->proj_w, w.wT_proj, nullptr, C, C, WP_TRANSPOSE, s));
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT_proj; g.N = C; g.C = w.d_att; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(tn_reduce(dy, C, C, sv->out_att, C, C, A_PLAIN, tp, M, w.slab, gr->proj_w, s));
+    DCPT_TRY(tn_reduce(dy, C, C, sv->out_att, C, C, A_PLAIN, tp, M, w.slab, gr->proj_w, sw));
     // B2: dattn[i][j] = sum_p d_att[p][i] v[p][j]   (batched TN)
     GemmTN t{};
     t.M = P; t.X = w.d_att; t.ldx = C; t.N = ch; t.Y = sv->qkv + 2 * C; t.ldy = C3; t.K = ch;
@@ -425,18 +434,20 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     // B5: depthwise backward
     DCPT_TRY(launch_dw_pack_weights(p->dw_w, w.w2p, C3, s));
     DCPT_TRY(launch_dw_generic_bwd(w.dqkv, sv->qkv1, w.w2p, w.dqkv1, w.wpart, B, H, W, C3, s));
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, C3, gr->dw_w, w.scr /*unused bias grad*/, s));
+    DCPT_TRY(side_fork(sd, 1, s));          // dqkv1, depthwise partial sums
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, C3, gr->dw_w, w.scr2 /*unused bias grad*/, sw));
     // B6: qkv 1x1
     DCPT_TRY(launch_wpack(p->qkv_w, w.wT_qkv, nullptr, C3, C, WP_TRANSPOSE, s));
     g = GemmNT{};
     g.M = M; g.A = w.dqkv1; g.lda = C3; g.K = C3; g.Bw = w.wT_qkv; g.N = C; g.C = w.dxn; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     tp = GemmTN{};
-    tp.mu = sv->mu; tp.rstd = sv->rstd; tp.lnw = p->norm_w; tp.lnb = p->norm_b;
-    DCPT_TRY(tn_reduce(w.dqkv1, C3, C3, x, C, C, yl, tp, M, w.slab, gr->qkv_w, s));
+    DCPT_TRY(tn_reduce(w.dqkv1, C3, C3, sv->xn, C, C, A_PLAIN, tp, M, w.slab, gr->qkv_w, sw));
     // B7: dx = dy + LN-backward
     DCPT_TRY(launch_ln_bwd_ex(w.dxn, x, sv->mu, sv->rstd, p->norm_w, dy, nullptr, nullptr, biasfree, dx, w.lnpart, w.ln_nblk, M, C, s));
-    return launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm_w, biasfree ? nullptr : gr->norm_b, nullptr, s);
+    DCPT_TRY(side_fork(sd, 2, s));          // LayerNorm partial sums
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm_w, biasfree ? nullptr : gr->norm_b, nullptr, sw));
+    return side_join(sd, s);                // the caller's stream continues only after every weight gradient is written
 }
 
 // =====================================================================================================
@@ -460,11 +471,11 @@ extern "C" int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)18 * hp)), dim3(256), 0, s>>>(p->dw_w, w.w2p, C, hidden, hp, 1);
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)C * hp)), dim3(256), 0, s>>>(p->out_w, w.wp_out, C, hidden, hp, 2);
     DCPT_CHECK_LAUNCH("gdfn_pack");
-    DCPT_TRY(launch_ln_stats(x, sv->mu, sv->rstd, M, C, 1e-6f, s));
+    DCPT_CHECK_ARG(sv->xn != nullptr, "gdfn_fwd: saved.xn missing");
+    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, 1e-6f, s));
     GemmNT g{};
-    g.M = M; g.A = x; g.lda = C; g.K = C; g.Bw = w.wp_in; g.N = 2 * hp; g.C = sv->u; g.ldc = 2 * hp;
-    g.mu = sv->mu; g.rstd = sv->rstd; g.lnw = p->norm_w; g.lnb = p->norm_b;
-    DCPT_TRY(launch_gemm_nt(g, biasfree ? A_LNBF : A_LN, E_PLAIN, s));
+    g.M = M; g.A = sv->xn; g.lda = C; g.K = C; g.Bw = w.wp_in; g.N = 2 * hp; g.C = sv->u; g.ldc = 2 * hp;
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, sv->t, B, H, W, hp, s));
     g = GemmNT{};
     g.M = M; g.A = sv->t; g.lda = hp; g.K = hp; g.Bw = w.wp_out; g.N = C; g.C = y; g.ldc = C; g.res = x;
@@ -484,7 +495,6 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
         return DCPT_ERR_WS;
     }
     const int64_t M = (int64_t)B * H * W;
-    const int yl = biasfree ? A_LNBF : A_LN;
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)18 * hp)), dim3(256), 0, s>>>(p->dw_w, w.w2p, C, hidden, hp, 1);
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)hp * C)), dim3(256), 0, s>>>(p->out_w, w.wT_out, C, hidden, hp, 3);
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)C * 2 * hp)), dim3(256), 0, s>>>(p->in_w, w.wT_in, C, hidden, hp, 4);
@@ -493,29 +503,34 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
     float* g_out = w.gpad + (size_t)2 * hp * (C > 9 ? C : 9);  // [c][hp]
     GemmNT g{};
     GemmTN tp{};
+    Side* sd = nullptr;                     // see dcpt_mdta_bwd: no side stream for the Restormer blocks
+    hipStream_t sw = side_stream(sd, s);
+    DCPT_TRY(side_fork(sd, 0, s));          // dy and the saved activations are ready
     // dt = dy * Wout ; dWout = dy^T t
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT_out; g.N = hp; g.C = w.dt; g.ldc = hp;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(tn_reduce(dy, C, C, sv->t, hp, hp, A_PLAIN, tp, M, w.slab, g_out, s));
-    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, s>>>(g_out, gr->out_w, C, hidden, hp, 2);
+    DCPT_TRY(tn_reduce(dy, C, C, sv->t, hp, hp, A_PLAIN, tp, M, w.slab, g_out, sw));
+    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, sw>>>(g_out, gr->out_w, C, hidden, hp, 2);
     DCPT_CHECK_LAUNCH("gdfn_unpack_out");
     // gate backward, depthwise backward
     DCPT_TRY(launch_dw_gelu_bwd_a(w.dt, sv->u, w.w2p, w.da, B, H, W, hp, s));
     DCPT_TRY(launch_dw_generic_bwd(w.da, sv->u, w.w2p, w.du, w.wpart, B, H, W, 2 * hp, s));
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, 2 * hp, g_in, w.dt /*unused bias grad, dt is dead*/, s));
-    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)2 * hidden * 9)), dim3(256), 0, s>>>(g_in, gr->dw_w, C, hidden, hp, 1);
+    DCPT_TRY(side_fork(sd, 1, s));          // du, depthwise partial sums (dt is dead from here on)
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, 2 * hp, g_in, w.dt /*unused bias grad*/, sw));
+    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)2 * hidden * 9)), dim3(256), 0, sw>>>(g_in, gr->dw_w, C, hidden, hp, 1);
     DCPT_CHECK_LAUNCH("gdfn_unpack_dw");
     // project_in
     g = GemmNT{};
     g.M = M; g.A = w.du; g.lda = 2 * hp; g.K = 2 * hp; g.Bw = w.wT_in; g.N = C; g.C = w.dxn; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     tp = GemmTN{};
-    tp.mu = sv->mu; tp.rstd = sv->rstd; tp.lnw = p->norm_w; tp.lnb = p->norm_b;
-    DCPT_TRY(tn_reduce(w.du, 2 * hp, 2 * hp, x, C, C, yl, tp, M, w.slab, g_in, s));
-    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)2 * hidden * C)), dim3(256), 0, s>>>(g_in, gr->in_w, C, hidden, hp, 0);
+    DCPT_TRY(tn_reduce(w.du, 2 * hp, 2 * hp, sv->xn, C, C, A_PLAIN, tp, M, w.slab, g_in, sw));
+    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)2 * hidden * C)), dim3(256), 0, sw>>>(g_in, gr->in_w, C, hidden, hp, 0);
     DCPT_CHECK_LAUNCH("gdfn_unpack_in");
     DCPT_TRY(launch_ln_bwd_ex(w.dxn, x, sv->mu, sv->rstd, p->norm_w, dy, nullptr, nullptr, biasfree, dx, w.lnpart, w.ln_nblk, M, C, s));
-    return launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm_w, biasfree ? nullptr : gr->norm_b, nullptr, s);
+    DCPT_TRY(side_fork(sd, 2, s));          // LayerNorm partial sums
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm_w, biasfree ? nullptr : gr->norm_b, nullptr, sw));
+    return side_join(sd, s);                // the caller's stream continues only after every weight gradient is written
 }
 
 // =====================================================================================================

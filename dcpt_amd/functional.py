@@ -721,13 +721,14 @@ class _MDTAFn(torch.autograd.Function):
         nrm = torch.empty((B, 2 * Cc), dtype=torch.float32, device=dev)
         att = torch.empty((3, B, heads, ch, ch), dtype=torch.float32, device=dev)
         out_att = _empty_nhwc(B, Cc, H, W, dev)
+        xn = _empty_nhwc(B, Cc, H, W, dev)
         sv = MdtaSaved(stats[0].data_ptr(), stats[1].data_ptr(), qkv1.data_ptr(), qkv.data_ptr(), nrm.data_ptr(),
-                       att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), out_att.data_ptr())
+                       att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), out_att.data_ptr(), xn.data_ptr())
         pp = MdtaParams(*[_p(t) for t in ps])
         ws = _workspace(dev, lib.dcpt_mdta_ws_bytes(B, H, W, Cc, heads, 0))
         check(lib.dcpt_mdta_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
                                 heads, int(biasfree), _stream(dev)), "dcpt_mdta_fwd")
-        ctx.save_for_backward(x, stats, qkv1, qkv, nrm, att, out_att, *[t for t in ps if t is not None])
+        ctx.save_for_backward(x, stats, qkv1, qkv, nrm, att, out_att, xn, *[t for t in ps if t is not None])
         ctx.has_bias = ps[1] is not None
         ctx.heads, ctx.biasfree = heads, bool(biasfree)
         return y
@@ -735,7 +736,7 @@ class _MDTAFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, stats, qkv1, qkv, nrm, att, out_att, *ps = ctx.saved_tensors
+        x, stats, qkv1, qkv, nrm, att, out_att, xn, *ps = ctx.saved_tensors
         if ctx.has_bias:
             norm_w, norm_b, qkv_w, dw_w, proj_w, temp = ps
         else:
@@ -748,7 +749,7 @@ class _MDTAFn(torch.autograd.Function):
         plist = [norm_w, norm_b, qkv_w, dw_w, proj_w, temp]
         grads = [None if t is None else torch.empty_like(t) for t in plist]
         sv = MdtaSaved(stats[0].data_ptr(), stats[1].data_ptr(), qkv1.data_ptr(), qkv.data_ptr(), nrm.data_ptr(),
-                       att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), out_att.data_ptr())
+                       att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), out_att.data_ptr(), xn.data_ptr())
         pp = MdtaParams(*[_p(t) for t in plist])
         gg = MdtaParams(*[_p(t) for t in grads])
         ws = _workspace(dev, lib.dcpt_mdta_ws_bytes(B, H, W, Cc, ctx.heads, 1))
@@ -779,19 +780,20 @@ class _GDFNFn(torch.autograd.Function):
         stats = torch.empty((2, M), dtype=torch.float32, device=dev)
         u = _empty_nhwc(B, 2 * hp, H, W, dev)
         t = _empty_nhwc(B, hp, H, W, dev)
-        sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), t.data_ptr())
+        xn = _empty_nhwc(B, Cc, H, W, dev)
+        sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), t.data_ptr(), xn.data_ptr())
         pp = GdfnParams(*[_p(q) for q in ps])
         ws = _workspace(dev, lib.dcpt_gdfn_ws_bytes(B, H, W, Cc, hidden, 0))
         check(lib.dcpt_gdfn_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
                                 hidden, int(biasfree), _stream(dev)), "dcpt_gdfn_fwd")
-        ctx.save_for_backward(x, stats, u, t, *[q for q in ps if q is not None])
+        ctx.save_for_backward(x, stats, u, t, xn, *[q for q in ps if q is not None])
         ctx.has_bias, ctx.biasfree, ctx.hidden = ps[1] is not None, bool(biasfree), hidden
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, stats, u, t, *ps = ctx.saved_tensors
+        x, stats, u, t, xn, *ps = ctx.saved_tensors
         if ctx.has_bias:
             norm_w, norm_b, in_w, dw_w, out_w = ps
         else:
@@ -803,7 +805,7 @@ class _GDFNFn(torch.autograd.Function):
         dx = _empty_nhwc(B, Cc, H, W, dev)
         plist = [norm_w, norm_b, in_w, dw_w, out_w]
         grads = [None if q is None else torch.empty_like(q) for q in plist]
-        sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), t.data_ptr())
+        sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), t.data_ptr(), xn.data_ptr())
         pp = GdfnParams(*[_p(q) for q in plist])
         gg = GdfnParams(*[_p(q) for q in grads])
         ws = _workspace(dev, lib.dcpt_gdfn_ws_bytes(B, H, W, Cc, ctx.hidden, 1))
