@@ -358,7 +358,10 @@ template <int AK, int EK>
 int launch_cfg(const GemmNT& p, hipStream_t s) {
     const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     constexpr bool GATE = (EK == E_BIASGATE);
-    if (p.N <= 64) {
+    // 128 x 64 tiles when N is narrow, and also when 128 x 128 tiles would leave CUs with fewer than their two resident
+    // blocks (small pixel counts, e.g. 128^2 training crops at the deepest level): twice the blocks, both SIMD wave slots busy
+    const int64_t tiles128 = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
+    if (p.N <= 64 || tiles128 * nbatch <= 256) {
         constexpr int BM = 128, BN = 64;
         const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
         gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
