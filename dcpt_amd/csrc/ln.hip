@@ -14,6 +14,9 @@ __host__ __device__ inline int ln_group(int C) {
     return g;
 }
 
+// NQ = float4 quads per lane (C <= 16 * G * NQ / 4): the row is loaded ONCE into registers and reused by the mean pass, the
+// centred-variance pass and the normalisation.
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ mu,
                                                        float* __restrict__ rstd, int64_t M, int C, float eps, int G,
                                                        const float* __restrict__ w, const float* __restrict__ b,
@@ -25,18 +28,25 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     const bool valid = row < M;
     const int nq = C / 4;
     const float* xr = x + (valid ? row : 0) * (int64_t)C;
+    float4 v[NQ];
     float sum = 0.f;
-    if (valid)
-        for (int q = lig; q < nq; q += G) sum += f4_sum(ldg4(xr + 4 * q));
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = lig + i * G;
+        v[i] = (valid && q < nq) ? ldg4(xr + 4 * q) : f4_zero();
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) sum += f4_sum(v[i]);
     sum = group_sum(sum, G);
     const float mean = sum / (float)C;
     float sq = 0.f;
-    if (valid)
-        for (int q = lig; q < nq; q += G) {
-            const float4 v = ldg4(xr + 4 * q);
-            const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        if (lig + i * G < nq) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
             sq += (a * a + bb * bb) + (c * c + d * d);
         }
+    }
     sq = group_sum(sq, G);
     const float var = sq / (float)C;
     const float rs = 1.0f / sqrtf(var + eps);
@@ -46,17 +56,20 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     }
     if (y != nullptr && valid) {
         float* yr = y + row * (int64_t)C;
-        for (int q = lig; q < nq; q += G) {
-            const float4 v = ldg4(xr + 4 * q), ww = ldg4(w + 4 * q);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            if (q >= nq) continue;
+            const float4 ww = ldg4(w + 4 * q);
             float4 o;
             if (b != nullptr) {
                 const float4 bb = ldg4(b + 4 * q);
-                o.x = fmaf((v.x - mean) * rs, ww.x, bb.x);
-                o.y = fmaf((v.y - mean) * rs, ww.y, bb.y);
-                o.z = fmaf((v.z - mean) * rs, ww.z, bb.z);
-                o.w = fmaf((v.w - mean) * rs, ww.w, bb.w);
+                o.x = fmaf((v[i].x - mean) * rs, ww.x, bb.x);
+                o.y = fmaf((v[i].y - mean) * rs, ww.y, bb.y);
+                o.z = fmaf((v[i].z - mean) * rs, ww.z, bb.z);
+                o.w = fmaf((v[i].w - mean) * rs, ww.w, bb.w);
             } else {  // Restormer BiasFree_LayerNorm (restormer_arch.py:36-40): x / sqrt(var + eps) * w, numerator not centred
-                o = make_float4(v.x * rs * ww.x, v.y * rs * ww.y, v.z * rs * ww.z, v.w * rs * ww.w);
+                o = make_float4(v[i].x * rs * ww.x, v[i].y * rs * ww.y, v[i].z * rs * ww.z, v[i].w * rs * ww.w);
             }
             if (res) o = f4_add(o, ldg4(res + row * (int64_t)C + 4 * q));
             if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
@@ -204,21 +217,30 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
 
 }  // namespace
 
+static int launch_ln_rows(const float* x, float* mu, float* rstd, int64_t M, int C, float eps, const float* w, const float* b,
+                          float* y, const float* res, int relu, hipStream_t s) {
+    DCPT_CHECK_ARG(C <= 2048, "LayerNorm: C=%d > 2048", C);
+    const int G = ln_group(C), gpb = 256 / G;
+    const int nqpl = cdiv(C / 4, G);
+    const dim3 grid((unsigned)cdiv64(M, gpb));
+    if (nqpl <= 1) ln_stats_kernel<1><<<grid, dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y, res, relu);
+    else if (nqpl <= 2) ln_stats_kernel<2><<<grid, dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y, res, relu);
+    else if (nqpl <= 4) ln_stats_kernel<4><<<grid, dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y, res, relu);
+    else ln_stats_kernel<8><<<grid, dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y, res, relu);
+    DCPT_CHECK_LAUNCH("ln_rows");
+    return DCPT_OK;
+}
+
 int launch_ln_stats(const float* x, float* mu, float* rstd, int64_t M, int C, float eps, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && M > 0, "ln_stats: C=%d must be a positive multiple of 4", C);
-    const int G = ln_group(C), gpb = 256 / G;
-    ln_stats_kernel<<<dim3((unsigned)cdiv64(M, gpb)), dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, nullptr, nullptr, nullptr,
-                                                                          nullptr, 0);
-    DCPT_CHECK_LAUNCH("ln_stats");
+    DCPT_TRY(launch_ln_rows(x, mu, rstd, M, C, eps, nullptr, nullptr, nullptr, nullptr, 0, s));
     return DCPT_OK;
 }
 
 int launch_ln_act_fwd(const float* x, const float* w, const float* b, const float* res, int relu, float* y, float* mu,
                       float* rstd, int64_t M, int C, float eps, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && C > 0 && M > 0, "ln_fwd: C=%d must be a positive multiple of 4", C);
-    const int G = ln_group(C), gpb = 256 / G;
-    ln_stats_kernel<<<dim3((unsigned)cdiv64(M, gpb)), dim3(256), 0, s>>>(x, mu, rstd, M, C, eps, G, w, b, y, res, relu);
-    DCPT_CHECK_LAUNCH("ln_fwd");
+    DCPT_TRY(launch_ln_rows(x, mu, rstd, M, C, eps, w, b, y, res, relu, s));
     return DCPT_OK;
 }
 
