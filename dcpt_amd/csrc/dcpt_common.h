@@ -74,9 +74,28 @@ __device__ __forceinline__ float f4_sum(float4 a) { return (a.x + a.y) + (a.z + 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// XOR-butterfly sum over `width` consecutive lanes (width a power of two <= 64).
+// Sum over `width` consecutive lanes (width a power of two <= 64), result in every lane of the group, bit-identical
+// across the group.  Done with DPP lane permutes and v_readlane only: the usual __shfl_xor lowers to ds_bpermute /
+// ds_swizzle, i.e. goes through the LDS pipeline -- where it queues behind the ds_reads of a co-resident MFMA GEMM
+// (the LayerNorm kernels ran 4-5x slower next to the weight-gradient GEMMs of the side stream because of that).
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float group_sum(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (width >= 2) v += dpp_perm<0xB1>(v);    // quad_perm [1,0,3,2]   (lane ^ 1)
+    if (width >= 4) v += dpp_perm<0x4E>(v);    // quad_perm [2,3,0,1]   (lane ^ 2)
+    if (width >= 8) v += dpp_perm<0x141>(v);   // row_half_mirror: the other quad of the 8-lane half row
+    if (width >= 16) v += dpp_perm<0x140>(v);  // row_mirror: the other half of the 16-lane row
+    if (width >= 32) {
+        const int vi = __builtin_bit_cast(int, v);
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+        if (width == 32) v = ((threadIdx.x & 32) == 0) ? r0 + r1 : r2 + r3;
+        else v = (r0 + r1) + (r2 + r3);
+    }
     return v;
 }
 

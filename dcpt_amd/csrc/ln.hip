@@ -23,10 +23,11 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
                                                        float* __restrict__ y, const float* __restrict__ res, int relu) {
     const int tid = threadIdx.x;
     const int gpb = 256 / G;
-    const int64_t row = (int64_t)blockIdx.x * gpb + tid / G;
     const int lig = tid % G;
-    const bool valid = row < M;
     const int nq = C / 4;
+    for (int64_t rb = blockIdx.x; rb * gpb < M; rb += gridDim.x) {
+    const int64_t row = rb * gpb + tid / G;
+    const bool valid = row < M;
     const float* xr = x + (valid ? row : 0) * (int64_t)C;
     float4 v[NQ];
     float sum = 0.f;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
             stg4(yr + 4 * q, o);
         }
     }
+    }
 }
 
 struct LnBwdP {
@@ -115,8 +117,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         const bool valid = row < p.M;
         const int64_t ro = (valid ? row : 0) * (int64_t)p.C;
         const float mean = valid ? p.mu[row] : 0.f, rs = valid ? p.rstd[row] : 0.f;
-        float4 g[NQ], xh[NQ];
+        float4 g[NQ], xh[NQ], dr[NQ];
         float s1 = 0.f, s2 = 0.f;
+        // all loads of the row are issued together (the residual gradient too: it used to be fetched after the row
+        // reductions, a second full memory round trip per row)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = lig + j * G;
+            dr[j] = (p.dres && valid && q < nq) ? ldg4(p.dres + ro + 4 * q) : f4_zero();
+        }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int q = lig + j * G;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
                 d.y = rs * (gw.y - xh[j].y * s2 - s1);
                 d.z = rs * (gw.z - xh[j].z * s2 - s1);
                 d.w = rs * (gw.w - xh[j].w * s2 - s1);
-                if (p.dres) d = f4_add(d, ldg4(p.dres + ro + 4 * q));
+                d = f4_add(d, dr[j]);
                 stg4(p.dx + ro + 4 * q, d);
                 if (p.biasfree) {
                     const float mr = mean * rs;
