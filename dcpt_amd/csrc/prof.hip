@@ -15,6 +15,8 @@ struct Rec {
 };
 std::mutex g_mu;
 bool g_on = false;
+int g_every = 1;       // bracket every g_every-th launch
+unsigned g_count = 0;
 std::vector<Rec> g_recs;         // records of the current session
 std::vector<hipEvent_t> g_pool;  // reusable events
 size_t g_pool_next = 0;
@@ -35,6 +37,7 @@ void prof_begin(hipStream_t s, int cls, int64_t M, int N, int K, double flops, d
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     g_open = -1;
+    if ((g_count++ % (unsigned)g_every) != 0) return;
     if (g_recs.size() >= MAXREC) return;
     Rec r{cls, M, N, K, flops, bytes, get_event(), get_event()};
     if (!r.e0 || !r.e1) return;
@@ -54,6 +57,8 @@ extern "C" int dcpt_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
     if (g_on) {
+        g_every = on > 1 ? on : 1;
+        g_count = 0;
         g_recs.clear();
         g_pool_next = 0;
     }

@@ -238,7 +238,8 @@ int dcpt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, dcpt_strea
 int dcpt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, dcpt_stream_t stream);
 
 /* ---- optional launch profiling (bench.py) -------------------------------------------------------
- * While enabled, every MFMA GEMM launch is bracketed by HIP events on its own stream.
+ * While enabled, MFMA GEMM launches are bracketed by HIP events on their own stream: every launch for on = 1, every
+ * on-th launch for on > 1 (sampling keeps the perturbation of a timed region small: an event pair costs ~3 us of queue time).
  * dcpt_prof_read waits for them and writes rows of 8 doubles {class id, M, N, K, launches, total ms,
  * algorithmic flops, algorithmic bytes}, one per (class, shape); class id = 16*loaderA + epilogue (NT) or
  * 512 + 8*loaderX + loaderY (TN). */
