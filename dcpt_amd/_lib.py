@@ -175,7 +175,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.dcpt_abi_version() != 1:
+        if lib.dcpt_abi_version() != 2:
             raise DcptHipError("libdcpt_hip.so ABI version mismatch")
         _lib = lib
         return lib
