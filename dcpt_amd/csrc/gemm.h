@@ -74,5 +74,7 @@ struct GemmTN {
 int launch_gemm_tn(const GemmTN& p, int xload, int yload, hipStream_t stream);
 // choose a split count / rows_per_split for a TN problem
 void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split);
+// same, with every split inside one image of P pixels; false if no such plan is near the occupancy target
+bool gemm_tn_plan_images(int64_t M, int N, int K, int P, int* splits, int64_t* rows_per_split);
 // number of k-tile columns of the TN grid for this shape (= partial colsum rows per split)
 int gemm_tn_tiles_k(int N, int K);

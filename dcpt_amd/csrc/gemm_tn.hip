@@ -255,6 +255,22 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
     *splits = (int)cdiv64(M, rps);
 }
 
+// Plan whose splits never straddle an image of P pixels (P % rows_per_split == 0); false if there is none close to the
+// occupancy target (the caller then keeps the scaled operand loader).
+bool gemm_tn_plan_images(int64_t M, int N, int K, int P, int* splits, int64_t* rows_per_split) {
+    int sp;
+    int64_t rps;
+    gemm_tn_plan(M, N, K, &sp, &rps);
+    if (P % 32 != 0 || M % P != 0) return false;
+    int64_t best = 0;
+    for (int64_t d = 32; d <= P; d += 32)
+        if (P % d == 0 && d <= rps + rps / 2) best = d;   // largest image-aligned chunk not much above the target
+    if (best == 0 || best * 2 < rps) return false;         // would need far more (smaller) splits than the target
+    *rows_per_split = best;
+    *splits = (int)(M / best);
+    return *splits <= 65535;
+}
+
 int launch_gemm_tn(const GemmTN& pin, int xload, int yload, hipStream_t s) {
     GemmTN p = pin;
     if (p.nb1 < 1) p.nb1 = 1;

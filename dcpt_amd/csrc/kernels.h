@@ -101,6 +101,10 @@ enum WReduceMode { WR_PLAIN = 0, WR_DOWN = 1, WR_UP = 2, WR_CONV3 = 3 };
 //           (cs = sum over the cs_rows partial rows colsum[r][n])
 int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int cs_rows, int N, int K, const float* rowscale,
                         const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s);
+// as above, with slab s weighted by kscale[(s / splits_per_image)][k] (every split inside one image; SCA scale folded into the reduce)
+int launch_wgrad_reduce_scaled(const float* slab, const float* colsum, int splits, int cs_rows, int N, int K, const float* rowscale,
+                               const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode,
+                               const float* kscale, int splits_per_image, hipStream_t s);
 
 // ---- conv3x3.hip ----------------------------------------------------------------------------
 // small (NCHW, Cs <= 4) -> big (NHWC, Cb % 4 == 0):  y[p][c] = sum_{s,tap} x[p+off(tap)][s] * W(c,s,tap) (+ bias[c])

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int splits, int N, int K, const float* __restrict__ rowscale,
                                                            const float* __restrict__ W, const float* __restrict__ wbias,
                                                            float* __restrict__ dW, float* __restrict__ dgain,
-                                                           float* __restrict__ dbias, int mode, int tpr, int cs_rows) {
+                                                           float* __restrict__ dbias, int mode, int tpr, int cs_rows,
+                                                           const float* __restrict__ kscale, int ks_div) {
     __shared__ float4 red4[256];
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -192,13 +193,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             const float* base = slab + (int64_t)n * K + k;
             const int64_t sstride = (int64_t)N * K;
             int s = sgi;
-            for (; s + 3 * sg < splits; s += 4 * sg) {
-                g = f4_add(g, ldg4(base + (int64_t)s * sstride));
-                g1 = f4_add(g1, ldg4(base + (int64_t)(s + sg) * sstride));
-                g2 = f4_add(g2, ldg4(base + (int64_t)(s + 2 * sg) * sstride));
-                g3 = f4_add(g3, ldg4(base + (int64_t)(s + 3 * sg) * sstride));
+            if (kscale == nullptr) {
+                for (; s + 3 * sg < splits; s += 4 * sg) {
+                    g = f4_add(g, ldg4(base + (int64_t)s * sstride));
+                    g1 = f4_add(g1, ldg4(base + (int64_t)(s + sg) * sstride));
+                    g2 = f4_add(g2, ldg4(base + (int64_t)(s + 2 * sg) * sstride));
+                    g3 = f4_add(g3, ldg4(base + (int64_t)(s + 3 * sg) * sstride));
+                }
+                for (; s < splits; s += sg) g = f4_add(g, ldg4(base + (int64_t)s * sstride));
+            } else {
+                // every split lies inside one image: its slab is weighted by that image's per-column scale (SCA)
+                const float* ks = kscale + k;
+                for (; s + 3 * sg < splits; s += 4 * sg) {
+                    g = f4_fma(ldg4(base + (int64_t)s * sstride), ldg4(ks + (int64_t)(s / ks_div) * K), g);
+                    g1 = f4_fma(ldg4(base + (int64_t)(s + sg) * sstride), ldg4(ks + (int64_t)((s + sg) / ks_div) * K), g1);
+                    g2 = f4_fma(ldg4(base + (int64_t)(s + 2 * sg) * sstride), ldg4(ks + (int64_t)((s + 2 * sg) / ks_div) * K), g2);
+                    g3 = f4_fma(ldg4(base + (int64_t)(s + 3 * sg) * sstride), ldg4(ks + (int64_t)((s + 3 * sg) / ks_div) * K), g3);
+                }
+                for (; s < splits; s += sg) g = f4_fma(ldg4(base + (int64_t)s * sstride), ldg4(ks + (int64_t)(s / ks_div) * K), g);
             }
-            for (; s < splits; s += sg) g = f4_add(g, ldg4(base + (int64_t)s * sstride));
             g = f4_add(f4_add(g, g1), f4_add(g2, g3));
         }
         if (sg > 1) {
@@ -394,12 +407,19 @@ int launch_wpack(const float* in, float* out, const float* rs, int N, int K, int
 
 int launch_wgrad_reduce(const float* slab, const float* colsum, int splits, int cs_rows, int N, int K, const float* rowscale,
                         const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode, hipStream_t s) {
+    return launch_wgrad_reduce_scaled(slab, colsum, splits, cs_rows, N, K, rowscale, W, wbias, dW, dgain, dbias, mode, nullptr, 1, s);
+}
+
+int launch_wgrad_reduce_scaled(const float* slab, const float* colsum, int splits, int cs_rows, int N, int K, const float* rowscale,
+                               const float* W, const float* wbias, float* dW, float* dgain, float* dbias, int mode,
+                               const float* kscale, int splits_per_image, hipStream_t s) {
     DCPT_CHECK_ARG(K % 4 == 0, "wgrad_reduce: K=%d", K);
     DCPT_CHECK_ARG(!(dgain || dbias) || colsum, "wgrad_reduce: gain/bias gradients need column sums");
     int tpr = 1;
     while (tpr < K / 4 && tpr < 256) tpr <<= 1;
+    DCPT_CHECK_ARG(splits_per_image >= 1, "wgrad_reduce: splits_per_image=%d", splits_per_image);
     wgrad_reduce_kernel<<<dim3(N), dim3(256), 0, s>>>(slab, colsum, splits, N, K, rowscale, W, wbias, dW, dgain, dbias, mode,
-                                                      tpr, cs_rows);
+                                                      tpr, cs_rows, kscale, splits_per_image);
     DCPT_CHECK_LAUNCH("wgrad_reduce");
     return DCPT_OK;
 }

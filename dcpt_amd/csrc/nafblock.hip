@@ -48,6 +48,7 @@ struct BwdWs {
     float *bca, *bcb, *bcc; // [M][C]
     float* slab;
     float* colsum;
+    size_t slab_elems, colsum_elems;
     float *lnpart, *lnpart2;
     float *ds_part, *ds, *dpool;
     float* wpart;
@@ -76,10 +77,21 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     int64_t r1, r2;
     gemm_tn_plan(M, 2 * C, C, &sp1, &r1);
     gemm_tn_plan(M, C, C, &sp2, &r2);
-    const size_t slab1 = (size_t)sp1 * 2 * C * C, slab2 = (size_t)sp2 * C * C;
-    w.slab = a.get<float>(slab1 > slab2 ? slab1 : slab2);
-    const size_t cs1 = (size_t)sp1 * gemm_tn_tiles_k(2 * C, C) * 2 * C, cs2 = (size_t)sp2 * gemm_tn_tiles_k(C, C) * C;
-    w.colsum = a.get<float>(cs1 > cs2 ? cs1 : cs2);
+    size_t slab1 = (size_t)sp1 * 2 * C * C, slab2 = (size_t)sp2 * C * C;
+    size_t cs1 = (size_t)sp1 * gemm_tn_tiles_k(2 * C, C) * 2 * C, cs2 = (size_t)sp2 * gemm_tn_tiles_k(C, C) * C;
+    {   // the image-aligned plan of conv3's weight gradient may use more splits
+        int sp3;
+        int64_t r3;
+        if (gemm_tn_plan_images(M, C, C, P, &sp3, &r3)) {
+            const size_t s3 = (size_t)sp3 * C * C, c3 = (size_t)sp3 * gemm_tn_tiles_k(C, C) * C;
+            if (s3 > slab2) slab2 = s3;
+            if (c3 > cs2) cs2 = c3;
+        }
+    }
+    w.slab_elems = slab1 > slab2 ? slab1 : slab2;
+    w.colsum_elems = cs1 > cs2 ? cs1 : cs2;
+    w.slab = a.get<float>(w.slab_elems);
+    w.colsum = a.get<float>(w.colsum_elems);
     w.ln_nblk = ln_bwd_num_blocks(M, C);
     w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * C);
     w.lnpart2 = a.get<float>((size_t)w.ln_nblk * 3 * C);
@@ -224,10 +236,24 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = dts; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     // B7: conv3 / beta gradients (Y = t2*s)
-    tp = GemmTN{};
-    tp.simg = sv->s; tp.P = P;
-    DCPT_TRY(wgrad(dy, C, C, sv->t2, C, C, A_SCALE, tp, M, w.slab, w.colsum, p->beta, p->conv3_w, p->conv3_b, gr->conv3_w,
-                   gr->beta, gr->conv3_b, sw));
+    {
+        // G = sum_m dy[m][n] * t2[m][k] * s[img(m)][k]: when every pixel chunk lies inside one image the scale leaves the
+        // GEMM (both operands plain, by LDS-DMA) and weights the per-chunk slabs in the reducer instead
+        GemmTN t{};
+        t.X = dy; t.ldx = C; t.N = C; t.Y = sv->t2; t.ldy = C; t.K = C; t.M = M; t.slab = w.slab; t.colsum = w.colsum;
+        if (gemm_tn_plan_images(M, C, C, P, &t.splits, &t.rows_per_split) &&
+            (size_t)t.splits * C * C <= w.slab_elems && (size_t)t.splits * gemm_tn_tiles_k(C, C) * C <= w.colsum_elems) {
+            DCPT_TRY(launch_gemm_tn(t, A_PLAIN, A_PLAIN, sw));
+            DCPT_TRY(launch_wgrad_reduce_scaled(w.slab, w.colsum, t.splits, t.splits * gemm_tn_tiles_k(C, C), C, C, p->beta, p->conv3_w,
+                                                p->conv3_b, gr->conv3_w, gr->beta, gr->conv3_b, WR_PLAIN, sv->s,
+                                                (int)(P / t.rows_per_split), sw));
+        } else {
+            tp = GemmTN{};
+            tp.simg = sv->s; tp.P = P;
+            DCPT_TRY(wgrad(dy, C, C, sv->t2, C, C, A_SCALE, tp, M, w.slab, w.colsum, p->beta, p->conv3_w, p->conv3_b, gr->conv3_w,
+                           gr->beta, gr->conv3_b, sw));
+        }
+    }
     // B8: SCA backward
     DCPT_TRY(launch_sca_ds_part(dts, sv->t2, w.ds_part, B, C, P, s));
     DCPT_TRY(launch_sca_dpool(w.ds_part, p->sca_w, w.dpool, B, C, P, s));
