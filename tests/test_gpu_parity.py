@@ -375,3 +375,35 @@ def test_tiled_inference_matches_per_tile_loop(dev):
                 out = m.net_g(lq[:, :, yp0:yp1, xp0:xp1].contiguous())
                 ref[:, :, y0:y1, x0:x1] = out[:, :, y0 - yp0:y0 - yp0 + (y1 - y0), x0 - xp0:x0 - xp0 + (x1 - x0)]
     check("tiled", got, ref[:, :, :75, :88].cpu(), 1e-5)
+
+
+def test_training_trajectory_matches_oracle(dev):
+    """Eight AdamW steps of the tiny NAFNet on a fixed batch (L1 loss): the HIP path and the CPU oracle must follow the same
+    loss trajectory -- forward, backward and the parameter gradients feeding the optimizer all agree step after step."""
+    net = _build_net(TINY, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = keyed_input("traj.x", (2, 3, 32, 32))
+    gt = keyed_input("traj.gt", (2, 3, 32, 32))
+    kw = dict(lr=2e-3, betas=(0.9, 0.9), weight_decay=0.0)
+    opt_g = torch.optim.AdamW(net.parameters(), **kw)
+    opt_r = torch.optim.AdamW([P[k] for k in sd], **kw)
+    xg, gg = x.to(dev), gt.to(dev)
+    lg, lr_ = [], []
+    for _ in range(8):
+        opt_g.zero_grad(set_to_none=True)
+        l = (net(xg) - gg).abs().mean()
+        l.backward()
+        opt_g.step()
+        lg.append(float(l))
+        opt_r.zero_grad(set_to_none=True)
+        yr, _ = O.nafnet_forward(x, P)
+        l2 = (yr - gt).abs().mean()
+        l2.backward()
+        opt_r.step()
+        lr_.append(float(l2))
+    assert lr_[-1] < lr_[0], "the oracle itself must be learning"
+    for a, b in zip(lg, lr_):
+        assert abs(a - b) <= 2e-4 * abs(b), (lg, lr_)
+    for k in sd:
+        check("param " + k, net.state_dict()[k], P[k].detach(), 5e-3)
