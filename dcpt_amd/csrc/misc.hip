@@ -6,7 +6,9 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// SCA forward. grid (B, row-chunks of 64 outputs); every block first rebuilds pooled[b][:] in LDS.
+// SCA forward. grid (B, row-chunks of SCA_OPB outputs); every block first rebuilds pooled[b][:] in LDS.  Latency-bound:
+// many small blocks, all loads of a wave's outputs issued together.
+constexpr int SCA_OPB = 16;   // outputs per block: 4 per wave
 __global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ pool_part, int nblk,
                                                       const float* __restrict__ Wsca, const float* __restrict__ bsca,
                                                       float* __restrict__ pooled, float* __restrict__ simg, int C, float invP) {
@@ -22,17 +24,23 @@ __global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
-    const int nbeg = blockIdx.y * 64;
-#pragma unroll 4
-    for (int n = nbeg + wave; n < nbeg + 64 && n < C; n += 4) {
-        float s = 0.f;
-        for (int k = 4 * lane; k < C; k += 256) {
-            const float4 w = ldg4(Wsca + (int64_t)n * C + k);
-            const float4 v = *reinterpret_cast<const float4*>(&pl[k]);
-            s += f4_sum(f4_mul(w, v));
+    const int nbeg = blockIdx.y * SCA_OPB + wave * (SCA_OPB / 4);
+    float acc[SCA_OPB / 4];
+#pragma unroll
+    for (int i = 0; i < SCA_OPB / 4; ++i) acc[i] = 0.f;
+    for (int k = 4 * lane; k < C; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(&pl[k]);
+#pragma unroll
+        for (int i = 0; i < SCA_OPB / 4; ++i) {
+            const int n = nbeg + i;
+            if (n < C) acc[i] += f4_sum(f4_mul(ldg4(Wsca + (int64_t)n * C + k), v));
         }
-        s = group_sum(s, 64);
-        if (lane == 0) simg[(int64_t)b * C + n] = s + bsca[n];
+    }
+#pragma unroll
+    for (int i = 0; i < SCA_OPB / 4; ++i) {
+        const float s = group_sum(acc[i], 64);
+        const int n = nbeg + i;
+        if (lane == 0 && n < C) simg[(int64_t)b * C + n] = s + bsca[n];
     }
 }
 
@@ -337,7 +345,7 @@ int launch_box_mean(const float* in, float* rowsum, float* out, int B, int H, in
 int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const float* bsca, float* pooled, float* simg,
                    int B, int C, int P, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && C * 4 <= 65536, "sca_fwd: C=%d unsupported", C);
-    sca_fwd_kernel<<<dim3(B, cdiv(C, 64)), dim3(256), C * sizeof(float), s>>>(pool_part, nblk, Wsca, bsca, pooled, simg, C,
+    sca_fwd_kernel<<<dim3(B, cdiv(C, SCA_OPB)), dim3(256), C * sizeof(float), s>>>(pool_part, nblk, Wsca, bsca, pooled, simg, C,
                                                                                 1.0f / (float)P);
     DCPT_CHECK_LAUNCH("sca_fwd");
     return DCPT_OK;
