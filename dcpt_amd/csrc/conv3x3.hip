@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restric
         }
     const float4 bv = (bias && k.qok) ? ldg4(bias + 4 * k.q) : f4_zero();
     const rsrc_t rs_x = make_rsrc(x + (int64_t)k.b * CS * H * W);
-    const rsrc_t rs_y = make_rsrc(y + (int64_t)k.b * H * W * Cb);
+    const rsrc_t rs_y = make_rsrc(y + ((int64_t)k.b * H + k.y0) * W * Cb);   // big side: window at the strip's first row
     const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
     float4 a0 = f4_zero(), a1 = f4_zero();
     for (int r = k.y0 - 1; r <= k.y1; ++r) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restric
             a2 = f4_fma(wv[s * 9 + 0], l4, f4_fma(wv[s * 9 + 1], c4, f4_fma(wv[s * 9 + 2], r4, a2)));   // ky = 0 -> row r+1
         }
         const int yo = r - 1;
-        buf_st4(rs_y, (k.ok && yo >= k.y0) ? ((uint32_t)(yo * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT, f4_add(a0, bv));
+        buf_st4(rs_y, (k.ok && yo >= k.y0) ? ((uint32_t)((yo - k.y0) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT, f4_add(a0, bv));
         a0 = a1;
         a1 = a2;
     }
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const float* __restric
             }
             wv[s * 9 + t] = v;
         }
-    const rsrc_t rs_x = make_rsrc(x + (int64_t)k.b * H * W * Cb);
+    const int rb = k.y0 > 0 ? k.y0 - 1 : 0;
+    const rsrc_t rs_x = make_rsrc(x + ((int64_t)k.b * H + rb) * W * Cb);   // big side: window one row above the strip
     const rsrc_t rs_y = make_rsrc(y + (int64_t)k.b * CS * H * W);
     const rsrc_t rs_r = make_rsrc(res ? res + (int64_t)k.b * CS * H * W : y);
     const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const float* __restric
 #pragma unroll
     for (int s = 0; s < CS; ++s) a0[s] = a1[s] = 0.f;
     for (int r = k.y0 - 1; r <= k.y1; ++r) {
-        const uint32_t o = (r >= 0 && r < H) ? ((uint32_t)(r * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT;
+        const uint32_t o = (r >= 0 && r < H) ? ((uint32_t)((r - rb) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT;
         const float4 xl = buf_ld4(rs_x, (o - st) | cl), xc = buf_ld4(rs_x, o | cc), xr = buf_ld4(rs_x, (o + st) | cr);
         float a2[CS];
 #pragma unroll
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     float4 acc[CS * 9 + 1];
 #pragma unroll
     for (int i = 0; i < CS * 9 + 1; ++i) acc[i] = f4_zero();
-    const rsrc_t rs_g = make_rsrc(big + (int64_t)k.b * H * W * Cb);
+    const rsrc_t rs_g = make_rsrc(big + ((int64_t)k.b * H + k.y0) * W * Cb);   // big side: window at the strip's first row
     const rsrc_t rs_s = make_rsrc(small + (int64_t)k.b * CS * H * W);
     const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
     // small-side window: rows r-1, r, r+1 x columns x-1, x, x+1 per small channel, shifted down one row per step
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     load_row(k.y0, 1);
     for (int r = k.y0; r < k.y1; ++r) {
         load_row(r + 1, 2);
-        const float4 g = buf_ld4(rs_g, k.ok ? ((uint32_t)(r * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT);
+        const float4 g = buf_ld4(rs_g, k.ok ? ((uint32_t)((r - k.y0) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT);
         acc[CS * 9] = f4_add(acc[CS * 9], g);
 #pragma unroll
         for (int s = 0; s < CS; ++s)
@@ -316,8 +317,9 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float* __re
 
 }  // namespace
 
-#define EDGE_CHECK(name)                                                                                                     \
-    DCPT_CHECK_ARG(Cb % 4 == 0 && Cs >= 1 && Cs <= MAXCS && B <= 65535 && (double)H * W * (Cb > Cs ? Cb : Cs) * 4.0 < 1.0e9, \
+#define EDGE_CHECK(name, TARGET)                                                                                                     \
+    DCPT_CHECK_ARG(Cb % 4 == 0 && Cs >= 1 && Cs <= MAXCS && B <= 65535 && (double)H * W * Cs * 4.0 < 1.0e9 &&                   \
+                       ((double)edge_map(B, H, W, Cb, TARGET).RS + 3.0) * W * Cb * 4.0 < 1.0e9,                                       \
                    name ": Cs=%d (1..4), Cb=%d (%%4), image %dx%d", Cs, Cb, H, W)
 #define EDGE_GO(KERNEL, ...)                                                     \
     do {                                                                         \
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float* __re
 
 int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cs, int Cb,
                        int wmode, hipStream_t s) {
-    EDGE_CHECK("conv3x3_s2b");
+    EDGE_CHECK("conv3x3_s2b", 2048);
     EDGE_GO(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_s2b");
     return DCPT_OK;
@@ -339,7 +341,7 @@ int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float*
 
 int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W,
                        int Cs, int Cb, int wmode, hipStream_t s) {
-    EDGE_CHECK("conv3x3_b2s");
+    EDGE_CHECK("conv3x3_b2s", 2048);
     DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
     EDGE_GO(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_b2s");
@@ -353,7 +355,7 @@ int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb) {
 
 int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H,
                          int W, int Cs, int Cb, int omode, hipStream_t s) {
-    EDGE_CHECK("conv3x3_wgrad");
+    EDGE_CHECK("conv3x3_wgrad", WGRAD_BLOCKS);
     DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad: nblk mismatch");
     {
         const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);

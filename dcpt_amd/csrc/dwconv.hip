@@ -98,6 +98,13 @@ __device__ __forceinline__ DwBlk dw_block(const DwMap& mp) {
     return k;
 }
 
+// first image row a block's windows must reach: two rows above its row range (the t1 window of the weight gradient)
+__device__ __forceinline__ int dw_row_base(const DwMap& mp, const DwBlk& bk, int H) {
+    const int nrp = gridDim.y / mp.nwc, rpp = (H + nrp - 1) / nrp;
+    const int rb = (bk.y / mp.nwc) * rpp - 2;
+    return rb > 0 ? rb : 0;
+}
+
 struct DwP {
     const float* in0;   // fwd/bwd_a: t1 [M][2C];  bwd_b: da [M][2C]
     const float* in1;   // bwd_a: dts [M][C];      bwd_b: t1 [M][2C]
@@ -167,8 +174,10 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
         dpv = gld<VW>(p.dpool + (int64_t)b * C + c1, true);
     }
     vf<VW> pool = vz<VW>();
-    // windows over image b (offsets fit 32 bits: checked by the launchers)
-    const int64_t img = (int64_t)b * p.H * p.W;
+    // windows start two rows above this block's row range of image b (offsets of the range fit 32 bits: checked by the
+    // launchers), rows are addressed relative to rb
+    const int rb = dw_row_base(mp, bk, p.H);
+    const int64_t img = ((int64_t)b * p.H + rb) * p.W;
     const rsrc_t rs_in = make_rsrc(p.in0 + img * C2);
     const rsrc_t rs_out = make_rsrc(p.out + img * (MODE == 0 ? C : C2));
     const rsrc_t rs_d = make_rsrc(MODE == 1 ? p.in1 + img * C : p.in0);
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
         const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
         vf<VW> a0_1 = vz<VW>(), a0_2 = vz<VW>(), a1_1 = vz<VW>(), a1_2 = vz<VW>();
         for (int r = h0 - 1; r <= h1; ++r) {
-            const uint32_t ro = (r >= 0 && r < p.H) ? (uint32_t)((r * p.W + x) * C2) * 4u : ROW_SENT;
+            const uint32_t ro = (r >= 0 && r < p.H) ? (uint32_t)(((r - rb) * p.W + x) * C2) * 4u : ROW_SENT;
             const uint32_t o1 = ro + 4u * (uint32_t)c1, o2 = ro + 4u * (uint32_t)c2;
             const vf<VW> xl1 = bld<VW>(rs_in, (o1 - st) | cl), xl2 = bld<VW>(rs_in, (o2 - st) | cl);
             const vf<VW> xc1 = bld<VW>(rs_in, o1 | cc), xc2 = bld<VW>(rs_in, o2 | cc);
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
             const int y = r - 1;
             const bool yok = ok && y >= h0;
             vf<VW> dts = vz<VW>();
-            if (MODE == 1) dts = bld<VW>(rs_d, yok ? (uint32_t)((y * p.W + x) * C + c1) * 4u : ROW_SENT);
+            if (MODE == 1) dts = bld<VW>(rs_d, yok ? (uint32_t)(((y - rb) * p.W + x) * C + c1) * 4u : ROW_SENT);
             // kernel row 2 completes output row r-1
             a0_1 = vfma(w1[6], xl1, vfma(w1[7], xc1, vfma(w1[8], xr1, a0_1)));
             a0_2 = vfma(w2[6], xl2, vfma(w2[7], xc2, vfma(w2[8], xr2, a0_2)));
@@ -204,11 +213,11 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
             const vf<VW> g1 = vadd(a0_1, bias1), g2 = vadd(a0_2, bias2);
             if (MODE == 0) {
                 const vf<VW> t = vmul(GATE == 0 ? g1 : vgelu(g1), g2);
-                bst<VW>(rs_out, yok ? (uint32_t)((y * p.W + x) * C + c1) * 4u : ROW_SENT, t);
+                bst<VW>(rs_out, yok ? (uint32_t)(((y - rb) * p.W + x) * C + c1) * 4u : ROW_SENT, t);
                 if (yok) pool = vadd(pool, t);
             } else {
                 const vf<VW> dt2 = vfma(dts, sv, dpv);
-                const uint32_t oo = yok ? (uint32_t)((y * p.W + x) * C2) * 4u : ROW_SENT;
+                const uint32_t oo = yok ? (uint32_t)(((y - rb) * p.W + x) * C2) * 4u : ROW_SENT;
                 if (GATE == 0) {
                     bst<VW>(rs_out, oo + 4u * (uint32_t)c1, vmul(dt2, g2));
                     bst<VW>(rs_out, oo + 4u * (uint32_t)c2, vmul(dt2, g1));
@@ -244,7 +253,8 @@ __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
     for (int t = 0; t < 9; ++t) w[t] = gld<VW>(p.w2p + t * C2 + c0, qok);
 #pragma unroll
     for (int t = 0; t < 10; ++t) wa[t] = vz<VW>();
-    const int64_t img = (int64_t)b * p.H * p.W;
+    const int rb = dw_row_base(mp, bk, p.H);
+    const int64_t img = ((int64_t)b * p.H + rb) * p.W;
     const rsrc_t rs_d = make_rsrc(p.in0 + img * C2);
     const rsrc_t rs_t = make_rsrc(p.in1 + img * C2);
     const rsrc_t rs_o = make_rsrc(p.out + img * C2);
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
         const int h0 = (bk.y / mp.nwc) * rpp;
         const int h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
         const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
-        auto rowoff = [&](int r) -> uint32_t { return (r >= 0 && r < p.H) ? ((uint32_t)((r * p.W + x) * C2) + (uint32_t)c0) * 4u : ROW_SENT; };
+        auto rowoff = [&](int r) -> uint32_t { return (r >= 0 && r < p.H) ? ((uint32_t)(((r - rb) * p.W + x) * C2) + (uint32_t)c0) * 4u : ROW_SENT; };
         vf<VW> a0 = vz<VW>(), a1 = vz<VW>();
         // t1 rows r-1, r at column x (for the weight gradient); row r+1 is loaded in the loop
         vf<VW> tm = bld<VW>(rs_t, rowoff(h0 - 2) | cc), tc = bld<VW>(rs_t, rowoff(h0 - 1) | cc);
@@ -315,7 +325,8 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const DwP p, int nsq) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = gld<VW>(p.w2p + t * C + c0, qok);
     vf<VW> sq = vz<VW>();
-    const int64_t img = (int64_t)b * p.H * p.W;
+    const int rb = dw_row_base(mp, bk, p.H);
+    const int64_t img = ((int64_t)b * p.H + rb) * p.W;
     const rsrc_t rs_in = make_rsrc(p.in0 + img * C);
     const rsrc_t rs_o = make_rsrc(p.out + img * C);
     const uint32_t st = 4u * (uint32_t)C;
@@ -328,14 +339,14 @@ __global__ __launch_bounds__(256) void dw_plain_kernel(const DwP p, int nsq) {
         const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
         vf<VW> a0 = vz<VW>(), a1 = vz<VW>();
         for (int r = h0 - 1; r <= h1; ++r) {
-            const uint32_t o = (r >= 0 && r < p.H) ? ((uint32_t)((r * p.W + x) * C) + (uint32_t)c0) * 4u : ROW_SENT;
+            const uint32_t o = (r >= 0 && r < p.H) ? ((uint32_t)(((r - rb) * p.W + x) * C) + (uint32_t)c0) * 4u : ROW_SENT;
             const vf<VW> xl = bld<VW>(rs_in, (o - st) | cl), xc = bld<VW>(rs_in, o | cc), xr = bld<VW>(rs_in, (o + st) | cr);
             a0 = vfma(w[6], xl, vfma(w[7], xc, vfma(w[8], xr, a0)));
             a1 = vfma(w[3], xl, vfma(w[4], xc, vfma(w[5], xr, a1)));
             const vf<VW> a2 = vfma(w[0], xl, vfma(w[1], xc, vmul(w[2], xr)));
             const int y = r - 1;
             const bool yok = ok && y >= h0;
-            bst<VW>(rs_o, yok ? ((uint32_t)((y * p.W + x) * C) + (uint32_t)c0) * 4u : ROW_SENT, a0);
+            bst<VW>(rs_o, yok ? ((uint32_t)(((y - rb) * p.W + x) * C) + (uint32_t)c0) * 4u : ROW_SENT, a0);
             if (yok) sq = vfma(a0, a0, sq);
             a0 = a1;
             a1 = a2;
@@ -409,7 +420,10 @@ int nblk_for(const DwGeom& g, int quads) {
 int dw_num_blocks_per_image(const DwGeom& g) { return nblk_for(g, g.C / dw_vw()); }
 int dw_num_blocks_per_image_b(const DwGeom& g) { return nblk_for(g, 2 * g.C / dw_vw()); }
 
-#define DW_CHECK_RANGE(H, W, Ct) DCPT_CHECK_ARG((double)(H) * (W) * (Ct) * 4.0 < 1.0e9, "depthwise conv: image of %d x %d x %d floats exceeds the 32-bit window", H, W, Ct)
+// a block's windows span its row range + halo: (rows/part + 5) * W * Ct floats must fit the 32-bit offsets
+#define DW_CHECK_RANGE(H, W, Ct, NBLK, NWC)                                                                             \
+    DCPT_CHECK_ARG(((double)cdiv((H), (NBLK) / (NWC) > 0 ? (NBLK) / (NWC) : 1) + 5.0) * (W) * (Ct) * 4.0 < 1.0e9,        \
+                   "depthwise conv: a row range of a %d x %d x %d image exceeds the 32-bit window", H, W, Ct)
 #define DW_LAUNCH(KERNEL, ...)                                  \
     do {                                                        \
         if (dw_vw() == 2) KERNEL<2 __VA_ARGS__;                 \
@@ -428,8 +442,8 @@ int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2,
     DwP p{};
     p.in0 = t1; p.w2p = w2p; p.b2 = b2; p.out = t2; p.part = pool_part;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
-    DW_CHECK_RANGE(g.H, g.W, 2 * g.C);
     const DwMap mp = dw_map(g.H, g.W, g.C / dw_vw());
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image(g), mp.nwc);
     DW_LAUNCH(dw_gate_kernel, , 0, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_fwd");
     return DCPT_OK;
@@ -441,8 +455,8 @@ int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const f
     DwP p{};
     p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = da;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
-    DW_CHECK_RANGE(g.H, g.W, 2 * g.C);
     const DwMap mp = dw_map(g.H, g.W, g.C / dw_vw());
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image(g), mp.nwc);
     DW_LAUNCH(dw_gate_kernel, , 1, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_bwd_a");
     return DCPT_OK;
@@ -454,8 +468,8 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
     DwP p{};
     p.in0 = da; p.in1 = t1; p.w2p = w2p; p.out = dt1; p.part = wpart;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.Ctot = 2 * g.C;
-    DW_CHECK_RANGE(g.H, g.W, 2 * g.C);
     const DwMap mp = dw_map(g.H, g.W, 2 * g.C / dw_vw());
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image_b(g), mp.nwc);
     DW_LAUNCH(dw_bwd_b_kernel, ><<<dim3(mp.nqc, dw_num_blocks_per_image_b(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_bwd_b");
     return DCPT_OK;
@@ -472,8 +486,8 @@ int launch_dw_gelu_fwd(const float* u, const float* w2p, float* t, int B, int H,
     DwP p{};
     p.in0 = u; p.w2p = w2p; p.out = t; p.B = B; p.H = H; p.W = W; p.C = Ch;
     DwGeom g{B, H, W, Ch};
-    DW_CHECK_RANGE(H, W, 2 * Ch);
     const DwMap mp = dw_map(H, W, Ch / dw_vw());
+    DW_CHECK_RANGE(H, W, 2 * Ch, dw_num_blocks_per_image(g), mp.nwc);
     DW_LAUNCH(dw_gate_kernel, , 0, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_gelu_fwd");
     return DCPT_OK;
@@ -484,8 +498,8 @@ int launch_dw_gelu_bwd_a(const float* dt, const float* u, const float* w2p, floa
     DwP p{};
     p.in0 = u; p.in1 = dt; p.w2p = w2p; p.out = da; p.B = B; p.H = H; p.W = W; p.C = Ch;
     DwGeom g{B, H, W, Ch};
-    DW_CHECK_RANGE(H, W, 2 * Ch);
     const DwMap mp = dw_map(H, W, Ch / dw_vw());
+    DW_CHECK_RANGE(H, W, 2 * Ch, dw_num_blocks_per_image(g), mp.nwc);
     DW_LAUNCH(dw_gate_kernel, , 1, 1><<<dim3(mp.nqc, dw_num_blocks_per_image(g), B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_gelu_bwd_a");
     return DCPT_OK;
@@ -496,8 +510,8 @@ int launch_dw_plain_fwd(const float* x, const float* w2p, float* y, float* sq_pa
     DCPT_CHECK_ARG(Ctot % 4 == 0 && nsq % 4 == 0 && B <= 65535, "dw_plain_fwd: Ctot=%d", Ctot);
     DwP p{};
     p.in0 = x; p.w2p = w2p; p.out = y; p.part = sq_part; p.B = B; p.H = H; p.W = W; p.Ctot = Ctot;
-    DW_CHECK_RANGE(H, W, Ctot);
     const DwMap mp = dw_map(H, W, Ctot / dw_vw());
+    DW_CHECK_RANGE(H, W, Ctot, dw_num_blocks_generic(B, H, W, Ctot), mp.nwc);
     DW_LAUNCH(dw_plain_kernel, ><<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p, nsq));
     DCPT_CHECK_LAUNCH("dw_plain_fwd");
     return DCPT_OK;
@@ -509,8 +523,8 @@ int launch_dw_generic_bwd(const float* dy, const float* x, const float* w2p, flo
     DCPT_CHECK_ARG(Ctot % 4 == 0 && B <= 65535, "dw_generic_bwd: Ctot=%d", Ctot);
     DwP p{};
     p.in0 = dy; p.in1 = x; p.w2p = w2p; p.out = dx; p.part = wpart; p.B = B; p.H = H; p.W = W; p.Ctot = Ctot;
-    DW_CHECK_RANGE(H, W, Ctot);
     const DwMap mp = dw_map(H, W, Ctot / dw_vw());
+    DW_CHECK_RANGE(H, W, Ctot, dw_num_blocks_generic(B, H, W, Ctot), mp.nwc);
     DW_LAUNCH(dw_bwd_b_kernel, ><<<dim3(mp.nqc, dw_num_blocks_generic(B, H, W, Ctot), B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_generic_bwd");
     return DCPT_OK;

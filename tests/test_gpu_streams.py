@@ -128,3 +128,26 @@ def test_backward_on_a_user_stream_and_under_graph_capture(dev):
     torch.cuda.synchronize()
     for a, b in zip(ref, outs):
         assert torch.equal(a, b.detach())
+
+
+def test_large_image_windows(dev):
+    """an image whose NHWC feature map exceeds 1 GiB per tensor (1536 x 1536 x 128 ch x 4 B = 1.2 GB): the depthwise and
+    edge-conv kernels address it through per-row-range windows, the GEMMs through per-tile windows"""
+    from dcpt_amd import functional as DF
+
+    H = W = 1536
+    c = 64
+    x = (torch.rand((1, 3, H, W), device=dev) - 0.5)
+    wi = keyed_tensor("big.intro.weight", (c, 3, 3, 3)).to(dev)
+    bi = keyed_tensor("big.intro.bias", (c,)).to(dev)
+    P = {k: v.to(dev) for k, v in block_params(c, "big.").items()}
+    with torch.no_grad():
+        f = DF.conv3x3_in(x, wi, bi)
+        y = DF.nafblock(f, {fk: P[rk] for fk, rk in FUSED.items()})
+        # reference on a crop whose receptive field (3x3 intro, 3x3 depthwise, global SCA pooling) we can reproduce: compare the
+        # intro conv exactly and the block through a second run (determinism) + finiteness; the global pool forbids cropping
+        r = F.conv2d(x[:, :, 700:900, 600:800], wi, bi, padding=1)[:, :, 1:-1, 1:-1]
+        check("intro crop", f[:, :, 701:899, 601:799], r, 1e-5)
+        y2 = DF.nafblock(f, {fk: P[rk] for fk, rk in FUSED.items()})
+    assert torch.isfinite(y).all() and torch.equal(y, y2)
+    assert float((y - f).abs().max()) > 0
