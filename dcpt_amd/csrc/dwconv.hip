@@ -307,6 +307,160 @@ __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
     for (int t = 0; t < 10; ++t) dw_block_reduce<VW>(red, wa[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + c0);
 }
 
+// Fused SimpleGate + depthwise backward (NAFNet):  dt1 = dw3x3^T(da),  da_1 = dt2 * a_2,  da_2 = dt2 * a_1,
+// a = dw3x3(t1) + b2 (recomputed),  dt2 = dts * s + dpool,  plus the per-block partial sums of dw2[ch][tap] and db2[ch].
+// `da` never goes to memory: a thread owns VW channels of BOTH halves at one pixel column and streams down its row range;
+// for every t1 row it loads columns x-2..x+2, advances the forward-conv accumulators of columns x-1, x, x+1, turns the
+// completed row of a into da at those three columns, and feeds it to the transposed-conv accumulators and the tap
+// gradients (which pair da[row][x] with the t1 rows it still holds).  HBM traffic: t1 and dts once (+2-row halos), dt1
+// once -- 5 tensor units instead of 11 for the two-kernel form; the extra column loads are L1 hits.
+template <int VW>
+__global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
+    __shared__ float red[256 * VW];
+    const DwMap mp = dw_map(p.H, p.W, p.C / VW);
+    const DwBlk bk = dw_block(mp);
+    const int tid = threadIdx.x;
+    const int ql = tid % mp.QB, pl = tid / mp.QB;
+    const int q = bk.x * mp.QB + ql;
+    const int b = bk.z;
+    const bool qok = q < mp.QW;
+    const int C = p.C, C2 = 2 * p.C;
+    const int c1 = VW * q, c2 = C + VW * q;
+    vf<VW> w1[9], w2[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        w1[t] = gld<VW>(p.w2p + t * C2 + c1, qok);
+        w2[t] = gld<VW>(p.w2p + t * C2 + c2, qok);
+    }
+    const vf<VW> bias1 = gld<VW>(p.b2 + c1, qok && p.b2), bias2 = gld<VW>(p.b2 + c2, qok && p.b2);
+    vf<VW> sv, dpv = vz<VW>();
+#pragma unroll
+    VFOR sv.v[i_] = 1.f;
+    if (qok && p.simg) {
+        sv = gld<VW>(p.simg + (int64_t)b * C + c1, true);
+        dpv = gld<VW>(p.dpool + (int64_t)b * C + c1, true);
+    }
+    vf<VW> g1[10], g2[10];   // tap gradients (0..8) and bias gradient (9) of the two halves
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        g1[t] = vz<VW>();
+        g2[t] = vz<VW>();
+    }
+    const int wc = bk.y % mp.nwc, nrp = gridDim.y / mp.nwc, rpp = (p.H + nrp - 1) / nrp;
+    const int x = wc * mp.PB + pl;
+    const bool ok = qok && x < p.W;
+    const int h0 = (bk.y / mp.nwc) * rpp;
+    const int h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
+    const int rb = h0 - 2 > 0 ? h0 - 2 : 0;
+    const int64_t img = ((int64_t)b * p.H + rb) * p.W;
+    const rsrc_t rs_t = make_rsrc(p.in0 + img * C2);
+    const rsrc_t rs_d = make_rsrc(p.in1 + img * C);
+    const rsrc_t rs_o = make_rsrc(p.out + img * C2);
+    // column validity of x-2 .. x+2 (a column outside the image: its t1 is zero padding, its da does not exist)
+    uint32_t cs[5];
+    bool cin[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        cin[j] = ok && x + j - 2 >= 0 && x + j - 2 < p.W;
+        cs[j] = cin[j] ? 0u : COL_SENT;
+    }
+    // forward-conv running accumulators of columns x-1, x, x+1 (index 0..2): A0 = row r-1 (complete after this step), A1 = row r
+    vf<VW> A0_1[3], A0_2[3], A1_1[3], A1_2[3];
+    // transposed-conv running accumulators at column x: B0 = output row rho-1, B1 = output row rho
+    vf<VW> B0_1 = vz<VW>(), B0_2 = vz<VW>(), B1_1 = vz<VW>(), B1_2 = vz<VW>();
+    // t1 at columns x-1..x+1 of the two previous rows (for the tap gradients)
+    vf<VW> Tm1[3], Tm2[3], Tc1[3], Tc2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        A0_1[j] = A0_2[j] = A1_1[j] = A1_2[j] = vz<VW>();
+        Tm1[j] = Tm2[j] = Tc1[j] = Tc2[j] = vz<VW>();
+    }
+    for (int r = h0 - 2; r <= h1 + 1; ++r) {
+        // ---- t1 row r, columns x-2..x+2, both halves
+        const bool rin = r >= 0 && r < p.H;
+        const uint32_t ro = rin ? (uint32_t)(((r - rb) * p.W + x) * C2) * 4u : ROW_SENT;
+        vf<VW> T1[5], T2[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t o = ro + (uint32_t)((j - 2) * C2 * 4);
+            T1[j] = bld<VW>(rs_t, (o + 4u * (uint32_t)c1) | cs[j]);
+            T2[j] = bld<VW>(rs_t, (o + 4u * (uint32_t)c2) | cs[j]);
+        }
+        // ---- dts of row rho = r-1 at columns x-1..x+1
+        const int rho = r - 1;
+        const bool rho_in = rho >= 0 && rho < p.H;
+        vf<VW> D[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            D[j] = bld<VW>(rs_d, rho_in ? ((uint32_t)(((rho - rb) * p.W + x + j - 1) * C + c1) * 4u) | cs[j + 1] : ROW_SENT);
+        // ---- forward conv: row r contributes kernel row 2 to a[r-1], row 1 to a[r], row 0 to a[r+1]
+        vf<VW> A2_1[3], A2_2[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A0_1[j] = vfma(w1[6], T1[j], vfma(w1[7], T1[j + 1], vfma(w1[8], T1[j + 2], A0_1[j])));
+            A0_2[j] = vfma(w2[6], T2[j], vfma(w2[7], T2[j + 1], vfma(w2[8], T2[j + 2], A0_2[j])));
+            A1_1[j] = vfma(w1[3], T1[j], vfma(w1[4], T1[j + 1], vfma(w1[5], T1[j + 2], A1_1[j])));
+            A1_2[j] = vfma(w2[3], T2[j], vfma(w2[4], T2[j + 1], vfma(w2[5], T2[j + 2], A1_2[j])));
+            A2_1[j] = vfma(w1[0], T1[j], vfma(w1[1], T1[j + 1], vmul(w1[2], T1[j + 2])));
+            A2_2[j] = vfma(w2[0], T2[j], vfma(w2[1], T2[j + 1], vmul(w2[2], T2[j + 2])));
+        }
+        // ---- da of row rho at columns x-1..x+1 (zero where the pixel does not exist)
+        vf<VW> da1[3], da2[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool pin = rho_in && cin[j + 1];
+            const vf<VW> dt2 = vfma(D[j], sv, dpv);
+            const vf<VW> a1 = vadd(A0_1[j], bias1), a2 = vadd(A0_2[j], bias2);
+            da1[j] = pin ? vmul(dt2, a2) : vz<VW>();
+            da2[j] = pin ? vmul(dt2, a1) : vz<VW>();
+        }
+        // ---- transposed conv: da row rho feeds dt1 rows rho-1 (ky = 0), rho (ky = 1), rho+1 (ky = 2); da[.][x-1+j] <-> kx = 2-j
+        B0_1 = vfma(w1[2], da1[0], vfma(w1[1], da1[1], vfma(w1[0], da1[2], B0_1)));
+        B0_2 = vfma(w2[2], da2[0], vfma(w2[1], da2[1], vfma(w2[0], da2[2], B0_2)));
+        B1_1 = vfma(w1[5], da1[0], vfma(w1[4], da1[1], vfma(w1[3], da1[2], B1_1)));
+        B1_2 = vfma(w2[5], da2[0], vfma(w2[4], da2[1], vfma(w2[3], da2[2], B1_2)));
+        const vf<VW> B2_1 = vfma(w1[8], da1[0], vfma(w1[7], da1[1], vmul(w1[6], da1[2])));
+        const vf<VW> B2_2 = vfma(w2[8], da2[0], vfma(w2[7], da2[1], vmul(w2[6], da2[2])));
+        {
+            const int y = rho - 1;   // complete now
+            const uint32_t oo = (ok && y >= h0 && y < h1) ? (uint32_t)(((y - rb) * p.W + x) * C2) * 4u : ROW_SENT;
+            bst<VW>(rs_o, oo + 4u * (uint32_t)c1, B0_1);
+            bst<VW>(rs_o, oo + 4u * (uint32_t)c2, B0_2);
+        }
+        // ---- tap gradients: da[rho][x] with t1 rows rho-1 (Tm), rho (Tc), rho+1 (= row r, T) at columns x-1..x+1; rows of this
+        //      block's range only, so that every pixel is counted once
+        if (rho >= h0 && rho < h1) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                g1[0 * 3 + kx] = vfma(da1[1], Tm1[kx], g1[0 * 3 + kx]);
+                g2[0 * 3 + kx] = vfma(da2[1], Tm2[kx], g2[0 * 3 + kx]);
+                g1[1 * 3 + kx] = vfma(da1[1], Tc1[kx], g1[1 * 3 + kx]);
+                g2[1 * 3 + kx] = vfma(da2[1], Tc2[kx], g2[1 * 3 + kx]);
+                g1[2 * 3 + kx] = vfma(da1[1], T1[kx + 1], g1[2 * 3 + kx]);
+                g2[2 * 3 + kx] = vfma(da2[1], T2[kx + 1], g2[2 * 3 + kx]);
+            }
+            g1[9] = vadd(g1[9], da1[1]);
+            g2[9] = vadd(g2[9], da2[1]);
+        }
+        // ---- shift the pipelines
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A0_1[j] = A1_1[j]; A0_2[j] = A1_2[j];
+            A1_1[j] = A2_1[j]; A1_2[j] = A2_2[j];
+            Tm1[j] = Tc1[j]; Tm2[j] = Tc2[j];
+            Tc1[j] = T1[j + 1]; Tc2[j] = T2[j + 1];
+        }
+        B0_1 = B1_1; B0_2 = B1_2;
+        B1_1 = B2_1; B1_2 = B2_2;
+    }
+    float* part = p.part + ((int64_t)b * gridDim.y + bk.y) * 10 * C2;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        dw_block_reduce<VW>(red, g1[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + c1);
+        dw_block_reduce<VW>(red, g2[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + c2);
+    }
+}
+
 // Plain depthwise 3x3 (no bias, no gate) over Ctot channels (Restormer MDTA qkv_dwconv), plus per-block partial
 // sums of out^2 for the first nsq channels (the L2 norms of q and k over the pixels).
 template <int VW>
@@ -417,6 +571,15 @@ int nblk_for(const DwGeom& g, int quads) {
 }
 }  // namespace
 
+int dw_fused_vw() {   // channels per thread of the fused backward kernel (DCPT_DW_FUSED_VW overrides for experiments)
+    static int v = 0;
+    if (v == 0) {
+        const char* e = getenv("DCPT_DW_FUSED_VW");
+        v = (e && e[0] == '4') ? 4 : 2;
+    }
+    return v;
+}
+int dw_num_blocks_per_image_fused(const DwGeom& g) { return nblk_for(g, g.C / dw_fused_vw()); }
 int dw_num_blocks_per_image(const DwGeom& g) { return nblk_for(g, g.C / dw_vw()); }
 int dw_num_blocks_per_image_b(const DwGeom& g) { return nblk_for(g, 2 * g.C / dw_vw()); }
 
@@ -472,6 +635,22 @@ int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* d
     DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image_b(g), mp.nwc);
     DW_LAUNCH(dw_bwd_b_kernel, ><<<dim3(mp.nqc, dw_num_blocks_per_image_b(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_bwd_b");
+    return DCPT_OK;
+}
+
+int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                        float* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+    DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd: C=%d must be a multiple of 4", g.C);
+    DwP p{};
+    p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = dt1; p.part = wpart;
+    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
+    const int vw = dw_fused_vw();
+    const DwMap mp = dw_map(g.H, g.W, g.C / vw);
+    const int nblk = dw_num_blocks_per_image_fused(g);
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, nblk, mp.nwc);
+    if (vw == 2) dw_bwd_fused_kernel<2><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
+    else dw_bwd_fused_kernel<4><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("dw_bwd_fused");
     return DCPT_OK;
 }
 

@@ -41,6 +41,10 @@ int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const f
 // dt1 = dw3x3^T(da); wpart[B*NBLKb][10][2C] partial sums for dw2 (taps 0..8) and db2 (9)
 int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* dt1, float* wpart, const DwGeom& g,
                     hipStream_t s);
+// both of the above in one pass (da is never written): dt1 and wpart[B*NBLKf][10][2C], NBLKf = dw_num_blocks_per_image_fused
+int dw_num_blocks_per_image_fused(const DwGeom& g);
+int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                        float* dt1, float* wpart, const DwGeom& g, hipStream_t s);
 // dw2[ch*9+tap] and db2[ch] from wpart[R][10][C2]
 int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float* db2, hipStream_t s);
 

@@ -98,7 +98,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.ds_part = a.get<float>((size_t)B * sca_ds_num_blocks(P) * C);
     w.ds = a.get<float>((size_t)B * C);
     w.dpool = a.get<float>((size_t)B * C);
-    w.nblk_b = dw_num_blocks_per_image_b(g);
+    w.nblk_b = dw_num_blocks_per_image_fused(g);
     w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
     if (out) *out = w;
     return a.off;
@@ -258,8 +258,8 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_sca_ds_part(dts, sv->t2, w.ds_part, B, C, P, s));
     DCPT_TRY(launch_sca_dpool(w.ds_part, p->sca_w, w.dpool, B, C, P, s));
     // B9/B10: SimpleGate + depthwise conv backward
-    DCPT_TRY(launch_dw_bwd_a(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, da, dg, s));
-    DCPT_TRY(launch_dw_bwd_b(da, sv->t1, w.w2p, dt1, w.wpart, dg, s));
+    (void)da;   // the fused kernel keeps da on chip
+    DCPT_TRY(launch_dw_bwd_fused(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s));
     DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise and SCA partial sums
     DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, P, sw));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
