@@ -128,11 +128,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     }
     const rsrc_t rsC = make_rsrc(p.C + cbase);
     rsrc_t rsR = rsC, rsX = rsC;
-    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
     if constexpr (EK == E_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
     if constexpr (EK == E_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
     constexpr int HALF = (EK == E_SGBWD) ? 2 : 1;   // SGBWD needs two loads per row: do it in two halves
     constexpr int ITH = IT / HALF;
+    float4 dot = f4_zero();   // E_DOTCOL: this thread's part of the column sums
 #pragma unroll
     for (int hh = 0; hh < HALF; ++hh) {
         float4 pre1[ITH], pre2[ITH];
@@ -149,7 +150,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 if constexpr (EK == E_SCATTER_ADD) pre1[it] = buf_ld4(rsR, addr[it]);
             } else {
                 addr[it] = ok ? (uint32_t)rl * (uint32_t)p.ldc * 4u + coladd : ROW_SENT;
-                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL)
+                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL)
                     pre1[it] = buf_ld4(rsR, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
                 if constexpr (EK == E_SGBWD) {
                     const uint32_t xo = ok ? (uint32_t)rl * (uint32_t)p.N * 8u + coladd : ROW_SENT;
@@ -162,7 +163,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
         for (int it = 0; it < ITH; ++it) {
             const int rl = r0 + (hh * ITH + it) * RPP;
             const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * BN + 4 * q]);
-            if constexpr (EK == E_PLAIN || EK == E_SCATTER) {
+            if constexpr (EK == E_DOTCOL) {
+                buf_st4(rsC, addr[it], v);
+                dot = f4_fma(v, pre1[it], dot);   // rows past M loaded 0
+            } else if constexpr (EK == E_PLAIN || EK == E_SCATTER) {
                 buf_st4(rsC, addr[it], v);
             } else if constexpr (EK == E_BIAS) {
                 buf_st4(rsC, addr[it], f4_add(v, bias));
@@ -178,6 +182,19 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
             } else {  // E_SCATTER_ADD
                 buf_st4(rsC, addr[it], f4_add(v, pre1[it]));
             }
+        }
+    }
+    if constexpr (EK == E_DOTCOL) {
+        // column sums over the tile's rows: RPP row groups through LDS (the staged C tile is dead), fixed order
+        float* sm = const_cast<float*>(Cs);
+        __syncthreads();
+        *reinterpret_cast<float4*>(&sm[r0 * BN + 4 * q]) = dot;
+        __syncthreads();
+        if (r0 == 0 && nok) {
+            float4 t = *reinterpret_cast<const float4*>(&sm[4 * q]);
+#pragma unroll
+            for (int g = 1; g < RPP; ++g) t = f4_add(t, *reinterpret_cast<const float4*>(&sm[g * BN + 4 * q]));
+            stg4(p.colpart + (m0 / ROWS) * (int64_t)p.N + n, t);
         }
     }
 }
@@ -390,11 +407,12 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     if (aload == A_GATHER) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 4 * p.gC, "gemm_nt: gather needs K == 4*gC, gC %% 4 == 0");
     if (epi == E_BIASGATE)
         DCPT_CHECK_ARG(p.gate && p.N % 8 == 0 && (double)p.N * p.K * 4.0 < 1.0e9, "gemm_nt: gate epilogue needs gate != null, N %% 8 == 0");
+    if (epi == E_DOTCOL) DCPT_CHECK_ARG(p.colpart && p.res && p.nb1 * p.nb2 == 1, "gemm_nt: column-dot epilogue needs colpart and res");
     if (aload == A_CONV3) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 9 * p.gC, "gemm_nt: conv3 needs K == 9*gC, gC %% 4 == 0");
     // algorithmic work of this launch (for the live roofline in bench.py)
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : epi == E_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
-    if (epi == E_RESID || epi == E_SCATTER_ADD) bytes += mn;
+    if (epi == E_RESID || epi == E_SCATTER_ADD || epi == E_DOTCOL) bytes += mn;
     const double nbat = (double)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     ProfScope prof(s, PROF_NT + aload * 16 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
 #define CASE(AK, EK) \
@@ -416,6 +434,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_ADDSCALED)
     CASE(A_PLAIN, E_MUL)
     CASE(A_PLAIN, E_BIASGATE)
+    CASE(A_PLAIN, E_DOTCOL)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

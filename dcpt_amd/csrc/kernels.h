@@ -68,10 +68,11 @@ int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const fl
 int sca_ds_num_blocks(int P);
 // backward: part[b][j][k] = sum over the j-th pixel slice of image b of dts*t2  (j < sca_ds_num_blocks(P))
 int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B, int C, int P, hipStream_t s);
+// (the slices may also come out of the dts GEMM's E_DOTCOL epilogue: 128-pixel slices, nslices = P / 128)
 // critical path: dpool[b][k] = (1/P) sum_n Wsca[n][k] * sum_j part[b][j][n]
-int launch_sca_dpool(const float* ds_part, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s);
+int launch_sca_dpool(const float* ds_part, int nslices, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s);
 // parameter gradients (off the critical path): ds = sum_j part, dWsca = ds^T pooled, dbsca = sum_b ds
-int launch_sca_wgrad(const float* ds_part, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C, int P,
+int launch_sca_wgrad(const float* ds_part, int nslices, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C,
                      hipStream_t s);
 // dpool[b][k] = (sum_n Wsca[n][k]*ds[b][n]) / P ; dWsca[n][k] = sum_b ds[b][n]*pooled[b][k] ; dbsca[n] = sum_b ds[b][n]
 

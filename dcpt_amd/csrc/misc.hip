@@ -369,17 +369,16 @@ int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B,
     return DCPT_OK;
 }
 
-int launch_sca_dpool(const float* ds_part, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s) {
-    DCPT_CHECK_ARG(B <= 65535 && C * 4 <= 65536, "sca_dpool: B=%d C=%d", B, C);
-    sca_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), C * sizeof(float), s>>>(ds_part, sca_ds_num_blocks(P), Wsca, dpool, C,
-                                                                                 1.0f / (float)P);
+int launch_sca_dpool(const float* ds_part, int nslices, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s) {
+    DCPT_CHECK_ARG(B <= 65535 && C * 4 <= 65536 && nslices >= 1, "sca_dpool: B=%d C=%d", B, C);
+    sca_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), C * sizeof(float), s>>>(ds_part, nslices, Wsca, dpool, C, 1.0f / (float)P);
     DCPT_CHECK_LAUNCH("sca_dpool");
     return DCPT_OK;
 }
 
-int launch_sca_wgrad(const float* ds_part, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C, int P,
+int launch_sca_wgrad(const float* ds_part, int nslices, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C,
                      hipStream_t s) {
-    sca_ds_final_kernel<<<dim3(cdiv(B * C, 256)), dim3(256), 0, s>>>(ds_part, ds, B * C, C, sca_ds_num_blocks(P));
+    sca_ds_final_kernel<<<dim3(cdiv(B * C, 256)), dim3(256), 0, s>>>(ds_part, ds, B * C, C, nslices);
     DCPT_CHECK_LAUNCH("sca_ds_final");
     sca_bwd_w_kernel<<<dim3((unsigned)cdiv64((int64_t)C * C, 256), 2), dim3(256), 0, s>>>(ds, pooled, dWsca, dbsca, B, C);
     DCPT_CHECK_LAUNCH("sca_bwd_w");

@@ -232,9 +232,18 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(side_fork(sd, 2, s));      // dy, LN2 partial sums
     DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2*s)
+    // when an image is a whole number of 128-pixel GEMM tiles, SCA's ds[b][k] = sum_p dts * t2 comes out of this GEMM's epilogue
+    // as per-tile column sums (one bandwidth pass and one launch less)
+    const bool ds_fused = (P % 128 == 0) && (P / 128 <= sca_ds_num_blocks(P));
+    const int ds_slices = ds_fused ? P / 128 : sca_ds_num_blocks(P);
     g = GemmNT{};
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = dts; g.ldc = C;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    if (ds_fused) {
+        g.res = sv->t2; g.ldres = C; g.colpart = w.ds_part;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_DOTCOL, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    }
     // B7: conv3 / beta gradients (Y = t2*s)
     {
         // G = sum_m dy[m][n] * t2[m][k] * s[img(m)][k]: when every pixel chunk lies inside one image the scale leaves the
@@ -255,13 +264,13 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
         }
     }
     // B8: SCA backward
-    DCPT_TRY(launch_sca_ds_part(dts, sv->t2, w.ds_part, B, C, P, s));
-    DCPT_TRY(launch_sca_dpool(w.ds_part, p->sca_w, w.dpool, B, C, P, s));
+    if (!ds_fused) DCPT_TRY(launch_sca_ds_part(dts, sv->t2, w.ds_part, B, C, P, s));
+    DCPT_TRY(launch_sca_dpool(w.ds_part, ds_slices, p->sca_w, w.dpool, B, C, P, s));
     // B9/B10: SimpleGate + depthwise conv backward
     (void)da;   // the fused kernel keeps da on chip
     DCPT_TRY(launch_dw_bwd_fused(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s));
     DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise and SCA partial sums
-    DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, P, sw));
+    DCPT_TRY(launch_sca_wgrad(w.ds_part, ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
     // B11: grad w.r.t. LN1 output
     g = GemmNT{};
