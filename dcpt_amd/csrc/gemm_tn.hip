@@ -11,6 +11,17 @@
 #include "gemm_operand.h"
 #include "prof.h"
 
+#ifdef DCPT_TIMELINE
+// Diagnostic build only (tools/timeline_tn.py): per-block phase stamps (100 MHz wall clock) + shader cycles around the loop
+__device__ unsigned long long g_tl_tn[1 << 15][8];
+extern "C" int dcpt_timeline_read_tn(unsigned long long* host, int nblk) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl_tn), sizeof(unsigned long long) * 8 * (size_t)nblk);
+}
+#define TLT(i) if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < (1 << 15)) { g_tl_tn[blockIdx.x][i] = wall_clock64(); g_tl_tn[blockIdx.x][4 + i] = clock64(); }
+#else
+#define TLT(i)
+#endif
+
 namespace {
 
 constexpr int BR = 32;  // reduction rows per LDS tile
@@ -23,6 +34,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     static_assert(WN * WK == 4, "4 waves");
     static_assert(is_dma<XK>(), "X (the output gradient) is never transformed");
     GemmTN p = pin;
+    TLT(0)
     if (gridDim.y > 1) {
         const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
         p.X += b1 * p.sX1 + b2 * p.sX2;
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     }
     dma_wait_all();
     __syncthreads();
+    TLT(1)
     const int x_off = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
     const int y_off = (lane >> 5) * BKo + wk * TK * 32 + (lane & 31);
     for (int64_t t = 0; t < nmt; ++t) {
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
         __syncthreads();
     }
 
+    TLT(2)
     // slab stores through a buffer window at the tile's first element; rows past N / columns past K are dropped
     const rsrc_t rsS = make_rsrc(p.slab + (int64_t)split * p.N * p.K + (int64_t)n0 * p.K + k0);
 #pragma unroll
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
             }
         }
     if (do_cs && n0 + tid < p.N) p.colsum[((int64_t)split * tilesK + tile_k) * p.N + n0 + tid] = cs;
+    TLT(3)
 }
 
 template <int XK, int YK>
