@@ -581,7 +581,6 @@ int dw_fused_vw() {   // channels per thread of the fused backward kernel (DCPT_
 }
 int dw_num_blocks_per_image_fused(const DwGeom& g) { return nblk_for(g, g.C / dw_fused_vw()); }
 int dw_num_blocks_per_image(const DwGeom& g) { return nblk_for(g, g.C / dw_vw()); }
-int dw_num_blocks_per_image_b(const DwGeom& g) { return nblk_for(g, 2 * g.C / dw_vw()); }
 
 // a block's windows span its row range + halo: (rows/part + 5) * W * Ct floats must fit the 32-bit offsets
 #define DW_CHECK_RANGE(H, W, Ct, NBLK, NWC)                                                                             \
@@ -609,32 +608,6 @@ int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2,
     DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image(g), mp.nwc);
     DW_LAUNCH(dw_gate_kernel, , 0, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p));
     DCPT_CHECK_LAUNCH("dw_fwd");
-    return DCPT_OK;
-}
-
-int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg,
-                    const float* dpool, float* da, const DwGeom& g, hipStream_t s) {
-    DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd_a: C=%d must be a multiple of 4", g.C);
-    DwP p{};
-    p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = da;
-    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
-    const DwMap mp = dw_map(g.H, g.W, g.C / dw_vw());
-    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image(g), mp.nwc);
-    DW_LAUNCH(dw_gate_kernel, , 1, 0><<<dim3(mp.nqc, dw_num_blocks_per_image(g), g.B), dim3(256), 0, s>>>(p));
-    DCPT_CHECK_LAUNCH("dw_bwd_a");
-    return DCPT_OK;
-}
-
-int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* dt1, float* wpart, const DwGeom& g,
-                    hipStream_t s) {
-    DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd_b: C=%d must be a multiple of 4", g.C);
-    DwP p{};
-    p.in0 = da; p.in1 = t1; p.w2p = w2p; p.out = dt1; p.part = wpart;
-    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.Ctot = 2 * g.C;
-    const DwMap mp = dw_map(g.H, g.W, 2 * g.C / dw_vw());
-    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, dw_num_blocks_per_image_b(g), mp.nwc);
-    DW_LAUNCH(dw_bwd_b_kernel, ><<<dim3(mp.nqc, dw_num_blocks_per_image_b(g), g.B), dim3(256), 0, s>>>(p));
-    DCPT_CHECK_LAUNCH("dw_bwd_b");
     return DCPT_OK;
 }
 

@@ -30,18 +30,12 @@ struct DwGeom {
     int B, H, W, C;  // C = gated channels (t1 has 2C)
 };
 int dw_num_blocks_per_image(const DwGeom& g);            // NBLK for fwd / bwd_a (quads of C)
-int dw_num_blocks_per_image_b(const DwGeom& g);          // NBLK for bwd_b (quads of 2C)
 int launch_dw_pack_weights(const float* w2, float* w2p, int C2, hipStream_t s);  // [C2][9] -> [9][C2]
 // t2 = SG(dw3x3(t1) + b2); pool_part[B][NBLK][C] partial sums of t2
 int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2, float* pool_part, const DwGeom& g,
                   hipStream_t s);
-// da = SimpleGate-backward(dts * s + dpool; a = dw3x3(t1) + b2)     da: [M][2C]
-int launch_dw_bwd_a(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg,
-                    const float* dpool, float* da, const DwGeom& g, hipStream_t s);
-// dt1 = dw3x3^T(da); wpart[B*NBLKb][10][2C] partial sums for dw2 (taps 0..8) and db2 (9)
-int launch_dw_bwd_b(const float* da, const float* t1, const float* w2p, float* dt1, float* wpart, const DwGeom& g,
-                    hipStream_t s);
-// both of the above in one pass (da is never written): dt1 and wpart[B*NBLKf][10][2C], NBLKf = dw_num_blocks_per_image_fused
+// SimpleGate-backward + transposed depthwise + tap-gradient partials in one pass (da = gate-backward(dts * s + dpool) is never
+// written): dt1 and wpart[B*NBLKf][10][2C], NBLKf = dw_num_blocks_per_image_fused
 int dw_num_blocks_per_image_fused(const DwGeom& g);
 int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                         float* dt1, float* wpart, const DwGeom& g, hipStream_t s);
