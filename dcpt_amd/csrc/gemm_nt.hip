@@ -97,13 +97,15 @@ __device__ __forceinline__ void epilogue_gate(const GemmNT& p, const float* __re
 
 template <int EK, int ROWS, int BN, int NT_>
 __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __restrict__ Cs, int64_t m0, int n0, int tid) {
-    constexpr int Q = BN / 4;          // float4 groups per row
-    constexpr int RPP = NT_ / Q;       // rows per pass
+    constexpr int Q = BN / 4;                        // float4 groups per row
+    constexpr int QP = (NT_ % Q == 0) ? Q : 32;      // lanes per row (BN = 96: 24 of 32 lanes carry a group)
+    constexpr int RPP = NT_ / QP;                    // rows per pass
     constexpr int IT = ROWS / RPP;
+    static_assert(QP >= Q && ROWS % RPP == 0, "epilogue row map");
     const int ldres = p.ldres ? p.ldres : p.ldc;
-    const int q = tid % Q, r0 = tid / Q;
+    const int q = tid % QP, r0 = tid / QP;
     const int n = n0 + 4 * q;
-    const bool nok = n < p.N;
+    const bool nok = (QP == Q || q < Q) && n < p.N;
     float4 bias = f4_zero(), cs = make_float4(1.f, 1.f, 1.f, 1.f);
     if constexpr (EK == E_BIAS || EK == E_RESID || EK == E_MUL) {
         if (p.bias && nok) bias = ldg4(p.bias + n);
@@ -188,7 +190,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
         // column sums over the tile's rows: RPP row groups through LDS (the staged C tile is dead), fixed order
         float* sm = const_cast<float*>(Cs);
         __syncthreads();
-        *reinterpret_cast<float4*>(&sm[r0 * BN + 4 * q]) = dot;
+        if (QP == Q || q < Q) *reinterpret_cast<float4*>(&sm[r0 * BN + 4 * q]) = dot;
         __syncthreads();
         if (r0 == 0 && nok) {
             float4 t = *reinterpret_cast<const float4*>(&sm[4 * q]);
@@ -378,7 +380,19 @@ int launch_cfg(const GemmNT& p, hipStream_t s) {
     // 128 x 64 tiles when N is narrow, and also when 128 x 128 tiles would leave CUs with fewer than their two resident
     // blocks (small pixel counts, e.g. 128^2 training crops at the deepest level): twice the blocks, both SIMD wave slots busy
     const int64_t tiles128 = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
-    if (p.N <= 64 || tiles128 * nbatch <= 256) {
+    static const int smallk = getenv("DCPT_NT_SMALLK") ? atoi(getenv("DCPT_NT_SMALLK")) : 0;
+    static const int use96 = getenv("DCPT_NT_96") ? atoi(getenv("DCPT_NT_96")) : 1;
+    if constexpr (!GATE) {
+        // 96-wide tiles when they pad N less than 128-wide ones (Restormer's 96 / 192 / 288 / 576-channel layers)
+        if (use96 && p.N > 64 && cdiv(p.N, 96) * 96 < cdiv(p.N, 128) * 128 && cdiv64(p.M, 128) * cdiv(p.N, 96) * nbatch > 256) {
+            constexpr int BM = 128, BN = 96;
+            const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
+            gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
+            DCPT_CHECK_LAUNCH("gemm_nt");
+            return DCPT_OK;
+        }
+    }
+    if (p.N <= 64 || tiles128 * nbatch <= 256 || p.K <= smallk) {
         constexpr int BM = 128, BN = 64;
         const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
         gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);

@@ -42,10 +42,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
         p.slab += (int64_t)blockIdx.y * p.splits * p.N * p.K;
     }
     constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
-    constexpr int XQ = BN / 4, YQ = BKo / 4;           // float4 per tile row
-    constexpr int XR = 256 / XQ, YR = 256 / YQ;        // rows covered per pass
-    constexpr int X_IT = BR / XR, Y_IT = BR / YR;
+    // staging: pass i of the 256 threads covers tile floats [1024 i, 1024 i + 1024) of the row-major [BR][width] tile
+    constexpr int X_IT = BR * BN / 1024, Y_IT = BR * BKo / 1024;
     constexpr bool Y_DMA = is_dma<YK>();
+    static_assert(1024 % BKo == 0 || (Y_DMA && YK == A_PLAIN), "96-wide Y tiles: plain operand only");
+    static_assert(1024 % BN == 0 || XK == A_PLAIN, "96-wide X tiles: plain operand only");
     __shared__ __attribute__((aligned(16))) float Xs[2][BR * BN];
     __shared__ __attribute__((aligned(16))) float Ys[2][BR * BKo];
 
@@ -76,8 +77,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     open_window<XK>(ox, mbeg < p.M ? mbeg : 0);
     open_window<YK>(oy, mbeg < p.M ? mbeg : 0);
 
-    const int xrow = tid / XQ, xc = (tid % XQ) * 4;
-    const int yrow = tid / YQ, yc = (tid % YQ) * 4;
+    int xrow[X_IT], xc[X_IT], yrow[Y_IT], ycol[Y_IT];
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+        xrow[i] = (1024 * i + 4 * tid) / BN;
+        xc[i] = (1024 * i + 4 * tid) % BN;
+    }
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+        yrow[i] = (1024 * i + 4 * tid) / BKo;
+        ycol[i] = (1024 * i + 4 * tid) % BKo;
+    }
+    const int yc = ycol[0];   // the same in every pass when 1024 % BKo == 0 (the transformed-Y loaders)
     RawVec ry[Y_IT];
     RowCtx rcy[Y_IT];
     // A_LN / A_LNBF on Y: this thread always handles the same 4 columns, so weight/bias are loaded once
@@ -95,34 +106,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     // a few VALU per tile instead of 64-bit row arithmetic per piece.
     uint32_t xfix[X_IT], yfix[Y_IT];
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i) xfix[i] = (n0 + xc < p.N) ? ((uint32_t)(xrow + XR * i) * (uint32_t)p.ldx + (uint32_t)(n0 + xc)) * 4u : COL_SENT;
+    for (int i = 0; i < X_IT; ++i) xfix[i] = (n0 + xc[i] < p.N) ? ((uint32_t)xrow[i] * (uint32_t)p.ldx + (uint32_t)(n0 + xc[i])) * 4u : COL_SENT;
 #pragma unroll
-    for (int i = 0; i < Y_IT; ++i) yfix[i] = (k0 + yc < p.K) ? ((uint32_t)(yrow + YR * i) * (uint32_t)p.ldy + (uint32_t)(k0 + yc)) * 4u : COL_SENT;
+    for (int i = 0; i < Y_IT; ++i) yfix[i] = (k0 + ycol[i] < p.K) ? ((uint32_t)yrow[i] * (uint32_t)p.ldy + (uint32_t)(k0 + ycol[i])) * 4u : COL_SENT;
     auto gload = [&](int64_t mt, int buf) {
         const int left = (int)(mend - mt);                    // rows of the chunk from this tile on (wave-uniform)
         const uint32_t step = (uint32_t)(mt - mbeg);          // tile's first row inside the chunk
         if constexpr (XK == A_PLAIN) {
 #pragma unroll
             for (int i = 0; i < X_IT; ++i)
-                dma16(ox.rsd, lds_x + (buf * BR * BN + i * XR * BN) * 4, (xrow + XR * i < left) ? xfix[i] : ROW_SENT, step * (uint32_t)p.ldx * 4u);
+                dma16(ox.rsd, lds_x + (buf * BR * BN + i * 1024) * 4, (xrow[i] < left) ? xfix[i] : ROW_SENT, step * (uint32_t)p.ldx * 4u);
         } else {
 #pragma unroll
             for (int i = 0; i < X_IT; ++i) {
                 RowCtx rc;
-                make_row<XK>(ox, mt + xrow + XR * i, rc);
-                dma16(ox.rsd, lds_x + (buf * BR * BN + i * XR * BN) * 4, elem_voff<XK>(ox, rc, n0 + xc), 0);
+                make_row<XK>(ox, mt + xrow[i], rc);
+                dma16(ox.rsd, lds_x + (buf * BR * BN + i * 1024) * 4, elem_voff<XK>(ox, rc, n0 + xc[i]), 0);
             }
         }
         if constexpr (YK == A_PLAIN) {
 #pragma unroll
             for (int i = 0; i < Y_IT; ++i)
-                dma16(oy.rsd, lds_y + (buf * BR * BKo + i * YR * BKo) * 4, (yrow + YR * i < left) ? yfix[i] : ROW_SENT, step * (uint32_t)p.ldy * 4u);
+                dma16(oy.rsd, lds_y + (buf * BR * BKo + i * 1024) * 4, (yrow[i] < left) ? yfix[i] : ROW_SENT, step * (uint32_t)p.ldy * 4u);
         } else {
 #pragma unroll
             for (int i = 0; i < Y_IT; ++i) {
-                make_row<YK>(oy, mt + yrow + YR * i, rcy[i]);
+                make_row<YK>(oy, mt + yrow[i], rcy[i]);
                 if constexpr (Y_DMA) {
-                    dma16(oy.rsd, lds_y + (buf * BR * BKo + i * YR * BKo) * 4, elem_voff<YK>(oy, rcy[i], k0 + yc), 0);
+                    dma16(oy.rsd, lds_y + (buf * BR * BKo + i * 1024) * 4, elem_voff<YK>(oy, rcy[i], k0 + yc), 0);
                 } else {
                     load_raw<YK>(oy, rcy[i], k0 + yc, ry[i]);
                     if constexpr (YK == A_LN || YK == A_LNBF) {
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
         if constexpr (!Y_DMA) {
 #pragma unroll
             for (int i = 0; i < Y_IT; ++i)
-                *reinterpret_cast<float4*>(&Ys[buf][(yrow + YR * i) * BKo + yc]) = finish<YK>(rcy[i], ry[i]);
+                *reinterpret_cast<float4*>(&Ys[buf][1024 * i + 4 * tid]) = finish<YK>(rcy[i], ry[i]);
         }
     };
 
@@ -227,9 +238,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     TLT(3)
 }
 
+}  // namespace
+
+// Output-tile shape for an N x K gradient: 64 for narrow sides, otherwise whichever of 128 x 128, 128 x 96, 96 x 128 pads the
+// least (Restormer's 96 / 192 / 288 / 576-wide layers); the 96-wide tiles take plain operands and no column sums.
+static void tn_tile_shape(int N, int K, bool plain, int* bn, int* bk) {
+    *bn = (N <= 64) ? 64 : 128;
+    *bk = (K <= 64) ? 64 : 128;
+    static const int use96 = getenv("DCPT_TN_96") ? atoi(getenv("DCPT_TN_96")) : 1;
+    if (N <= 64 || K <= 64 || !plain || !use96) return;
+    const int64_t a128 = (int64_t)cdiv(N, 128) * 128 * cdiv(K, 128) * 128;
+    const int64_t a_k96 = (int64_t)cdiv(N, 128) * 128 * cdiv(K, 96) * 96;
+    const int64_t a_n96 = (int64_t)cdiv(N, 96) * 96 * cdiv(K, 128) * 128;
+    if (a_k96 < a128 && a_k96 <= a_n96) *bk = 96;
+    else if (a_n96 < a128) *bn = 96;
+}
+
+namespace {
+
 template <int XK, int YK>
 int launch_cfg(const GemmTN& p, hipStream_t s) {
     const unsigned nbatch = (unsigned)(p.nb1 * p.nb2);
+    constexpr bool PLAIN = (XK == A_PLAIN && YK == A_PLAIN);
+    int bn, bk;
+    tn_tile_shape(p.N, p.K, PLAIN && p.colsum == nullptr, &bn, &bk);   // colsum layouts assume gemm_tn_tiles_k()
+    if constexpr (PLAIN) {
+        if (bk == 96) {
+            const int tiles = cdiv(p.N, 128) * cdiv(p.K, 96);
+            gemm_tn_kernel<128, 96, 4, 1, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
+            DCPT_CHECK_LAUNCH("gemm_tn");
+            return DCPT_OK;
+        }
+        if (bn == 96) {
+            const int tiles = cdiv(p.N, 96) * cdiv(p.K, 128);
+            gemm_tn_kernel<96, 128, 1, 4, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
+            DCPT_CHECK_LAUNCH("gemm_tn");
+            return DCPT_OK;
+        }
+    }
     if (p.N <= 64 && p.K <= 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 64);
         gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
@@ -249,14 +295,15 @@ int launch_cfg(const GemmTN& p, hipStream_t s) {
 
 }  // namespace
 
-int gemm_tn_tiles_k(int N, int K) {
+int gemm_tn_tiles_k(int N, int K) {   // launches with column sums never use the 96-wide tiles
     (void)N;
     const int bk = (K <= 64) ? 64 : 128;
     return cdiv(K, bk);
 }
 
 void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split) {
-    const int bn = (N <= 64) ? 64 : 128, bk = (K <= 64) ? 64 : 128;
+    int bn, bk;
+    tn_tile_shape(N, K, true, &bn, &bk);   // (a transformed-operand launch of the same shape uses at most as many tiles)
     const int64_t tiles = (int64_t)cdiv(N, bn) * cdiv(K, bk);
     // 2 blocks are co-resident per CU (LDS), 256 CUs: aim at exactly one full wave of 512 blocks so
     // that no partially filled second wave trails the launch

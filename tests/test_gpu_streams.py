@@ -53,7 +53,10 @@ def test_side_stream_is_bit_identical(dev, c, shape):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(1, 16, 16, 16, 32), (2, 12, 20, 16, 16), (1, 9, 7, 36, 40), (1, 16, 16, 48, 200),
-                                         (3, 5, 5, 132, 4), (1, 20, 13, 256, 260)])
+                                         (3, 5, 5, 132, 4), (1, 20, 13, 256, 260),
+                                         # 96-wide GEMM tiles (chosen when they pad less than 128-wide ones and the grid is large)
+                                         (3, 128, 128, 96, 288), (3, 128, 128, 192, 96), (3, 128, 128, 256, 96),
+                                         (3, 128, 127, 100, 180), (3, 128, 128, 480, 96)])
 def test_conv1x1_ragged_shapes(dev, B, H, W, Ci, Co):
     """forward (NT GEMM), input gradient (NT) and weight gradient (TN, split slabs) of a bias-free 1x1 conv"""
     from dcpt_amd import functional as DF

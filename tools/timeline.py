@@ -5,12 +5,12 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dcpt_amd import functional as DF, _lib
 dev = torch.device('cuda:0')
-B, H, W = 32, 32, 32
+B, H, W = (int(v) for v in os.environ.get('TL_BHW', '32,32,32').split(','))
 Ci, Co = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 512)
 x = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=torch.channels_last); w = torch.randn(Co, Ci, 1, 1, device=dev)
 lib = _lib.load()
 rd = lib.dcpt_timeline_read; rd.restype = C.c_int; rd.argtypes = [C.c_void_p, C.c_int]
-nblk = (B * H * W // 128) * ((Co + 127) // 128)
+nblk = min(1 << 15, (B * H * W // 128) * ((Co + 127) // 128))
 with torch.no_grad():
     for _ in range(200): DF.conv_nobias(x, w)
     torch.cuda.synchronize()
