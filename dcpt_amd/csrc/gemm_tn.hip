@@ -305,13 +305,37 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
     int bn, bk;
     tn_tile_shape(N, K, true, &bn, &bk);   // (a transformed-operand launch of the same shape uses at most as many tiles)
     const int64_t tiles = (int64_t)cdiv(N, bn) * cdiv(K, bk);
-    // 2 blocks are co-resident per CU (LDS), 256 CUs: aim at exactly one full wave of 512 blocks so
-    // that no partially filled second wave trails the launch
-    int64_t want = 512 / tiles;
+    // 2 blocks are co-resident per CU (LDS), 256 CUs = 512 block slots.  Cost model in units of one reduction row of a block:
+    // rounds(s) * (rows per split + ~96 rows of prologue/epilogue) for the GEMM, plus the slab round trip (written here, read
+    // by the reducer) at ~2e-5 row units per slab element.  The common shapes land on one full round (tiles * s = 512); the
+    // model also handles shapes with more tiles than slots (a dense 3x3 at 1024 channels has 576: one split would run
+    // 1.125 rounds, 8 splits run 9.0) and keeps the split count low where the slab traffic would dominate.
     const int64_t max_by_rows = cdiv64(M, 256);  // at least 256 rows per split
-    if (want > max_by_rows) want = max_by_rows;
-    if (want < 1) want = 1;
-    if (want > 65535) want = 65535;
+    int64_t smax = 4 * 512 / tiles;
+    if (smax < 16) smax = 16;
+    if (smax > max_by_rows) smax = max_by_rows;
+    if (smax > 65535) smax = 65535;
+    if (smax < 1) smax = 1;
+    static const int plan_model = getenv("DCPT_TN_PLAN") ? atoi(getenv("DCPT_TN_PLAN")) : 1;
+    int64_t want = 1;
+    if (plan_model) {
+        double best = 1e300;
+        for (int64_t sp = 1; sp <= smax; ++sp) {
+            const int64_t r = cdiv64(cdiv64(M, sp), 32) * 32;
+            const int64_t nsp = cdiv64(M, r);
+            const double rounds = (double)cdiv64(tiles * nsp, 512);
+            const double cost = rounds * (double)(r + 96) + 2.0e-5 * (double)nsp * N * K;
+            if (cost < best * 0.999) {
+                best = cost;
+                want = sp;
+            }
+        }
+    } else {
+        want = 512 / tiles;
+        if (want > max_by_rows) want = max_by_rows;
+        if (want < 1) want = 1;
+        if (want > 65535) want = 65535;
+    }
     int64_t rps = cdiv64(cdiv64(M, want), 32) * 32;
     *rows_per_split = rps;
     *splits = (int)cdiv64(M, rps);
