@@ -1,8 +1,9 @@
 """Degradation-classifier head of DCPT, MI355X-native.
 
-Same registry name, constructor kwargs, ``forward(lq, features)`` contract and ``state_dict`` keys/shapes as
+Same registry names, constructor kwargs, ``forward(lq, features)`` contract and ``state_dict`` keys/shapes as
 the reference's ``PromptIR_NoImg_DC`` (basicsr/archs/degrad_classify_arch.py:558-641; 97 keys for
-feature_dims of length 4 with 2 blocks).  Every conv -> LayerNorm(channels) -> (+shortcut) -> ReLU group is one
+feature_dims of length 4 with 2 blocks) and ``PromptIR_DC`` (:480-555: the same head seeded by a 7x7 stride-2
+embedding of ``lq``, so its feature maps start at half the image resolution).  Every conv -> LayerNorm(channels) -> (+shortcut) -> ReLU group is one
 autograd node backed by ``dcpt_conv_ln_fwd/bwd`` (1x1 and dense 3x3 convolutions run as fp32 MFMA GEMMs, the 3x3
 as an implicit GEMM), the downsample layers by ``dcpt_conv1x1_pool_relu_*``, the softmax feature mixing by
 ``dcpt_mix_*`` and the head by ``dcpt_meanpool_fc_*``.  Child modules only own the parameters.
@@ -70,14 +71,11 @@ class _Downsample(nn.Sequential):
         return DF.conv1x1_pool_relu(x, self[0].weight)
 
 
-@ARCH_REGISTRY.register()
-class PromptIR_NoImg_DC(nn.Module):
-    def __init__(self, feature_dims, num_res_blocks=2, num_classes=3, downsample=False):
-        super().__init__()
-        if downsample:
-            raise NotImplementedError("downsample=True (token inputs) is not on the DCPT path")
+class _DCHead(nn.Module):
+    """stages shared by the two heads (reference :497-552 and :576-619 build the same modules)"""
+
+    def _build_stages(self, feature_dims, num_res_blocks, num_classes):
         self.feature_dims = list(feature_dims)
-        self.downsample = downsample
         self.bottleneck_layers = nn.ModuleList()
         self.downsample_layers = nn.ModuleList()
         for l, dim in enumerate(self.feature_dims):
@@ -91,12 +89,44 @@ class PromptIR_NoImg_DC(nn.Module):
         self.mixing_weights = nn.Parameter(torch.ones(len(self.bottleneck_layers)), requires_grad=True)
         self.fc = nn.Linear(last, num_classes)
 
-    def forward(self, lq, features):
-        """``lq`` is accepted and ignored, exactly like the reference (:621, SURVEY 8a D1)."""
-        x = None
+    def _run_stages(self, x, features):
         for i, feature in enumerate(features):
             x = DF.mix(x, feature, self.mixing_weights, i)
             x = self.bottleneck_layers[i](x)
             x = self.downsample_layers[i](x)
         x = self.last_stage(x)
         return DF.meanpool_fc(x, self.fc.weight, self.fc.bias)
+
+
+@ARCH_REGISTRY.register()
+class PromptIR_NoImg_DC(_DCHead):
+    def __init__(self, feature_dims, num_res_blocks=2, num_classes=3, downsample=False):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("downsample=True (token inputs) is not on the DCPT path")
+        self.downsample = downsample
+        self._build_stages(feature_dims, num_res_blocks, num_classes)
+
+    def forward(self, lq, features):
+        """``lq`` is accepted and ignored, exactly like the reference (:621, SURVEY 8a D1)."""
+        return self._run_stages(None, features)
+
+
+@ARCH_REGISTRY.register()
+class PromptIR_DC(_DCHead):
+    """reference :480-555.  ``features[i]`` must have the resolution of the embedded image at stage i (H/2, H/4, ...);
+    like the reference, anything else fails (there with a broadcast error in ``lq_feats + w * feature``)."""
+
+    def __init__(self, feature_dims, num_res_blocks=2, num_classes=3):
+        super().__init__()
+        self.conv_embed = nn.Sequential(nn.Conv2d(3, feature_dims[0], 7, 2, 3), LayerNorm(feature_dims[0]))
+        self._build_stages(feature_dims, num_res_blocks, num_classes)
+
+    def forward(self, lq, features):
+        conv, norm = self.conv_embed[0], self.conv_embed[1]
+        x = DF.conv_embed_ln(lq, conv.weight, conv.bias, norm.weight, norm.bias, stride=2, pad=3)
+        for i, feature in enumerate(features):
+            want = (x.shape[0], self.feature_dims[i], x.shape[2] >> i, x.shape[3] >> i)
+            if tuple(feature.shape) != want:
+                raise RuntimeError(f"PromptIR_DC: feature {i} has shape {tuple(feature.shape)}, the embedded image needs {want}")
+        return self._run_stages(x, features)

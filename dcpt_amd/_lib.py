@@ -109,6 +109,8 @@ SIGNATURES = {
     "dcpt_meanpool_fc_ws_bytes": (sz, [cint, cint, cint]),
     "dcpt_meanpool_fc_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_meanpool_fc_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_patch_unfold": (cint, [f32p, f32p, cint, cint, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_patch_fold": (cint, [f32p, f32p, cint, cint, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint, cint]),
     "dcpt_conv_fwd": (cint, [f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint, stream_t]),

@@ -482,3 +482,91 @@ extern "C" int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, c
     DCPT_CHECK_LAUNCH("bcast_rows");
     return DCPT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Image embedding of PromptIR_DC (reference basicsr/archs/degrad_classify_arch.py:491-494: Conv2d(3, dim, 7, stride 2, pad 3)
+// + bias -> LayerNorm): the strided 7x7 over a 3-channel NCHW image is unfolded into patch rows
+//   A[m][k],  m = (b, oy, ox),  k = (c * ks + ky) * ks + kx  (the weight's own (Cin, ks, ks) order),
+// followed by one column of ones (so the conv bias is one more weight column) and zero padding to a multiple of 4 columns;
+// the product runs on the fp32 MFMA GEMM + LayerNorm path of the head (dcpt_conv_ln_*, 1x1 over the patch rows).
+namespace {
+
+__global__ __launch_bounds__(256) void patch_unfold_kernel(const float* __restrict__ x, float* __restrict__ A, int B, int Cin, int H, int W,
+                                                           int Ho, int Wo, int ks, int stride, int pad, int Kp) {
+    const int nq = Kp / 4;
+    const int64_t total = (int64_t)B * Ho * Wo * nq;
+    const int kreal = Cin * ks * ks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % nq);
+        const int64_t m = i / nq;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int b = (int)(m / ((int64_t)Wo * Ho));
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * q + j;
+            float t = 0.f;
+            if (k < kreal) {
+                const int kx = k % ks, ky = (k / ks) % ks, c = k / (ks * ks);
+                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) t = x[(((int64_t)b * Cin + c) * H + iy) * W + ix];
+            } else if (k == kreal) {
+                t = 1.f;
+            }
+            v[j] = t;
+        }
+        stg4(A + m * Kp + 4 * q, make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
+// gradient of the image: every input element gathers the patch entries it was copied to (fixed order, no atomics)
+__global__ __launch_bounds__(256) void patch_fold_kernel(const float* __restrict__ dA, float* __restrict__ dx, int B, int Cin, int H, int W,
+                                                         int Ho, int Wo, int ks, int stride, int pad, int Kp) {
+    const int64_t total = (int64_t)B * Cin * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(i % W);
+        const int iy = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % Cin);
+        const int b = (int)(i / ((int64_t)W * H * Cin));
+        float s = 0.f;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || ty % stride != 0 || ty / stride >= Ho) continue;
+            const int oy = ty / stride;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || tx % stride != 0 || tx / stride >= Wo) continue;
+                const int ox = tx / stride;
+                s += dA[(((int64_t)b * Ho + oy) * Wo + ox) * Kp + (c * ks + ky) * ks + kx];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int dcpt_patch_unfold(const float* x, float* A, int B, int Cin, int H, int W, int ksize, int stride, int pad, int Kp,
+                                 dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(x && A && B > 0 && Cin > 0 && H > 0 && W > 0 && ksize > 0 && stride > 0 && pad >= 0, "patch_unfold: bad argument");
+    DCPT_CHECK_ARG(Kp % 4 == 0 && Kp >= Cin * ksize * ksize + 1, "patch_unfold: Kp=%d must be a multiple of 4 and >= Cin*k*k + 1", Kp);
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    DCPT_CHECK_ARG(Ho > 0 && Wo > 0, "patch_unfold: image smaller than the kernel");
+    patch_unfold_kernel<<<dim3(grid_for((int64_t)B * Ho * Wo * (Kp / 4))), dim3(256), 0, (hipStream_t)stream>>>(x, A, B, Cin, H, W, Ho, Wo, ksize,
+                                                                                                          stride, pad, Kp);
+    DCPT_CHECK_LAUNCH("patch_unfold");
+    return DCPT_OK;
+}
+
+extern "C" int dcpt_patch_fold(const float* dA, float* dx, int B, int Cin, int H, int W, int ksize, int stride, int pad, int Kp,
+                               dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(dA && dx && B > 0 && Cin > 0 && H > 0 && W > 0 && ksize > 0 && stride > 0 && pad >= 0, "patch_fold: bad argument");
+    DCPT_CHECK_ARG(Kp % 4 == 0 && Kp >= Cin * ksize * ksize + 1, "patch_fold: Kp=%d must be a multiple of 4 and >= Cin*k*k + 1", Kp);
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    DCPT_CHECK_ARG(Ho > 0 && Wo > 0, "patch_fold: image smaller than the kernel");
+    patch_fold_kernel<<<dim3(grid_for((int64_t)B * Cin * H * W)), dim3(256), 0, (hipStream_t)stream>>>(dA, dx, B, Cin, H, W, Ho, Wo, ksize, stride,
+                                                                                                   pad, Kp);
+    DCPT_CHECK_LAUNCH("patch_fold");
+    return DCPT_OK;
+}

@@ -457,6 +457,48 @@ def conv_ln(x, weight, lnw, lnb, res=None, relu=True):
     return _ConvLNFn.apply(x, weight, lnw, lnb, res, relu)
 
 
+class _PatchUnfoldFn(torch.autograd.Function):
+    """NCHW image -> patch rows (B, Kp, Ho, Wo) in NHWC memory, last real column = 1 (carries the conv bias);
+    the unfolding half of PromptIR_DC.conv_embed (degrad_classify_arch.py:491-494)."""
+
+    @staticmethod
+    def forward(ctx, x, ksize, stride, pad):
+        lib = _lib.load()
+        _require_gpu(x)
+        x = _contig(x)
+        B, Cin, H, W = x.shape
+        Kp = (Cin * ksize * ksize + 1 + 3) // 4 * 4
+        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        A = _empty_nhwc(B, Kp, Ho, Wo, x.device)
+        check(lib.dcpt_patch_unfold(x.data_ptr(), A.data_ptr(), B, Cin, H, W, ksize, stride, pad, Kp, _stream(x.device)),
+              "dcpt_patch_unfold")
+        ctx.geom = (B, Cin, H, W, ksize, stride, pad, Kp)
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        lib = _lib.load()
+        B, Cin, H, W, ksize, stride, pad, Kp = ctx.geom
+        dA = _nhwc(dA)
+        dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dA.device)
+        check(lib.dcpt_patch_fold(dA.data_ptr(), dx.data_ptr(), B, Cin, H, W, ksize, stride, pad, Kp, _stream(dA.device)),
+              "dcpt_patch_fold")
+        return dx, None, None, None
+
+
+def conv_embed_ln(x, weight, bias, lnw, lnb, stride=2, pad=3):
+    """Conv2d(Cin, dim, k, stride, pad) + bias -> channels-first LayerNorm (PromptIR_DC.conv_embed, :491-494):
+    patch rows x [weight | bias | 0] on the MFMA GEMM, LayerNorm fused behind it."""
+    dim, cin, ks, _ = weight.shape
+    A = _PatchUnfoldFn.apply(x, ks, stride, pad)
+    kp = A.shape[1]
+    cols = [weight.reshape(dim, cin * ks * ks), bias.reshape(dim, 1)]
+    if kp > cin * ks * ks + 1:
+        cols.append(weight.new_zeros(dim, kp - cin * ks * ks - 1))
+    wext = torch.cat(cols, dim=1).reshape(dim, kp, 1, 1)
+    return conv_ln(A, wext, lnw, lnb, None, relu=False)
+
+
 class _ConvPoolReluFn(torch.autograd.Function):
     """Conv2d(1x1, bias=False) -> MaxPool2d(2,2) -> ReLU (degrad_classify_arch.py:596-602)."""
 

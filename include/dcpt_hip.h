@@ -161,6 +161,14 @@ int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float* fb, float
                          int B, int P, int C, int NC, dcpt_stream_t stream);
 int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, const float* fw, float* dx, float* dfw, float* dfb, void* ws,
                          size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream);
+/* PromptIR_DC.conv_embed (:491-494, Conv2d(3, dim, 7, 2, 3) + bias -> LayerNorm): the strided conv over the NCHW image is
+ * unfolded into patch rows A[(b,oy,ox)][Kp], column k = (c*ksize + ky)*ksize + kx (the weight's own order), column
+ * Cin*ksize*ksize = 1 (the bias column), the rest 0 up to Kp (a multiple of 4); the product + LayerNorm then run through
+ * dcpt_conv_ln_* as a 1x1 conv over the patch rows.  dcpt_patch_fold is the gradient of the image (gather, fixed order). */
+int dcpt_patch_unfold(const float* x, float* A, int B, int Cin, int H, int W, int ksize, int stride, int pad, int Kp,
+                      dcpt_stream_t stream);
+int dcpt_patch_fold(const float* dA, float* dx, int B, int Cin, int H, int W, int ksize, int stride, int pad, int Kp,
+                    dcpt_stream_t stream);
 
 /* plain conv (ksize 1 or dense 3x3 / pad 1, no bias), NHWC -> NHWC: Restormer Downsample/Upsample convs
  * (restormer_arch.py:179-185,194-200) and reduce_chan_level{2,3} (:300-302,:315-317) */

@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure, not product code) -- CPU restatement of the degradation-classifier head
-``PromptIR_NoImg_DC`` (reference basicsr/archs/degrad_classify_arch.py:558-641) in plain PyTorch fp32.
-Pinned by tests/golden/dc_head.npz (oracle/make_golden.py imports the real reference).
+``PromptIR_NoImg_DC`` (reference basicsr/archs/degrad_classify_arch.py:558-641) and of ``PromptIR_DC`` (:480-555, the
+variant seeded by a 7x7 stride-2 embedding of the image) in plain PyTorch fp32.
+Pinned by tests/golden/dc_head.npz and tests/golden/dc_img_head.npz (oracle/make_golden.py imports the real reference).
 Functional: parameters come as a flat dict keyed by the reference's state-dict names."""
 from __future__ import annotations
 
@@ -25,13 +26,13 @@ def bottleneck(x, P, pre):
     return F.relu(out + x)
 
 
-def dc_forward(features, P):
+def dc_forward(features, P, x0=0):
     """PromptIR_NoImg_DC.forward (:621-641) with downsample=False; ``lq`` is ignored by the reference.
-    features: list of NCHW maps, highest resolution first."""
+    features: list of NCHW maps, highest resolution first.  ``x0``: running map before the first stage."""
     n = len(features)
     mix = torch.softmax(P["mixing_weights"], dim=0)  # F.softmax without dim on a 1-D tensor -> dim 0 (:633)
     nblk = len({k.split(".")[2] for k in P if k.startswith("bottleneck_layers.0.")})
-    x = 0
+    x = x0
     for i, f in enumerate(features):
         x = x + mix[i] * f
         for b in range(nblk):
@@ -43,8 +44,21 @@ def dc_forward(features, P):
     return F.linear(x, P["fc.weight"], P["fc.bias"])
 
 
-def dc_param_shapes(feature_dims, num_res_blocks=2, num_classes=3):
+def dc_img_forward(lq, features, P):
+    """PromptIR_DC.forward (:546-555): lq_feats = LayerNorm(Conv2d(3, dim0, 7, stride 2, pad 3)(lq)) (:491-494), then the
+    same stages as above starting from lq_feats (features[0] lives at half the image resolution)."""
+    e = F.conv2d(lq, P["conv_embed.0.weight"], P["conv_embed.0.bias"], stride=2, padding=3)
+    e = layernorm_cf(e, P["conv_embed.1.weight"], P["conv_embed.1.bias"])
+    return dc_forward(features, P, x0=e)
+
+
+def dc_param_shapes(feature_dims, num_res_blocks=2, num_classes=3, img_embed=False):
     shapes = {"mixing_weights": (len(feature_dims),)}
+    if img_embed:
+        shapes["conv_embed.0.weight"] = (feature_dims[0], 3, 7, 7)
+        shapes["conv_embed.0.bias"] = (feature_dims[0],)
+        shapes["conv_embed.1.weight"] = (feature_dims[0],)
+        shapes["conv_embed.1.bias"] = (feature_dims[0],)
 
     def block(pre, c):
         for name, (co, ci, k) in (("conv1", (2 * c, c, 1)), ("conv2", (2 * c, 2 * c, 3)), ("conv3", (c, 2 * c, 1))):

@@ -168,6 +168,46 @@ def gen_dc_head(ref):
     np.savez_compressed(os.path.join(OUT, "dc_head.npz"), **out)
 
 
+def gen_dc_img_head(ref):
+    """PromptIR_DC (degrad_classify_arch.py:480-555): 7x7 stride-2 image embedding + LayerNorm, then the same stages; the
+    feature maps live at H/2, H/4, ... of the image.  CE loss, gradients of the image, the features and the parameters.
+    Also records that the reference rejects feature maps at the image resolution (NAFNet's taps)."""
+    net = ref.dc.PromptIR_DC(**DC_CFG)
+    fill_module_(net, seed=0)
+    lq = keyed_input("dci.lq", (3, 3, 36, 28)).requires_grad_(True)
+    # (36 x 28 embeds to 18 x 14, which MaxPool2d floors to 9 x 7 -> 4 x 3: that image only exercises the embedding;
+    # the four-stage path uses a power-of-two image)
+    lq2 = keyed_input("dci.lq2", (2, 3, 64, 32)).requires_grad_(True)
+    feats2 = [keyed_input(f"dci.g{i}", (2, c, 32 >> i, 16 >> i), lo=-1.0, hi=1.0).requires_grad_(True)
+              for i, c in enumerate(DC_CFG["feature_dims"])]
+    labels = torch.tensor([5, 2])
+    logits = net(lq2, list(feats2))
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out = {"logits": _np(logits), "loss": np.float64(loss.item()), "dlq": _np(lq2.grad)}
+    for i, f in enumerate(feats2):
+        out[f"df{i}"] = _np(f.grad)
+    names, l2, sm, ab = _grad_summary(net)
+    out["g_names"], out["g_l2"], out["g_sum"], out["g_abs"] = names, l2, sm, ab
+    for k, p in net.named_parameters():
+        if p.numel() <= 4096 or k.startswith("conv_embed."):
+            out["g." + k] = _np(p.grad)
+    out["keys"] = np.array(list(net.state_dict().keys()))
+    # the embedding alone on an odd-sized image (36 x 28 -> 18 x 14), with its input gradient
+    e = net.conv_embed(lq)
+    ge = keyed_input("dci.ge", tuple(e.shape), lo=-1.0, hi=1.0)
+    (dlq,) = torch.autograd.grad((e * ge).sum(), lq)
+    out["embed"], out["embed_dlq"] = _np(e), _np(dlq)
+    lq3 = keyed_input("dci.lq3", (1, 3, 37, 29))
+    out["embed_odd"] = _np(net.conv_embed(lq3))
+    try:  # features at the image resolution (what net_g's decoder taps have): shape error in the reference
+        net(lq2.detach(), [keyed_input("dci.bad", (2, 8, 64, 32))] + [f.detach() for f in feats2[1:]])
+        out["full_res_features_fail"] = np.array(False)
+    except RuntimeError:
+        out["full_res_features_fail"] = np.array(True)
+    np.savez_compressed(os.path.join(OUT, "dc_img_head.npz"), **out)
+
+
 def gen_dcpt_step(ref):
     """Re-enact DCPTModel.optimize_parameters (degradation_classification_pretrain_model.py:133-169) with the
     reference archs: net_g(gt) -> L1; net_g(lq, hook=True) with hooks on decoder{i}.0; net_dc(taps[::-1]) -> CE;
@@ -252,6 +292,7 @@ def main():
     gen_nafnet_full(ref)
     gen_tlsc(ref)
     gen_dc_head(ref)
+    gen_dc_img_head(ref)
     gen_dcpt_step(ref)
     gen_restormer(ref)
     for f in sorted(os.listdir(OUT)):

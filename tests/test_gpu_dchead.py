@@ -140,3 +140,48 @@ def test_dc_head_golden(dev, golden_dir):
     for k in g.files:
         if k.startswith("g.") and k != "g_names":
             check("grad " + k[2:], params[k[2:]].grad, g[k], 1e-3)
+
+
+def test_dc_img_head_golden(dev, golden_dir):
+    """PromptIR_DC (reference :480-555): embedding (patch rows -> MFMA GEMM + LayerNorm) + stages vs the real reference"""
+    from basicsr.archs import build_network
+    from dcpt_amd import functional as DF
+
+    g = np.load(os.path.join(golden_dir, "dc_img_head.npz"))
+    net = build_network(dict(type="PromptIR_DC", **DC_CFG))
+    sd = keyed_state_dict(D.dc_param_shapes(**DC_CFG, img_embed=True), seed=0)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    lq2 = keyed_input("dci.lq2", (2, 3, 64, 32)).to(dev).requires_grad_(True)
+    feats = [keyed_input(f"dci.g{i}", (2, c, 32 >> i, 16 >> i), lo=-1.0, hi=1.0).to(dev).requires_grad_(True)
+             for i, c in enumerate(DC_CFG["feature_dims"])]
+    logits = net(lq2, feats)
+    loss = F.cross_entropy(logits, torch.tensor([5, 2], device=dev))
+    loss.backward()
+    check("logits", logits, g["logits"], 1e-4)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    check("dlq", lq2.grad, g["dlq"], 1e-3)
+    for i, f in enumerate(feats):
+        check(f"df{i}", f.grad, g[f"df{i}"], 1e-3)
+    params = dict(net.named_parameters())
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(params[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 1e-3 * max(1e-9, l2), (n, mine, l2)
+    for k in g.files:
+        if k.startswith("g.") and k != "g_names":
+            check("grad " + k[2:], params[k[2:]].grad, g[k], 1e-3)
+    # the embedding alone on odd-sized images (36 x 28 -> 18 x 14, 37 x 29 -> 19 x 15), with its image gradient
+    conv, norm = net.conv_embed[0], net.conv_embed[1]
+    lq = keyed_input("dci.lq", (3, 3, 36, 28)).to(dev).requires_grad_(True)
+    e = DF.conv_embed_ln(lq, conv.weight, conv.bias, norm.weight, norm.bias)
+    check("embed", e, g["embed"], 2e-5)
+    (dlq,) = torch.autograd.grad((e * keyed_input("dci.ge", tuple(e.shape), lo=-1.0, hi=1.0).to(dev)).sum(), lq)
+    check("embed dlq", dlq, g["embed_dlq"], 1e-4)
+    with torch.no_grad():
+        check("embed odd", DF.conv_embed_ln(keyed_input("dci.lq3", (1, 3, 37, 29)).to(dev), conv.weight, conv.bias, norm.weight,
+                                            norm.bias), g["embed_odd"], 2e-5)
+    # like the reference, feature maps at the image resolution (NAFNet's taps) are rejected
+    assert bool(g["full_res_features_fail"])
+    with pytest.raises(RuntimeError):
+        net(lq2.detach(), [keyed_input("dci.bad", (2, 8, 64, 32)).to(dev)] + [f.detach() for f in feats[1:]])

@@ -135,6 +135,44 @@ def test_dc_head(golden_dir):
             assert np.abs(P[k[2:]].grad.numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), k
 
 
+def test_dc_img_head(golden_dir):
+    """PromptIR_DC (7x7 stride-2 image embedding + the same stages) == the reference: logits, loss, image / feature /
+    parameter gradients, the embedding on odd-sized images, and the reference's refusal of full-resolution features"""
+    from oracle import dc_oracle as D
+
+    g = np.load(os.path.join(golden_dir, "dc_img_head.npz"))
+    cfg = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+    shapes = D.dc_param_shapes(**cfg, img_embed=True)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]] and len(shapes) == 101
+    P = _req(keyed_state_dict(shapes, seed=0))
+    lq2 = keyed_input("dci.lq2", (2, 3, 64, 32)).requires_grad_(True)
+    feats = [keyed_input(f"dci.g{i}", (2, c, 32 >> i, 16 >> i), lo=-1.0, hi=1.0).requires_grad_(True)
+             for i, c in enumerate(cfg["feature_dims"])]
+    logits = D.dc_img_forward(lq2, feats, P)
+    loss = torch.nn.functional.cross_entropy(logits, torch.tensor([5, 2]))
+    loss.backward()
+    _close(logits, g["logits"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for name, t in [("dlq", lq2)] + [(f"df{i}", f) for i, f in enumerate(feats)]:
+        ref = g[name]
+        assert np.abs(t.grad.numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), name
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(P[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 1e-4 * max(1e-6, l2), (n, mine, l2)
+    for k in g.files:
+        if k.startswith("g.") and k != "g_names":
+            ref = g[k]
+            assert np.abs(P[k[2:]].grad.numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), k
+    with torch.no_grad():
+        embed = lambda x: D.layernorm_cf(torch.nn.functional.conv2d(x, P["conv_embed.0.weight"], P["conv_embed.0.bias"], stride=2,
+                                                                    padding=3), P["conv_embed.1.weight"], P["conv_embed.1.bias"])
+        _close(embed(keyed_input("dci.lq", (3, 3, 36, 28))), g["embed"], rtol=1e-4, atol=1e-5)
+        _close(embed(keyed_input("dci.lq3", (1, 3, 37, 29))), g["embed_odd"], rtol=1e-4, atol=1e-5)
+    assert bool(g["full_res_features_fail"])
+    with pytest.raises(RuntimeError):
+        D.dc_img_forward(lq2.detach(), [keyed_input("dci.bad", (2, 8, 64, 32))] + [f.detach() for f in feats[1:]], P)
+
+
 def test_dcpt_step(golden_dir):
     """oracle re-enactment of DCPTModel.optimize_parameters == the reference's (losses + all grad norms)."""
     from oracle import dc_oracle as D

@@ -57,6 +57,23 @@ def test_registry_contract():
         r.get("nope")
     with pytest.raises(AssertionError):
         r.register(A)
+    # the names the reference's option files resolve, auto-imported by file-name suffix
+    import basicsr.archs  # noqa: F401
+    import basicsr.models  # noqa: F401
+    from basicsr.utils.registry import MODEL_REGISTRY
+
+    for name in ("NAFNetBaseline", "NAFNet", "Restormer", "Restormer_origin", "PromptIR_NoImg_DC", "PromptIR_DC"):
+        assert name in ARCH_REGISTRY, name
+    for name in ("SRModel", "DCPTModel", "DCTModel", "DCModel"):
+        assert name in MODEL_REGISTRY, name
+    # PromptIR_DC: the reference's 101 state-dict keys (mixing_weights first, then conv_embed.{0,1}.{weight,bias})
+    net = ARCH_REGISTRY.get("PromptIR_DC")(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+    keys = list(net.state_dict().keys())
+    assert len(keys) == 101 and keys[:5] == ["mixing_weights", "conv_embed.0.weight", "conv_embed.0.bias", "conv_embed.1.weight",
+                                             "conv_embed.1.bias"]
+    assert tuple(net.conv_embed[0].weight.shape) == (8, 3, 7, 7) and net.conv_embed[0].stride == (2, 2)
+    with pytest.raises(TypeError):
+        ARCH_REGISTRY.get("PromptIR_DC")(feature_dims=[8], downsample=False)   # not a kwarg of this head in the reference
 
 
 def test_parse_options_and_force_yml(tmp_path):
