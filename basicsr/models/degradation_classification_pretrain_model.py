@@ -56,8 +56,9 @@ class DCPTModel(BaseModel):
         hook_names = self.opt.get("hook_names", None)
         if hook_names is None:
             raise ValueError("hook_names is required (e.g. 'decoder' for NAFNet, 'decoder_level' for Restormer)")
-        for name, module in self.net_g.named_modules():
-            if hook_names in name and name.count(".") == 1:  # reference :65-68
+        # reference :65-68 (it walks the wrapped net, whose names gain a "module." prefix under DDP and then never match)
+        for name, module in self.get_bare_model(self.net_g).named_modules():
+            if hook_names in name and name.count(".") == 1:
                 self.hooks.append(module.register_forward_hook(self.hook_forward_fn))
         if not self.hooks:
             raise ValueError(f"no module of net_g matches hook_names={hook_names!r}")

@@ -243,6 +243,49 @@ def gen_dcpt_step(ref):
     np.savez_compressed(os.path.join(OUT, "dcpt_step.npz"), **out)
 
 
+DIST_G = dict(dim=16, num_blocks=[4, 6, 6, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
+DIST_DC = dict(feature_dims=[32, 32, 64], num_res_blocks=1, num_classes=5)
+
+
+def gen_dcdist_step(ref):
+    """Re-enact DCDistModel.optimize_parameters (degradation_classification_distillation_model.py:152-185) with the reference
+    archs: hooks on block 5 of decoder_level3/2 and block 3 of decoder_level1 of Restormer_origin (:81-88), ONE forward of
+    net_g(lq), frozen eval net_dc on the reversed taps, L1 + CE, one backward.  Stores the losses, the logits, the restored
+    image and every parameter-gradient norm of net_g."""
+    net_g = ref.restormer.Restormer_origin(**DIST_G)
+    net_dc = ref.dc.PromptIR_NoImg_DC(**DIST_DC)
+    fill_module_(net_g, seed=0)
+    fill_module_(net_dc, seed=0)
+    net_dc.eval()
+    for p in net_dc.parameters():
+        p.requires_grad = False
+    taps, hooked = [], []
+    for name, module in net_g.named_modules():
+        if "decoder_level" in name and name.count(".") == 1:
+            pre, idx = name.split(".")[0], int(name.split(".")[-1])
+            if (idx == 5 and int(pre[-1]) in [2, 3]) or (idx == 3 and int(pre[-1]) == 1):
+                module.register_forward_hook(lambda m, i, o: taps.append(o))
+                hooked.append(name)
+    lq = keyed_input("dist.lq", (2, 3, 32, 32))
+    gt = keyed_input("dist.gt", (2, 3, 32, 32))
+    labels = torch.tensor([4, 1])
+    pix = net_g(lq)
+    assert len(taps) == 3
+    cls = net_dc(lq, taps[::-1])
+    l_pix = (pix - gt).abs().mean()
+    l_cls = torch.nn.functional.cross_entropy(cls, labels)
+    (l_pix + l_cls).backward()
+    assert all(p.grad is None for p in net_dc.parameters())
+    out = {"l_pixel": np.float64(l_pix.item()), "l_classify": np.float64(l_cls.item()), "logits": _np(cls), "pix": _np(pix),
+           "hooked": np.array(hooked), "tap_shapes": np.array([list(t.shape) for t in taps])}
+    names, l2, sm, ab = _grad_summary(net_g)
+    out["g_names"], out["g_l2"], out["g_sum"] = names, l2, sm
+    for k in ("patch_embed.proj.weight", "output.weight", "decoder_level1.3.ffn.project_out.weight", "decoder_level3.5.attn.temperature",
+              "refinement.0.norm1.body.weight"):
+        out["g." + k] = _np(dict(net_g.named_parameters())[k].grad)
+    np.savez_compressed(os.path.join(OUT, "dcdist_step.npz"), **out)
+
+
 R_CFG = dict(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
 
 
@@ -294,6 +337,7 @@ def main():
     gen_dc_head(ref)
     gen_dc_img_head(ref)
     gen_dcpt_step(ref)
+    gen_dcdist_step(ref)
     gen_restormer(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

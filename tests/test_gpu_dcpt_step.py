@@ -97,3 +97,97 @@ def test_variants_vs_oracle(model_type, recon_on_lq, freeze):
             assert float((p.grad.cpu() - ref).abs().max()) <= 2e-3 * max(1e-7, float(ref.abs().max())), name
     m.test()
     assert m.cls_output.shape == (2, 10)
+
+
+# ------------------------------------------------------------------------------------------------
+DIST_G = dict(dim=16, num_blocks=[4, 6, 6, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
+DIST_DC = dict(feature_dims=[32, 32, 64], num_res_blocks=1, num_classes=5)
+
+
+def _dist_model(**over):
+    from basicsr.archs import build_network
+    from basicsr.models import build_model
+
+    opt = dict(name="t", model_type="DCDistModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+               hook_names="decoder_level", network_g=dict(type="Restormer_origin", **DIST_G),
+               network_dc=dict(type="PromptIR_NoImg_DC", **DIST_DC), path=dict(),
+               train=dict(pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"),
+                          classify_opt=dict(type="CrossEntropyLoss", loss_weight=1.0), optim_g=dict(type="SGD", lr=0.0)))
+    opt.update(over)
+    m = build_model(opt)
+    shapes = {k: tuple(v.shape) for k, v in build_network(dict(type="Restormer_origin", **DIST_G)).state_dict().items()}
+    m.net_g.load_state_dict(keyed_state_dict(shapes, seed=0), strict=True)
+    m.net_dc.load_state_dict(keyed_state_dict(D.dc_param_shapes(**DIST_DC), seed=0), strict=True)
+    if hasattr(m, "net_g_ema"):
+        m.model_ema(0)   # re-copy: the EMA net was initialised from the constructor's weights
+    return m
+
+
+def test_dcdist_step_golden(golden_dir):
+    """DCDistModel.optimize_parameters (reference ..._distillation_model.py:152-185) on the HIP path vs the re-enactment with
+    the real reference archs: one net_g forward, taps = last block of each decoder level, frozen head, one backward"""
+    from basicsr.models.degradation_classification_distillation_model import tap_modules
+
+    g = np.load(os.path.join(golden_dir, "dcdist_step.npz"))
+    m = _dist_model()
+    assert [n for n, _ in tap_modules(m.net_g, "decoder_level")] == [str(s) for s in g["hooked"]]
+    assert len(m.hooks) == 3 and not m.net_dc.training and all(not p.requires_grad for p in m.net_dc.parameters())
+    m.feed_data({"lq": keyed_input("dist.lq", (2, 3, 32, 32)), "gt": keyed_input("dist.gt", (2, 3, 32, 32)),
+                 "dataset_idx": torch.tensor([4, 1])})
+    m.optimize_parameters(1)
+    log = m.get_current_log()
+    assert abs(log["l_pixel"] - float(g["l_pixel"])) < 1e-5 and abs(log["l_classify"] - float(g["l_classify"])) < 1e-4
+    assert np.abs(m.cls_output.detach().cpu().numpy() - g["logits"]).max() < 1e-3 * np.abs(g["logits"]).max()
+    assert np.abs(m.pix_output.detach().cpu().numpy() - g["pix"]).max() < 1e-4 * np.abs(g["pix"]).max()
+    params = dict(m.net_g.named_parameters())
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(params[n].grad.double().pow(2).sum().sqrt())
+        # a temperature gradient is ONE scalar summed over ReLU-masked products with heavy cancellation: in this network the
+        # reference's own fp32 value differs from an fp64 evaluation by up to 1e-2 relative (4e-4 absolute), so it gets an
+        # absolute allowance on top of the relative one
+        slack = 1e-3 if n.endswith(".temperature") else 0.0
+        assert abs(mine - l2) <= 2e-3 * max(1e-7, l2) + slack, (n, mine, l2)
+    # full gradients: this 34-block network amplifies fp32 rounding (ReLU attention masks flip), the reference's own fp32
+    # gradients are up to 2e-3 (scale-relative) away from an fp64 evaluation -- so measure both against the fp64 oracle and
+    # require the HIP path to be as accurate as the reference (2x + 1e-4)
+    from oracle import restormer_oracle as R
+
+    P64 = {k: v.double().requires_grad_(True) for k, v in m.net_g.state_dict().items()}
+    Pd64 = {k: v.double() for k, v in m.net_dc.state_dict().items()}
+    P64 = {k: v.detach().cpu().requires_grad_(True) for k, v in P64.items()}
+    Pd64 = {k: v.cpu() for k, v in Pd64.items()}
+    lq, gt = keyed_input("dist.lq", (2, 3, 32, 32)).double(), keyed_input("dist.gt", (2, 3, 32, 32)).double()
+    pix, taps = R.restormer_forward(lq, P64, origin=True)
+    ((pix - gt).abs().mean() + torch.nn.functional.cross_entropy(D.dc_forward(taps[::-1], Pd64), torch.tensor([4, 1]))).backward()
+    for k in g.files:
+        if k.startswith("g.") and k != "g_names":
+            truth = P64[k[2:]].grad.numpy()
+            scale = np.abs(truth).max()
+            err_ref = np.abs(g[k] - truth).max() / scale
+            err_hip = np.abs(params[k[2:]].grad.cpu().numpy() - truth).max() / scale
+            assert err_hip <= 2 * err_ref + 1e-4, (k, err_hip, err_ref)
+    assert all(p.grad is None for p in m.net_dc.parameters()) and m.hook_outputs == []
+
+
+def test_dcdist_training_options():
+    """constant ``dataset_idx`` from the options, gradient clipping, EMA, and the SRModel-style test path"""
+    m = _dist_model(dataset_idx=3, grad_clip=0.01,
+                    train=dict(pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"),
+                               classify_opt=dict(type="CrossEntropyLoss", loss_weight=1.0), optim_g=dict(type="SGD", lr=0.1),
+                               ema_decay=0.9))
+    before = {k: v.detach().clone() for k, v in m.net_g.named_parameters()}
+    m.feed_data({"lq": keyed_input("dist.lq", (2, 3, 32, 32)), "gt": keyed_input("dist.gt", (2, 3, 32, 32))})
+    assert m.dataset_idx.tolist() == [3, 3]
+    m.optimize_parameters(1)
+    sq = sum(float((p.detach() - before[k]).double().pow(2).sum()) for k, p in m.net_g.named_parameters())
+    assert 0 < sq ** 0.5 <= 0.1 * 0.01 * 1.0001   # |step| = lr * clipped gradient norm
+    ema = dict(m.net_g_ema.named_parameters())
+    for k, p in m.net_g.named_parameters():   # ema = 0.9 * old + 0.1 * new (model_ema(0) copied the initial weights)
+        want = 0.9 * before[k] + 0.1 * p.detach()
+        assert float((ema[k].detach() - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), k
+    m.feed_data({"lq": keyed_input("dist.lq", (1, 3, 30, 27)), "gt": keyed_input("dist.gt", (1, 3, 30, 27))})
+    m.opt["network_g"]["window_size"] = 8
+    m.pre_test(); m.test(); m.post_test()
+    assert tuple(m.output.shape) == (1, 3, 30, 27) and m.hook_outputs == []
+    with pytest.raises(ValueError):
+        _dist_model(train=dict(optim_g=dict(type="SGD", lr=0.0)))

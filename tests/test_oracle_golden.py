@@ -196,6 +196,38 @@ def test_dcpt_step(golden_dir):
             assert abs(mine - l2) <= 2e-4 * max(1e-7, l2), (tag, n, mine, l2)
 
 
+def test_dcdist_step(golden_dir):
+    """oracle re-enactment of DCDistModel.optimize_parameters (one net_g forward with taps on the last block of each decoder
+    level, frozen head, L1 + CE) == the reference's: losses, logits, restored image, all net_g gradient norms"""
+    from basicsr.archs import build_network
+    from oracle import dc_oracle as D
+    from oracle import restormer_oracle as R
+
+    g = np.load(os.path.join(golden_dir, "dcdist_step.npz"))
+    cfg_g = dict(dim=16, num_blocks=[4, 6, 6, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
+    cfg_dc = dict(feature_dims=[32, 32, 64], num_res_blocks=1, num_classes=5)
+    shapes = {k: tuple(v.shape) for k, v in build_network(dict(type="Restormer_origin", **cfg_g)).state_dict().items()}
+    Pg = _req(keyed_state_dict(shapes, seed=0))
+    Pd = keyed_state_dict(D.dc_param_shapes(**cfg_dc), seed=0)   # frozen
+    lq, gt = keyed_input("dist.lq", (2, 3, 32, 32)), keyed_input("dist.gt", (2, 3, 32, 32))
+    pix, taps = R.restormer_forward(lq, Pg, origin=True)
+    assert [list(t.shape) for t in taps] == g["tap_shapes"].tolist()
+    logits = D.dc_forward(taps[::-1], Pd)
+    l_pix = (pix - gt).abs().mean()
+    l_cls = torch.nn.functional.cross_entropy(logits, torch.tensor([4, 1]))
+    (l_pix + l_cls).backward()
+    assert abs(float(l_pix) - float(g["l_pixel"])) < 1e-5 and abs(float(l_cls) - float(g["l_classify"])) < 1e-5
+    _close(logits, g["logits"], rtol=1e-4, atol=1e-5)
+    _close(pix, g["pix"], rtol=1e-4, atol=1e-5)
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(Pg[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 2e-4 * max(1e-7, l2), (n, mine, l2)
+    for k in g.files:
+        if k.startswith("g.") and k != "g_names":
+            ref = g[k]
+            assert np.abs(Pg[k[2:]].grad.numpy() - ref).max() <= 2e-4 * max(1e-7, np.abs(ref).max()), k
+
+
 R_CFG = dict(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
 
 
