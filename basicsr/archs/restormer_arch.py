@@ -69,6 +69,9 @@ class Attention(nn.Module):
 
 
 class TransformerBlock(nn.Module):
+    eps_1e5 = False   # PromptIR's copies of these blocks use LayerNorm eps 1e-5 ...
+    softmax = False   # ... and softmax instead of ReLU attention (basicsr/archs/promptir_arch.py)
+
     def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type):
         super().__init__()
         if bias:
@@ -83,10 +86,10 @@ class TransformerBlock(nn.Module):
     def forward(self, x):
         w1, b1 = self.norm1.wb()
         x = DF.mdta(x, w1, b1, self.attn.qkv.weight, self.attn.qkv_dwconv.weight, self.attn.project_out.weight,
-                    self.attn.temperature, self.attn.num_heads, self.norm1.biasfree)
+                    self.attn.temperature, self.attn.num_heads, self.norm1.biasfree, self.eps_1e5, self.softmax)
         w2, b2 = self.norm2.wb()
         return DF.gdfn(x, w2, b2, self.ffn.project_in.weight, self.ffn.dwconv.weight, self.ffn.project_out.weight,
-                       self.norm2.biasfree)
+                       self.norm2.biasfree, self.eps_1e5)
 
 
 class OverlapPatchEmbed(nn.Module):

@@ -124,6 +124,9 @@ SIGNATURES = {
                              cint, cint, stream_t]),
     "dcpt_gdfn_bwd": (cint, [C.POINTER(GdfnParams), C.POINTER(GdfnParams), f32p, C.POINTER(GdfnSaved), f32p, f32p, C.c_void_p,
                              sz, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_prompt_mix_fwd": (cint, [f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_prompt_mix_bwd_ws_bytes": (sz, [cint, cint, cint]),
+    "dcpt_prompt_mix_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_pixel_unshuffle": (cint, [f32p, f32p, cint, cint, cint, cint, stream_t]),
     "dcpt_pixel_shuffle": (cint, [f32p, f32p, cint, cint, cint, cint, stream_t]),
     "dcpt_concat_channels": (cint, [f32p, f32p, f32p, i64, cint, cint, stream_t]),

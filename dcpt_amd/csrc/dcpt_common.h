@@ -99,6 +99,21 @@ __device__ __forceinline__ float group_sum(float v, int width) {
     return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
+// maximum over the 64 lanes of a wave, result in every lane
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_perm<0xB1>(v));
+    v = fmaxf(v, dpp_perm<0x4E>(v));
+    v = fmaxf(v, dpp_perm<0x141>(v));
+    v = fmaxf(v, dpp_perm<0x140>(v));
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // XCD-aware, bijective remap of a 1-D block id: blocks that land on the same XCD (bid % 8 by
 // observed dispatch) get a contiguous range of logical ids, so neighbouring tiles share that
 // XCD's private L2.  Only a speed choice; any placement is correct.

@@ -51,7 +51,59 @@ __global__ __launch_bounds__(256) void attn_finalize_kernel(const float* __restr
     }
 }
 
+// PromptIR's Attention (reference basicsr/archs/promptir_arch.py:129-141) applies softmax over j instead of ReLU.  Same
+// inputs/outputs as attn_finalize_kernel; a wave owns rows i = wave, wave + 4, ..., its lanes the columns j = lane + 64 u.
+constexpr int SM_MAXU = 4;   // ch <= 256
+__global__ __launch_bounds__(256) void attn_finalize_softmax_kernel(const float* __restrict__ slab, int splits,
+                                                                    const float* __restrict__ nrm, const float* __restrict__ temp,
+                                                                    float* __restrict__ ghat, float* __restrict__ attn,
+                                                                    float* __restrict__ attnT, int heads, int ch, int c) {
+    const int z = blockIdx.x, b = z / heads, h = z % heads;
+    const float t = temp[h];
+    const float* nq = nrm + (int64_t)b * 2 * c + h * ch;
+    const float* nk = nrm + (int64_t)b * 2 * c + c + h * ch;
+    const int64_t zo = (int64_t)z * ch * ch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < ch; i += 4) {
+        float pre[SM_MAXU], gh[SM_MAXU];
+        float m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < SM_MAXU; ++u) {
+            const int j = lane + 64 * u;
+            pre[u] = -INFINITY;
+            gh[u] = 0.f;
+            if (j < ch) {
+                float g = 0.f;
+                for (int sp = 0; sp < splits; ++sp) g += slab[((int64_t)z * splits + sp) * ch * ch + i * ch + j];
+                gh[u] = g / (nq[i] * nk[j]);
+                pre[u] = t * gh[u];
+                m = fmaxf(m, pre[u]);
+            }
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < SM_MAXU; ++u) {
+            pre[u] = (lane + 64 * u < ch) ? expf(pre[u] - m) : 0.f;
+            sum += pre[u];
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int u = 0; u < SM_MAXU; ++u) {
+            const int j = lane + 64 * u;
+            if (j < ch) {
+                const float a = pre[u] / sum;
+                ghat[zo + i * ch + j] = gh[u];
+                attn[zo + i * ch + j] = a;
+                attnT[zo + (int64_t)j * ch + i] = a;
+            }
+        }
+    }
+}
+
 // one block per (b, head).  dattn = sum_splits slab.  Outputs dG, dG^T, cq/ck (norm-path coefficients), dtemp_part[z]
+// SOFTMAX (PromptIR): dpre_ij = attn_ij * (dattn_ij - sum_j' dattn_ij' attn_ij'), the row dots first (a wave per row) into LDS.
+template <bool SOFTMAX>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ slab, int splits, const float* __restrict__ attn,
                                                        const float* __restrict__ ghat, const float* __restrict__ nrm,
                                                        const float* __restrict__ temp, float* __restrict__ dG,
@@ -59,18 +111,33 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ dtemp_part, float* __restrict__ scratch, int heads,
                                                        int ch, int c) {
     __shared__ float red[256];
+    __shared__ float rowdot[256];
     const int z = blockIdx.x, b = z / heads, h = z % heads;
     const float t = temp[h];
     const float* nq = nrm + (int64_t)b * 2 * c + h * ch;
     const float* nk = nrm + (int64_t)b * 2 * c + c + h * ch;
     const int64_t zo = (int64_t)z * ch * ch;
     float* prod = scratch + zo;  // dGhat * Ghat
+    if (SOFTMAX) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i = wave; i < ch; i += 4) {
+            float d = 0.f;
+            for (int j = lane; j < ch; j += 64) {
+                float da = 0.f;
+                for (int s = 0; s < splits; ++s) da += slab[((int64_t)z * splits + s) * ch * ch + i * ch + j];
+                d += da * attn[zo + i * ch + j];
+            }
+            d = wave_sum(d);
+            if (lane == 0) rowdot[i] = d;
+        }
+        __syncthreads();
+    }
     float acc = 0.f;
     for (int e = threadIdx.x; e < ch * ch; e += 256) {
         const int i = e / ch, j = e % ch;
         float da = 0.f;
         for (int s = 0; s < splits; ++s) da += slab[((int64_t)z * splits + s) * ch * ch + e];
-        const float dpre = attn[zo + e] > 0.f ? da : 0.f;
+        const float dpre = SOFTMAX ? attn[zo + e] * (da - rowdot[i]) : (attn[zo + e] > 0.f ? da : 0.f);
         const float gh = ghat[zo + e];
         acc += dpre * gh;
         const float dgh = dpre * t;
@@ -332,7 +399,11 @@ extern "C" size_t dcpt_mdta_ws_bytes(int B, int H, int W, int C, int heads, int 
 }
 
 extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y, const dcpt_mdta_saved* sv, void* ws,
-                             size_t ws_bytes, int B, int H, int W, int C, int heads, int biasfree, dcpt_stream_t stream) {
+                             size_t ws_bytes, int B, int H, int W, int C, int heads, int flags, dcpt_stream_t stream) {
+    const int biasfree = flags & DCPT_LN_BIASFREE;
+    const float ln_eps = (flags & DCPT_LN_EPS_1E5) ? 1e-5f : 1e-6f;
+    const bool softmax_attn = (flags & DCPT_ATTN_SOFTMAX) != 0;
+    (void)ln_eps; (void)softmax_attn;
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && x && y && sv, "mdta_fwd: null argument");
     DCPT_CHECK_ARG(heads > 0 && C % heads == 0 && (C / heads) % 4 == 0, "mdta_fwd: C=%d heads=%d (C/heads must be a multiple of 4)", C, heads);
@@ -347,7 +418,7 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
     DCPT_CHECK_ARG(sv->xn != nullptr, "mdta_fwd: saved.xn missing");
     // the normalised activations are materialised once (restormer_arch.py:40,59); the qkv conv and, in backward, its weight
     // gradient then take them as plain operands (global -> LDS by DMA)
-    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, 1e-6f, s));
+    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, ln_eps, s));
     GemmNT g{};
     g.M = M; g.A = sv->xn; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = sv->qkv1; g.ldc = C3;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
@@ -362,8 +433,14 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
     t.slab = w.gslab; t.splits = w.splits_a; t.rows_per_split = cdiv64(cdiv64(P, w.splits_a), 32) * 32;
     t.splits = (int)cdiv64(P, t.rows_per_split);
     DCPT_TRY(launch_gemm_tn(t, A_PLAIN, A_PLAIN, s));
-    attn_finalize_kernel<<<dim3(B * heads), dim3(256), 0, s>>>(w.gslab, t.splits, sv->nrm, p->temperature, sv->ghat, sv->attn,
-                                                               sv->attnT, heads, ch, C);
+    if (softmax_attn) {
+        DCPT_CHECK_ARG(ch <= 64 * SM_MAXU, "mdta: softmax attention supports up to %d channels per head", 64 * SM_MAXU);
+        attn_finalize_softmax_kernel<<<dim3(B * heads), dim3(256), 0, s>>>(w.gslab, t.splits, sv->nrm, p->temperature, sv->ghat,
+                                                                           sv->attn, sv->attnT, heads, ch, C);
+    } else {
+        attn_finalize_kernel<<<dim3(B * heads), dim3(256), 0, s>>>(w.gslab, t.splits, sv->nrm, p->temperature, sv->ghat, sv->attn,
+                                                                   sv->attnT, heads, ch, C);
+    }
     DCPT_CHECK_LAUNCH("attn_finalize");
     // out_att[p][i] = sum_j attn[i][j] v[p][j]
     g = GemmNT{};
@@ -379,7 +456,11 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
 
 extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_grads* gr, const float* x,
                              const dcpt_mdta_saved* sv, const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H,
-                             int W, int C, int heads, int biasfree, dcpt_stream_t stream) {
+                             int W, int C, int heads, int flags, dcpt_stream_t stream) {
+    const int biasfree = flags & DCPT_LN_BIASFREE;
+    const float ln_eps = (flags & DCPT_LN_EPS_1E5) ? 1e-5f : 1e-6f;
+    const bool softmax_attn = (flags & DCPT_ATTN_SOFTMAX) != 0;
+    (void)ln_eps; (void)softmax_attn;
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && gr && x && sv && dy && dx, "mdta_bwd: null argument");
     DCPT_CHECK_ARG(heads > 0 && C % heads == 0 && (C / heads) % 4 == 0, "mdta_bwd: bad shape");
@@ -417,8 +498,14 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     g.sC1 = (int64_t)P * C3; g.sC2 = ch;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     // B3: through relu / temperature / normalisation
-    attn_bwd_kernel<<<dim3(B * heads), dim3(256), 0, s>>>(w.gslab, t.splits, sv->attn, sv->ghat, sv->nrm, p->temperature, w.dG,
-                                                          w.dGT, w.cqk, w.dtpart, w.scr, heads, ch, C);
+    if (softmax_attn) {
+        DCPT_CHECK_ARG(ch <= 256, "mdta: softmax attention supports up to 256 channels per head");
+        attn_bwd_kernel<true><<<dim3(B * heads), dim3(256), 0, s>>>(w.gslab, t.splits, sv->attn, sv->ghat, sv->nrm, p->temperature,
+                                                                    w.dG, w.dGT, w.cqk, w.dtpart, w.scr, heads, ch, C);
+    } else {
+        attn_bwd_kernel<false><<<dim3(B * heads), dim3(256), 0, s>>>(w.gslab, t.splits, sv->attn, sv->ghat, sv->nrm, p->temperature,
+                                                                     w.dG, w.dGT, w.cqk, w.dtpart, w.scr, heads, ch, C);
+    }
     DCPT_CHECK_LAUNCH("attn_bwd");
     dtemp_reduce_kernel<<<dim3(cdiv(heads, 64)), dim3(64), 0, s>>>(w.dtpart, gr->temperature, B, heads);
     DCPT_CHECK_LAUNCH("dtemp_reduce");
@@ -456,7 +543,11 @@ extern "C" size_t dcpt_gdfn_ws_bytes(int B, int H, int W, int C, int hidden, int
 }
 
 extern "C" int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y, const dcpt_gdfn_saved* sv, void* ws,
-                             size_t ws_bytes, int B, int H, int W, int C, int hidden, int biasfree, dcpt_stream_t stream) {
+                             size_t ws_bytes, int B, int H, int W, int C, int hidden, int flags, dcpt_stream_t stream) {
+    const int biasfree = flags & DCPT_LN_BIASFREE;
+    const float ln_eps = (flags & DCPT_LN_EPS_1E5) ? 1e-5f : 1e-6f;
+    const bool softmax_attn = (flags & DCPT_ATTN_SOFTMAX) != 0;
+    (void)ln_eps; (void)softmax_attn;
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && x && y && sv && hidden > 0 && C % 4 == 0, "gdfn_fwd: bad argument");
     const int hp = (hidden + 3) / 4 * 4;
@@ -472,7 +563,7 @@ extern "C" int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)C * hp)), dim3(256), 0, s>>>(p->out_w, w.wp_out, C, hidden, hp, 2);
     DCPT_CHECK_LAUNCH("gdfn_pack");
     DCPT_CHECK_ARG(sv->xn != nullptr, "gdfn_fwd: saved.xn missing");
-    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, 1e-6f, s));
+    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, ln_eps, s));
     GemmNT g{};
     g.M = M; g.A = sv->xn; g.lda = C; g.K = C; g.Bw = w.wp_in; g.N = 2 * hp; g.C = sv->u; g.ldc = 2 * hp;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
@@ -484,7 +575,11 @@ extern "C" int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y
 
 extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_grads* gr, const float* x,
                              const dcpt_gdfn_saved* sv, const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H,
-                             int W, int C, int hidden, int biasfree, dcpt_stream_t stream) {
+                             int W, int C, int hidden, int flags, dcpt_stream_t stream) {
+    const int biasfree = flags & DCPT_LN_BIASFREE;
+    const float ln_eps = (flags & DCPT_LN_EPS_1E5) ? 1e-5f : 1e-6f;
+    const bool softmax_attn = (flags & DCPT_ATTN_SOFTMAX) != 0;
+    (void)ln_eps; (void)softmax_attn;
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && gr && x && sv && dy && dx && hidden > 0 && C % 4 == 0, "gdfn_bwd: bad argument");
     const int hp = (hidden + 3) / 4 * 4;

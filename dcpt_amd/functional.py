@@ -772,7 +772,7 @@ class _MDTAFn(torch.autograd.Function):
                                 heads, int(biasfree), _stream(dev)), "dcpt_mdta_fwd")
         ctx.save_for_backward(x, stats, qkv1, qkv, nrm, att, out_att, xn, *[t for t in ps if t is not None])
         ctx.has_bias = ps[1] is not None
-        ctx.heads, ctx.biasfree = heads, bool(biasfree)
+        ctx.heads, ctx.biasfree = heads, int(biasfree)
         return y
 
     @staticmethod
@@ -800,8 +800,13 @@ class _MDTAFn(torch.autograd.Function):
         return (dx, *grads, None, None)
 
 
-def mdta(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree):
-    return _MDTAFn.apply(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree)
+LN_BIASFREE, LN_EPS_1E5, ATTN_SOFTMAX = 1, 2, 4   # include/dcpt_hip.h: DCPT_LN_BIASFREE, DCPT_LN_EPS_1E5, DCPT_ATTN_SOFTMAX
+
+
+def mdta(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree, eps_1e5=False, softmax=False):
+    """``eps_1e5`` / ``softmax``: the PromptIR variants (LayerNorm eps 1e-5, softmax instead of ReLU attention)."""
+    flags = (LN_BIASFREE if biasfree else 0) | (LN_EPS_1E5 if eps_1e5 else 0) | (ATTN_SOFTMAX if softmax else 0)
+    return _MDTAFn.apply(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, flags)
 
 
 class _GDFNFn(torch.autograd.Function):
@@ -829,7 +834,7 @@ class _GDFNFn(torch.autograd.Function):
         check(lib.dcpt_gdfn_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
                                 hidden, int(biasfree), _stream(dev)), "dcpt_gdfn_fwd")
         ctx.save_for_backward(x, stats, u, t, xn, *[q for q in ps if q is not None])
-        ctx.has_bias, ctx.biasfree, ctx.hidden = ps[1] is not None, bool(biasfree), hidden
+        ctx.has_bias, ctx.biasfree, ctx.hidden = ps[1] is not None, int(biasfree), hidden
         return y
 
     @staticmethod
@@ -856,5 +861,48 @@ class _GDFNFn(torch.autograd.Function):
         return (dx, *grads, None)
 
 
-def gdfn(x, norm_w, norm_b, in_w, dw_w, out_w, biasfree):
-    return _GDFNFn.apply(x, norm_w, norm_b, in_w, dw_w, out_w, biasfree)
+def gdfn(x, norm_w, norm_b, in_w, dw_w, out_w, biasfree, eps_1e5=False):
+    flags = (LN_BIASFREE if biasfree else 0) | (LN_EPS_1E5 if eps_1e5 else 0)
+    return _GDFNFn.apply(x, norm_w, norm_b, in_w, dw_w, out_w, flags)
+
+
+# ------------------------------------------------------------------------------------------------
+class _PromptMixFn(torch.autograd.Function):
+    """bilinear_(H,W)( sum_l softmax(logits)[b, l] * prompt_param[l] ) as an NHWC map
+    (PromptGenBlock.forward, basicsr/archs/promptir_arch.py:253-259)."""
+
+    @staticmethod
+    def forward(ctx, logits, prompt_param, H, W):
+        lib = _lib.load()
+        _require_gpu(logits, prompt_param)
+        lg, pp = _contig(logits.detach()), _contig(prompt_param.detach())
+        B, L = lg.shape
+        _, L2, D, S, S2 = pp.shape
+        if L2 != L or S2 != S:
+            raise ValueError(f"prompt_param {tuple(pp.shape)} does not match logits {tuple(lg.shape)}")
+        dev = lg.device
+        wsm = torch.empty((B, L), dtype=torch.float32, device=dev)
+        out = _empty_nhwc(B, D, H, W, dev)
+        check(lib.dcpt_prompt_mix_fwd(lg.data_ptr(), pp.data_ptr(), wsm.data_ptr(), out.data_ptr(), B, L, D, S, H, W, _stream(dev)),
+              "dcpt_prompt_mix_fwd")
+        ctx.save_for_backward(pp, wsm)
+        ctx.geom = (B, L, D, S, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        pp, wsm = ctx.saved_tensors
+        B, L, D, S, H, W = ctx.geom
+        dout = _nhwc(dout)
+        dev = dout.device
+        dlogits = torch.empty((B, L), dtype=torch.float32, device=dev)
+        dparam = torch.empty_like(pp)
+        ws = _workspace(dev, lib.dcpt_prompt_mix_bwd_ws_bytes(B, D, S))
+        check(lib.dcpt_prompt_mix_bwd(dout.data_ptr(), pp.data_ptr(), wsm.data_ptr(), dlogits.data_ptr(), dparam.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), B, L, D, S, H, W, _stream(dev)), "dcpt_prompt_mix_bwd")
+        return dlogits, dparam, None, None
+
+
+def prompt_mix(logits, prompt_param, H, W):
+    return _PromptMixFn.apply(logits, prompt_param, H, W)

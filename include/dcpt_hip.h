@@ -180,8 +180,14 @@ int dcpt_conv_bwd(const float* dy, const float* x, const float* w, float* dx, fl
 
 /* ---- Restormer blocks (basicsr/archs/restormer_arch.py) -------------------------------------------------
  * MDTA half of a TransformerBlock (:148-159 with Attention :103-145):  y = x + project_out(attn(LN(x))).
- * biasfree = 1: BiasFree_LayerNorm (:26-40, norm_b ignored), 0: WithBias_LayerNorm (:43-59).  heads: C % heads == 0 and
- * (C / heads) % 4 == 0.  ReLU attention (:134-136), F.normalize over the pixels (eps 1e-12). */
+ * flags: DCPT_LN_BIASFREE = BiasFree_LayerNorm (:26-40, norm_b ignored), else WithBias_LayerNorm (:43-59); 0 / 1 are the
+ * Restormer settings of this repo's reference (LayerNorm eps 1e-6, ReLU attention :134-136).  DCPT_LN_EPS_1E5 and
+ * DCPT_ATTN_SOFTMAX select the PromptIR variants of the same blocks (basicsr/archs/promptir_arch.py:39-40,57-59: eps 1e-5;
+ * :136: softmax over the last dimension).  heads: C % heads == 0 and (C / heads) % 4 == 0 (<= 256 for softmax).
+ * F.normalize over the pixels (eps 1e-12). */
+#define DCPT_LN_BIASFREE 1
+#define DCPT_LN_EPS_1E5 2
+#define DCPT_ATTN_SOFTMAX 4
 typedef struct {
     const float* norm_w; const float* norm_b;   /* [C] */
     const float* qkv_w;                         /* [3C][C][1][1] */
@@ -203,12 +209,13 @@ typedef struct {   /* saved for backward; M = B*H*W, ch = C/heads */
 } dcpt_mdta_saved;
 size_t dcpt_mdta_ws_bytes(int B, int H, int W, int C, int heads, int backward);
 int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y, const dcpt_mdta_saved* saved, void* ws, size_t ws_bytes,
-                  int B, int H, int W, int C, int heads, int biasfree, dcpt_stream_t stream);
+                  int B, int H, int W, int C, int heads, int flags, dcpt_stream_t stream);
 int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_grads* g, const float* x, const dcpt_mdta_saved* saved,
-                  const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int heads, int biasfree,
+                  const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int heads, int flags,
                   dcpt_stream_t stream);
 /* GDFN half (:75-100):  y = x + project_out(gelu(x1) * x2), (x1,x2) = dwconv(project_in(LN(x))).chunk(2); exact erf GELU.
- * hidden = int(C * ffn_expansion_factor) may be any positive integer (padded to a multiple of 4 internally). */
+ * hidden = int(C * ffn_expansion_factor) may be any positive integer (padded to a multiple of 4 internally).
+ * flags: DCPT_LN_BIASFREE | DCPT_LN_EPS_1E5 as for dcpt_mdta_fwd. */
 typedef struct {
     const float* norm_w; const float* norm_b;   /* [C] */
     const float* in_w;                          /* [2*hidden][C][1][1] */
@@ -224,10 +231,19 @@ typedef struct {   /* hp = hidden rounded up to a multiple of 4 */
 } dcpt_gdfn_saved;
 size_t dcpt_gdfn_ws_bytes(int B, int H, int W, int C, int hidden, int backward);
 int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y, const dcpt_gdfn_saved* saved, void* ws, size_t ws_bytes,
-                  int B, int H, int W, int C, int hidden, int biasfree, dcpt_stream_t stream);
+                  int B, int H, int W, int C, int hidden, int flags, dcpt_stream_t stream);
 int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_grads* g, const float* x, const dcpt_gdfn_saved* saved,
-                  const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int hidden, int biasfree,
+                  const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int hidden, int flags,
                   dcpt_stream_t stream);
+/* PromptIR's PromptGenBlock (basicsr/archs/promptir_arch.py:237-262) between its linear layer and its 3x3 conv:
+ *   out[b] = bilinear_{(S,S)->(H,W), align_corners=False}( sum_l softmax(logits[b])[l] * param[l] )   as NHWC [B][H][W][D].
+ * logits [B][L] (= dcpt_meanpool_fc_fwd of the block input), param [L][D][S][S] (the (1,L,D,S,S) parameter), weights [B][L]
+ * receives the softmax (saved for backward).  L <= 8, D % 4 == 0. */
+int dcpt_prompt_mix_fwd(const float* logits, const float* param, float* weights, float* out, int B, int L, int D, int S, int H, int W,
+                        dcpt_stream_t stream);
+size_t dcpt_prompt_mix_bwd_ws_bytes(int B, int D, int S);
+int dcpt_prompt_mix_bwd(const float* dout, const float* param, const float* weights, float* dlogits, float* dparam, void* ws,
+                        size_t ws_bytes, int B, int L, int D, int S, int H, int W, dcpt_stream_t stream);
 /* NHWC PixelUnshuffle(2): x [B][H][W][C] -> y [B][H/2][W/2][4C];  PixelShuffle(2): x [B][H][W][C4] -> y [B][2H][2W][C4/4] */
 int dcpt_pixel_unshuffle(const float* x, float* y, int B, int H, int W, int C, dcpt_stream_t stream);
 int dcpt_pixel_shuffle(const float* x, float* y, int B, int H, int W, int C4, dcpt_stream_t stream);

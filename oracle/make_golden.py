@@ -322,6 +322,61 @@ def gen_restormer(ref):
         np.savez_compressed(os.path.join(OUT, f"restormer_block_{lnt}.npz"), **out)
 
 
+P_CFG = dict(num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)   # dim 48 is hard-wired into the prompt sizes (:288-296)
+
+
+def gen_promptir(ref):
+    """PromptIR (basicsr/archs/promptir_arch.py:266-518), one block per level: output, dL/dinput, every parameter-gradient
+    norm, full gradients of the prompt blocks / one noise block; a 40 x 24 image (prompts resized 16->5x3, 32->10x6,
+    64->20x12: the downsampling side of the bilinear resize) forward only; hook=True returns None."""
+    net = ref.promptir.PromptIR(**P_CFG)
+    fill_module_(net, seed=0)
+    x = keyed_input("pir.x", (2, 3, 64, 64)).requires_grad_(True)
+    gw = keyed_input("pir.gw", (2, 3, 64, 64), lo=-1.0, hi=1.0)
+    y = net(x)
+    (y * gw).sum().backward()
+    out = {"y": _np(y), "dx": _np(x.grad), "keys": np.array(list(net.state_dict().keys()))}
+    names, l2, sm, ab = _grad_summary(net)
+    out["g_names"], out["g_l2"], out["g_sum"] = names, l2, sm
+    for k, p in net.named_parameters():
+        if (k.startswith("prompt") and p.numel() <= 65536) or k.startswith("noise_level1.norm1") or \
+                k in ("noise_level1.attn.temperature", "noise_level1.attn.qkv_dwconv.weight", "noise_level3.attn.temperature"):
+            out["g." + k] = _np(p.grad)
+    out["g.prompt1.prompt_param.sub"] = _np(net.prompt1.prompt_param.grad[0, :, ::8, ::4, ::4])
+    assert net(x.detach(), hook=True) is None
+    with torch.no_grad():
+        out["y_small"] = _np(net(keyed_input("pir.xs", (1, 3, 40, 24))))
+        out["y_large"] = _np(net(keyed_input("pir.xl", (1, 3, 160, 136)))[..., ::4, ::4])
+    np.savez_compressed(os.path.join(OUT, "promptir_tiny.npz"), **out)
+    # one PromptIR transformer block (softmax attention, eps 1e-5) with every gradient, both LayerNorm types
+    for lnt in ("BiasFree", "WithBias"):
+        blk = ref.promptir.TransformerBlock(dim=48, num_heads=2, ffn_expansion_factor=2.66, bias=False, LayerNorm_type=lnt)
+        sd = {k: keyed_tensor(f"ptb{lnt}." + k, tuple(v.shape)) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd, strict=True)
+        xb = keyed_input(f"ptb{lnt}.x", (2, 48, 12, 10), lo=-1.0, hi=1.0).requires_grad_(True)
+        go = keyed_input(f"ptb{lnt}.go", (2, 48, 12, 10), lo=-1.0, hi=1.0)
+        yb = blk(xb)
+        yb.backward(go)
+        o = {"y": _np(yb), "dx": _np(xb.grad)}
+        for k, p in blk.named_parameters():
+            o["g." + k] = _np(p.grad)
+        np.savez_compressed(os.path.join(OUT, f"promptir_block_{lnt}.npz"), **o)
+    # one PromptGenBlock, up- and down-sampling resize, every gradient
+    pg = ref.promptir.PromptGenBlock(prompt_dim=8, prompt_len=5, prompt_size=6, lin_dim=12)
+    pg.load_state_dict({k: keyed_tensor("pg." + k, tuple(v.shape)) for k, v in pg.state_dict().items()}, strict=True)
+    o = {}
+    for tag, hw in (("up", (13, 9)), ("down", (4, 5)), ("same", (6, 6))):
+        xp = keyed_input(f"pg.{tag}.x", (3, 12) + hw, lo=-1.0, hi=1.0).requires_grad_(True)
+        go = keyed_input(f"pg.{tag}.go", (3, 8) + hw, lo=-1.0, hi=1.0)
+        pg.zero_grad()
+        yp = pg(xp)
+        yp.backward(go)
+        o[f"{tag}.y"], o[f"{tag}.dx"] = _np(yp), _np(xp.grad)
+        for k, p in pg.named_parameters():
+            o[f"{tag}.g.{k}"] = _np(p.grad)
+    np.savez_compressed(os.path.join(OUT, "promptir_promptgen.npz"), **o)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -339,6 +394,7 @@ def main():
     gen_dcpt_step(ref)
     gen_dcdist_step(ref)
     gen_restormer(ref)
+    gen_promptir(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

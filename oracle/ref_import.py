@@ -48,6 +48,11 @@ def load_reference_archs():
         except Exception as e:  # einops missing etc.
             ns.restormer = None
             ns.restormer_error = e
+        try:
+            ns.promptir = _load("basicsr.archs.promptir_arch", "basicsr/archs/promptir_arch.py")
+        except Exception as e:
+            ns.promptir = None
+            ns.promptir_error = e
         # fvcore is not installed; c2_msra_fill only initialises weights (degrad_classify_arch.py:213)
         if "fvcore" not in sys.modules:
             import torch.nn as nn

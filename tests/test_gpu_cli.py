@@ -28,7 +28,7 @@ def _run(yml, extra=()):
     return out, vals
 
 
-@pytest.mark.parametrize("yml", ["test_NAFNet_5d.yml", "test_Restormer_5d.yml"])
+@pytest.mark.parametrize("yml", ["test_NAFNet_5d.yml", "test_Restormer_5d.yml", "test_PromptIR_5d.yml"])
 def test_cli_on_shipped_options(yml):
     out, vals = _run(yml)
     assert {("Rain100L", "psnr"), ("Rain100L", "ssim"), ("CBSD68", "psnr"), ("CBSD68", "ssim")} <= set(vals), out[-1500:]

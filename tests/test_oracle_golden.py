@@ -273,3 +273,62 @@ def test_restormer_block(golden_dir, lnt):
     for k in P:
         ref = g["g." + k]
         assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-4 * max(1e-7, np.abs(ref).max()), k
+
+
+# ------------------------------------------------------------------------------------------------ PromptIR
+P_CFG = dict(num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+PG_SHAPES = {"prompt_param": (1, 5, 8, 6, 6), "linear_layer.weight": (5, 12), "linear_layer.bias": (5,), "conv3x3.weight": (8, 8, 3, 3)}
+
+
+def test_promptir_tiny(golden_dir):
+    from basicsr.archs import build_network
+    from oracle import promptir_oracle as PO
+
+    g = np.load(os.path.join(golden_dir, "promptir_tiny.npz"))
+    shapes = {k: tuple(v.shape) for k, v in build_network(dict(type="PromptIR", **P_CFG)).state_dict().items()}
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    P = _req(keyed_state_dict(shapes, seed=0))
+    x = keyed_input("pir.x", (2, 3, 64, 64)).requires_grad_(True)
+    gw = keyed_input("pir.gw", (2, 3, 64, 64), lo=-1.0, hi=1.0)
+    y = PO.promptir_forward(x, P)
+    (y * gw).sum().backward()
+    _close(y, g["y"], rtol=1e-4, atol=1e-5)
+    assert np.abs(x.grad.numpy() - g["dx"]).max() <= 1e-4 * np.abs(g["dx"]).max()
+    for n, l2 in zip([str(s) for s in g["g_names"]], g["g_l2"]):
+        mine = float(P[n].grad.double().pow(2).sum().sqrt())
+        assert abs(mine - l2) <= 2e-4 * max(1e-7, l2), (n, mine, l2)
+    assert PO.promptir_forward(x.detach(), P, hook=True) is None
+    with torch.no_grad():
+        _close(PO.promptir_forward(keyed_input("pir.xs", (1, 3, 40, 24)), P), g["y_small"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("lnt", ["BiasFree", "WithBias"])
+def test_promptir_block(golden_dir, lnt):
+    from oracle import promptir_oracle as PO
+
+    g = np.load(os.path.join(golden_dir, f"promptir_block_{lnt}.npz"))
+    P = _req({k[2:]: keyed_tensor(f"ptb{lnt}." + k[2:], g[k].shape) for k in g.files if k.startswith("g.")})
+    x = keyed_input(f"ptb{lnt}.x", (2, 48, 12, 10), lo=-1.0, hi=1.0).requires_grad_(True)
+    y = PO.transformer_block(x, P, "")
+    y.backward(keyed_input(f"ptb{lnt}.go", (2, 48, 12, 10), lo=-1.0, hi=1.0))
+    _close(y, g["y"], rtol=1e-4, atol=1e-5)
+    assert np.abs(x.grad.numpy() - g["dx"]).max() <= 1e-4 * np.abs(g["dx"]).max()
+    for k in P:
+        ref = g["g." + k]
+        assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-4 * max(1e-7, np.abs(ref).max()), k
+
+
+def test_promptir_promptgen(golden_dir):
+    from oracle import promptir_oracle as PO
+
+    g = np.load(os.path.join(golden_dir, "promptir_promptgen.npz"))
+    for tag, hw in (("up", (13, 9)), ("down", (4, 5)), ("same", (6, 6))):
+        P = _req({k: keyed_tensor("pg." + k, s) for k, s in PG_SHAPES.items()})
+        x = keyed_input(f"pg.{tag}.x", (3, 12) + hw, lo=-1.0, hi=1.0).requires_grad_(True)
+        y = PO.prompt_block(x, P, "")
+        y.backward(keyed_input(f"pg.{tag}.go", (3, 8) + hw, lo=-1.0, hi=1.0))
+        _close(y, g[f"{tag}.y"], rtol=1e-5, atol=1e-6)
+        assert np.abs(x.grad.numpy() - g[f"{tag}.dx"]).max() <= 1e-5 * max(1e-9, np.abs(g[f"{tag}.dx"]).max())
+        for k in P:
+            ref = g[f"{tag}.g.{k}"]
+            assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-5 * max(1e-9, np.abs(ref).max()), (tag, k)
