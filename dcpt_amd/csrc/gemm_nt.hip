@@ -377,8 +377,7 @@ template <int AK, int EK>
 int launch_cfg(const GemmNT& p, hipStream_t s) {
     const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     constexpr bool GATE = (EK == E_BIASGATE);
-    // 128 x 64 tiles when N is narrow, and also when 128 x 128 tiles would leave CUs with fewer than their two resident
-    // blocks (small pixel counts, e.g. 128^2 training crops at the deepest level): twice the blocks, both SIMD wave slots busy
+    // 128 x 64 tiles when N is narrow
     const int64_t tiles128 = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
     static const int smallk = getenv("DCPT_NT_SMALLK") ? atoi(getenv("DCPT_NT_SMALLK")) : 0;
     static const int use96 = getenv("DCPT_NT_96") ? atoi(getenv("DCPT_NT_96")) : 1;
@@ -392,7 +391,13 @@ int launch_cfg(const GemmNT& p, hipStream_t s) {
             return DCPT_OK;
         }
     }
-    if (p.N <= 64 || tiles128 * nbatch <= 256 || p.K <= smallk) {
+    // 128 x 64 tiles (48 KB of LDS: three resident blocks per CU instead of two) whenever the grid is only a few rounds of
+    // the resident slots: a grid of 580 128 x 128 tiles is 1.13 rounds of 512 slots and runs as two, the same work as 1160
+    // narrower tiles is 1.5 rounds of 768 slots, and three co-resident blocks hide each other's prologue / epilogue better.
+    // Measured: 2K tiled inference -9 %, the training step -0.9 % (its 1024- and 2048-tile launches at the deepest level);
+    // grids of many rounds keep the wider tile (fewer LDS reads per flop).
+    static const int use64_below = getenv("DCPT_NT_64_BELOW") ? atoi(getenv("DCPT_NT_64_BELOW")) : 2100;
+    if (p.N <= 64 || tiles128 * nbatch < use64_below || p.K <= smallk) {
         constexpr int BM = 128, BN = 64;
         const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
         gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
