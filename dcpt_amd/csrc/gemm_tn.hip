@@ -242,9 +242,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
 
 // Output-tile shape for an N x K gradient: 64 for narrow sides, otherwise whichever of 128 x 128, 128 x 96, 96 x 128 pads the
 // least (Restormer's 96 / 192 / 288 / 576-wide layers); the 96-wide tiles take plain operands and no column sums.
+static int tn_narrow() {   // experiment knob: 128 x 64 output tiles everywhere (three resident blocks per CU); measured +-0 on the training step
+    static const int v = getenv("DCPT_TN_NARROW") ? atoi(getenv("DCPT_TN_NARROW")) : 0;
+    return v;
+}
+
 static void tn_tile_shape(int N, int K, bool plain, int* bn, int* bk) {
     *bn = (N <= 64) ? 64 : 128;
-    *bk = (K <= 64) ? 64 : 128;
+    *bk = (K <= 64 || tn_narrow()) ? 64 : 128;
+    if (tn_narrow()) return;
     static const int use96 = getenv("DCPT_TN_96") ? atoi(getenv("DCPT_TN_96")) : 1;
     if (N <= 64 || K <= 64 || !plain || !use96) return;
     const int64_t a128 = (int64_t)cdiv(N, 128) * 128 * cdiv(K, 128) * 128;
@@ -276,13 +282,13 @@ int launch_cfg(const GemmTN& p, hipStream_t s) {
             return DCPT_OK;
         }
     }
-    if (p.N <= 64 && p.K <= 64) {
+    if (bn == 64 && bk == 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 64);
         gemm_tn_kernel<64, 64, 2, 2, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
-    } else if (p.K <= 64) {
+    } else if (bk == 64) {
         const int tiles = cdiv(p.N, 128) * cdiv(p.K, 64);
         gemm_tn_kernel<128, 64, 4, 1, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
-    } else if (p.N <= 64) {
+    } else if (bn == 64) {
         const int tiles = cdiv(p.N, 64) * cdiv(p.K, 128);
         gemm_tn_kernel<64, 128, 1, 4, XK, YK><<<dim3(tiles * p.splits, nbatch), dim3(256), 0, s>>>(p);
     } else {
@@ -297,7 +303,7 @@ int launch_cfg(const GemmTN& p, hipStream_t s) {
 
 int gemm_tn_tiles_k(int N, int K) {   // launches with column sums never use the 96-wide tiles
     (void)N;
-    const int bk = (K <= 64) ? 64 : 128;
+    const int bk = (K <= 64 || tn_narrow()) ? 64 : 128;
     return cdiv(K, bk);
 }
 
@@ -311,7 +317,8 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
     // model also handles shapes with more tiles than slots (a dense 3x3 at 1024 channels has 576: one split would run
     // 1.125 rounds, 8 splits run 9.0) and keeps the split count low where the slab traffic would dominate.
     const int64_t max_by_rows = cdiv64(M, 256);  // at least 256 rows per split
-    int64_t smax = 4 * 512 / tiles;
+    const int64_t slots = (bn == 64 || bk == 64) ? 768 : 512;
+    int64_t smax = 4 * slots / tiles;
     if (smax < 16) smax = 16;
     if (smax > max_by_rows) smax = max_by_rows;
     if (smax > 65535) smax = 65535;
@@ -323,7 +330,7 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
         for (int64_t sp = 1; sp <= smax; ++sp) {
             const int64_t r = cdiv64(cdiv64(M, sp), 32) * 32;
             const int64_t nsp = cdiv64(M, r);
-            const double rounds = (double)cdiv64(tiles * nsp, 512);
+            const double rounds = (double)cdiv64(tiles * nsp, slots);
             const double cost = rounds * (double)(r + 96) + 2.0e-5 * (double)nsp * N * K;
             if (cost < best * 0.999) {
                 best = cost;
@@ -331,7 +338,7 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
             }
         }
     } else {
-        want = 512 / tiles;
+        want = slots / tiles;
         if (want > max_by_rows) want = max_by_rows;
         if (want < 1) want = 1;
         if (want > 65535) want = 65535;
