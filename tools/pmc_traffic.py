@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv'),
                 (int(r['End_Timestamp']) - int(r['Start_Timestamp']), float(r['Counter_Value'])))
 out = {}
 for sym, d in rows.items():
-    m = re.match(r'gemm_(nt|tn)_kernel<128, 128, 2, 2, (\d+), (\d+)', sym)
+    m = re.match(r'gemm_(nt|tn)_kernel<(?:128, 128, 2, 2|128, 64, 4, 1), (\d+), (\d+)', sym)
     if not m or 'FETCH_SIZE' not in d or 'WRITE_SIZE' not in d:
         continue
     vals = {}
@@ -33,6 +33,8 @@ for sym, d in rows.items():
     rd, wr = vals['FETCH_SIZE'][0] * 1024 * 2, vals['WRITE_SIZE'][0] * 1024
     a, b = int(m.group(2)), int(m.group(3))
     name = f"gemm_nt<a={ALOAD[a]},epi={EPI[b]}>" if m.group(1) == 'nt' else f"gemm_tn<x={ALOAD[a]},y={ALOAD[b]}>"
+    if name in out and out[name]["launches_used"] >= vals['FETCH_SIZE'][1]:
+        continue   # two tile shapes of one class: keep the one with more launches (the level-3 blocks)
     out[name] = dict(hbm_bytes_per_launch=round(rd + wr), read_bytes=round(rd), write_bytes=round(wr), symbol=sym,
                      launches_used=vals['FETCH_SIZE'][1], median_us=round(vals['FETCH_SIZE'][2], 1))
 json.dump({"source": __doc__.strip() + f"  Raw passes: {os.path.basename(root)}.", "kernels": out},
