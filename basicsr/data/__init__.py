@@ -13,7 +13,7 @@ from torch.utils import data as tdata
 from basicsr.utils import get_root_logger, scandir
 from basicsr.utils.registry import DATASET_REGISTRY
 
-__all__ = ["build_dataset", "build_dataloader"]
+__all__ = ["build_dataset", "build_dataloader", "paired_random_crop_augment"]
 _IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".PNG", ".JPG")
 
 
@@ -22,6 +22,41 @@ def _read_rgb(path):
 
     with Image.open(path) as im:
         return torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
+
+
+def _labelled(sample, opt):
+    """a fixed degradation label for a stand-alone (validation) set: ``dataset_idx: k`` in its options"""
+    if "dataset_idx" in opt:
+        sample["dataset_idx"] = int(opt["dataset_idx"])
+    return sample
+
+
+def paired_random_crop_augment(lq, gt, opt):
+    """train phase (reference basicsr/data/paired_image_dataset.py:152-166 with transforms.py paired_random_crop / augment,
+    scale 1): the same random ``gt_size`` crop, horizontal flip and 90-degree rotation (vertical flip + transpose) of both
+    images, drawn from Python's ``random`` like the reference."""
+    import random
+
+    size = opt.get("gt_size")
+    if size:
+        _, h, w = gt.shape
+        if h < size or w < size:
+            raise ValueError(f"image ({h}, {w}) is smaller than the training patch ({size}, {size})")
+        top, left = random.randint(0, h - size), random.randint(0, w - size)
+        lq, gt = lq[:, top:top + size, left:left + size], gt[:, top:top + size, left:left + size]
+    hflip = opt.get("use_hflip", opt.get("use_flip", False)) and random.random() < 0.5
+    vflip = opt.get("use_rot", False) and random.random() < 0.5
+    rot90 = opt.get("use_rot", False) and random.random() < 0.5
+    out = []
+    for t in (lq, gt):
+        if hflip:
+            t = t.flip(2)
+        if vflip:
+            t = t.flip(1)
+        if rot90:
+            t = t.transpose(1, 2)
+        out.append(t.contiguous())
+    return out[0], out[1]
 
 
 @DATASET_REGISTRY.register()
@@ -46,8 +81,10 @@ class SyntheticPairedDataset(tdata.Dataset):
         low = torch.rand((1, 3, max(2, h // 16), max(2, w // 16)), generator=g)
         gt = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0].clamp(0, 1)
         lq = (gt + self.sigma * torch.randn((3, h, w), generator=g)).clamp(0, 1)
+        if self.opt.get("phase") == "train":
+            lq, gt = paired_random_crop_augment(lq, gt, self.opt)
         name = f"synthetic_{index:04d}"
-        return {"lq": lq, "gt": gt, "lq_path": name, "gt_path": name}
+        return _labelled({"lq": lq, "gt": gt, "lq_path": name, "gt_path": name}, self.opt)
 
 
 @DATASET_REGISTRY.register()
@@ -73,7 +110,9 @@ class PairedImageDataset(tdata.Dataset):
             lq = gt + torch.from_numpy(rs.normal(0, self.sigma / 255.0, tuple(gt.shape)).astype(np.float32))
         else:
             lq = _read_rgb(osp.join(self.lq_root, name))
-        return {"lq": lq, "gt": gt, "lq_path": osp.join(self.lq_root, name), "gt_path": osp.join(self.gt_root, name)}
+        if self.opt.get("phase") == "train":
+            lq, gt = paired_random_crop_augment(lq, gt, self.opt)
+        return _labelled({"lq": lq, "gt": gt, "lq_path": osp.join(self.lq_root, name), "gt_path": osp.join(self.gt_root, name)}, self.opt)
 
 
 for _alias in ("PairedImageDenoiseDataset", "PairedImageDehazeDataset"):
@@ -97,4 +136,19 @@ def build_dataloader(dataset, dataset_opt, num_gpu=1, dist=False, sampler=None, 
     phase = dataset_opt.get("phase", "test")
     if phase in ("val", "test"):
         return tdata.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=0)
-    raise ValueError(f"Wrong dataset phase: {phase}. Supported ones are 'val' and 'test' (the reference ships no train loop).")
+    if phase == "train":  # reference basicsr/data/__init__.py:64-92: per-GPU batch, sampler-driven order, drop_last
+        workers = dataset_opt.get("num_worker_per_gpu", 0) * (1 if dist else max(1, num_gpu))
+        batch = dataset_opt["batch_size_per_gpu"] * (1 if dist else max(1, num_gpu))
+        rank = torch.distributed.get_rank() if dist else 0
+
+        def worker_init(worker_id):
+            import random
+
+            s = (seed or 0) + workers * rank + worker_id
+            np.random.seed(s)
+            random.seed(s)
+
+        return tdata.DataLoader(dataset, batch_size=batch, shuffle=sampler is None, sampler=sampler, num_workers=workers,
+                                drop_last=True, worker_init_fn=worker_init if seed is not None else None,
+                                pin_memory=dataset_opt.get("pin_memory", False), persistent_workers=False)
+    raise ValueError(f"Wrong dataset phase: {phase}. Supported ones are 'train', 'val' and 'test'.")

@@ -75,15 +75,16 @@ class BaseModel:
         return table[optim_type](params, lr, **kwargs)
 
     def setup_schedulers(self):
-        train_opt = self.opt["train"]
-        sched = dict(train_opt["scheduler"])
+        """reference :141-158: MultiStepLR / MultiStepRestartLR / CosineAnnealingRestartLR by name"""
+        from . import lr_scheduler as lrs
+
+        sched = dict(self.opt["train"]["scheduler"])
         kind = sched.pop("type")
         for optimizer in self.optimizers:
             if kind in ("MultiStepLR", "MultiStepRestartLR"):
-                self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(optimizer, sched["milestones"], sched.get("gamma", 0.1)))
+                self.schedulers.append(lrs.MultiStepRestartLR(optimizer, **sched))
             elif kind == "CosineAnnealingRestartLR":
-                period = sched["periods"][0]
-                self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, period, sched.get("eta_min", 0)))
+                self.schedulers.append(lrs.CosineAnnealingRestartLR(optimizer, **sched))
             else:
                 raise NotImplementedError(f"Scheduler {kind} is not implemented yet.")
 
@@ -99,6 +100,33 @@ class BaseModel:
     def get_current_learning_rate(self):
         return [g["lr"] for g in self.optimizers[0].param_groups]
 
+    # -- training state (reference :371-430) -------------------------------------------------------
+    @master_only
+    def save_training_state(self, epoch, current_iter):
+        if current_iter == -1:
+            return
+        state = {"epoch": epoch, "iter": current_iter, "optimizers": [o.state_dict() for o in self.optimizers],
+                 "schedulers": [s.state_dict() for s in self.schedulers]}
+        path = os.path.join(self.opt["path"]["training_states"], f"{current_iter}.state")
+        logger = get_root_logger()
+        for attempt in range(3):
+            try:
+                torch.save(state, path)
+                return
+            except Exception as e:  # noqa: BLE001
+                logger.warning(f"Save training state error: {e}, remaining retry times: {2 - attempt}")
+                time.sleep(1)
+        logger.warning(f"Still cannot save {path}. Just ignore it.")
+
+    def resume_training(self, resume_state):
+        opts, scheds = resume_state["optimizers"], resume_state["schedulers"]
+        assert len(opts) == len(self.optimizers), "Wrong lengths of optimizers"
+        assert len(scheds) == len(self.schedulers), "Wrong lengths of schedulers"
+        for o, sd in zip(self.optimizers, opts):
+            o.load_state_dict(sd)
+        for s, sd in zip(self.schedulers, scheds):
+            s.load_state_dict(sd)
+
     def model_ema(self, decay=0.999):
         src = dict(self.get_bare_model(self.net_g).named_parameters())
         dst = dict(self.net_g_ema.named_parameters())
@@ -111,7 +139,7 @@ class BaseModel:
     @master_only
     def save_network(self, net, net_label, current_iter, param_key="params"):
         name = "latest" if current_iter == -1 else current_iter
-        path = os.path.join(self.opt["path"]["models"], f"net_{net_label}_{name}.pth")
+        path = os.path.join(self.opt["path"]["models"], f"{net_label}_{name}.pth")
         nets = net if isinstance(net, list) else [net]
         keys = param_key if isinstance(param_key, list) else [param_key]
         assert len(nets) == len(keys), "The lengths of net and param_key should be the same."

@@ -164,6 +164,7 @@ class DCPTModel(BaseModel):
     def save(self, epoch, current_iter):
         self.save_network(self.net_g, "net_g", current_iter)
         self.save_network(self.net_dc, "net_dc", current_iter)
+        self.save_training_state(epoch, current_iter)
 
 
 @MODEL_REGISTRY.register()

@@ -217,3 +217,4 @@ class SRModel(BaseModel):
             self.save_network([self.net_g, self.net_g_ema], "net_g", current_iter, param_key=["params", "params_ema"])
         else:
             self.save_network(self.net_g, "net_g", current_iter)
+        self.save_training_state(epoch, current_iter)

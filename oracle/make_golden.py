@@ -377,6 +377,63 @@ def gen_promptir(ref):
     np.savez_compressed(os.path.join(OUT, "promptir_promptgen.npz"), **o)
 
 
+def gen_train_plumbing(ref):
+    """learning-rate sequences of the reference's two schedulers and the index maps of its ConcatDataset / EnlargedSampler
+    (host-side training plumbing; basicsr/models/lr_scheduler.py, basicsr/data/concat_dataset.py, data_sampler.py)"""
+    import importlib.util
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_import.REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    lrs = load("_ref_lr_scheduler", "basicsr/models/lr_scheduler.py")
+    cds = load("_ref_concat_dataset", "basicsr/data/concat_dataset.py")
+    smp = load("_ref_data_sampler", "basicsr/data/data_sampler.py")
+    out = {}
+
+    def run(make, n):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=2e-4)
+        sch = make(opt)
+        seq = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            opt.step()
+            sch.step()
+            seq.append(opt.param_groups[0]["lr"])
+        return np.array(seq, dtype=np.float64)
+
+    out["multistep"] = run(lambda o: lrs.MultiStepRestartLR(o, milestones=[5, 9, 9, 14], gamma=0.5), 20)
+    out["multistep_restart"] = run(lambda o: lrs.MultiStepRestartLR(o, milestones=[3, 6, 13, 16], gamma=0.5, restarts=[0, 10],
+                                                                   restart_weights=[1, 0.5]), 20)
+    out["cosine"] = run(lambda o: lrs.CosineAnnealingRestartLR(o, periods=[8, 6, 6], restart_weights=[1, 0.5, 0.25],
+                                                              eta_min=[1e-7, 2e-7, 3e-7]), 20)
+    out["cosine_single"] = run(lambda o: lrs.CosineAnnealingRestartLR(o, periods=[20], restart_weights=[1], eta_min=1e-6), 20)
+
+    class Toy(torch.utils.data.Dataset):
+        def __init__(self, n, tag):
+            self.n, self.tag = n, tag
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return {"v": self.tag * 100 + i}
+
+    cat = cds.ConcatDataset([Toy(3, 1), Toy(5, 2), Toy(2, 3)], [2, 1, 3])
+    out["concat_len"] = np.array(len(cat))
+    out["concat_map"] = np.array([[cat[i]["v"], cat[i]["dataset_idx"]] for i in range(len(cat))] + [[cat[-1]["v"], cat[-1]["dataset_idx"]]])
+    for world, rank, ratio in ((1, 0, 1), (2, 1, 3), (4, 2, 2)):
+        sp = smp.EnlargedSampler(Toy(11, 0), world, rank, ratio)
+        seqs = []
+        for ep in (0, 3):
+            sp.set_epoch(ep)
+            seqs.append(list(iter(sp)))
+        out[f"sampler_{world}_{rank}_{ratio}"] = np.array(seqs)
+    np.savez_compressed(os.path.join(OUT, "train_plumbing.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -395,6 +452,7 @@ def main():
     gen_dcdist_step(ref)
     gen_restormer(ref)
     gen_promptir(ref)
+    gen_train_plumbing(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -206,6 +206,108 @@ def test_cli_refuses_cpu_for_product_arch(tmp_path):
                                            "network_g:enc_blk_nums=[1,1]", "network_g:dec_blk_nums=[1,1]"])
 
 
+# ------------------------------------------------------------------------------------------------ training plumbing
+def test_schedulers_concat_sampler_match_the_reference(golden_dir):
+    """lr sequences of MultiStepRestartLR / CosineAnnealingRestartLR, ConcatDataset's index -> (sample, dataset_idx) map and
+    EnlargedSampler's per-rank index streams == the reference's (tests/golden/train_plumbing.npz)"""
+    from basicsr.data.concat_dataset import ConcatDataset
+    from basicsr.data.data_sampler import EnlargedSampler
+    from basicsr.models import lr_scheduler as lrs
+
+    g = np.load(os.path.join(golden_dir, "train_plumbing.npz"))
+
+    def run(make, n):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=2e-4)
+        sch = make(opt)
+        seq = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            opt.step()
+            sch.step()
+            seq.append(opt.param_groups[0]["lr"])
+        return np.array(seq)
+
+    cases = {"multistep": lambda o: lrs.MultiStepRestartLR(o, milestones=[5, 9, 9, 14], gamma=0.5),
+             "multistep_restart": lambda o: lrs.MultiStepRestartLR(o, milestones=[3, 6, 13, 16], gamma=0.5, restarts=[0, 10],
+                                                                   restart_weights=[1, 0.5]),
+             "cosine": lambda o: lrs.CosineAnnealingRestartLR(o, periods=[8, 6, 6], restart_weights=[1, 0.5, 0.25],
+                                                              eta_min=[1e-7, 2e-7, 3e-7]),
+             "cosine_single": lambda o: lrs.CosineAnnealingRestartLR(o, periods=[20], restart_weights=[1], eta_min=1e-6)}
+    for name, make in cases.items():
+        np.testing.assert_allclose(run(make, 20), g[name], rtol=1e-12, atol=1e-18, err_msg=name)
+
+    class Toy(torch.utils.data.Dataset):
+        def __init__(self, n, tag):
+            self.n, self.tag = n, tag
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return {"v": self.tag * 100 + i}
+
+    cat = ConcatDataset([Toy(3, 1), Toy(5, 2), Toy(2, 3)], [2, 1, 3])
+    assert len(cat) == int(g["concat_len"])
+    mine = [[cat[i]["v"], cat[i]["dataset_idx"]] for i in range(len(cat))] + [[cat[-1]["v"], cat[-1]["dataset_idx"]]]
+    assert np.array_equal(np.array(mine), g["concat_map"])
+    with pytest.raises(ValueError):
+        cat[-len(cat) - 1]
+    for world, rank, ratio in ((1, 0, 1), (2, 1, 3), (4, 2, 2)):
+        sp = EnlargedSampler(Toy(11, 0), world, rank, ratio)
+        seqs = []
+        for ep in (0, 3):
+            sp.set_epoch(ep)
+            seqs.append(list(iter(sp)))
+        assert np.array_equal(np.array(seqs), g[f"sampler_{world}_{rank}_{ratio}"]) and len(sp) == len(seqs[0])
+
+
+def _train_yaml(tmp_path, total_iter, **extra):
+    import yaml
+
+    opt = dict(name="cpu_train", model_type="SRModel", scale=1, num_gpu=0, manual_seed=3,
+               datasets=dict(train_1=dict(name="a", type="SyntheticPairedDataset", num=6, size=48, seed=1, gt_size=32, use_hflip=True,
+                                          use_rot=True, batch_size_per_gpu=2, num_worker_per_gpu=0, enlarge_ratio=2),
+                             train_2=dict(name="b", type="SyntheticPairedDataset", num=4, size=40, seed=2, gt_size=32, sigma_range=50,
+                                          enlarge_ratio=1),
+                             val_1=dict(name="v", type="SyntheticPairedDataset", num=2, size=32, seed=9)),
+               network_g=dict(type="_TestConvArch", window_size=8),
+               path=dict(pretrain_network_g=None, resume_state=None),
+               train=dict(total_iter=total_iter, warmup_iter=3, optim_g=dict(type="Adam", lr=2e-3),
+                          scheduler=dict(type="MultiStepLR", milestones=[6, 10], gamma=0.5),
+                          pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"), ema_decay=0.9),
+               val=dict(val_freq=5, save_img=False, metrics=dict(psnr=dict(type="calculate_psnr", crop_border=0, test_y_channel=False))),
+               logger=dict(print_freq=2, save_checkpoint_freq=4))
+    opt.update(extra)
+    path = tmp_path / "train.yml"
+    path.write_text(yaml.safe_dump(opt))
+    return str(path)
+
+
+def test_train_loop_checkpoint_and_resume(tmp_path):
+    """basicsr/train.py end to end on CPU with the test arch: concatenated train sets, warm-up + MultiStepLR, EMA, periodic
+    validation and checkpoints, then --auto_resume from the newest state continues at the right iteration and learning rate"""
+    import logging
+
+    from basicsr.train import train_pipeline
+
+    logging.getLogger("basicsr").handlers.clear()
+    model, res = train_pipeline(str(tmp_path), argv=["-opt", _train_yaml(tmp_path, 9)])
+    exp = tmp_path / "experiments" / "cpu_train"
+    assert (exp / "models" / "net_g_8.pth").exists() and (exp / "models" / "net_g_latest.pth").exists()
+    assert (exp / "training_states" / "8.state").exists()
+    assert set(torch.load(exp / "models" / "net_g_8.pth").keys()) == {"params", "params_ema"}
+    assert abs(model.get_current_learning_rate()[0] - 1e-3) < 1e-12        # 2e-3 halved at iteration 6
+    assert 5.0 < res["v"]["psnr"] < 80.0
+    first = model.get_current_log()["l_pix"]
+    # resume: 8.state -> runs iterations 9..12 of a 12-iteration schedule (second milestone at 10)
+    model2, _ = train_pipeline(str(tmp_path), argv=["-opt", _train_yaml(tmp_path, 12), "--auto_resume"])
+    assert (exp / "training_states" / "12.state").exists()
+    assert abs(model2.get_current_learning_rate()[0] - 5e-4) < 1e-12
+    st = torch.load(exp / "training_states" / "12.state", weights_only=False)
+    assert st["iter"] == 12 and st["optimizers"][0]["state"][0]["step"] == 12   # Adam continued from step 8, not from 0
+    assert model2.get_current_log()["l_pix"] < 1.5 * first
+
+
 # ------------------------------------------------------------------------------------------------
 def _ddp_worker(rank, world, port, out):
     import torch.distributed as dist
