@@ -20,7 +20,7 @@ for lvl, (c, hw, nblk) in enumerate([(64, 256, 2), (128, 128, 2), (256, 64, 2), 
         tf += e0.elapsed_time(e1); tb += e1.elapsed_time(e2)
     tf /= n; tb /= n
     M = 32 * hw * hw
-    gf = 18.0 * M * c * c / 1e9   # fwd+bwd GEMM flops of a block
+    gf = 36.0 * M * c * c / 1e9   # fwd+bwd GEMM flops of a block (6 c^2 MACs per pixel forward, x3)
     unit = M * c * 4 / 1e6        # MB of one [M][C] tensor
     print(f"level {lvl}: C={c:4d} {hw}x{hw}  fwd {tf*1e3:7.0f} us  bwd {tb*1e3:7.0f} us  x{nblk:2d} blocks = {(tf+tb)*nblk:6.1f} ms   "
           f"GEMM {gf:6.1f} GF -> {gf/(tf+tb):6.1f} TF/s    [M][C] = {unit:6.1f} MB -> {(tf+tb)*1e-3*5.0e12/ (unit*1e6):5.1f} tensor passes at 5 TB/s")

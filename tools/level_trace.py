@@ -1,0 +1,15 @@
+"""One NAFBlock forward + backward at one level of the bench configuration, 5 times (run under rocprofv3 --kernel-trace)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from basicsr.archs.nafnet_arch import NAFBlock
+from dcpt_amd.keyed_init import fill_module_
+from dcpt_amd import _lib
+_lib.load().dcpt_set_side_stream(int(os.environ.get("SIDE", "0")))
+lvl = int(sys.argv[1]); c, hw = [(64, 256), (128, 128), (256, 64), (512, 32), (1024, 16)][lvl]
+dev = torch.device('cuda:0')
+blk = fill_module_(NAFBlock(c)).to(dev)
+x = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+go = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+for _ in range(5):
+    y = blk(x); y.backward(go)
+torch.cuda.synchronize()
