@@ -309,43 +309,43 @@ __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
 
 // Fused SimpleGate + depthwise backward (NAFNet):  dt1 = dw3x3^T(da),  da_1 = dt2 * a_2,  da_2 = dt2 * a_1,
 // a = dw3x3(t1) + b2 (recomputed),  dt2 = dts * s + dpool,  plus the per-block partial sums of dw2[ch][tap] and db2[ch].
-// `da` never goes to memory: a thread owns VW channels of BOTH halves at one pixel column and streams down its row range;
-// for every t1 row it loads columns x-2..x+2, advances the forward-conv accumulators of columns x-1, x, x+1, turns the
-// completed row of a into da at those three columns, and feeds it to the transposed-conv accumulators and the tap
-// gradients (which pair da[row][x] with the t1 rows it still holds).  HBM traffic: t1 and dts once (+2-row halos), dt1
-// once -- 5 tensor units instead of 11 for the two-kernel form; the extra column loads are L1 hits.
+// `da` never goes to memory.  A thread owns VW channels of ONE half at one pixel column and streams down its row range; the
+// thread of the other half sits in the neighbouring lane (lane ^ 1), and the only thing the two exchange is the recomputed
+// conv output: da_own = dt2 * a_other, one DPP quad-permute per value.  For every t1 row a thread loads columns x-2..x+2,
+// advances the forward-conv accumulators of columns x-1, x, x+1, turns the completed row of a into da at those three
+// columns, and feeds it to the transposed-conv accumulators and the tap gradients (which pair da[row][x] with the t1 rows
+// it still holds).  Splitting the halves across lanes halves the per-thread state of the earlier one-thread-both-halves form,
+// which makes VW = 4 (16-byte accesses) fit: measured on the training step, split + VW 4 is +0.5 % over the unsplit VW 2
+// kernel, while split + VW 2 (106 VGPRs, 4 waves/SIMD) is -1 % -- the kernel is limited by memory instructions issued per
+// byte, not by occupancy.
+// HBM traffic: t1 and dts once (+2-row halos), dt1 once -- 5 tensor units instead of 11 for the two-kernel form.
 template <int VW>
 __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
     __shared__ float red[256 * VW];
-    const DwMap mp = dw_map(p.H, p.W, p.C / VW);
+    const int C = p.C, C2 = 2 * p.C;
+    const DwMap mp = dw_map(p.H, p.W, C2 / VW);   // "groups" = (channel group, half) pairs
     const DwBlk bk = dw_block(mp);
     const int tid = threadIdx.x;
     const int ql = tid % mp.QB, pl = tid / mp.QB;
-    const int q = bk.x * mp.QB + ql;
+    const int hq = bk.x * mp.QB + ql;             // even: first half, odd: second half of channel group hq / 2
     const int b = bk.z;
-    const bool qok = q < mp.QW;
-    const int C = p.C, C2 = 2 * p.C;
-    const int c1 = VW * q, c2 = C + VW * q;
-    vf<VW> w1[9], w2[9];
+    const bool qok = hq < mp.QW;
+    const int cg = VW * (hq >> 1);                // channels inside a half (dts / s / dpool index)
+    const int co = (hq & 1) * C + cg;             // this thread's channels of t1 / dt1 / the depthwise weights
+    vf<VW> w[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        w1[t] = gld<VW>(p.w2p + t * C2 + c1, qok);
-        w2[t] = gld<VW>(p.w2p + t * C2 + c2, qok);
-    }
-    const vf<VW> bias1 = gld<VW>(p.b2 + c1, qok && p.b2), bias2 = gld<VW>(p.b2 + c2, qok && p.b2);
+    for (int t = 0; t < 9; ++t) w[t] = gld<VW>(p.w2p + t * C2 + co, qok);
+    const vf<VW> bias = gld<VW>(p.b2 + co, qok && p.b2);
     vf<VW> sv, dpv = vz<VW>();
 #pragma unroll
     VFOR sv.v[i_] = 1.f;
     if (qok && p.simg) {
-        sv = gld<VW>(p.simg + (int64_t)b * C + c1, true);
-        dpv = gld<VW>(p.dpool + (int64_t)b * C + c1, true);
+        sv = gld<VW>(p.simg + (int64_t)b * C + cg, true);
+        dpv = gld<VW>(p.dpool + (int64_t)b * C + cg, true);
     }
-    vf<VW> g1[10], g2[10];   // tap gradients (0..8) and bias gradient (9) of the two halves
+    vf<VW> g[10];   // tap gradients (0..8) and bias gradient (9)
 #pragma unroll
-    for (int t = 0; t < 10; ++t) {
-        g1[t] = vz<VW>();
-        g2[t] = vz<VW>();
-    }
+    for (int t = 0; t < 10; ++t) g[t] = vz<VW>();
     const int wc = bk.y % mp.nwc, nrp = gridDim.y / mp.nwc, rpp = (p.H + nrp - 1) / nrp;
     const int x = wc * mp.PB + pl;
     const bool ok = qok && x < p.W;
@@ -365,100 +365,80 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
         cs[j] = cin[j] ? 0u : COL_SENT;
     }
     // forward-conv running accumulators of columns x-1, x, x+1 (index 0..2): A0 = row r-1 (complete after this step), A1 = row r
-    vf<VW> A0_1[3], A0_2[3], A1_1[3], A1_2[3];
+    vf<VW> A0[3], A1[3];
     // transposed-conv running accumulators at column x: B0 = output row rho-1, B1 = output row rho
-    vf<VW> B0_1 = vz<VW>(), B0_2 = vz<VW>(), B1_1 = vz<VW>(), B1_2 = vz<VW>();
+    vf<VW> B0 = vz<VW>(), B1 = vz<VW>();
     // t1 at columns x-1..x+1 of the two previous rows (for the tap gradients)
-    vf<VW> Tm1[3], Tm2[3], Tc1[3], Tc2[3];
+    vf<VW> Tm[3], Tc[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        A0_1[j] = A0_2[j] = A1_1[j] = A1_2[j] = vz<VW>();
-        Tm1[j] = Tm2[j] = Tc1[j] = Tc2[j] = vz<VW>();
-    }
+    for (int j = 0; j < 3; ++j) A0[j] = A1[j] = Tm[j] = Tc[j] = vz<VW>();
     for (int r = h0 - 2; r <= h1 + 1; ++r) {
-        // ---- t1 row r, columns x-2..x+2, both halves
+        // ---- t1 row r, columns x-2..x+2
         const bool rin = r >= 0 && r < p.H;
-        const uint32_t ro = rin ? (uint32_t)(((r - rb) * p.W + x) * C2) * 4u : ROW_SENT;
-        vf<VW> T1[5], T2[5];
+        const uint32_t ro = rin ? (uint32_t)(((r - rb) * p.W + x) * C2 + co) * 4u : ROW_SENT;
+        vf<VW> T[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint32_t o = ro + (uint32_t)((j - 2) * C2 * 4);
-            T1[j] = bld<VW>(rs_t, (o + 4u * (uint32_t)c1) | cs[j]);
-            T2[j] = bld<VW>(rs_t, (o + 4u * (uint32_t)c2) | cs[j]);
-        }
+        for (int j = 0; j < 5; ++j) T[j] = bld<VW>(rs_t, (ro + (uint32_t)((j - 2) * C2 * 4)) | cs[j]);
         // ---- dts of row rho = r-1 at columns x-1..x+1
         const int rho = r - 1;
         const bool rho_in = rho >= 0 && rho < p.H;
         vf<VW> D[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            D[j] = bld<VW>(rs_d, rho_in ? ((uint32_t)(((rho - rb) * p.W + x + j - 1) * C + c1) * 4u) | cs[j + 1] : ROW_SENT);
+            D[j] = bld<VW>(rs_d, rho_in ? ((uint32_t)(((rho - rb) * p.W + x + j - 1) * C + cg) * 4u) | cs[j + 1] : ROW_SENT);
         // ---- forward conv: row r contributes kernel row 2 to a[r-1], row 1 to a[r], row 0 to a[r+1]
-        vf<VW> A2_1[3], A2_2[3];
+        vf<VW> A2[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            A0_1[j] = vfma(w1[6], T1[j], vfma(w1[7], T1[j + 1], vfma(w1[8], T1[j + 2], A0_1[j])));
-            A0_2[j] = vfma(w2[6], T2[j], vfma(w2[7], T2[j + 1], vfma(w2[8], T2[j + 2], A0_2[j])));
-            A1_1[j] = vfma(w1[3], T1[j], vfma(w1[4], T1[j + 1], vfma(w1[5], T1[j + 2], A1_1[j])));
-            A1_2[j] = vfma(w2[3], T2[j], vfma(w2[4], T2[j + 1], vfma(w2[5], T2[j + 2], A1_2[j])));
-            A2_1[j] = vfma(w1[0], T1[j], vfma(w1[1], T1[j + 1], vmul(w1[2], T1[j + 2])));
-            A2_2[j] = vfma(w2[0], T2[j], vfma(w2[1], T2[j + 1], vmul(w2[2], T2[j + 2])));
+            A0[j] = vfma(w[6], T[j], vfma(w[7], T[j + 1], vfma(w[8], T[j + 2], A0[j])));
+            A1[j] = vfma(w[3], T[j], vfma(w[4], T[j + 1], vfma(w[5], T[j + 2], A1[j])));
+            A2[j] = vfma(w[0], T[j], vfma(w[1], T[j + 1], vmul(w[2], T[j + 2])));
         }
-        // ---- da of row rho at columns x-1..x+1 (zero where the pixel does not exist)
-        vf<VW> da1[3], da2[3];
+        // ---- da of row rho at columns x-1..x+1 (zero where the pixel does not exist): dt2 * (a of the OTHER half, lane ^ 1)
+        vf<VW> da[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const bool pin = rho_in && cin[j + 1];
             const vf<VW> dt2 = vfma(D[j], sv, dpv);
-            const vf<VW> a1 = vadd(A0_1[j], bias1), a2 = vadd(A0_2[j], bias2);
-            da1[j] = pin ? vmul(dt2, a2) : vz<VW>();
-            da2[j] = pin ? vmul(dt2, a1) : vz<VW>();
+            const vf<VW> a_own = vadd(A0[j], bias);
+            vf<VW> a_other;
+#pragma unroll
+            VFOR a_other.v[i_] = dpp_perm<0xB1>(a_own.v[i_]);
+            da[j] = pin ? vmul(dt2, a_other) : vz<VW>();
         }
         // ---- transposed conv: da row rho feeds dt1 rows rho-1 (ky = 0), rho (ky = 1), rho+1 (ky = 2); da[.][x-1+j] <-> kx = 2-j
-        B0_1 = vfma(w1[2], da1[0], vfma(w1[1], da1[1], vfma(w1[0], da1[2], B0_1)));
-        B0_2 = vfma(w2[2], da2[0], vfma(w2[1], da2[1], vfma(w2[0], da2[2], B0_2)));
-        B1_1 = vfma(w1[5], da1[0], vfma(w1[4], da1[1], vfma(w1[3], da1[2], B1_1)));
-        B1_2 = vfma(w2[5], da2[0], vfma(w2[4], da2[1], vfma(w2[3], da2[2], B1_2)));
-        const vf<VW> B2_1 = vfma(w1[8], da1[0], vfma(w1[7], da1[1], vmul(w1[6], da1[2])));
-        const vf<VW> B2_2 = vfma(w2[8], da2[0], vfma(w2[7], da2[1], vmul(w2[6], da2[2])));
+        B0 = vfma(w[2], da[0], vfma(w[1], da[1], vfma(w[0], da[2], B0)));
+        B1 = vfma(w[5], da[0], vfma(w[4], da[1], vfma(w[3], da[2], B1)));
+        const vf<VW> B2 = vfma(w[8], da[0], vfma(w[7], da[1], vmul(w[6], da[2])));
         {
             const int y = rho - 1;   // complete now
-            const uint32_t oo = (ok && y >= h0 && y < h1) ? (uint32_t)(((y - rb) * p.W + x) * C2) * 4u : ROW_SENT;
-            bst<VW>(rs_o, oo + 4u * (uint32_t)c1, B0_1);
-            bst<VW>(rs_o, oo + 4u * (uint32_t)c2, B0_2);
+            bst<VW>(rs_o, (ok && y >= h0 && y < h1) ? (uint32_t)(((y - rb) * p.W + x) * C2 + co) * 4u : ROW_SENT, B0);
         }
         // ---- tap gradients: da[rho][x] with t1 rows rho-1 (Tm), rho (Tc), rho+1 (= row r, T) at columns x-1..x+1; rows of this
         //      block's range only, so that every pixel is counted once
         if (rho >= h0 && rho < h1) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                g1[0 * 3 + kx] = vfma(da1[1], Tm1[kx], g1[0 * 3 + kx]);
-                g2[0 * 3 + kx] = vfma(da2[1], Tm2[kx], g2[0 * 3 + kx]);
-                g1[1 * 3 + kx] = vfma(da1[1], Tc1[kx], g1[1 * 3 + kx]);
-                g2[1 * 3 + kx] = vfma(da2[1], Tc2[kx], g2[1 * 3 + kx]);
-                g1[2 * 3 + kx] = vfma(da1[1], T1[kx + 1], g1[2 * 3 + kx]);
-                g2[2 * 3 + kx] = vfma(da2[1], T2[kx + 1], g2[2 * 3 + kx]);
+                g[0 * 3 + kx] = vfma(da[1], Tm[kx], g[0 * 3 + kx]);
+                g[1 * 3 + kx] = vfma(da[1], Tc[kx], g[1 * 3 + kx]);
+                g[2 * 3 + kx] = vfma(da[1], T[kx + 1], g[2 * 3 + kx]);
             }
-            g1[9] = vadd(g1[9], da1[1]);
-            g2[9] = vadd(g2[9], da2[1]);
+            g[9] = vadd(g[9], da[1]);
         }
         // ---- shift the pipelines
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            A0_1[j] = A1_1[j]; A0_2[j] = A1_2[j];
-            A1_1[j] = A2_1[j]; A1_2[j] = A2_2[j];
-            Tm1[j] = Tc1[j]; Tm2[j] = Tc2[j];
-            Tc1[j] = T1[j + 1]; Tc2[j] = T2[j + 1];
+            A0[j] = A1[j];
+            A1[j] = A2[j];
+            Tm[j] = Tc[j];
+            Tc[j] = T[j + 1];
         }
-        B0_1 = B1_1; B0_2 = B1_2;
-        B1_1 = B2_1; B1_2 = B2_2;
+        B0 = B1;
+        B1 = B2;
     }
     float* part = p.part + ((int64_t)b * gridDim.y + bk.y) * 10 * C2;
 #pragma unroll
-    for (int t = 0; t < 10; ++t) {
-        dw_block_reduce<VW>(red, g1[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + c1);
-        dw_block_reduce<VW>(red, g2[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + c2);
-    }
+    for (int t = 0; t < 10; ++t) dw_block_reduce<VW>(red, g[t], tid, ql, pl, mp.QB, mp.PB, qok, part + t * C2 + co);
 }
 
 // Plain depthwise 3x3 (no bias, no gate) over Ctot channels (Restormer MDTA qkv_dwconv), plus per-block partial
@@ -575,11 +555,11 @@ int dw_fused_vw() {   // channels per thread of the fused backward kernel (DCPT_
     static int v = 0;
     if (v == 0) {
         const char* e = getenv("DCPT_DW_FUSED_VW");
-        v = (e && e[0] == '4') ? 4 : 2;
+        v = (e && e[0] == '2') ? 2 : 4;
     }
     return v;
 }
-int dw_num_blocks_per_image_fused(const DwGeom& g) { return nblk_for(g, g.C / dw_fused_vw()); }
+int dw_num_blocks_per_image_fused(const DwGeom& g) { return nblk_for(g, 2 * g.C / dw_fused_vw()); }
 int dw_num_blocks_per_image(const DwGeom& g) { return nblk_for(g, g.C / dw_vw()); }
 
 // a block's windows span its row range + halo: (rows/part + 5) * W * Ct floats must fit the 32-bit offsets
@@ -618,7 +598,7 @@ int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, con
     p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = dt1; p.part = wpart;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
     const int vw = dw_fused_vw();
-    const DwMap mp = dw_map(g.H, g.W, g.C / vw);
+    const DwMap mp = dw_map(g.H, g.W, 2 * g.C / vw);
     const int nblk = dw_num_blocks_per_image_fused(g);
     DW_CHECK_RANGE(g.H, g.W, 2 * g.C, nblk, mp.nwc);
     if (vw == 2) dw_bwd_fused_kernel<2><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
