@@ -312,6 +312,39 @@ def test_batch_consistency_full_size(dev):
     check("batch vs single", y2[0:1], y1, 1e-6)
 
 
+def test_directional_derivative_full_size(dev):
+    """Size-independent property at BASELINE.json's full size (NAFNet-64 [1,1,1,28], B = 32, 256 x 256): along a random direction
+    d in parameter AND input space, the analytic derivative <grad L, d> of the whole backward pass equals the central difference
+    (L(w + e d) - L(w - e d)) / 2e of two more forward passes.  The loss is a smooth one (mean square), reduced in fp64 so
+    that only the fp32 forward noise and the O(e^2) truncation remain."""
+    net = _build_net(FULL, dev)
+    x = torch.rand((32, 3, 256, 256), generator=torch.Generator().manual_seed(11)).to(dev).requires_grad_(True)
+    gt = torch.rand((32, 3, 256, 256), generator=torch.Generator().manual_seed(12)).to(dev)
+
+    def loss_of(inp):
+        return (net(inp).double() - gt.double()).pow(2).mean()
+
+    loss = loss_of(x)
+    loss.backward()
+    gen = torch.Generator().manual_seed(13)
+    params = [p for p in net.parameters()]
+    dirs = [torch.randn(p.shape, generator=gen).to(dev) * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    dx = torch.randn(x.shape, generator=gen).to(dev) * 0.1
+    analytic = float(sum((p.grad.double() * d.double()).sum() for p, d in zip(params, dirs)) + (x.grad.double() * dx.double()).sum())
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sign in (+1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=sign * eps)
+            vals.append(float(loss_of(x.detach() + sign * eps * dx)))
+            for p, d in zip(params, dirs):
+                p.sub_(d, alpha=sign * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(analytic) > 1e-4, analytic
+    assert abs(numeric - analytic) <= 2e-2 * abs(analytic), (numeric, analytic, float(loss))
+
+
 def test_nafnet_local_tlsc_golden(dev, golden_dir):
     """TLSC `NAFNet` (N10): local-window SCA at inference, vs the real reference's output."""
     from basicsr.archs import build_network

@@ -143,3 +143,38 @@ def test_restormer_tiny_golden(dev, golden_dir, tag, name):
     if name == "Restormer":
         assert [tuple(t.shape) for t in taps] == [(2, 64, 8, 8), (2, 32, 16, 16), (2, 32, 32, 32)]
         assert net(x.detach(), hook=True) is None
+
+
+def test_directional_derivative_full_size(dev):
+    """Size-independent property at BASELINE.json's Restormer configuration (defaults: dim 48, [4,6,6,8], B = 64, 128 x 128):
+    analytic directional derivative of the whole backward pass == central difference of two forward passes (smooth loss, fp64
+    reduction); see tests/test_gpu_parity.py::test_directional_derivative_full_size."""
+    from basicsr.archs import build_network
+
+    net = build_network(dict(type="Restormer"))
+    net.load_state_dict(keyed_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=0), strict=True)
+    net = net.to(dev)
+    x = torch.rand((64, 3, 128, 128), generator=torch.Generator().manual_seed(21)).to(dev).requires_grad_(True)
+    gt = torch.rand((64, 3, 128, 128), generator=torch.Generator().manual_seed(22)).to(dev)
+
+    def loss_of(inp):
+        return (net(inp).double() - gt.double()).pow(2).mean()
+
+    loss = loss_of(x)
+    loss.backward()
+    gen = torch.Generator().manual_seed(23)
+    params = list(net.parameters())
+    dirs = [torch.randn(p.shape, generator=gen).to(dev) * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    dx = torch.randn(x.shape, generator=gen).to(dev) * 0.1
+    analytic = float(sum((p.grad.double() * d.double()).sum() for p, d in zip(params, dirs)) + (x.grad.double() * dx.double()).sum())
+    eps, vals = 1e-3, []
+    with torch.no_grad():
+        for sign in (+1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=sign * eps)
+            vals.append(float(loss_of(x.detach() + sign * eps * dx)))
+            for p, d in zip(params, dirs):
+                p.sub_(d, alpha=sign * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(analytic) > 1e-4, analytic
+    assert abs(numeric - analytic) <= 3e-2 * abs(analytic), (numeric, analytic, float(loss))
