@@ -60,6 +60,7 @@ int launch_sca_fwd(const float* pool_part, int nblk, const float* Wsca, const fl
                    int B, int C, int P, hipStream_t s);
 // ds[b][k] = sum_{m in image b} dts[m][k] * t2[m][k]   (two-stage, deterministic)
 int sca_ds_num_blocks(int P);
+int sca_ds_fused_slices(int P);   // P / 128 when the E_DOTCOL form applies, else 0
 // backward: part[b][j][k] = sum over the j-th pixel slice of image b of dts*t2  (j < sca_ds_num_blocks(P))
 int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B, int C, int P, hipStream_t s);
 // (the slices may also come out of the dts GEMM's E_DOTCOL epilogue: 128-pixel slices, nslices = P / 128)

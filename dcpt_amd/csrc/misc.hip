@@ -92,12 +92,29 @@ __global__ __launch_bounds__(256) void sca_dpool_kernel(const float* __restrict_
                                                         float* __restrict__ dpool, int C, float invP) {
     extern __shared__ __attribute__((aligned(16))) float dsl[];   // ds[C]
     __shared__ float red[8][32];
+    __shared__ float psum[256];
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int n = tid; n < C; n += 256) {
+    if (C < 256 && (256 % C) == 0) {
+        // narrow levels have many slices (up to 512 per image) and few columns: 256 / C threads share a column, each sums
+        // every (256 / C)-th slice, and the partial sums are combined in a fixed order
+        const int parts = 256 / C, n = tid % C, pt = tid / C;
         float v = 0.f;
 #pragma unroll 8
-        for (int j = 0; j < nslices; ++j) v += part[((int64_t)b * nslices + j) * C + n];
-        dsl[n] = v;
+        for (int j = pt; j < nslices; j += parts) v += part[((int64_t)b * nslices + j) * C + n];
+        psum[tid] = v;
+        __syncthreads();
+        if (pt == 0) {
+            float t = psum[n];
+            for (int q = 1; q < parts; ++q) t += psum[q * C + n];
+            dsl[n] = t;
+        }
+    } else {
+        for (int n = tid; n < C; n += 256) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < nslices; ++j) v += part[((int64_t)b * nslices + j) * C + n];
+            dsl[n] = v;
+        }
     }
     __syncthreads();
     const int kl = tid & 31, ng = tid >> 5;
@@ -357,6 +374,9 @@ int sca_ds_num_blocks(int P) {
     if (n > 64) n = 64;
     return n;
 }
+
+// slices when the sums come out of the dts GEMM's E_DOTCOL epilogue (one per 128-pixel tile), 0 if that form does not apply
+int sca_ds_fused_slices(int P) { return (P % 128 == 0 && P / 128 <= 1024) ? P / 128 : 0; }
 
 int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B, int C, int P, hipStream_t s) {
     DCPT_CHECK_ARG(C % 4 == 0 && B <= 65535, "sca_ds: C=%d", C);

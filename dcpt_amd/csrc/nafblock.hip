@@ -95,7 +95,10 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.ln_nblk = ln_bwd_num_blocks(M, C);
     w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * C);
     w.lnpart2 = a.get<float>((size_t)w.ln_nblk * 3 * C);
-    w.ds_part = a.get<float>((size_t)B * sca_ds_num_blocks(P) * C);
+    {
+        const int fs = sca_ds_fused_slices(P), ns = sca_ds_num_blocks(P);
+        w.ds_part = a.get<float>((size_t)B * (fs > ns ? fs : ns) * C);
+    }
     w.ds = a.get<float>((size_t)B * C);
     w.dpool = a.get<float>((size_t)B * C);
     w.nblk_b = dw_num_blocks_per_image_fused(g);
@@ -234,8 +237,8 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     // B6: dts = d(t2*s)
     // when an image is a whole number of 128-pixel GEMM tiles, SCA's ds[b][k] = sum_p dts * t2 comes out of this GEMM's epilogue
     // as per-tile column sums (one bandwidth pass and one launch less)
-    const bool ds_fused = (P % 128 == 0) && (P / 128 <= sca_ds_num_blocks(P));
-    const int ds_slices = ds_fused ? P / 128 : sca_ds_num_blocks(P);
+    const bool ds_fused = sca_ds_fused_slices(P) > 0;
+    const int ds_slices = ds_fused ? sca_ds_fused_slices(P) : sca_ds_num_blocks(P);
     g = GemmNT{};
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = dts; g.ldc = C;
     if (ds_fused) {
