@@ -169,7 +169,8 @@ def main():
         rows.sort(key=lambda r: -r["ms"])
         return rows
 
-    SAMPLE = 10  # in the timed region every 10th GEMM launch is bracketed (an event pair costs ~3 us of queue time)
+    SAMPLE = 7   # in the timed region every 7th GEMM launch is bracketed (an event pair costs ~3 us of queue time; 7 is
+                 # co-prime with the number of GEMM launches per block, so every launch class gets sampled)
     barrier()
     if use_prof:
         lib.dcpt_prof_enable(SAMPLE)
@@ -264,9 +265,9 @@ def main():
                 "whole_step": whole,
                 "measured": ("HIP events around every launch of the kernel, on its stream, " +
                              (f"in a serialized pass of {args.iso_steps} steps right after the timed region (weight-gradient side "
-                              f"stream off, {iso_ms:.1f} ms/step); as_run = events around every {SAMPLE}th launch inside the timed "
+                              f"stream off, {iso_ms:.1f} ms/step); as_run = events around every {SAMPLE}th GEMM launch inside the timed "
                               "region, where launches of the two streams overlap" if asrun_rows is not None else
-                              f"around every {SAMPLE}th launch inside the timed region")),
+                              f"around every {SAMPLE}th GEMM launch inside the timed region")),
                 "by_kernel": [dict(kernel=r["kernel"], MNK=[r["M"], r["N"], r["K"]], launches=r["launches"],
                                    ms_per_step=round(r["ms"] / args.steps, 3),
                                    tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
