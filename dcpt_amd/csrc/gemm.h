@@ -9,7 +9,7 @@
 #include "dcpt_common.h"
 
 enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5, A_LNBF = 6 };
-enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7, E_BIASGATE = 8, E_DOTCOL = 9 };
+enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7, E_BIASGATE = 8, E_DOTCOL = 9, E_LNBWD = 10 };
 
 struct GemmNT {
     const float* A;   // [M][lda]   (A_SG: 2K columns; A_GATHER: fine NHWC image, see g*)
@@ -37,6 +37,9 @@ struct GemmNT {
     const float* cscale;  // E_RESID: C = res + (acc+bias)*cscale[n] (null = 1); E_ADDSCALED: C = acc + cscale[n]*res
                           // E_MUL: C = (acc+bias)*res
     const float* aux;     // E_SGBWD: v [M][2N]
+    // E_LNBWD (N <= 128, one tile spans the row): the accumulator row g is the gradient of a LayerNorm output whose input was
+    // res (x); C = rstd*(g*lnw - mean_c(g*lnw) - xhat*mean_c(g*lnw*xhat)) + aux (the residual gradient, may be null), and
+    // colpart[m / 128][0][n] = sum_rows g*xhat (-> dweight), colpart[m / 128][1][n] = sum_rows g (-> dbias); uses mu, rstd, lnw
     float* colpart;       // E_DOTCOL: C = acc as E_PLAIN AND colpart[m / 128][n] = sum over the tile's 128 rows of acc * res[m][n]
                           // (fixed order; SCA backward's per-image channel sums come out of the producing GEMM)
     float* gate;          // E_BIASGATE (N = 2*Ch, SimpleGate input): C = acc + bias as usual AND gate[m][c] = C[m][c] * C[m][Ch + c],

@@ -130,12 +130,18 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     }
     const rsrc_t rsC = make_rsrc(p.C + cbase);
     rsrc_t rsR = rsC, rsX = rsC;
-    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_LNBWD) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
     if constexpr (EK == E_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
     if constexpr (EK == E_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
     constexpr int HALF = (EK == E_SGBWD) ? 2 : 1;   // SGBWD needs two loads per row: do it in two halves
     constexpr int ITH = IT / HALF;
-    float4 dot = f4_zero();   // E_DOTCOL: this thread's part of the column sums
+    float4 dot = f4_zero();   // E_DOTCOL / E_LNBWD: this thread's part of the column sums
+    float4 dot2 = f4_zero();  // E_LNBWD: second plane (sum of g)
+    float4 lnw4 = f4_zero();
+    if constexpr (EK == E_LNBWD) {
+        if (nok) lnw4 = ldg4(p.lnw + n);
+    }
 #pragma unroll
     for (int hh = 0; hh < HALF; ++hh) {
         float4 pre1[ITH], pre2[ITH];
@@ -152,8 +158,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 if constexpr (EK == E_SCATTER_ADD) pre1[it] = buf_ld4(rsR, addr[it]);
             } else {
                 addr[it] = ok ? (uint32_t)rl * (uint32_t)p.ldc * 4u + coladd : ROW_SENT;
-                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL)
+                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD)
                     pre1[it] = buf_ld4(rsR, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
+                if constexpr (EK == E_LNBWD) {
+                    if (p.aux) pre2[it] = buf_ld4(rsX, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
+                }
                 if constexpr (EK == E_SGBWD) {
                     const uint32_t xo = ok ? (uint32_t)rl * (uint32_t)p.N * 8u + coladd : ROW_SENT;
                     pre1[it] = buf_ld4(rsX, xo);
@@ -165,7 +174,28 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
         for (int it = 0; it < ITH; ++it) {
             const int rl = r0 + (hh * ITH + it) * RPP;
             const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * BN + 4 * q]);
-            if constexpr (EK == E_DOTCOL) {
+            if constexpr (EK == E_LNBWD) {
+                // LayerNorm backward of this row (the tile spans all N columns; a row lives in QP consecutive lanes)
+                const int64_t m = m0 + rl;
+                const bool rok = m < p.M;
+                const float mean = rok ? p.mu[m] : 0.f, rs = rok ? p.rstd[m] : 0.f;
+                const float4 xh = make_float4((pre1[it].x - mean) * rs, (pre1[it].y - mean) * rs, (pre1[it].z - mean) * rs,
+                                              (pre1[it].w - mean) * rs);
+                const float4 gw = f4_mul(v, lnw4);
+                const float invN = 1.0f / (float)p.N;
+                const float s1 = group_sum(nok ? f4_sum(gw) : 0.f, QP) * invN;
+                const float s2 = group_sum(nok ? f4_sum(f4_mul(gw, xh)) : 0.f, QP) * invN;
+                float4 d;
+                d.x = rs * (gw.x - xh.x * s2 - s1);
+                d.y = rs * (gw.y - xh.y * s2 - s1);
+                d.z = rs * (gw.z - xh.z * s2 - s1);
+                d.w = rs * (gw.w - xh.w * s2 - s1);
+                buf_st4(rsC, addr[it], f4_add(d, pre2[it]));
+                if (rok && nok) {
+                    dot = f4_fma(v, xh, dot);
+                    dot2 = f4_add(dot2, v);
+                }
+            } else if constexpr (EK == E_DOTCOL) {
                 buf_st4(rsC, addr[it], v);
                 dot = f4_fma(v, pre1[it], dot);   // rows past M loaded 0
             } else if constexpr (EK == E_PLAIN || EK == E_SCATTER) {
@@ -183,6 +213,21 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 buf_st4(rsC, addr[it] + 4u * (uint32_t)p.N, f4_mul(v, pre1[it]));
             } else {  // E_SCATTER_ADD
                 buf_st4(rsC, addr[it], f4_add(v, pre1[it]));
+            }
+        }
+    }
+    if constexpr (EK == E_LNBWD) {
+        // the two column-sum planes over the tile's rows, as for E_DOTCOL
+        float* sm = const_cast<float*>(Cs);
+        for (int pl = 0; pl < 2; ++pl) {
+            __syncthreads();
+            if (QP == Q || q < Q) *reinterpret_cast<float4*>(&sm[r0 * BN + 4 * q]) = pl == 0 ? dot : dot2;
+            __syncthreads();
+            if (r0 == 0 && nok) {
+                float4 t = *reinterpret_cast<const float4*>(&sm[4 * q]);
+#pragma unroll
+                for (int g = 1; g < RPP; ++g) t = f4_add(t, *reinterpret_cast<const float4*>(&sm[g * BN + 4 * q]));
+                stg4(p.colpart + ((m0 / ROWS) * 2 + pl) * (int64_t)p.N + n, t);
             }
         }
     }
@@ -379,6 +424,15 @@ int launch_cfg(const GemmNT& p, hipStream_t s) {
     constexpr bool GATE = (EK == E_BIASGATE);
     // 128 x 64 tiles when N is narrow
     const int64_t tiles128 = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
+    if constexpr (EK == E_LNBWD) {   // the tile must span the whole row
+        if (p.N <= 64) {
+            gemm_nt_kernel<128, 64, 4, 1, AK, EK, 32><<<dim3((unsigned)cdiv64(p.M, 128), nbatch), dim3(256), 0, s>>>(p);
+        } else {
+            gemm_nt_kernel<128, 128, 2, 2, AK, EK, 32><<<dim3((unsigned)cdiv64(p.M, 128), nbatch), dim3(256), 0, s>>>(p);
+        }
+        DCPT_CHECK_LAUNCH("gemm_nt");
+        return DCPT_OK;
+    }
     static const int smallk = getenv("DCPT_NT_SMALLK") ? atoi(getenv("DCPT_NT_SMALLK")) : 0;
     static const int use96 = getenv("DCPT_NT_96") ? atoi(getenv("DCPT_NT_96")) : 1;
     if constexpr (!GATE) {
@@ -427,11 +481,15 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     if (epi == E_BIASGATE)
         DCPT_CHECK_ARG(p.gate && p.N % 8 == 0 && (double)p.N * p.K * 4.0 < 1.0e9, "gemm_nt: gate epilogue needs gate != null, N %% 8 == 0");
     if (epi == E_DOTCOL) DCPT_CHECK_ARG(p.colpart && p.res && p.nb1 * p.nb2 == 1, "gemm_nt: column-dot epilogue needs colpart and res");
+    if (epi == E_LNBWD)
+        DCPT_CHECK_ARG(p.colpart && p.res && p.mu && p.rstd && p.lnw && p.N <= 128 && p.N % 4 == 0 && p.nb1 * p.nb2 == 1,
+                       "gemm_nt: LayerNorm-backward epilogue needs N <= 128 and res / mu / rstd / lnw / colpart");
     if (aload == A_CONV3) DCPT_CHECK_ARG(p.gC % 4 == 0 && p.K == 9 * p.gC, "gemm_nt: conv3 needs K == 9*gC, gC %% 4 == 0");
     // algorithmic work of this launch (for the live roofline in bench.py)
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : epi == E_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
     if (epi == E_RESID || epi == E_SCATTER_ADD || epi == E_DOTCOL) bytes += mn;
+    if (epi == E_LNBWD) bytes += 2 * mn;
     const double nbat = (double)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     ProfScope prof(s, PROF_NT + aload * 16 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
 #define CASE(AK, EK) \
@@ -454,6 +512,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_MUL)
     CASE(A_PLAIN, E_BIASGATE)
     CASE(A_PLAIN, E_DOTCOL)
+    CASE(A_PLAIN, E_LNBWD)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

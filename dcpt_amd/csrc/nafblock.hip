@@ -55,6 +55,7 @@ struct BwdWs {
     int ln_nblk, nblk_b;
 };
 
+bool ln_in_epilogue(int C);
 size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs* out) {
     WsAlloc a(base, base ? bytes : (size_t)-1);
     const int64_t M = (int64_t)B * H * W;
@@ -93,8 +94,12 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.slab = a.get<float>(w.slab_elems);
     w.colsum = a.get<float>(w.colsum_elems);
     w.ln_nblk = ln_bwd_num_blocks(M, C);
-    w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * C);
-    w.lnpart2 = a.get<float>((size_t)w.ln_nblk * 3 * C);
+    {
+        // LayerNorm column partials: [ln_nblk][3][C] from ln_bwd, or [M / 128 tiles][2][C] from the E_LNBWD GEMM epilogue
+        const size_t a1 = (size_t)w.ln_nblk * 3 * C, a2 = ln_in_epilogue(C) ? (size_t)cdiv64(M, 128) * 2 * C : 0;
+        w.lnpart = a.get<float>(a1 > a2 ? a1 : a2);
+        w.lnpart2 = a.get<float>(a1 > a2 ? a1 : a2);
+    }
     {
         const int fs = sca_ds_fused_slices(P), ns = sca_ds_num_blocks(P);
         w.ds_part = a.get<float>((size_t)B * (fs > ns ? fs : ns) * C);
@@ -105,6 +110,14 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
     if (out) *out = w;
     return a.off;
+}
+
+// Narrow levels (C <= 128: one GEMM tile spans all channels): LayerNorm backward runs inside the epilogue of the dgrad GEMM
+// that produces its incoming gradient, so that gradient is never written and re-read (2 tensor passes and one launch per
+// LayerNorm).  DCPT_LN_EPILOGUE=0 switches back to the separate kernel.
+bool ln_in_epilogue(int C) {
+    static const int on = getenv("DCPT_LN_EPILOGUE") ? atoi(getenv("DCPT_LN_EPILOGUE")) : 1;
+    return on && C <= 128;
 }
 
 int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yload, const GemmTN& proto, int64_t M,
@@ -224,16 +237,24 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(side_fork(sd, 1, s));      // dv
     // B3: grad w.r.t. LN2 output
     g = GemmNT{};
+    const bool lne = ln_in_epilogue(C);
+    const int ln_tiles = (int)cdiv64(M, 128);
     g.M = M; g.A = dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = gln; g.ldc = C;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    if (lne) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv * W4^T)
+        g.C = dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    }
     // B4: conv4 gradients (Y = LN2(y), kept by the forward pass)
     tp = GemmTN{};
     DCPT_TRY(wgrad(dv, C2, C2, sv->xn2, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
                    gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
-    DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
+    if (!lne) DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 2, s));      // dy, LN2 partial sums
-    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    if (lne) DCPT_TRY(launch_colpart_reduce(w.lnpart, ln_tiles, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    else DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2*s)
     // when an image is a whole number of 128-pixel GEMM tiles, SCA's ds[b][k] = sum_p dts * t2 comes out of this GEMM's epilogue
     // as per-tile column sums (one bandwidth pass and one launch less)
@@ -278,15 +299,21 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     // B11: grad w.r.t. LN1 output
     g = GemmNT{};
     g.M = M; g.A = dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = gln; g.ldc = C;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    if (lne) {   // B11 + B13 in one launch: dinp = dy + LN1-backward(dt1 * W1^T)
+        g.C = dinp; g.res = inp; g.ldres = C; g.aux = dy; g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.colpart = w.lnpart2;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+    }
     // B12: conv1 gradients (Y = LN1(inp), kept by the forward pass)
     tp = GemmTN{};
     DCPT_TRY(wgrad(dt1, C2, C2, sv->xn1, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
                    gr->conv1_b, sw));
     // B13: dinp = dy + LN1-backward
-    DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
+    if (!lne) DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 5, s));      // LN1 partial sums
-    DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+    if (lne) DCPT_TRY(launch_colpart_reduce(w.lnpart2, ln_tiles, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+    else DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     DCPT_TRY(side_join(sd, s));      // the caller's stream continues only after every weight gradient is written
     return DCPT_OK;
 }
