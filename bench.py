@@ -34,7 +34,7 @@ PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
 PEAK_HBM_TBS = 8.0
 
 ALOAD = {0: "plain", 1: "ln", 2: "scale", 3: "sg", 4: "gather", 5: "conv3", 6: "lnbf"}
-EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_add", 6: "addscaled", 7: "mul", 8: "biasgate", 9: "dotcol", 10: "lnbwd"}
+EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_add", 6: "addscaled", 7: "mul", 8: "biasgate", 9: "dotcol", 10: "lnbwd", 11: "resid+ln"}
 
 
 def prof_class_name(cls: int) -> str:

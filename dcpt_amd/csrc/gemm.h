@@ -9,7 +9,7 @@
 #include "dcpt_common.h"
 
 enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5, A_LNBF = 6 };
-enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7, E_BIASGATE = 8, E_DOTCOL = 9, E_LNBWD = 10 };
+enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7, E_BIASGATE = 8, E_DOTCOL = 9, E_LNBWD = 10, E_RESIDLN = 11 };
 
 struct GemmNT {
     const float* A;   // [M][lda]   (A_SG: 2K columns; A_GATHER: fine NHWC image, see g*)
@@ -40,6 +40,12 @@ struct GemmNT {
     // E_LNBWD (N <= 128, one tile spans the row): the accumulator row g is the gradient of a LayerNorm output whose input was
     // res (x); C = rstd*(g*lnw - mean_c(g*lnw) - xhat*mean_c(g*lnw*xhat)) + aux (the residual gradient, may be null), and
     // colpart[m / 128][0][n] = sum_rows g*xhat (-> dweight), colpart[m / 128][1][n] = sum_rows g (-> dbias); uses mu, rstd, lnw
+    // E_RESIDLN (N <= 128): C as E_RESID AND the LayerNorm of that output row: ln_out[m][n] = (C - mean) * rstd * lnw[n] + lnb[n],
+    // ln_mu[m], ln_rstd[m] (biased variance about the mean, eps inside the sqrt) -- the next LayerNorm's forward pass
+    float* ln_out;
+    float* ln_mu;
+    float* ln_rstd;
+    float ln_eps;
     float* colpart;       // E_DOTCOL: C = acc as E_PLAIN AND colpart[m / 128][n] = sum over the tile's 128 rows of acc * res[m][n]
                           // (fixed order; SCA backward's per-image channel sums come out of the producing GEMM)
     float* gate;          // E_BIASGATE (N = 2*Ch, SimpleGate input): C = acc + bias as usual AND gate[m][c] = C[m][c] * C[m][Ch + c],

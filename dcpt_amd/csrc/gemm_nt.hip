@@ -107,10 +107,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     const int n = n0 + 4 * q;
     const bool nok = (QP == Q || q < Q) && n < p.N;
     float4 bias = f4_zero(), cs = make_float4(1.f, 1.f, 1.f, 1.f);
-    if constexpr (EK == E_BIAS || EK == E_RESID || EK == E_MUL) {
+    if constexpr (EK == E_BIAS || EK == E_RESID || EK == E_MUL || EK == E_RESIDLN) {
         if (p.bias && nok) bias = ldg4(p.bias + n);
     }
-    if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_RESIDLN) {
         if (p.cscale && nok) cs = ldg4(p.cscale + n);
     }
     constexpr bool SCAT = (EK == E_SCATTER || EK == E_SCATTER_ADD);
@@ -130,7 +130,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     }
     const rsrc_t rsC = make_rsrc(p.C + cbase);
     rsrc_t rsR = rsC, rsX = rsC;
-    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD || EK == E_RESIDLN) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_RESIDLN) rsX = make_rsrc(p.ln_out + m0 * (int64_t)p.ldc);
     if constexpr (EK == E_LNBWD) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
     if constexpr (EK == E_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
     if constexpr (EK == E_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
@@ -138,9 +139,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     constexpr int ITH = IT / HALF;
     float4 dot = f4_zero();   // E_DOTCOL / E_LNBWD: this thread's part of the column sums
     float4 dot2 = f4_zero();  // E_LNBWD: second plane (sum of g)
-    float4 lnw4 = f4_zero();
-    if constexpr (EK == E_LNBWD) {
+    float4 lnw4 = f4_zero(), lnb4 = f4_zero();
+    if constexpr (EK == E_LNBWD || EK == E_RESIDLN) {
         if (nok) lnw4 = ldg4(p.lnw + n);
+    }
+    if constexpr (EK == E_RESIDLN) {
+        if (nok && p.lnb) lnb4 = ldg4(p.lnb + n);
     }
 #pragma unroll
     for (int hh = 0; hh < HALF; ++hh) {
@@ -158,7 +162,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 if constexpr (EK == E_SCATTER_ADD) pre1[it] = buf_ld4(rsR, addr[it]);
             } else {
                 addr[it] = ok ? (uint32_t)rl * (uint32_t)p.ldc * 4u + coladd : ROW_SENT;
-                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD)
+                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD || EK == E_RESIDLN)
                     pre1[it] = buf_ld4(rsR, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
                 if constexpr (EK == E_LNBWD) {
                     if (p.aux) pre2[it] = buf_ld4(rsX, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
@@ -174,7 +178,22 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
         for (int it = 0; it < ITH; ++it) {
             const int rl = r0 + (hh * ITH + it) * RPP;
             const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * BN + 4 * q]);
-            if constexpr (EK == E_LNBWD) {
+            if constexpr (EK == E_RESIDLN) {
+                // y = res + (acc + bias) * gain, then LayerNorm of the row y (two-pass mean / variance like ln_fwd)
+                const int64_t m = m0 + rl;
+                const float4 y = f4_fma(f4_add(v, bias), cs, pre1[it]);
+                buf_st4(rsC, addr[it], y);
+                const float invN = 1.0f / (float)p.N;
+                const float mean = group_sum(nok ? f4_sum(y) : 0.f, QP) * invN;
+                const float4 dlt = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+                const float var = group_sum(nok ? f4_sum(f4_mul(dlt, dlt)) : 0.f, QP) * invN;
+                const float rs = 1.0f / sqrtf(var + p.ln_eps);
+                buf_st4(rsX, addr[it], f4_fma(make_float4(dlt.x * rs, dlt.y * rs, dlt.z * rs, dlt.w * rs), lnw4, lnb4));
+                if (q == 0 && m < p.M) {
+                    p.ln_mu[m] = mean;
+                    p.ln_rstd[m] = rs;
+                }
+            } else if constexpr (EK == E_LNBWD) {
                 // LayerNorm backward of this row (the tile spans all N columns; a row lives in QP consecutive lanes)
                 const int64_t m = m0 + rl;
                 const bool rok = m < p.M;
@@ -424,7 +443,7 @@ int launch_cfg(const GemmNT& p, hipStream_t s) {
     constexpr bool GATE = (EK == E_BIASGATE);
     // 128 x 64 tiles when N is narrow
     const int64_t tiles128 = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
-    if constexpr (EK == E_LNBWD) {   // the tile must span the whole row
+    if constexpr (EK == E_LNBWD || EK == E_RESIDLN) {   // the tile must span the whole row
         if (p.N <= 64) {
             gemm_nt_kernel<128, 64, 4, 1, AK, EK, 32><<<dim3((unsigned)cdiv64(p.M, 128), nbatch), dim3(256), 0, s>>>(p);
         } else {
@@ -481,6 +500,9 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     if (epi == E_BIASGATE)
         DCPT_CHECK_ARG(p.gate && p.N % 8 == 0 && (double)p.N * p.K * 4.0 < 1.0e9, "gemm_nt: gate epilogue needs gate != null, N %% 8 == 0");
     if (epi == E_DOTCOL) DCPT_CHECK_ARG(p.colpart && p.res && p.nb1 * p.nb2 == 1, "gemm_nt: column-dot epilogue needs colpart and res");
+    if (epi == E_RESIDLN)
+        DCPT_CHECK_ARG(p.res && p.ln_out && p.ln_mu && p.ln_rstd && p.lnw && p.N <= 128 && p.N % 4 == 0 && p.nb1 * p.nb2 == 1 && p.ldc == p.N,
+                       "gemm_nt: residual + LayerNorm epilogue needs N <= 128, ldc == N and res / lnw / ln_out / ln_mu / ln_rstd");
     if (epi == E_LNBWD)
         DCPT_CHECK_ARG(p.colpart && p.res && p.mu && p.rstd && p.lnw && p.N <= 128 && p.N % 4 == 0 && p.nb1 * p.nb2 == 1,
                        "gemm_nt: LayerNorm-backward epilogue needs N <= 128 and res / mu / rstd / lnw / colpart");
@@ -490,6 +512,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : epi == E_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
     if (epi == E_RESID || epi == E_SCATTER_ADD || epi == E_DOTCOL) bytes += mn;
     if (epi == E_LNBWD) bytes += 2 * mn;
+    if (epi == E_RESIDLN) bytes += 2 * mn;
     const double nbat = (double)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     ProfScope prof(s, PROF_NT + aload * 16 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
 #define CASE(AK, EK) \
@@ -513,6 +536,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_BIASGATE)
     CASE(A_PLAIN, E_DOTCOL)
     CASE(A_PLAIN, E_LNBWD)
+    CASE(A_SCALE, E_RESIDLN)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);
     return DCPT_ERR_ARG;

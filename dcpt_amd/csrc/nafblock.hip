@@ -171,8 +171,13 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     g = GemmNT{};
     g.M = M; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = p->conv3_w; g.N = C; g.C = sv->y; g.ldc = C;
     g.simg = sv->s; g.P = P; g.bias = p->conv3_b; g.res = inp; g.cscale = p->beta;
-    DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESID, s));
-    DCPT_TRY(launch_ln_fwd(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
+    if (ln_in_epilogue(C)) {   // narrow levels: LN2(y) (statistics and normalised tensor) comes out of the same epilogue
+        g.lnw = p->norm2_w; g.lnb = p->norm2_b; g.ln_out = sv->xn2; g.ln_mu = sv->mu2; g.ln_rstd = sv->rstd2; g.ln_eps = eps;
+        DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESIDLN, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESID, s));
+        DCPT_TRY(launch_ln_fwd(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
+    }
     // v = conv4(LN2(y))
     g = GemmNT{};
     g.M = M; g.A = sv->xn2; g.lda = C; g.K = C; g.Bw = p->conv4_w; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b;
