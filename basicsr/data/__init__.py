@@ -87,17 +87,24 @@ class SyntheticPairedDataset(tdata.Dataset):
         return _labelled({"lq": lq, "gt": gt, "lq_path": name, "gt_path": name}, self.opt)
 
 
+def _center_crop(t, size):
+    """transforms.center_crop on a CHW tensor"""
+    size = (size, size) if isinstance(size, int) else tuple(size)
+    _, h, w = t.shape
+    top, left = (h - size[0]) // 2, (w - size[1]) // 2
+    return t[:, top:top + size[0], left:left + size[1]]
+
+
 @DATASET_REGISTRY.register()
 class PairedImageDataset(tdata.Dataset):
-    """Paired folders with identical file names (reference basicsr/data/paired_image_dataset.py:25-192,
-    test phase only: no crops / augmentation)."""
+    """Paired folders with identical file names (reference basicsr/data/paired_image_dataset.py:25-192, folder mode,
+    PIL instead of cv2): train phase = paired random crop + flips / rotation, other phases = optional centre crop."""
 
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
         self.gt_root, self.lq_root = opt["dataroot_gt"], opt.get("dataroot_lq") or opt["dataroot_gt"]
         self.names = sorted(f for f in scandir(self.gt_root) if f.endswith(_IMG_EXT))
-        self.sigma = opt.get("sigma_range") if opt.get("dataroot_lq") is None else None
 
     def __len__(self):
         return len(self.names)
@@ -105,18 +112,56 @@ class PairedImageDataset(tdata.Dataset):
     def __getitem__(self, index):
         name = self.names[index]
         gt = _read_rgb(osp.join(self.gt_root, name))
-        if self.sigma is not None:  # PairedImageDenoiseDataset: seeded Gaussian noise (paired_image_dataset.py:397-402)
-            rs = np.random.RandomState(0)
-            lq = gt + torch.from_numpy(rs.normal(0, self.sigma / 255.0, tuple(gt.shape)).astype(np.float32))
-        else:
-            lq = _read_rgb(osp.join(self.lq_root, name))
+        lq = _read_rgb(osp.join(self.lq_root, name))
         if self.opt.get("phase") == "train":
             lq, gt = paired_random_crop_augment(lq, gt, self.opt)
+        elif self.opt.get("center_crop") is not None:
+            lq, gt = _center_crop(lq, self.opt["center_crop"]), _center_crop(gt, self.opt["center_crop"])
         return _labelled({"lq": lq, "gt": gt, "lq_path": osp.join(self.lq_root, name), "gt_path": osp.join(self.gt_root, name)}, self.opt)
 
 
-for _alias in ("PairedImageDenoiseDataset", "PairedImageDehazeDataset"):
-    DATASET_REGISTRY._obj_map[_alias] = PairedImageDataset
+@DATASET_REGISTRY.register()
+class PairedImageDenoiseDataset(tdata.Dataset):
+    """GT folder + on-the-fly Gaussian noise (reference basicsr/data/paired_image_dataset.py:276-421).  The noise reproduces
+    the reference's draw exactly (:388-402): ``sigma`` from ``sigma_type`` constant / random / choice (Python's ``random``),
+    ``np.random.seed(index)`` in the train phase and ``seed(0)`` otherwise, ``normal(0, sigma / 255, (H, W, 3))`` on the
+    **HWC**, RGB-ordered float32 image AFTER the crop / augmentation, added in float32."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.gt_root = opt["dataroot_gt"]
+        self.sigma_type = opt.get("sigma_type", "constant")
+        self.sigma_range = opt["sigma_range"]
+        assert self.sigma_type in ["constant", "random", "choice"]
+        self.names = sorted(f for f in scandir(self.gt_root) if f.endswith(_IMG_EXT))
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, index):
+        import random
+
+        path = osp.join(self.gt_root, self.names[index])
+        gt = _read_rgb(path)
+        if self.opt.get("phase") == "train":
+            _, gt = paired_random_crop_augment(gt, gt, self.opt)
+        elif self.opt.get("center_crop") is not None:
+            gt = _center_crop(gt, self.opt["center_crop"])
+        if self.sigma_type == "constant":
+            sigma = self.sigma_range
+        elif self.sigma_type == "random":
+            sigma = random.uniform(self.sigma_range[0], self.sigma_range[1])
+        else:
+            sigma = random.choice(self.sigma_range)
+        rs = np.random.RandomState(index if self.opt.get("phase") == "train" else 0)   # == np.random.seed(...); np.random.normal
+        hwc = gt.permute(1, 2, 0).contiguous().numpy().copy()
+        hwc += rs.normal(0, sigma / 255.0, hwc.shape)   # float64 noise accumulated into the float32 image, as `img_lq += ...`
+        lq = torch.from_numpy(hwc.transpose(2, 0, 1)).float().contiguous()
+        return _labelled({"lq": lq, "gt": gt.contiguous(), "lq_path": path, "gt_path": path}, self.opt)
+
+
+DATASET_REGISTRY._obj_map["PairedImageDehazeDataset"] = PairedImageDataset
 
 
 def build_dataset(dataset_opt):
@@ -124,6 +169,9 @@ def build_dataset(dataset_opt):
     logger = get_root_logger()
     root = dataset_opt.get("dataroot_gt")
     if dataset_opt["type"] != "SyntheticPairedDataset" and (root is None or not osp.isdir(root)):
+        if dataset_opt.get("phase") == "train" and not dataset_opt.get("allow_synthetic", False):
+            raise FileNotFoundError(f"Dataset root {root} of the training set [{dataset_opt.get('name')}] does not exist "
+                                    "(set `allow_synthetic: true` in the dataset options to train on seeded synthetic pairs)")
         logger.warning(f"Dataset root {root} of [{dataset_opt.get('name')}] not found: using a seeded synthetic pair instead.")
         dataset = SyntheticPairedDataset(dataset_opt)
     else:

@@ -64,7 +64,7 @@ class DCDistModel(SRModel):
         if self.ema_decay > 0:
             get_root_logger().info(f"Use Exponential Moving Average with decay: {self.ema_decay}")
             self.net_g_ema = build_network(self.opt["network_g"]).to(self.device)
-            self.model_ema(0)
+            self._init_ema()
             self.net_g_ema.eval()
         self.hook_outputs, self.hooks = [], []
         hook_names = self.opt.get("hook_names", None)
@@ -83,6 +83,8 @@ class DCDistModel(SRModel):
             self.setup_schedulers()
 
     def hook_forward_fn(self, module, input, output):  # noqa: A002
+        if not torch.is_grad_enabled():
+            return   # inference (test / test_tile / validation run under no_grad): the taps are not used, do not keep them alive
         if isinstance(output, tuple):
             output = output[-1]
         self.hook_outputs.append(output)

@@ -54,7 +54,7 @@ class SRModel(BaseModel):
         self.ema_decay = train_opt.get("ema_decay", 0)
         if self.ema_decay > 0:
             self.net_g_ema = build_network(self.opt["network_g"]).to(self.device)
-            self.model_ema(0)
+            self._init_ema()
             self.net_g_ema.eval()
         self.cri_pix = build_loss(train_opt["pixel_opt"]).to(self.device) if train_opt.get("pixel_opt") else None
         if self.cri_pix is None:
@@ -62,6 +62,16 @@ class SRModel(BaseModel):
         self.setup_optimizers()
         if train_opt.get("scheduler"):
             self.setup_schedulers()
+
+    def _init_ema(self):
+        """reference sr_model.py:70-79: with a pretrained / resumed network the EMA copy is loaded from the checkpoint's
+        ``params_ema`` (load_network falls back to ``params`` when the key is missing) so that a restart keeps the EMA
+        history; only a fresh start copies net_g."""
+        load_path = self.opt["path"].get("pretrain_network_g", None)
+        if load_path is not None and osp.exists(load_path):
+            self.load_network(self.net_g_ema, load_path, self.opt["path"].get("strict_load_g", True), "params_ema")
+        else:
+            self.model_ema(0)
 
     def setup_optimizers(self):
         train_opt = self.opt["train"]
@@ -184,20 +194,21 @@ class SRModel(BaseModel):
                 self.test()
             self.post_test()
             vis = self.get_current_visuals()
-            sr = tensor2img_rgb(vis["result"])
+            result = vis["result"].clamp(0, 1) if clamp else vis["result"]   # reference sr_model.py:408-413
             if save_img:
+                import os
+
                 from PIL import Image
 
                 stem = osp.splitext(osp.basename(val_data["lq_path"][0]))[0]
                 folder = osp.join(self.opt["path"]["visualization"], name)
-                import os
-
                 os.makedirs(folder, exist_ok=True)
-                Image.fromarray(sr).save(osp.join(folder, f"{stem}_{self.opt['name']}.png"))
+                Image.fromarray(tensor2img_rgb(result)).save(osp.join(folder, f"{stem}_{self.opt['name']}.png"))
             if "gt" in vis and metrics_opt:
-                gt = tensor2img_rgb(vis["gt"])
+                # the reference hands the float BCHW arrays in [0,1] to the metric, which quantises them to uint8 (:421-430)
+                gt = (vis["gt"].clamp(0, 1) if clamp else vis["gt"]).numpy()
                 for m, mo in metrics_opt.items():
-                    results[m] += calculate_metric(dict(img=sr, img2=gt), mo)
+                    results[m] += calculate_metric(dict(img=result.numpy(), img2=gt), mo)
             n += 1
             del self.lq, self.output
             if hasattr(self, "gt"):

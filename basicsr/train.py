@@ -24,7 +24,8 @@ from basicsr.utils.options import dict2str, parse_options  # noqa: E402
 
 def create_train_val_dataloader(opt, logger):
     train_sets, train_opts, val_loaders = [], [], []
-    for phase, dataset_opt in sorted(opt["datasets"].items()):
+    for phase, dataset_opt in opt["datasets"].items():   # file order (the YAML loader builds OrderedDicts): train_2 before train_10,
+        # and ``dataset_idx`` -- the degradation label ConcatDataset injects -- counts the train sets in the order they are written
         kind = phase.split("_")[0]
         if kind == "train":
             train_sets.append(build_dataset(dataset_opt))

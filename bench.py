@@ -83,6 +83,27 @@ def cpu_baseline(seconds_budget: float = 25.0):
     }
 
 
+def spawn_ranks(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run, one process per GPU."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n} but only {have} device(s) visible on this node: refusing to report a {have}-GPU number as n_gpus={n}")
+    from dcpt_amd import build as _build
+
+    _build.build()   # once, before the ranks exist (the ranks only load the finished library)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it across processes)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,13 +118,22 @@ def main():
     ap.add_argument("--iso-steps", type=int, default=3, help="steps of the serialized per-kernel timing pass (0 = skip)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one GPU")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- build the library once, then one rank per GPU under
+        # torch.distributed.run (the same command line the driver uses); rank 0 of the children prints the JSON line
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible on this node")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -204,10 +234,15 @@ def main():
             for k in ("launches", "ms", "flops", "bytes"):
                 r[k] = r[k] * args.steps / args.iso_steps
         lib.dcpt_set_side_stream(1)
+    rccl_ranks = None
     if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)   # every rank that took part in the timed region contributes 1
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -230,7 +265,7 @@ def main():
                 "workload": "NAFNet-width64 enc[1,1,1,28] mid1 dec[1,1,1,1] fwd+L1+bwd(+all-reduce)+AdamW, 256x256, fp32 "
                             "(BASELINE.json configs[1])",
                 "per_gpu_batch": args.batch, "global_batch": world * args.batch, "image": [SIZE, SIZE],
-                "parallelism": f"dp{world}", "loss": round(loss_val, 6), "stream_chunks": args.chunks,
+                "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "loss": round(loss_val, 6), "stream_chunks": args.chunks,
                 "wgrad_side_stream": bool(args.side_stream),
             },
         }

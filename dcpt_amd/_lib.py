@@ -10,8 +10,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DCPT_HIP_LIB") or os.path.join(_HERE, "lib", "libdcpt_hip.so")  # env override: diagnostic builds (tools/)
+LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
+ABI_VERSION = 3
 _lib = None
 _lock = threading.Lock()
 
@@ -134,6 +135,7 @@ SIGNATURES = {
     "dcpt_prof_enable": (cint, [cint]),
     "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
     "dcpt_set_side_stream": (cint, [cint]),
+    "dcpt_allreduce_flat": (cint, [f32p, sz, C.c_void_p, C.c_float, stream_t]),
     "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
     "dcpt_nhwc_to_nchw": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
 }
@@ -180,7 +182,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.dcpt_abi_version() != 2:
+        if lib.dcpt_abi_version() != ABI_VERSION:
             raise DcptHipError("libdcpt_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libdcpt_hip.so")
 ARCH = "gfx950"
-SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip", "prof.hip", "side.hip", "dchead.hip", "restormer.hip", "promptir.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip", "prof.hip", "side.hip", "dchead.hip", "restormer.hip", "promptir.hip", "comm.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
@@ -52,18 +52,33 @@ def _compile(src: str) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile + link if the sources changed.  Safe to call from several processes at once (one rank per GPU): an exclusive
+    file lock serialises the builders, and whoever comes second finds the digest up to date."""
+    import fcntl
+
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     stamp = os.path.join(LIBDIR, "libdcpt_hip.digest")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    tmp = LIB + ".tmp"   # link next to the target and rename: a reader never maps a half-written library
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, LIB)
     with open(stamp, "w") as f:
         f.write(dig)
     if verbose:

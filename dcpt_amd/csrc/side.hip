@@ -10,6 +10,7 @@
 
 #include <map>
 #include <mutex>
+#include <utility>
 
 #include "../../include/dcpt_hip.h"
 
@@ -20,7 +21,7 @@ struct Side {
 
 namespace {
 std::mutex g_side_mu;
-std::map<hipStream_t, Side*> g_sides;
+std::map<std::pair<int, hipStream_t>, Side*> g_sides;   // keyed by (device, stream): the null-stream handle is the same on every device
 int g_side_enabled = -1;
 
 void side_init_locked() {
@@ -40,7 +41,13 @@ Side* side_for(hipStream_t main) {
         (void)hipGetLastError();
         return nullptr;   // keep graph captures single-stream
     }
-    auto it = g_sides.find(main);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const auto key = std::make_pair(dev, main);
+    auto it = g_sides.find(key);
     if (it != g_sides.end()) return it->second;
     Side* sd = new Side();
     int least = 0, greatest = 0;
@@ -52,7 +59,7 @@ Side* side_for(hipStream_t main) {
         delete sd;
         sd = nullptr;
     }
-    g_sides[main] = sd;
+    g_sides[key] = sd;
     return sd;
 }
 

@@ -15,8 +15,16 @@
  *    network's image input/output is NCHW (3 channels);
  *  - weights keep the reference's state-dict layouts (conv: [out][in][kh][kw]);
  *  - every call enqueues work on `stream` (a hipStream_t) and returns immediately: 0 on success,
- *    non-zero on error (dcpt_last_error() gives the message).  No call synchronises, allocates or
- *    keeps state between calls; all of them are re-entrant.
+ *    non-zero on error (dcpt_last_error() gives the message, per host thread).  No compute call
+ *    synchronises with the host or allocates device memory, and none keeps DATA between calls.
+ *    Process-wide state that does exist, all of it listed here: (1) two global toggles,
+ *    dcpt_set_side_stream() and dcpt_prof_enable() (the latter also owns the event pairs it recorded
+ *    until dcpt_prof_read() drains them -- dcpt_prof_read is the one call that waits on the device);
+ *    (2) a cache of one internal low-priority HIP stream + 8 events per (device, caller stream),
+ *    created on the first backward call that uses it and kept for the life of the process;
+ *    (3) the lazily resolved RCCL entry point of dcpt_allreduce_flat().  Calls on different
+ *    streams / devices are re-entrant; the toggles are not meant to be flipped concurrently with
+ *    launches.
  *  - channel counts must be multiples of 4.
  */
 #ifndef DCPT_HIP_H
@@ -276,6 +284,18 @@ int dcpt_prof_read(double* out, int max_rows);
  * stream semantics).  on = 0 keeps everything on the caller's stream (also: DCPT_SIDE_STREAM=0 in the
  * environment, and automatically while `stream` is being captured into a graph).  Returns the previous setting. */
 int dcpt_set_side_stream(int on);
+
+/* ---- gradient all-reduce (data-parallel step) -------------------------------------------------------
+ * replaces what torch DistributedDataParallel does for the reference (basicsr/models/base_model.py:108-115: bucketed
+ * all-reduce(SUM) / world of the gradients; :448 the loss reduce) for hosts that drive the collective themselves:
+ * in-place `ncclAllReduce(SUM, fp32)` of buf[0..n) over the CALLER-PROVIDED RCCL communicator (an ncclComm_t created by the
+ * launcher, one rank per GPU), enqueued on `stream`, followed by buf *= scale (pass 1/world for the mean, 1 to skip).
+ * The library does not create communicators or bootstrap ranks, and it does not link RCCL: the entry point is resolved on
+ * first use from the copy already loaded in the process (torch's) or the system's librccl.so.1.  Overlap with backward
+ * is the caller's choice of stream (a side stream + events, as DDP's bucket hooks do).
+ * basicsr/ in this repository keeps the reference's own mechanism (torch DDP over backend "nccl" = RCCL) for the training
+ * step; this entry point is the C-ABI form of the same collective (SURVEY 8b minimum export set). */
+int dcpt_allreduce_flat(float* buf, size_t n, void* rccl_comm, float scale, dcpt_stream_t stream);
 
 #ifdef __cplusplus
 }

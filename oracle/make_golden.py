@@ -434,6 +434,71 @@ def gen_train_plumbing(ref):
     np.savez_compressed(os.path.join(OUT, "train_plumbing.npz"), **out)
 
 
+def gen_metrics(ref):
+    """PSNR of the reference's own ``calculate_psnr`` (basicsr/metrics/psnr_ssim.py:11-75) on keyed float BCHW batches.
+    The module imports cv2 (absent here); PSNR only uses ``cv2.cvtColor(img, COLOR_RGB2BGR)``, a channel flip, so a module
+    object providing just that is put in sys.modules for the import.  ``calculate_ssim`` needs cv2.filter2D / getGaussianKernel
+    and is NOT generated (SSIM stays pinned by an independent scipy implementation in tests/test_plumbing_cpu.py)."""
+    import importlib.util
+    import types
+
+    saved = {k: v for k, v in sys.modules.items() if k == "basicsr" or k.startswith("basicsr.") or k == "cv2"}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        cv2 = types.ModuleType("cv2")
+        cv2.COLOR_RGB2BGR = 4
+        cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[..., ::-1])
+        sys.modules["cv2"] = cv2
+        for name, path in [("basicsr", "basicsr"), ("basicsr.utils", "basicsr/utils"), ("basicsr.metrics", "basicsr/metrics")]:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(ref_import.REF, path)]
+            sys.modules[name] = m
+
+        def load(name, rel):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(ref_import.REF, rel))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            return mod
+
+        load("basicsr.utils.registry", "basicsr/utils/registry.py")
+        cu = load("basicsr.utils.color_util", "basicsr/utils/color_util.py")
+        sys.modules["basicsr.utils"].bgr2ycbcr = cu.bgr2ycbcr
+        load("basicsr.metrics.metric_util", "basicsr/metrics/metric_util.py")
+        ps = load("basicsr.metrics.psnr_ssim", "basicsr/metrics/psnr_ssim.py")
+        a = keyed_input("metrics.a", (2, 3, 24, 20)).numpy()
+        b = np.clip(a + keyed_input("metrics.n", (2, 3, 24, 20), lo=-0.08, hi=0.08).numpy(), 0, 1).astype(np.float32)
+        out = {}
+        for cb in (0, 3):
+            for ych in (False, True):
+                out[f"psnr_cb{cb}_y{int(ych)}"] = np.float64(ps.calculate_psnr(a, b, cb, test_y_channel=ych, image_range=255.0))
+        out["psnr_range1"] = np.float64(ps.calculate_psnr(a, b, 0, image_range=1))
+        out["psnr_single_chw"] = np.float64(ps.calculate_psnr(a[0], b[0], 2, image_range=255.0))
+        out["psnr_bhwc"] = np.float64(ps.calculate_psnr(a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1), 0, input_order="BHWC"))
+        out["psnr_equal"] = np.float64(ps.calculate_psnr(a, a.copy(), 0))
+        np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    finally:
+        for k in [k for k in sys.modules if k == "basicsr" or k.startswith("basicsr.") or k == "cv2"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def gen_denoise_noise(ref):
+    """The noise field of ``PairedImageDenoiseDataset.__getitem__`` (basicsr/data/paired_image_dataset.py:388-402).  The class
+    itself needs cv2 / the file clients, so its five numpy lines are re-enacted verbatim on a keyed HWC float32 image:
+    ``np.random.seed(index | 0)``; ``img_lq += np.random.normal(0, sigma / 255.0, img_lq.shape)``."""
+    img = keyed_input("denoise.img", (6, 5, 3)).numpy()   # HWC, RGB order (after the reference's BGR2RGB)
+    img = (np.round(img * 255.0) / 255.0).astype(np.float32)   # values a PNG can hold
+    out = {"img_hwc_u8": np.round(img * 255.0).astype(np.uint8)}
+    for tag, seed in (("test", 0), ("train_idx3", 3)):
+        lq = img.copy()
+        np.random.seed(seed=seed)
+        lq += np.random.normal(0, 25 / 255.0, lq.shape)
+        out[f"lq_{tag}"] = lq
+    np.savez_compressed(os.path.join(OUT, "denoise_noise.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -453,6 +518,8 @@ def main():
     gen_restormer(ref)
     gen_promptir(ref)
     gen_train_plumbing(ref)
+    gen_metrics(ref)
+    gen_denoise_noise(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

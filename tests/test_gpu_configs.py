@@ -1,0 +1,246 @@
+"""BASELINE.json configurations at their REAL sizes on the HIP path (round-1 verdict: `configs[2]` and `configs[4]` were only
+exercised with tiny nets), the data-parallel wrap on the device, and the PSNR acceptance gate of `north_star`.
+
+* configs[4] -- 2048 x 2048 image, `tile: {infer_size: 512, tile_pad: 16}`, NAFNet-64: pasted tiles vs the ORACLE run on the same
+  padded crops (reference basicsr/models/sr_model.py:273-361), and batched-by-shape == one-tile-at-a-time.
+* configs[2] (fp32 arithmetic) -- `DCPTModel.optimize_parameters` with NAFNet-64 + `PromptIR_NoImg_DC(feature_dims=[64,128,256,512])`,
+  B = 32, 128 x 128: directional derivative of the whole step (reference ...pretrain_model.py:133-169).
+* M3 -- the tiny HIP NAFNet wrapped by `BaseModel.model_to_device` in DistributedDataParallel on a 1-rank `nccl` (= RCCL) group:
+  gradients bit-identical to the unwrapped run (reference base_model.py:108-115).
+* PSNR gate -- NAFNet-64, 4 synthetic 256 x 256 pairs: |PSNR(HIP) - PSNR(oracle)| <= 0.01 dB, |SSIM diff| <= 1e-4 with the uint8
+  rounding of reference basicsr/metrics/psnr_ssim.py:47-75.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from dcpt_amd.keyed_init import keyed_input, keyed_state_dict
+from oracle import dc_oracle as D
+from oracle import nafnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(img_channel=3, width=8, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 2], dec_blk_nums=[1, 1, 1, 1])
+FULL = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1])
+DC_FULL = dict(feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from dcpt_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _smooth_pair(index, size=256, sigma=25.0 / 255.0):
+    """a seeded (gt, lq) pair that looks like an image: smooth random field + Gaussian noise"""
+    g = torch.Generator().manual_seed(1000 + index)
+    low = torch.rand((1, 3, size // 16, size // 16), generator=g)
+    gt = torch.nn.functional.interpolate(low, size=(size, size), mode="bicubic", align_corners=False)[0].clamp(0, 1)
+    lq = (gt + sigma * torch.randn((3, size, size), generator=g)).clamp(0, 1)
+    return gt, lq
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_tiled_2k_inference_vs_oracle(dev):
+    """BASELINE.json configs[4]."""
+    from basicsr.models import build_model
+
+    opt = dict(name="t", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
+               network_g=dict(type="NAFNetBaseline", window_size=16, **FULL), path=dict(), tile=dict(infer_size=512, tile_pad=16),
+               val=dict(save_img=False))
+    m = build_model(opt)
+    sd = keyed_state_dict(O.nafnet_param_shapes(**FULL), seed=0)
+    m.net_g.load_state_dict(sd, strict=True)
+    img = torch.rand((1, 3, 2048, 2048), generator=torch.Generator().manual_seed(2048))
+    m.feed_data({"lq": img})
+    m.pre_test()
+    assert m.lq.shape == (1, 3, 2048, 2048)
+    m.test_tile()
+    m.post_test()
+    got = m.output.cpu()
+    assert got.shape == (1, 3, 2048, 2048) and bool(torch.isfinite(got).all())
+
+    # (1) the reference's loop (sr_model.py:291-361), one tile at a time on the device: same tiles, same paste arithmetic
+    size, pad = 512, 16
+    seq = torch.zeros_like(img)
+    lq = img.to(dev)
+    with torch.no_grad():
+        for ty in range(4):
+            for tx in range(4):
+                x0, y0 = tx * size, ty * size
+                x1, y1 = min(x0 + size, 2048), min(y0 + size, 2048)
+                xp0, yp0, xp1, yp1 = max(x0 - pad, 0), max(y0 - pad, 0), min(x1 + pad, 2048), min(y1 + pad, 2048)
+                out = m.net_g(lq[:, :, yp0:yp1, xp0:xp1].contiguous())
+                seq[:, :, y0:y1, x0:x1] = out[:, :, y0 - yp0:y0 - yp0 + size, x0 - xp0:x0 - xp0 + size].cpu()
+    # batched-by-shape vs sequential: every output pixel is the same chain of fp32 operations; only the per-image pooling
+    # partial sums may be grouped differently for a different batch size, hence 2e-6 instead of bit equality
+    err = _relerr(got, seq)
+    assert err <= 2e-6, f"batched tiles vs sequential tiles: {err:.3e} (bit-equal: {torch.equal(got, seq)})"
+
+    # (2) the ORACLE on the padded crop of one corner tile (528 x 528) and one interior tile (544 x 544)
+    P = {k: v for k, v in sd.items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for ty, tx in ((0, 0), (1, 2)):
+        x0, y0 = tx * size, ty * size
+        xp0, yp0, xp1, yp1 = max(x0 - pad, 0), max(y0 - pad, 0), min(x0 + size + pad, 2048), min(y0 + size + pad, 2048)
+        with torch.no_grad():
+            ref, _ = O.nafnet_forward(img[:, :, yp0:yp1, xp0:xp1].contiguous(), P)
+        want = ref[:, :, y0 - yp0:y0 - yp0 + size, x0 - xp0:x0 - xp0 + size]
+        e = _relerr(got[:, :, y0:y0 + size, x0:x0 + size], want)
+        assert e <= 1e-3, f"tile ({ty},{tx}) vs oracle: {e:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_dcpt_step_full_size_directional_derivative(dev):
+    """BASELINE.json configs[2] in fp32: the analytic gradients left in `.grad` by DCPTModel.optimize_parameters (lr = 0), contracted
+    with a random direction in the parameter space of BOTH networks, equal the central difference of the step's loss
+    (l_pix + l_classify) evaluated by forward passes only."""
+    from basicsr.models import build_model
+
+    B, S = 32, 128
+    opt = dict(name="t", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+               hook_names="decoder", network_g=dict(type="NAFNetBaseline", **FULL),
+               network_dc=dict(type="PromptIR_NoImg_DC", **DC_FULL), path=dict(),
+               train=dict(pixel_opt=dict(type="MSELoss", loss_weight=1.0, reduction="mean"),
+                          classify_opt=dict(type="CrossEntropyLoss", loss_weight=1.0),
+                          optim_g=dict(type="SGD", lr=0.0), optim_dc=dict(type="SGD", lr=0.0)))
+    m = build_model(opt)
+    m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**FULL), seed=0), strict=True)
+    m.net_dc.load_state_dict(keyed_state_dict(D.dc_param_shapes(**DC_FULL), seed=0), strict=True)
+    assert len(m.hooks) == 4
+    gen = torch.Generator().manual_seed(21)
+    gt = torch.rand((B, 3, S, S), generator=gen)
+    lq = (gt + 0.1 * torch.randn((B, 3, S, S), generator=gen)).clamp(0, 1)
+    labels = torch.randint(0, 10, (B,), generator=gen)
+    m.feed_data({"lq": lq, "gt": gt, "dataset_idx": labels})
+    m.optimize_parameters(1)
+    log = m.get_current_log()
+
+    def losses():   # the step's forward half (…pretrain_model.py:140-160), losses reduced in fp64
+        with torch.no_grad():
+            pix = m.net_g(m.gt, hook=False)
+            m.hook_outputs = []
+            m.net_g(m.lq, hook=True)
+            cls = m.net_dc(m.lq, m.hook_outputs[::-1])
+            m.hook_outputs = []
+            l_pix = (pix.double() - m.gt.double()).pow(2).mean()
+            l_cls = torch.nn.functional.cross_entropy(cls.double(), m.dataset_idx)
+        return float(l_pix), float(l_cls)
+
+    lp, lc = losses()
+    assert abs(lp - log["l_pix"]) <= 1e-5 * max(1.0, abs(lp)) and abs(lc - log["l_classify"]) <= 1e-4 * max(1.0, abs(lc)), (lp, lc, log)
+    params = [p for p in m.net_g.parameters()] + [p for p in m.net_dc.parameters()]
+    assert all(p.grad is not None for p in params)
+    dirs = [torch.randn(p.shape, generator=gen).to(dev) * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    analytic = float(sum((p.grad.double() * d.double()).sum() for p, d in zip(params, dirs)))
+    eps = 1e-3
+    vals = []
+    with torch.no_grad():
+        for sign in (+1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=sign * eps)
+            vals.append(sum(losses()))
+            for p, d in zip(params, dirs):
+                p.sub_(d, alpha=sign * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(analytic) > 1e-3, analytic
+    assert abs(numeric - analytic) <= 3e-2 * abs(analytic), (numeric, analytic, lp, lc)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_ddp_wrapped_hip_net_one_rank_rccl(dev):
+    """reference base_model.py:108-115: the DDP wrap of the HIP network on an `nccl` (RCCL) process group of one rank -- bucket
+    views, autograd hooks firing block by block and the all-reduce leave exactly the gradients of the unwrapped run."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+
+    from basicsr.archs import build_network
+    from basicsr.models.base_model import BaseModel
+
+    sd = keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0)
+    x = keyed_input("ddp.x", (4, 3, 32, 32)).to(dev)
+    gw = keyed_input("ddp.gw", (4, 3, 32, 32), lo=-1, hi=1).to(dev)
+
+    def run(wrap):
+        net = build_network(dict(type="NAFNetBaseline", **TINY))
+        net.load_state_dict(sd, strict=True)
+        if wrap:
+            bm = BaseModel(dict(num_gpu=1, is_train=True, dist=True, rank=0, world_size=1))
+            model = bm.model_to_device(net)
+            assert isinstance(model, DistributedDataParallel)
+        else:
+            model = net.to(dev)
+        for _ in range(2):   # second iteration: DDP has rebuilt its buckets in gradient-arrival order
+            model.zero_grad(set_to_none=True)
+            y = model(x)
+            (y * gw).sum().backward()
+        torch.cuda.synchronize()
+        bare = model.module if wrap else model
+        return y.detach().clone(), {k: p.grad.detach().clone() for k, p in bare.named_parameters()}
+
+    y0, g0 = run(False)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        t = torch.ones(8, device=dev)
+        dist.all_reduce(t)
+        assert float(t.sum()) == 8.0
+        y1, g1 = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(y0, y1)
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_psnr_gate_hip_vs_oracle(dev):
+    """north_star: "PSNR within 0.01 dB".  The released weights / test sets are not available offline; the substitute
+    named there: NAFNet-64 with keyed weights on synthetic pairs, PSNR / SSIM of the HIP output and of the oracle's output against
+    the same ground truth, through the uint8 rounding of metrics/psnr_ssim.py:47-75 as SRModel.nondist_validation applies it."""
+    from basicsr.archs import build_network
+    from basicsr.metrics import calculate_psnr, calculate_ssim
+    from basicsr.models.sr_model import tensor2img_rgb
+
+    sd = keyed_state_dict(O.nafnet_param_shapes(**FULL), seed=0)
+    # a restoration-like network: small residual branch so that outputs stay in the image range (keyed ending conv scaled down)
+    sd = {k: (v * 0.01 if k.startswith("ending.") else v) for k, v in sd.items()}
+    net = build_network(dict(type="NAFNetBaseline", **FULL))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    worst_p, worst_s = 0.0, 0.0
+    for i in range(4):
+        gt, lq = _smooth_pair(i)
+        with torch.no_grad():
+            out_h = net(lq[None].to(dev)).cpu()
+            out_o, _ = O.nafnet_forward(lq[None], sd)
+        h8, o8 = tensor2img_rgb(out_h), tensor2img_rgb(out_o)
+        f = lambda t: t.clamp(0, 1).numpy()   # noqa: E731  (SRModel.nondist_validation: clamped float BCHW into the metric)
+        kw = dict(crop_border=0, test_y_channel=False, image_range=255.0)   # options/all_in_one/test/test_NAFNet_5d.yml
+        ph, po = calculate_psnr(f(out_h), f(gt[None]), **kw), calculate_psnr(f(out_o), f(gt[None]), **kw)
+        sh, so = calculate_ssim(f(out_h), f(gt[None]), **kw), calculate_ssim(f(out_o), f(gt[None]), **kw)
+        assert 5.0 < po < 60.0, po
+        worst_p, worst_s = max(worst_p, abs(ph - po)), max(worst_s, abs(sh - so))
+        assert (h8 != o8).mean() < 2e-3, f"image {i}: {(h8 != o8).mean():.2e} of the uint8 pixels differ"
+    assert worst_p <= 0.01, f"PSNR differs by {worst_p:.4f} dB"
+    assert worst_s <= 1e-4, f"SSIM differs by {worst_s:.2e}"

@@ -149,9 +149,15 @@ def test_metrics_match_independent_implementations():
     a = rs.randint(0, 256, (40, 37, 3)).astype(np.uint8)
     b = np.clip(a.astype(np.int32) + rs.randint(-9, 10, a.shape), 0, 255).astype(np.uint8)
     mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
-    assert abs(calculate_psnr(a, b, 0) - 10 * np.log10(255.0 ** 2 / mse)) < 1e-9
-    assert calculate_psnr(a, a, 0) == float("inf")
-    assert abs(calculate_ssim(a, a, 0) - 1.0) < 1e-12
+    assert abs(calculate_psnr(a, b, 0, input_order="HWC") - 10 * np.log10(255.0 ** 2 / mse)) < 1e-9
+    assert calculate_psnr(a, a, 0, input_order="HWC") == float("inf")
+    assert abs(calculate_ssim(a, a, 0, input_order="HWC") - 1.0) < 1e-12
+    # the reference's calling convention: float BCHW batches in [0,1], quantised inside the metric
+    fa, fb = a.transpose(2, 0, 1)[None] / 255.0, b.transpose(2, 0, 1)[None] / 255.0
+    assert abs(calculate_psnr(fa, fb, 0, image_range=255.0) - calculate_psnr(a, b, 0, input_order="HWC")) < 1e-12
+    assert abs(calculate_ssim(fa, fb, 0, image_range=255.0) - calculate_ssim(a, b, 0, input_order="HWC")) < 1e-12
+    two = calculate_psnr(np.concatenate([fa, fb]), np.concatenate([fb, fb * 0.5]), 0)
+    assert abs(two - 0.5 * (calculate_psnr(fa, fb, 0) + calculate_psnr(fb, fb * 0.5, 0))) < 1e-12
     # independent SSIM: 2-D 11x11 sigma-1.5 window, 'valid'
     g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
     win = np.outer(g / g.sum(), g / g.sum())
@@ -163,8 +169,8 @@ def test_metrics_match_independent_implementations():
         sx, sy, sxy = f(x * x) - mx * mx, f(y * y) - my * my, f(x * y) - mx * my
         c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
         vals.append((((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sx + sy + c2))).mean())
-    assert abs(calculate_ssim(a, b, 0) - np.mean(vals)) < 1e-9
-    assert abs(calculate_psnr(a, b, 4) - calculate_psnr(a[4:-4, 4:-4], b[4:-4, 4:-4], 0)) < 1e-12
+    assert abs(calculate_ssim(a, b, 0, input_order="HWC") - np.mean(vals)) < 1e-9
+    assert abs(calculate_psnr(a, b, 4, input_order="HWC") - calculate_psnr(a[4:-4, 4:-4], b[4:-4, 4:-4], 0, input_order="HWC")) < 1e-12
 
 
 def test_cli_end_to_end_with_cpu_test_arch(tmp_path):
@@ -306,6 +312,20 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
     st = torch.load(exp / "training_states" / "12.state", weights_only=False)
     assert st["iter"] == 12 and st["optimizers"][0]["state"][0]["step"] == 12   # Adam continued from step 8, not from 0
     assert model2.get_current_log()["l_pix"] < 1.5 * first
+    # the EMA history survives the restart (reference sr_model.py:70-79): a model built on net_g_8.pth starts its EMA network
+    # from the checkpoint's params_ema, not from a copy of params
+    from basicsr.models import build_model
+    from basicsr.utils.options import parse_options
+
+    ck = torch.load(exp / "models" / "net_g_8.pth")
+    assert any(not torch.equal(ck["params"][k], ck["params_ema"][k]) for k in ck["params"])
+    opt, _ = parse_options(str(tmp_path), is_train=True, argv=["-opt", _train_yaml(tmp_path, 12)])
+    opt["path"]["pretrain_network_g"] = str(exp / "models" / "net_g_8.pth")
+    m3 = build_model(opt)
+    for k, v in m3.net_g_ema.state_dict().items():
+        assert torch.equal(v, ck["params_ema"][k]), k
+    for k, v in m3.net_g.state_dict().items():
+        assert torch.equal(v, ck["params"][k]), k
 
 
 # ------------------------------------------------------------------------------------------------
@@ -351,3 +371,63 @@ def test_two_rank_ddp_step_gloo(tmp_path):
         losses.append(m.get_current_log()["l_pix"])
     assert torch.allclose(r0["grads"], (local[0] + local[1]) / 2, atol=1e-6)
     assert abs(r0["log"]["l_pix"] - (losses[0] + losses[1]) / 2) < 1e-6  # reduce(dst=0) / world
+
+
+def test_psnr_matches_reference_fixture():
+    """basicsr.metrics.calculate_psnr vs the reference's own function (tests/golden/metrics.npz, oracle/make_golden.py::gen_metrics):
+    same interface -- float BCHW / BHWC batches in [0,1], uint8 rounding inside, border crop, BT.601 luma, batch mean."""
+    from basicsr.metrics import calculate_psnr
+    from dcpt_amd.keyed_init import keyed_input
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "metrics.npz"))
+    a = keyed_input("metrics.a", (2, 3, 24, 20)).numpy()
+    b = np.clip(a + keyed_input("metrics.n", (2, 3, 24, 20), lo=-0.08, hi=0.08).numpy(), 0, 1).astype(np.float32)
+    for cb in (0, 3):
+        for ych in (False, True):
+            mine = calculate_psnr(a, b, cb, test_y_channel=ych, image_range=255.0)
+            assert abs(mine - float(g[f"psnr_cb{cb}_y{int(ych)}"])) < 1e-9, (cb, ych, mine)
+    assert abs(calculate_psnr(a, b, 0, image_range=1) - float(g["psnr_range1"])) < 1e-9
+    assert abs(calculate_psnr(a[0], b[0], 2, image_range=255.0) - float(g["psnr_single_chw"])) < 1e-9
+    assert abs(calculate_psnr(a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1), 0, input_order="BHWC") - float(g["psnr_bhwc"])) < 1e-9
+    assert calculate_psnr(a, a.copy(), 0) == float("inf") and np.isinf(g["psnr_equal"])
+    with pytest.raises(ValueError):
+        calculate_psnr(a, b, 0, input_order="NCHW")
+
+
+def test_denoise_dataset_noise_matches_reference(tmp_path):
+    """PairedImageDenoiseDataset draws the reference's noise field (paired_image_dataset.py:388-402): seed 0 outside training,
+    seed = index in the train phase, normal(0, sigma/255) on the HWC RGB image -- pinned by tests/golden/denoise_noise.npz."""
+    from PIL import Image
+
+    from basicsr.data import build_dataset
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "denoise_noise.npz"))
+    root = tmp_path / "gt"
+    root.mkdir()
+    for i in range(4):   # four identical files: index 3 exists for the train-phase seed
+        Image.fromarray(g["img_hwc_u8"]).save(root / f"{i:02d}.png")
+    common = dict(name="n", type="PairedImageDenoiseDataset", dataroot_gt=str(root), io_backend=dict(type="disk"),
+                  sigma_type="constant", sigma_range=25)
+    test_set = build_dataset(dict(common, phase="test"))
+    assert len(test_set) == 4
+    for idx in (0, 2):   # seed 0 for every test image
+        s = test_set[idx]
+        assert s["lq"].shape == (3, 6, 5) and s["lq"].dtype == torch.float32
+        assert np.array_equal(s["lq"].permute(1, 2, 0).numpy(), g["lq_test"]), idx
+        assert np.array_equal((s["gt"].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8), g["img_hwc_u8"])
+    train_set = build_dataset(dict(common, phase="train", use_hflip=False, use_rot=False))
+    assert np.array_equal(train_set[3]["lq"].permute(1, 2, 0).numpy(), g["lq_train_idx3"])
+    assert not np.array_equal(train_set[1]["lq"].numpy(), train_set[3]["lq"].numpy())   # per-index noise
+    # sigma_type random / choice draw sigma from Python's `random` (:388-393)
+    import random
+
+    random.seed(5)
+    want = random.choice([15, 25, 50])
+    random.seed(5)
+    s = build_dataset(dict(common, phase="test", sigma_type="choice", sigma_range=[15, 25, 50]))[0]
+    rs = np.random.RandomState(0)
+    ref = (g["img_hwc_u8"].astype(np.float32) / 255.0)
+    ref += rs.normal(0, want / 255.0, ref.shape)
+    assert np.array_equal(s["lq"].permute(1, 2, 0).numpy(), ref)
+    with pytest.raises(FileNotFoundError):
+        build_dataset(dict(common, phase="train", dataroot_gt=str(tmp_path / "missing")))

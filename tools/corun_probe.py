@@ -2,6 +2,7 @@
 Stream B loops an NT GEMM (1x1 conv forward, level-3 shape); stream A times LayerNorm forward / backward alone and co-running."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from dcpt_amd import functional as DF
 dev = torch.device('cuda:0')
 B, C, H, W = 32, 512, 32, 32

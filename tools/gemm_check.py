@@ -1,6 +1,7 @@
 """Spot-check the NT GEMM (1x1 conv, no bias) against torch on awkward shapes."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from dcpt_amd import functional as DF
 dev = torch.device('cuda:0')
 torch.manual_seed(0)

@@ -2,6 +2,7 @@
 MFMA GEMMs on the same shapes (1x1 conv forward = NT, weight gradient = TN).  Context for DESIGN.md, not part of the product."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from dcpt_amd import functional as DF, _lib
 dev = torch.device("cuda:0")
 lib = _lib.load(); lib.dcpt_set_side_stream(0)

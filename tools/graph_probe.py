@@ -2,6 +2,7 @@
 graph captures on the capturing stream)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from basicsr.archs import build_network
 from dcpt_amd import _lib
 from dcpt_amd.keyed_init import fill_module_

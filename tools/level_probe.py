@@ -1,6 +1,7 @@
 """Time one NAFBlock forward / backward at every level of the bench configuration (B=32, 256^2, width 64)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from basicsr.archs.nafnet_arch import NAFBlock
 from dcpt_amd.keyed_init import fill_module_
 dev = torch.device('cuda:0')

@@ -1,6 +1,7 @@
 """One NAFBlock forward + backward at one level of the bench configuration, 5 times (run under rocprofv3 --kernel-trace)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from basicsr.archs.nafnet_arch import NAFBlock
 from dcpt_amd.keyed_init import fill_module_
 from dcpt_amd import _lib

@@ -1,5 +1,6 @@
 import os, sys, torch
 sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from basicsr.archs import build_network
 from dcpt_amd.keyed_init import fill_module_
 CFG = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1])

@@ -1,6 +1,8 @@
+import os
 """Per-GEMM-class timing (library HIP-event profiler, side stream off) of one bench_extra workload step."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 import bench
 from dcpt_amd import _lib
 lib = _lib.load(); lib.dcpt_set_side_stream(0)

@@ -1,5 +1,5 @@
 """Phase timeline of one NT-GEMM launch (diagnostic build: tools/build_variant.sh tl -DDCPT_TIMELINE;
-run with DCPT_HIP_LIB=dcpt_amd/lib/libdcpt_hip_tl.so).  Stamps are the 100 MHz wall clock (10 ns)."""
+run with DCPT_TOOL_LIB=experiments/lib/libdcpt_hip_tl.so).  Stamps are the 100 MHz wall clock (10 ns)."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

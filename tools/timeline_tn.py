@@ -1,5 +1,5 @@
 """Phase timeline of one TN (weight-gradient) GEMM launch (diagnostic build: tools/build_variant.sh tl "gemm_nt.hip gemm_tn.hip"
--DDCPT_TIMELINE=1; run with DCPT_HIP_LIB=dcpt_amd/lib/libdcpt_hip_tl.so)."""
+-DDCPT_TIMELINE=1; run with DCPT_TOOL_LIB=experiments/lib/libdcpt_hip_tl.so)."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 """TN (wgrad) GEMM speed by loader at the level-3 shape, through the public conv ops' backward."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
 from dcpt_amd import functional as DF, _lib
 import ctypes
 lib = _lib.load(); lib.dcpt_set_side_stream(0)
