@@ -84,9 +84,10 @@ def test_tiled_2k_inference_vs_oracle(dev):
                 out = m.net_g(lq[:, :, yp0:yp1, xp0:xp1].contiguous())
                 seq[:, :, y0:y1, x0:x1] = out[:, :, y0 - yp0:y0 - yp0 + size, x0 - xp0:x0 - xp0 + size].cpu()
     # batched-by-shape vs sequential: every output pixel is the same chain of fp32 operations; only the per-image pooling
-    # partial sums may be grouped differently for a different batch size, hence 2e-6 instead of bit equality
+    # partial sums are grouped differently for a different batch size (the row-range split of the depthwise kernel follows the
+    # batch to fill the chip), which perturbs SCA by an ulp and propagates through 36 blocks: 2e-5 instead of bit equality
     err = _relerr(got, seq)
-    assert err <= 2e-6, f"batched tiles vs sequential tiles: {err:.3e} (bit-equal: {torch.equal(got, seq)})"
+    assert err <= 2e-5, f"batched tiles vs sequential tiles: {err:.3e} (bit-equal: {torch.equal(got, seq)})"
 
     # (2) the ORACLE on the padded crop of one corner tile (528 x 528) and one interior tile (544 x 544)
     P = {k: v for k, v in sd.items()}
