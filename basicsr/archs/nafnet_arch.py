@@ -4,9 +4,15 @@ Same registry names, constructor kwargs, ``forward(inp, hook=False)`` contract, 
 ``state_dict`` keys/shapes as the reference (basicsr/archs/nafnet_arch.py), so checkpoints load
 with ``strict=True`` and forward hooks on ``decoder{i}`` see the block-group outputs.  The math does
 not run through torch ops: every NAFBlock is ONE autograd node backed by ``dcpt_nafblock_fwd/bwd``
-(LayerNorm fused into the MFMA GEMM loaders, depthwise 3x3 + SimpleGate + pooling in one pass,
-SCA / residual scales in GEMM epilogues), and the convs between blocks are ``dcpt_conv3x3_*``,
-``dcpt_down2x2_*`` and ``dcpt_up_ps_*``.  Feature maps are channels_last (NHWC) tensors.
+(LayerNorm as its own bandwidth kernel whose output feeds the MFMA GEMMs as a plain LDS-DMA operand --
+or, at C <= 128, inside the producing GEMM's epilogue --, depthwise 3x3 + SimpleGate + pooling in one
+pass, SCA / residual scales / SimpleGate in GEMM epilogues), and the convs between
+blocks are ``dcpt_conv3x3_*``, ``dcpt_down2x2_*`` and ``dcpt_up_ps_*``.  Feature maps are channels_last
+(NHWC) tensors.
+
+``act_dtype="bf16"`` (an extension; the reference computes in fp32 only) runs every NAFBlock group with
+bfloat16 activations / saved tensors and fp32 accumulation (``dcpt_nafblock_fwd_bf16/bwd_bf16``); the
+layers between the groups and all parameters stay fp32, with one cast kernel at each group edge.
 
 The child ``nn.Conv2d`` / ``LayerNorm2d`` modules below only OWN the parameters (for state-dict and
 optimizer compatibility); they are never called on the fused path.
@@ -92,6 +98,21 @@ class NAFBlock(nn.Module):
         return DF.nafblock(inp, self.fused_params())
 
 
+class _BlockGroup(nn.Sequential):
+    """A level's NAFBlocks (an ``nn.Sequential`` in the reference, so the state-dict keys and the forward hooks on
+    ``decoder{i}`` are unchanged).  With ``act_bf16`` the whole group runs on the bf16-storage kernels between two casts."""
+
+    act_bf16 = False
+
+    def forward(self, x):
+        if not self.act_bf16 or len(self) == 0:
+            return super().forward(x)
+        x = DF.to_bf16(x)
+        for blk in self:
+            x = DF.nafblock_bf16(x, blk.fused_params())
+        return DF.to_f32(x)
+
+
 class _Down(nn.Conv2d):
     """Conv2d(c, 2c, 2, 2) run as a gathered MFMA GEMM (reference nafnet_arch.py:230)."""
 
@@ -106,8 +127,10 @@ class _UpConv(nn.Conv2d):
 
 @ARCH_REGISTRY.register()
 class NAFNetBaseline(nn.Module):
-    def __init__(self, img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=[], dec_blk_nums=[], window_size=8):
+    def __init__(self, img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=[], dec_blk_nums=[], window_size=8, act_dtype="fp32"):
         super().__init__()
+        if act_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"act_dtype must be 'fp32' or 'bf16', got {act_dtype!r}")
         self.intro = nn.Conv2d(img_channel, width, 3, padding=1, bias=True)
         self.ending = nn.Conv2d(width, img_channel, 3, padding=1, bias=True)
         self.encoders = nn.ModuleList()
@@ -117,20 +140,28 @@ class NAFNetBaseline(nn.Module):
 
         chan = width
         for num in enc_blk_nums:
-            self.encoders.append(nn.Sequential(*[NAFBlock(chan) for _ in range(num)]))
+            self.encoders.append(_BlockGroup(*[NAFBlock(chan) for _ in range(num)]))
             self.downs.append(_Down(chan, 2 * chan, 2, 2))
             chan *= 2
-        self.middle_blks = nn.Sequential(*[NAFBlock(chan) for _ in range(middle_blk_num)])
+        self.middle_blks = _BlockGroup(*[NAFBlock(chan) for _ in range(middle_blk_num)])
         for i, num in enumerate(dec_blk_nums):
             self.ups.append(nn.Sequential(_UpConv(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2)))
             chan //= 2
-            setattr(self, f"decoder{i}", nn.Sequential(*[NAFBlock(chan) for _ in range(num)]))
+            setattr(self, f"decoder{i}", _BlockGroup(*[NAFBlock(chan) for _ in range(num)]))
         self._n_dec = len(dec_blk_nums)
+        self.set_act_dtype(act_dtype)
         # >1: the batch is processed as that many sub-batches on separate HIP streams, so the HBM-bound kernels of one
         # sub-batch (LayerNorm, depthwise conv, reductions) overlap the MFMA-bound GEMMs of the other (same arithmetic,
         # same results; autograd replays each sub-batch's backward on its own stream)
         self.stream_chunks = 1
         self._side_streams = []
+
+    def set_act_dtype(self, act_dtype):
+        """'fp32' (the reference's arithmetic) or 'bf16' (bf16 storage of the NAFBlock activations, fp32 accumulate)"""
+        self.act_dtype = act_dtype
+        for m in self.modules():
+            if isinstance(m, _BlockGroup):
+                m.act_bf16 = act_dtype == "bf16"
 
     def _streams(self, n, device):
         while len(self._side_streams) < n:

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 _lock = threading.Lock()
 
@@ -47,6 +47,10 @@ GDFN_PARAM_FIELDS = ("norm_w", "norm_b", "in_w", "dw_w", "out_w")
 GDFN_SAVED_FIELDS = ("mu", "rstd", "u", "t", "xn")
 
 
+class NafBlockSavedBf16(C.Structure):   # same field order as NafBlockSaved; the [M][.] tensors are bf16
+    _fields_ = [(n, C.c_void_p) for n in _SAVED_FIELDS]
+
+
 class MdtaParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in MDTA_PARAM_FIELDS]
 
@@ -79,6 +83,14 @@ SIGNATURES = {
                                  cint, cint, cint, cint, stream_t]),
     "dcpt_nafblock_bwd": (cint, [C.POINTER(NafBlockParams), C.POINTER(NafBlockGrads), f32p, C.POINTER(NafBlockSaved),
                                  f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_nafblock_fwd_bf16_ws_bytes": (sz, [cint, cint, cint, cint]),
+    "dcpt_nafblock_bwd_bf16_ws_bytes": (sz, [cint, cint, cint, cint]),
+    "dcpt_nafblock_fwd_bf16": (cint, [C.POINTER(NafBlockParams), f32p, f32p, C.POINTER(NafBlockSavedBf16), C.c_void_p, sz,
+                                      cint, cint, cint, cint, stream_t]),
+    "dcpt_nafblock_bwd_bf16": (cint, [C.POINTER(NafBlockParams), C.POINTER(NafBlockGrads), f32p, C.POINTER(NafBlockSavedBf16),
+                                      f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_cast_f32_bf16": (cint, [f32p, f32p, i64, stream_t]),
+    "dcpt_cast_bf16_f32": (cint, [f32p, f32p, i64, stream_t]),
     "dcpt_nafblock_local_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
     "dcpt_nafblock_local_fwd": (cint, [C.POINTER(NafBlockParams), f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint,
                                        stream_t]),

@@ -1,0 +1,106 @@
+// bf16-storage path (BASELINE.json configs[2]): activations and saved tensors are bfloat16 in HBM, every kernel computes in
+// fp32 (MFMA accumulators, LayerNorm statistics, reductions), parameters and their gradients stay fp32.  A bf16 value is the
+// upper half of an fp32; conversion to bf16 is round-to-nearest-even (v_cvt_pk_bf16_f32), conversion back is a shift.
+#pragma once
+#include "bufops.h"
+#include "dcpt_common.h"
+
+typedef uint16_t bf16_t;   // raw storage
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t bf_pack(float lo, float hi) {   // two fp32 -> {bf16 lo, bf16 hi}, RNE
+    floatx2 v;
+    v.x = lo;
+    v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_round(float x) { return bf_lo(bf_pack(x, 0.f)); }   // fp32 -> bf16 -> fp32
+
+__device__ __forceinline__ float4 bf4_unpack(u32x2 w) { return make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y)); }
+__device__ __forceinline__ u32x2 bf4_pack(float4 f) {
+    u32x2 w;
+    w.x = bf_pack(f.x, f.y);
+    w.y = bf_pack(f.z, f.w);
+    return w;
+}
+// 4 consecutive bf16 (8 bytes) through a range-checked buffer window (sentinel offsets load 0 / drop the store)
+__device__ __forceinline__ float4 bbuf_ld4(rsrc_t r, uint32_t voff) {
+    return bf4_unpack(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0)));
+}
+__device__ __forceinline__ void bbuf_st4(rsrc_t r, uint32_t voff, float4 f) {
+    __builtin_amdgcn_raw_buffer_store_b64(bf4_pack(f), r, voff, 0, 0);
+}
+// 8 consecutive bf16 (16 bytes)
+struct f8 {
+    float4 lo, hi;
+};
+__device__ __forceinline__ f8 bbuf_ld8(rsrc_t r, uint32_t voff) {
+    const u32x4 w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    f8 o;
+    o.lo = make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y));
+    o.hi = make_float4(bf_lo(w.z), bf_hi(w.z), bf_lo(w.w), bf_hi(w.w));
+    return o;
+}
+__device__ __forceinline__ void bbuf_st8(rsrc_t r, uint32_t voff, f8 v) {
+    u32x4 w;
+    w.x = bf_pack(v.lo.x, v.lo.y);
+    w.y = bf_pack(v.lo.z, v.lo.w);
+    w.z = bf_pack(v.hi.x, v.hi.y);
+    w.w = bf_pack(v.hi.z, v.hi.w);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+}
+__device__ __forceinline__ f8 f8_zero() { return f8{f4_zero(), f4_zero()}; }
+__device__ __forceinline__ f8 f8_ld(const float* p) { return f8{ldg4(p), ldg4(p + 4)}; }   // 8 fp32 (parameters)
+__device__ __forceinline__ f8 f8_add(f8 a, f8 b) { return f8{f4_add(a.lo, b.lo), f4_add(a.hi, b.hi)}; }
+__device__ __forceinline__ f8 f8_mul(f8 a, f8 b) { return f8{f4_mul(a.lo, b.lo), f4_mul(a.hi, b.hi)}; }
+__device__ __forceinline__ f8 f8_fma(f8 a, f8 b, f8 c) { return f8{f4_fma(a.lo, b.lo, c.lo), f4_fma(a.hi, b.hi, c.hi)}; }
+__device__ __forceinline__ float f8_sum(f8 a) { return f4_sum(a.lo) + f4_sum(a.hi); }
+#endif
+
+// ---- launchers of the bf16 kernels (gemm_bf16.hip, bf16_ops.hip) ----------------------------------------------------------
+enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5 };
+
+// C[m][n] = sum_k A[m][k] * Bw[n][k]  on v_mfma_f32_32x32x16_bf16; A, Bw, C, res, aux, gate bf16; bias / cscale / colpart fp32.
+struct GemmNTB {
+    const bf16_t* A;    // [M][lda]
+    const bf16_t* Bw;   // [N][K], K contiguous, K % 8 == 0
+    bf16_t* C;          // [M][ldc]  (EB_SGBWD: 2N columns)
+    int64_t M;
+    int N, K, lda, ldc;
+    const float* bias;      // [N] or null
+    const bf16_t* res;      // EB_RESID: C = res + (acc + bias) * cscale[n];  EB_DOTCOL: colpart[m/128][n] = sum_rows acc * res
+    int ldres;              // 0 = ldc
+    const float* cscale;    // [N] or null (= 1)
+    const bf16_t* aux;      // EB_SGBWD: v [M][2N]:  C[:, n] = acc * v[:, N + n],  C[:, N + n] = acc * v[:, n]
+    bf16_t* gate;           // EB_BIASGATE (N = 2 Ch): C = acc + bias AND gate[m][c] = C[m][c] * C[m][Ch + c]   ([M][Ch])
+    float* colpart;         // EB_DOTCOL
+    // grid.y = nb independent problems (one per image): element offsets b * s?
+    int nb;
+    int64_t sA, sB, sC, sR;
+};
+int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
+
+// G[n][k] = sum_m X[m][n] * Y[m][k]  (weight gradients): X, Y bf16 row-major, fp32 slabs [splits][N][K] + column sums of X as in
+// the fp32 TN kernel (gemm.h); operands are transposed on the way out of LDS by ds_read_b64_tr_b16.
+struct GemmTNB {
+    const bf16_t* X;
+    const bf16_t* Y;
+    float* slab;
+    float* colsum;   // [splits * tiles_k][N] or null
+    int64_t M;
+    int N, K, ldx, ldy;
+    int splits;
+    int64_t rows_per_split;
+};
+int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s);
+int gemm_tn_bf16_tiles_k(int N, int K);
+void gemm_tn_bf16_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split);
+bool gemm_tn_bf16_plan_images(int64_t M, int N, int K, int P, int* splits, int64_t* rows_per_split);

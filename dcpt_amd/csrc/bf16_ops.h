@@ -1,0 +1,33 @@
+// Launchers of the bf16-path bandwidth kernels (bf16_ops.hip, dwconv.hip).
+#pragma once
+#include "bf16.h"
+#include "kernels.h"
+
+int launch_ln_fwd_bf16(const bf16_t* x, const float* w, const float* b, bf16_t* y, float* mu, float* rstd, int64_t M, int C, float eps,
+                       hipStream_t s);
+int ln_bwd_bf16_num_blocks(int64_t M, int C);
+// part: [nblk][2][C] fp32 (0: sum gy*xhat -> dweight, 1: sum gy -> dbias); reduce with launch_colpart_reduce(part, nblk, 2, C, ...)
+int launch_ln_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* dres, bf16_t* dx,
+                       float* part, int nblk, int64_t M, int C, hipStream_t s);
+int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
+int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
+
+constexpr int WPACKB_MAX_JOBS = 8;
+struct WpackBJobs {   // job j: in [N][K] fp32 ->  transpose ? out[k][n] = in[n][k] * rs[n]  :  out[img][n][k] = in[n][k] * kscale[img][k]
+    const float* in[WPACKB_MAX_JOBS];
+    bf16_t* out[WPACKB_MAX_JOBS];
+    const float* rs[WPACKB_MAX_JOBS];
+    const float* kscale[WPACKB_MAX_JOBS];
+    int N[WPACKB_MAX_JOBS], K[WPACKB_MAX_JOBS], nimg[WPACKB_MAX_JOBS], transpose[WPACKB_MAX_JOBS];
+    int n;
+};
+int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s);
+int launch_scale_rows_bf16(const bf16_t* x, const float* simg, bf16_t* out, int64_t M, int C, int P, hipStream_t s);
+int launch_sca_ds_part_bf16(const bf16_t* dts, const bf16_t* t2, float* ds_part, int B, int C, int P, int nslices, hipStream_t s);
+
+// dwconv.hip
+int dw_num_blocks_per_image_bf16(const DwGeom& g);
+int dw_num_blocks_per_image_fused_bf16(const DwGeom& g);
+int launch_dw_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s);
+int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                             bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s);

@@ -1,0 +1,356 @@
+// Bandwidth kernels of the bf16-storage path (bf16.h): per-pixel channel LayerNorm forward / backward on bf16 rows with fp32
+// statistics (reference basicsr/archs/nafnet_arch.py:25-64), fp32 <-> bf16 casts at the path's edges, the bf16 weight packs of the
+// MFMA GEMMs (straight, transposed + gain-scaled, per-image SCA-scaled), and SCA's channel sums when they do not come out of a
+// GEMM epilogue.  A lane owns 8 consecutive channels (one 16-byte access); a row lives in G = pow2 >= C / 8 lanes of one wave.
+#include "bf16.h"
+#include "bf16_ops.h"
+
+namespace {
+
+// 8 consecutive bf16 through a plain (per-lane) pointer, predicated
+__device__ __forceinline__ f8 ld8(const bf16_t* p, bool ok) {
+    if (!ok) return f8_zero();
+    const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+    return f8{make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y)), make_float4(bf_lo(w.z), bf_hi(w.z), bf_lo(w.w), bf_hi(w.w))};
+}
+__device__ __forceinline__ void st8(bf16_t* p, bool ok, f8 v) {
+    if (!ok) return;
+    u32x4 w;
+    w.x = bf_pack(v.lo.x, v.lo.y);
+    w.y = bf_pack(v.lo.z, v.lo.w);
+    w.z = bf_pack(v.hi.x, v.hi.y);
+    w.w = bf_pack(v.hi.z, v.hi.w);
+    *reinterpret_cast<u32x4*>(p) = w;
+}
+
+__host__ __device__ inline int lnb_group(int C) {
+    const int q = C / 8;
+    int g = 1;
+    while (g < q && g < 64) g <<= 1;
+    return g;
+}
+
+// y = (x - mean) * rstd * w + b, statistics two-pass in fp32 over the bf16 inputs (biased variance, eps inside the sqrt)
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          bf16_t* __restrict__ y, float* __restrict__ mu, float* __restrict__ rstd, int64_t M,
+                                                          int C, float eps, int G) {
+    const int tid = threadIdx.x, gpb = 256 / G, lig = tid % G, nq = C / 8;
+    f8 ww[NQ], bb[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = lig + i * G;
+        ww[i] = q < nq ? f8_ld(w + 8 * q) : f8_zero();
+        bb[i] = q < nq ? f8_ld(b + 8 * q) : f8_zero();
+    }
+    for (int64_t rb = blockIdx.x; rb * gpb < M; rb += gridDim.x) {
+        const int64_t row = rb * gpb + tid / G;
+        const bool valid = row < M;
+        const bf16_t* xr = x + (valid ? row : 0) * (int64_t)C;
+        f8 v[NQ];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            v[i] = ld8(xr + 8 * q, valid && q < nq);
+            sum += f8_sum(v[i]);
+        }
+        sum = group_sum(sum, G);
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (lig + i * G < nq) {
+                f8 d;
+                d.lo = make_float4(v[i].lo.x - mean, v[i].lo.y - mean, v[i].lo.z - mean, v[i].lo.w - mean);
+                d.hi = make_float4(v[i].hi.x - mean, v[i].hi.y - mean, v[i].hi.z - mean, v[i].hi.w - mean);
+                sq += f8_sum(f8_mul(d, d));
+                v[i] = d;
+            }
+        }
+        sq = group_sum(sq, G);
+        const float rs = 1.0f / sqrtf(sq / (float)C + eps);
+        if (valid && lig == 0) {
+            mu[row] = mean;
+            rstd[row] = rs;
+        }
+        bf16_t* yr = y + (valid ? row : 0) * (int64_t)C;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            const f8 r8 = f8{make_float4(rs, rs, rs, rs), make_float4(rs, rs, rs, rs)};
+            st8(yr + 8 * q, valid && q < nq, f8_fma(f8_mul(v[i], r8), ww[i], bb[i]));
+        }
+    }
+}
+
+// dx = rstd * (g w - xhat mean_c(g w xhat) - mean_c(g w)) + dres;  part[blk][0][c] = sum_rows g xhat, part[blk][1][c] = sum_rows g
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ mu,
+                                                          const float* __restrict__ rstd, const float* __restrict__ w,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ part,
+                                                          int64_t M, int C, int G, int64_t iters) {
+    __shared__ float red[2][256 * 8 * NQ];
+    const int tid = threadIdx.x, gpb = 256 / G, gid = tid / G, lig = tid % G, nq = C / 8;
+    f8 ww[NQ], aw[NQ], ab[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = lig + i * G;
+        ww[i] = q < nq ? f8_ld(w + 8 * q) : f8_zero();
+        aw[i] = f8_zero();
+        ab[i] = f8_zero();
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t row = (it * gridDim.x + blockIdx.x) * gpb + gid;
+        const bool valid = row < M;
+        const int64_t ro = (valid ? row : 0) * (int64_t)C;
+        const float mean = valid ? mu[row] : 0.f, rs = valid ? rstd[row] : 0.f;
+        f8 g[NQ], xh[NQ], dr[NQ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            const bool ok = valid && q < nq;
+            g[i] = ld8(gy + ro + 8 * q, ok);
+            const f8 xv = ld8(x + ro + 8 * q, ok);
+            dr[i] = dres ? ld8(dres + ro + 8 * q, ok) : f8_zero();
+            xh[i].lo = make_float4((xv.lo.x - mean) * rs, (xv.lo.y - mean) * rs, (xv.lo.z - mean) * rs, (xv.lo.w - mean) * rs);
+            xh[i].hi = make_float4((xv.hi.x - mean) * rs, (xv.hi.y - mean) * rs, (xv.hi.z - mean) * rs, (xv.hi.w - mean) * rs);
+            if (!ok) xh[i] = f8_zero();
+            const f8 gw = f8_mul(g[i], ww[i]);
+            s1 += f8_sum(gw);
+            s2 += f8_sum(f8_mul(gw, xh[i]));
+            aw[i] = f8_fma(g[i], xh[i], aw[i]);
+            ab[i] = f8_add(ab[i], g[i]);
+        }
+        s1 = group_sum(s1, G) * invC;
+        s2 = group_sum(s2, G) * invC;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            const f8 gw = f8_mul(g[i], ww[i]);
+            f8 d;
+            d.lo = make_float4(rs * (gw.lo.x - xh[i].lo.x * s2 - s1), rs * (gw.lo.y - xh[i].lo.y * s2 - s1), rs * (gw.lo.z - xh[i].lo.z * s2 - s1),
+                               rs * (gw.lo.w - xh[i].lo.w * s2 - s1));
+            d.hi = make_float4(rs * (gw.hi.x - xh[i].hi.x * s2 - s1), rs * (gw.hi.y - xh[i].hi.y * s2 - s1), rs * (gw.hi.z - xh[i].hi.z * s2 - s1),
+                               rs * (gw.hi.w - xh[i].hi.w * s2 - s1));
+            st8(dx + ro + 8 * q, valid && q < nq, f8_add(d, dr[i]));
+        }
+    }
+    // column partials of this block: the gpb row groups through LDS, fixed order
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        float* r0 = &red[0][(tid * NQ + i) * 8];
+        float* r1 = &red[1][(tid * NQ + i) * 8];
+        *reinterpret_cast<float4*>(r0) = aw[i].lo;
+        *reinterpret_cast<float4*>(r0 + 4) = aw[i].hi;
+        *reinterpret_cast<float4*>(r1) = ab[i].lo;
+        *reinterpret_cast<float4*>(r1 + 4) = ab[i].hi;
+    }
+    __syncthreads();
+    if (gid == 0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            if (q >= nq) continue;
+            for (int pl = 0; pl < 2; ++pl) {
+                float4 a = f4_zero(), c = f4_zero();
+                for (int gg = 0; gg < gpb; ++gg) {
+                    const float* r = &red[pl][((gg * G + lig) * NQ + i) * 8];
+                    a = f4_add(a, *reinterpret_cast<const float4*>(r));
+                    c = f4_add(c, *reinterpret_cast<const float4*>(r + 4));
+                }
+                float* dst = part + ((int64_t)blockIdx.x * 2 + pl) * C + 8 * q;
+                stg4(dst, a);
+                stg4(dst + 4, c);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f8 v = f8_ld(x + 8 * i);
+        u32x4 w;
+        w.x = bf_pack(v.lo.x, v.lo.y);
+        w.y = bf_pack(v.lo.z, v.lo.w);
+        w.z = bf_pack(v.hi.x, v.hi.y);
+        w.w = bf_pack(v.hi.z, v.hi.w);
+        *reinterpret_cast<u32x4*>(y + 8 * i) = w;
+    }
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(x + 8 * i);
+        stg4(y + 8 * i, make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y)));
+        stg4(y + 8 * i + 4, make_float4(bf_lo(w.z), bf_hi(w.z), bf_lo(w.w), bf_hi(w.w)));
+    }
+}
+
+// weight packs: one launch, grid.y = job
+__global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobs jobs) {
+    const int j = blockIdx.y;
+    const float* __restrict__ in = jobs.in[j];
+    bf16_t* __restrict__ out = jobs.out[j];
+    const float* __restrict__ rs = jobs.rs[j];
+    const float* __restrict__ ks = jobs.kscale[j];
+    const int N = jobs.N[j], K = jobs.K[j], nimg = jobs.nimg[j] > 0 ? jobs.nimg[j] : 1;
+    const int64_t total = (int64_t)nimg * N * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // i indexes the OUTPUT
+        const int64_t img = i / ((int64_t)N * K);
+        const int64_t e = i % ((int64_t)N * K);
+        float v;
+        if (jobs.transpose[j]) {   // out[k][n] = in[n][k] * rs[n]
+            const int k = (int)(e / N), n = (int)(e % N);
+            v = in[(int64_t)n * K + k] * (rs ? rs[n] : 1.f);
+        } else {                   // out[img][n][k] = in[n][k] * kscale[img][k]
+            const int k = (int)(e % K);
+            v = in[e] * (ks ? ks[img * K + k] : 1.f);
+        }
+        out[i] = (bf16_t)(bf_pack(v, 0.f) & 0xffffu);
+    }
+}
+
+// out[m][k] = x[m][k] * s[m / P][k]
+__global__ __launch_bounds__(256) void scale_rows_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ simg, bf16_t* __restrict__ out,
+                                                              int64_t M, int C, int P) {
+    const int nq = C / 8;
+    const int64_t total = M * nq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nq;
+        const int q = (int)(i % nq);
+        const u32x4 w = *reinterpret_cast<const u32x4*>(x + m * C + 8 * q);
+        const f8 sc = f8_ld(simg + (m / P) * C + 8 * q);
+        u32x4 o;
+        o.x = bf_pack(bf_lo(w.x) * sc.lo.x, bf_hi(w.x) * sc.lo.y);
+        o.y = bf_pack(bf_lo(w.y) * sc.lo.z, bf_hi(w.y) * sc.lo.w);
+        o.z = bf_pack(bf_lo(w.z) * sc.hi.x, bf_hi(w.z) * sc.hi.y);
+        o.w = bf_pack(bf_lo(w.w) * sc.hi.z, bf_hi(w.w) * sc.hi.w);
+        *reinterpret_cast<u32x4*>(out + m * C + 8 * q) = o;
+    }
+}
+
+// part[b][j][k] = sum over the j-th pixel slice of image b of dts * t2   (layout of misc.hip's sca_ds_part_kernel)
+__global__ __launch_bounds__(256) void sca_ds_part_bf16_kernel(const bf16_t* __restrict__ dts, const bf16_t* __restrict__ t2, float* __restrict__ part,
+                                                               int C, int P, int nslices) {
+    __shared__ float red[256 * 8];
+    const int b = blockIdx.z, j = blockIdx.y;
+    const int nq = C / 8;
+    int qb = 1;
+    while (qb < nq && qb < 256) qb <<= 1;
+    const int pb = 256 / qb;
+    const int tid = threadIdx.x, ql = tid % qb, pl = tid / qb;
+    const int q = blockIdx.x * qb + ql;
+    const bool qok = q < nq;
+    const int per = (P + nslices - 1) / nslices;
+    const int pbeg = j * per;
+    int pend = pbeg + per;
+    if (pend > P) pend = P;
+    f8 acc = f8_zero();
+    if (qok)
+        for (int px = pbeg + pl; px < pend; px += pb) {
+            const int64_t o = ((int64_t)b * P + px) * C + 8 * q;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(dts + o), c = *reinterpret_cast<const u32x4*>(t2 + o);
+            acc.lo = f4_fma(make_float4(bf_lo(a.x), bf_hi(a.x), bf_lo(a.y), bf_hi(a.y)), make_float4(bf_lo(c.x), bf_hi(c.x), bf_lo(c.y), bf_hi(c.y)), acc.lo);
+            acc.hi = f4_fma(make_float4(bf_lo(a.z), bf_hi(a.z), bf_lo(a.w), bf_hi(a.w)), make_float4(bf_lo(c.z), bf_hi(c.z), bf_lo(c.w), bf_hi(c.w)), acc.hi);
+        }
+    *reinterpret_cast<float4*>(&red[tid * 8]) = acc.lo;
+    *reinterpret_cast<float4*>(&red[tid * 8 + 4]) = acc.hi;
+    __syncthreads();
+    if (pl == 0 && qok) {
+        float4 s0 = *reinterpret_cast<const float4*>(&red[ql * 8]), s1 = *reinterpret_cast<const float4*>(&red[ql * 8 + 4]);
+        for (int i = 1; i < pb; ++i) {
+            s0 = f4_add(s0, *reinterpret_cast<const float4*>(&red[(i * qb + ql) * 8]));
+            s1 = f4_add(s1, *reinterpret_cast<const float4*>(&red[(i * qb + ql) * 8 + 4]));
+        }
+        float* dst = part + ((int64_t)b * nslices + j) * C + 8 * q;
+        stg4(dst, s0);
+        stg4(dst + 4, s1);
+    }
+}
+
+int grid_for(int64_t items) {
+    int64_t g = cdiv64(items, 256);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+int ln_bwd_bf16_num_blocks(int64_t M, int C) {
+    const int G = lnb_group(C), gpb = 256 / G;
+    int64_t nb = cdiv64(M, gpb);
+    if (nb > 1024) nb = 1024;   // column partials: [nblk][2][C] fp32 read back once by the reducer
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+int launch_ln_fwd_bf16(const bf16_t* x, const float* w, const float* b, bf16_t* y, float* mu, float* rstd, int64_t M, int C, float eps,
+                       hipStream_t s) {
+    DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_fwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
+    const int G = lnb_group(C), gpb = 256 / G;
+    int64_t nb = cdiv64(M, gpb);
+    if (nb > 8192) nb = 8192;
+    if (C / 8 <= G) ln_fwd_bf16_kernel<1><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G);
+    else ln_fwd_bf16_kernel<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G);
+    DCPT_CHECK_LAUNCH("ln_fwd_bf16");
+    return DCPT_OK;
+}
+
+int launch_ln_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* dres, bf16_t* dx,
+                       float* part, int nblk, int64_t M, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_bwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
+    const int G = lnb_group(C), gpb = 256 / G;
+    const int64_t iters = cdiv64(M, (int64_t)nblk * gpb);
+    if (C / 8 <= G) ln_bwd_bf16_kernel<1><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, dres, dx, part, M, C, G, iters);
+    else ln_bwd_bf16_kernel<2><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, dres, dx, part, M, C, G, iters);
+    DCPT_CHECK_LAUNCH("ln_bwd_bf16");
+    return DCPT_OK;
+}
+
+int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s) {
+    DCPT_CHECK_ARG(n % 8 == 0, "cast: element count must be a multiple of 8");
+    cast_f2b_kernel<<<dim3(grid_for(n / 8)), dim3(256), 0, s>>>(x, y, n / 8);
+    DCPT_CHECK_LAUNCH("cast_f32_bf16");
+    return DCPT_OK;
+}
+int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s) {
+    DCPT_CHECK_ARG(n % 8 == 0, "cast: element count must be a multiple of 8");
+    cast_b2f_kernel<<<dim3(grid_for(n / 8)), dim3(256), 0, s>>>(x, y, n / 8);
+    DCPT_CHECK_LAUNCH("cast_bf16_f32");
+    return DCPT_OK;
+}
+
+int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s) {
+    DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= WPACKB_MAX_JOBS, "wpack_bf16: bad job count");
+    int64_t mx = 0;
+    for (int j = 0; j < jobs.n; ++j) {
+        const int64_t t = (int64_t)(jobs.nimg[j] > 0 ? jobs.nimg[j] : 1) * jobs.N[j] * jobs.K[j];
+        if (t > mx) mx = t;
+    }
+    int g = grid_for(mx);
+    if (g > 512) g = 512;
+    wpack_bf16_kernel<<<dim3(g, jobs.n), dim3(256), 0, s>>>(jobs);
+    DCPT_CHECK_LAUNCH("wpack_bf16");
+    return DCPT_OK;
+}
+
+int launch_scale_rows_bf16(const bf16_t* x, const float* simg, bf16_t* out, int64_t M, int C, int P, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 8 == 0, "scale_rows_bf16: C=%d", C);
+    scale_rows_bf16_kernel<<<dim3(grid_for(M * (C / 8))), dim3(256), 0, s>>>(x, simg, out, M, C, P);
+    DCPT_CHECK_LAUNCH("scale_rows_bf16");
+    return DCPT_OK;
+}
+
+int launch_sca_ds_part_bf16(const bf16_t* dts, const bf16_t* t2, float* ds_part, int B, int C, int P, int nslices, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 8 == 0 && B <= 65535, "sca_ds_bf16: C=%d", C);
+    const int nq = C / 8;
+    int qb = 1;
+    while (qb < nq && qb < 256) qb <<= 1;
+    sca_ds_part_bf16_kernel<<<dim3(cdiv(nq, qb), nslices, B), dim3(256), 0, s>>>(dts, t2, ds_part, C, P, nslices);
+    DCPT_CHECK_LAUNCH("sca_ds_part_bf16");
+    return DCPT_OK;
+}

@@ -10,6 +10,7 @@
 // written as per-block partials: deterministic, no float atomics.
 #include <stdlib.h>
 
+#include "bf16.h"
 #include "bufops.h"
 #include "kernels.h"
 
@@ -50,6 +51,31 @@ template <int VW> __device__ __forceinline__ void bst(rsrc_t rs, uint32_t off, v
     } else {
         floatx2 t; t.x = a.v[0]; t.y = a.v[1];
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), rs, off, 0, 0);
+    }
+}
+// storage-typed variants: T = float (as above) or bf16_t (VW bf16 values = VW * 2 bytes per access, converted to / from fp32)
+template <int VW, typename T> __device__ __forceinline__ vf<VW> bldT(rsrc_t rs, uint32_t off) {
+    if constexpr (sizeof(T) == 4) {
+        return bld<VW>(rs, off);
+    } else {
+        vf<VW> r;
+        if constexpr (VW == 4) {
+            const float4 t = bbuf_ld4(rs, off);
+            r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+        } else {
+            const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+            r.v[0] = bf_lo(w); r.v[1] = bf_hi(w);
+        }
+        return r;
+    }
+}
+template <int VW, typename T> __device__ __forceinline__ void bstT(rsrc_t rs, uint32_t off, vf<VW> a) {
+    if constexpr (sizeof(T) == 4) {
+        bst<VW>(rs, off, a);
+    } else if constexpr (VW == 4) {
+        bbuf_st4(rs, off, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(bf_pack(a.v[0], a.v[1]), rs, off, 0, 0);
     }
 }
 template <int VW> __device__ __forceinline__ vf<VW> gld(const float* p, bool ok) {   // small per-channel vectors
@@ -146,8 +172,9 @@ __device__ __forceinline__ void dw_block_reduce(float* red, vf<VW> val, int tid,
 
 // MODE 0: forward (t2 + pool partials);  MODE 1: backward-a (da)
 // GATE 0: SimpleGate g1*g2 (NAFNet);  GATE 1: gelu(g1)*g2 (Restormer GDFN, exact erf GELU)
-template <int VW, int MODE, int GATE>
+template <int VW, int MODE, int GATE, typename ST = float>
 __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
+    constexpr uint32_t ES = sizeof(ST);   // bytes per stored activation element (fp32 or bf16); arithmetic is fp32 either way
     __shared__ float red[256 * VW];
     const DwMap mp = dw_map(p.H, p.W, p.C / VW);
     const DwBlk bk = dw_block(mp);
@@ -178,10 +205,10 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
     // launchers), rows are addressed relative to rb
     const int rb = dw_row_base(mp, bk, p.H);
     const int64_t img = ((int64_t)b * p.H + rb) * p.W;
-    const rsrc_t rs_in = make_rsrc(p.in0 + img * C2);
-    const rsrc_t rs_out = make_rsrc(p.out + img * (MODE == 0 ? C : C2));
-    const rsrc_t rs_d = make_rsrc(MODE == 1 ? p.in1 + img * C : p.in0);
-    const uint32_t st = 4u * (uint32_t)C2;
+    const rsrc_t rs_in = make_rsrc((const ST*)p.in0 + img * C2);
+    const rsrc_t rs_out = make_rsrc((ST*)p.out + img * (MODE == 0 ? C : C2));
+    const rsrc_t rs_d = make_rsrc(MODE == 1 ? (const ST*)p.in1 + img * C : (const ST*)p.in0);
+    const uint32_t st = ES * (uint32_t)C2;
 
     {
         const int wc = bk.y % mp.nwc, nrp = gridDim.y / mp.nwc, rpp = (p.H + nrp - 1) / nrp;
@@ -192,15 +219,15 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
         const uint32_t cl = (ok && x > 0) ? 0u : COL_SENT, cc = ok ? 0u : COL_SENT, cr = (ok && x + 1 < p.W) ? 0u : COL_SENT;
         vf<VW> a0_1 = vz<VW>(), a0_2 = vz<VW>(), a1_1 = vz<VW>(), a1_2 = vz<VW>();
         for (int r = h0 - 1; r <= h1; ++r) {
-            const uint32_t ro = (r >= 0 && r < p.H) ? (uint32_t)(((r - rb) * p.W + x) * C2) * 4u : ROW_SENT;
-            const uint32_t o1 = ro + 4u * (uint32_t)c1, o2 = ro + 4u * (uint32_t)c2;
-            const vf<VW> xl1 = bld<VW>(rs_in, (o1 - st) | cl), xl2 = bld<VW>(rs_in, (o2 - st) | cl);
-            const vf<VW> xc1 = bld<VW>(rs_in, o1 | cc), xc2 = bld<VW>(rs_in, o2 | cc);
-            const vf<VW> xr1 = bld<VW>(rs_in, (o1 + st) | cr), xr2 = bld<VW>(rs_in, (o2 + st) | cr);
+            const uint32_t ro = (r >= 0 && r < p.H) ? (uint32_t)(((r - rb) * p.W + x) * C2) * ES : ROW_SENT;
+            const uint32_t o1 = ro + ES * (uint32_t)c1, o2 = ro + ES * (uint32_t)c2;
+            const vf<VW> xl1 = bldT<VW, ST>(rs_in, (o1 - st) | cl), xl2 = bldT<VW, ST>(rs_in, (o2 - st) | cl);
+            const vf<VW> xc1 = bldT<VW, ST>(rs_in, o1 | cc), xc2 = bldT<VW, ST>(rs_in, o2 | cc);
+            const vf<VW> xr1 = bldT<VW, ST>(rs_in, (o1 + st) | cr), xr2 = bldT<VW, ST>(rs_in, (o2 + st) | cr);
             const int y = r - 1;
             const bool yok = ok && y >= h0;
             vf<VW> dts = vz<VW>();
-            if (MODE == 1) dts = bld<VW>(rs_d, yok ? (uint32_t)(((y - rb) * p.W + x) * C + c1) * 4u : ROW_SENT);
+            if (MODE == 1) dts = bldT<VW, ST>(rs_d, yok ? (uint32_t)(((y - rb) * p.W + x) * C + c1) * ES : ROW_SENT);
             // kernel row 2 completes output row r-1
             a0_1 = vfma(w1[6], xl1, vfma(w1[7], xc1, vfma(w1[8], xr1, a0_1)));
             a0_2 = vfma(w2[6], xl2, vfma(w2[7], xc2, vfma(w2[8], xr2, a0_2)));
@@ -213,17 +240,17 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const DwP p) {
             const vf<VW> g1 = vadd(a0_1, bias1), g2 = vadd(a0_2, bias2);
             if (MODE == 0) {
                 const vf<VW> t = vmul(GATE == 0 ? g1 : vgelu(g1), g2);
-                bst<VW>(rs_out, yok ? (uint32_t)(((y - rb) * p.W + x) * C + c1) * 4u : ROW_SENT, t);
+                bstT<VW, ST>(rs_out, yok ? (uint32_t)(((y - rb) * p.W + x) * C + c1) * ES : ROW_SENT, t);
                 if (yok) pool = vadd(pool, t);
             } else {
                 const vf<VW> dt2 = vfma(dts, sv, dpv);
-                const uint32_t oo = yok ? (uint32_t)(((y - rb) * p.W + x) * C2) * 4u : ROW_SENT;
+                const uint32_t oo = yok ? (uint32_t)(((y - rb) * p.W + x) * C2) * ES : ROW_SENT;
                 if (GATE == 0) {
-                    bst<VW>(rs_out, oo + 4u * (uint32_t)c1, vmul(dt2, g2));
-                    bst<VW>(rs_out, oo + 4u * (uint32_t)c2, vmul(dt2, g1));
+                    bstT<VW, ST>(rs_out, oo + ES * (uint32_t)c1, vmul(dt2, g2));
+                    bstT<VW, ST>(rs_out, oo + ES * (uint32_t)c2, vmul(dt2, g1));
                 } else {
-                    bst<VW>(rs_out, oo + 4u * (uint32_t)c1, vmul(vmul(dt2, g2), vgelu_d(g1)));
-                    bst<VW>(rs_out, oo + 4u * (uint32_t)c2, vmul(dt2, vgelu(g1)));
+                    bstT<VW, ST>(rs_out, oo + ES * (uint32_t)c1, vmul(vmul(dt2, g2), vgelu_d(g1)));
+                    bstT<VW, ST>(rs_out, oo + ES * (uint32_t)c2, vmul(dt2, vgelu(g1)));
                 }
             }
             a0_1 = a1_1; a0_2 = a1_2;
@@ -319,8 +346,9 @@ __global__ __launch_bounds__(256) void dw_bwd_b_kernel(const DwP p) {
 // kernel, while split + VW 2 (106 VGPRs, 4 waves/SIMD) is -1 % -- the kernel is limited by memory instructions issued per
 // byte, not by occupancy.
 // HBM traffic: t1 and dts once (+2-row halos), dt1 once -- 5 tensor units instead of 11 for the two-kernel form.
-template <int VW>
+template <int VW, typename ST = float>
 __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
+    constexpr uint32_t ES = sizeof(ST);
     __shared__ float red[256 * VW];
     const int C = p.C, C2 = 2 * p.C;
     const DwMap mp = dw_map(p.H, p.W, C2 / VW);   // "groups" = (channel group, half) pairs
@@ -353,9 +381,9 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
     const int h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
     const int rb = h0 - 2 > 0 ? h0 - 2 : 0;
     const int64_t img = ((int64_t)b * p.H + rb) * p.W;
-    const rsrc_t rs_t = make_rsrc(p.in0 + img * C2);
-    const rsrc_t rs_d = make_rsrc(p.in1 + img * C);
-    const rsrc_t rs_o = make_rsrc(p.out + img * C2);
+    const rsrc_t rs_t = make_rsrc((const ST*)p.in0 + img * C2);
+    const rsrc_t rs_d = make_rsrc((const ST*)p.in1 + img * C);
+    const rsrc_t rs_o = make_rsrc((ST*)p.out + img * C2);
     // column validity of x-2 .. x+2 (a column outside the image: its t1 is zero padding, its da does not exist)
     uint32_t cs[5];
     bool cin[5];
@@ -375,17 +403,17 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
     for (int r = h0 - 2; r <= h1 + 1; ++r) {
         // ---- t1 row r, columns x-2..x+2
         const bool rin = r >= 0 && r < p.H;
-        const uint32_t ro = rin ? (uint32_t)(((r - rb) * p.W + x) * C2 + co) * 4u : ROW_SENT;
+        const uint32_t ro = rin ? (uint32_t)(((r - rb) * p.W + x) * C2 + co) * ES : ROW_SENT;
         vf<VW> T[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) T[j] = bld<VW>(rs_t, (ro + (uint32_t)((j - 2) * C2 * 4)) | cs[j]);
+        for (int j = 0; j < 5; ++j) T[j] = bldT<VW, ST>(rs_t, (ro + (uint32_t)((j - 2) * C2 * (int)ES)) | cs[j]);
         // ---- dts of row rho = r-1 at columns x-1..x+1
         const int rho = r - 1;
         const bool rho_in = rho >= 0 && rho < p.H;
         vf<VW> D[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            D[j] = bld<VW>(rs_d, rho_in ? ((uint32_t)(((rho - rb) * p.W + x + j - 1) * C + cg) * 4u) | cs[j + 1] : ROW_SENT);
+            D[j] = bldT<VW, ST>(rs_d, rho_in ? ((uint32_t)(((rho - rb) * p.W + x + j - 1) * C + cg) * ES) | cs[j + 1] : ROW_SENT);
         // ---- forward conv: row r contributes kernel row 2 to a[r-1], row 1 to a[r], row 0 to a[r+1]
         vf<VW> A2[3];
 #pragma unroll
@@ -412,7 +440,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
         const vf<VW> B2 = vfma(w[8], da[0], vfma(w[7], da[1], vmul(w[6], da[2])));
         {
             const int y = rho - 1;   // complete now
-            bst<VW>(rs_o, (ok && y >= h0 && y < h1) ? (uint32_t)(((y - rb) * p.W + x) * C2 + co) * 4u : ROW_SENT, B0);
+            bstT<VW, ST>(rs_o, (ok && y >= h0 && y < h1) ? (uint32_t)(((y - rb) * p.W + x) * C2 + co) * ES : ROW_SENT, B0);
         }
         // ---- tap gradients: da[rho][x] with t1 rows rho-1 (Tm), rho (Tc), rho+1 (= row r, T) at columns x-1..x+1; rows of this
         //      block's range only, so that every pixel is counted once
@@ -604,6 +632,37 @@ int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, con
     if (vw == 2) dw_bwd_fused_kernel<2><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
     else dw_bwd_fused_kernel<4><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("dw_bwd_fused");
+    return DCPT_OK;
+}
+
+// ---- bf16-storage variants (bf16.h): same kernels, activations read / written as bf16, partial sums and parameters fp32
+int launch_dw_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s) {
+    DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_fwd_bf16: C=%d must be a multiple of 4, B<=65535", g.C);
+    DwP p{};
+    p.in0 = reinterpret_cast<const float*>(t1); p.w2p = w2p; p.b2 = b2; p.out = reinterpret_cast<float*>(t2); p.part = pool_part;
+    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
+    const DwMap mp = dw_map(g.H, g.W, g.C / 4);
+    const int nblk = nblk_for(g, g.C / 4);
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, nblk, mp.nwc);
+    dw_gate_kernel<4, 0, 0, bf16_t><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("dw_fwd_bf16");
+    return DCPT_OK;
+}
+int dw_num_blocks_per_image_bf16(const DwGeom& g) { return nblk_for(g, g.C / 4); }
+int dw_num_blocks_per_image_fused_bf16(const DwGeom& g) { return nblk_for(g, 2 * g.C / 4); }
+
+int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                             bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+    DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd_bf16: C=%d must be a multiple of 4", g.C);
+    DwP p{};
+    p.in0 = reinterpret_cast<const float*>(t1); p.in1 = reinterpret_cast<const float*>(dts); p.w2p = w2p; p.b2 = b2; p.simg = simg;
+    p.dpool = dpool; p.out = reinterpret_cast<float*>(dt1); p.part = wpart;
+    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
+    const DwMap mp = dw_map(g.H, g.W, 2 * g.C / 4);
+    const int nblk = nblk_for(g, 2 * g.C / 4);
+    DW_CHECK_RANGE(g.H, g.W, 2 * g.C, nblk, mp.nwc);
+    dw_bwd_fused_kernel<4, bf16_t><<<dim3(mp.nqc, nblk, g.B), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("dw_bwd_fused_bf16");
     return DCPT_OK;
 }
 

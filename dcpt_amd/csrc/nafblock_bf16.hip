@@ -1,0 +1,274 @@
+// NAFBlock forward / backward with bf16 STORAGE (BASELINE.json configs[2]; reference basicsr/archs/nafnet_arch.py:165-186; the
+// reference itself has no reduced-precision mode -- its AMP / TF32 switches are commented out, basicsr/test.py:26-27 -- so this
+// is new behaviour with its own parity bar: tests/test_gpu_bf16.py against oracle/nafnet_oracle.py's bf16 mode, which rounds to
+// bf16 at exactly the points listed here).
+//
+// What is bf16: every [M][.] activation that crosses HBM -- the block's input / output, LN1(inp), t1, t2, y, LN2(y), v,
+// SimpleGate(v) and in backward dv, the two LayerNorm input gradients, dy, dts, dt1, dinp -- and the operand copies of the
+// weights made per call.  What stays fp32: parameters and parameter gradients, MFMA accumulators (v_mfma_f32_32x32x16_bf16),
+// LayerNorm statistics, every reduction (pooling sums, SCA, weight-gradient slabs, LayerNorm / depthwise / bias column sums).
+// Epilogue values are computed from the fp32 accumulator and rounded once on store (RNE); SimpleGate(v) is the product of the
+// UNROUNDED conv4 outputs, rounded once; SCA's pooling sums the unrounded SimpleGate outputs.
+//
+// Schedule = the fp32 block's (nafblock.hip) with two changes that remove every register-staged operand loader:
+//   * conv3's SCA scale is folded into per-image weights  W3s[b][n][k] = W3[n][k] * s[b][k]  (a [B][C][C] bf16 pack, <= 16 MB),
+//     and conv3 runs as one batched GEMM per image -- both operands by LDS-DMA;
+//   * LayerNorm always runs as its own bandwidth kernel (no C <= 128 epilogue variants yet).
+// Weight gradients go through the transposing-LDS-read TN GEMM into fp32 slabs and the fp32 path's deterministic reducers, on
+// the same side stream as the fp32 block.
+#include "bf16_ops.h"
+#include "side.h"
+#include "../../include/dcpt_hip.h"
+
+namespace {
+
+struct FwdWsB {
+    float* w2p;
+    float* pool_part;
+    bf16_t *W1, *W4, *W5, *W3s;
+    int nblk_pool;
+};
+
+size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    DwGeom g{B, H, W, C};
+    FwdWsB w{};
+    w.nblk_pool = dw_num_blocks_per_image_bf16(g);
+    w.w2p = a.get<float>((size_t)18 * C);
+    w.pool_part = a.get<float>((size_t)B * w.nblk_pool * C);
+    w.W1 = a.get<bf16_t>((size_t)2 * C * C);
+    w.W4 = a.get<bf16_t>((size_t)2 * C * C);
+    w.W5 = a.get<bf16_t>((size_t)C * C);
+    w.W3s = a.get<bf16_t>((size_t)B * C * C);
+    if (out) *out = w;
+    return a.off;
+}
+
+struct BwdWsB {
+    bf16_t *wT5, *wT4, *wT3, *wT1;
+    float* w2p;
+    bf16_t *dv, *gln, *dy, *dts, *dt1, *t2s;
+    float *slab, *colsum;
+    size_t slab_elems, colsum_elems;
+    float *lnpart, *lnpart2;
+    float *ds_part, *ds, *dpool, *wpart;
+    int ln_nblk, nblk_b, ds_slices;
+    bool ds_fused;
+};
+
+size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    const int64_t M = (int64_t)B * H * W;
+    const int P = H * W;
+    DwGeom g{B, H, W, C};
+    BwdWsB w{};
+    w.wT5 = a.get<bf16_t>((size_t)C * C);
+    w.wT4 = a.get<bf16_t>((size_t)2 * C * C);
+    w.wT3 = a.get<bf16_t>((size_t)C * C);
+    w.wT1 = a.get<bf16_t>((size_t)2 * C * C);
+    w.w2p = a.get<float>((size_t)18 * C);
+    w.dv = a.get<bf16_t>((size_t)M * 2 * C);
+    w.gln = a.get<bf16_t>((size_t)M * C);
+    w.dy = a.get<bf16_t>((size_t)M * C);
+    w.dts = a.get<bf16_t>((size_t)M * C);
+    w.dt1 = a.get<bf16_t>((size_t)M * 2 * C);
+    w.t2s = a.get<bf16_t>((size_t)M * C);
+    int sp1, sp2, sp3;
+    int64_t r1, r2, r3;
+    gemm_tn_bf16_plan(M, 2 * C, C, &sp1, &r1);
+    gemm_tn_bf16_plan(M, C, C, &sp2, &r2);
+    size_t slab1 = (size_t)sp1 * 2 * C * C, slab2 = (size_t)sp2 * C * C;
+    size_t cs1 = (size_t)sp1 * gemm_tn_bf16_tiles_k(2 * C, C) * 2 * C, cs2 = (size_t)sp2 * gemm_tn_bf16_tiles_k(C, C) * C;
+    if (gemm_tn_bf16_plan_images(M, C, C, P, &sp3, &r3)) {
+        const size_t s3 = (size_t)sp3 * C * C, c3 = (size_t)sp3 * gemm_tn_bf16_tiles_k(C, C) * C;
+        if (s3 > slab2) slab2 = s3;
+        if (c3 > cs2) cs2 = c3;
+    }
+    w.slab_elems = slab1 > slab2 ? slab1 : slab2;
+    w.colsum_elems = cs1 > cs2 ? cs1 : cs2;
+    w.slab = a.get<float>(w.slab_elems);
+    w.colsum = a.get<float>(w.colsum_elems);
+    w.ln_nblk = ln_bwd_bf16_num_blocks(M, C);
+    w.lnpart = a.get<float>((size_t)w.ln_nblk * 2 * C);
+    w.lnpart2 = a.get<float>((size_t)w.ln_nblk * 2 * C);
+    w.ds_fused = sca_ds_fused_slices(P) > 0;
+    w.ds_slices = w.ds_fused ? sca_ds_fused_slices(P) : sca_ds_num_blocks(P);
+    w.ds_part = a.get<float>((size_t)B * w.ds_slices * C);
+    w.ds = a.get<float>((size_t)B * C);
+    w.dpool = a.get<float>((size_t)B * C);
+    w.nblk_b = dw_num_blocks_per_image_fused_bf16(g);
+    w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
+    if (out) *out = w;
+    return a.off;
+}
+
+// G[n][k] = sum_m X[m][n] Y[m][k] into fp32 slabs, then dW = rowscale * sum(slabs) (+ gain / bias gradients) -- fp32 reducer of misc.hip
+int wgrad_b(const bf16_t* X, int N, const bf16_t* Y, int K, int64_t M, float* slab, float* colsum, const float* rowscale, const float* Wfor_gain,
+            const float* wbias, float* dW, float* dgain, float* dbias, hipStream_t s) {
+    GemmTNB t{};
+    t.X = X; t.ldx = N; t.N = N; t.Y = Y; t.ldy = K; t.K = K; t.M = M; t.slab = slab; t.colsum = colsum;
+    gemm_tn_bf16_plan(M, N, K, &t.splits, &t.rows_per_split);
+    DCPT_TRY(launch_gemm_tn_bf16(t, s));
+    return launch_wgrad_reduce(slab, colsum, t.splits, t.splits * gemm_tn_bf16_tiles_k(N, K), N, K, rowscale, Wfor_gain, wbias, dW, dgain, dbias,
+                               WR_PLAIN, s);
+}
+
+bool shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 1024; }
+
+}  // namespace
+
+extern "C" size_t dcpt_nafblock_fwd_bf16_ws_bytes(int B, int H, int W, int C) { return fwd_layout(B, H, W, C, nullptr, 0, nullptr); }
+extern "C" size_t dcpt_nafblock_bwd_bf16_ws_bytes(int B, int H, int W, int C) { return bwd_layout(B, H, W, C, nullptr, 0, nullptr); }
+
+extern "C" int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint16_t* inp, uint16_t* out, const dcpt_nafblock_saved_bf16* sv,
+                                      void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(p && inp && out && sv, "nafblock_fwd_bf16: null argument");
+    DCPT_CHECK_ARG(shape_ok(B, H, W, C), "nafblock_fwd_bf16: bad shape B=%d H=%d W=%d C=%d (C %% 8 == 0, C <= 1024)", B, H, W, C);
+    DCPT_CHECK_ARG(sv->t1 && sv->t2 && sv->y && sv->v && sv->xn1 && sv->xn2 && sv->g && sv->mu1 && sv->rstd1 && sv->mu2 && sv->rstd2 &&
+                       sv->pooled && sv->s, "nafblock_fwd_bf16: saved buffers missing");
+    FwdWsB w;
+    const size_t need = fwd_layout(B, H, W, C, ws, ws_bytes, &w);
+    if (need > ws_bytes || ws == nullptr) {
+        dcpt_set_error("nafblock_fwd_bf16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DCPT_ERR_WS;
+    }
+    const int64_t M = (int64_t)B * H * W;
+    const int P = H * W;
+    const float eps = 1e-6f;
+    // operand copies of the weights that do not depend on SCA
+    WpackBJobs j{};
+    j.n = 3;
+    j.in[0] = p->conv1_w; j.out[0] = w.W1; j.N[0] = 2 * C; j.K[0] = C;
+    j.in[1] = p->conv4_w; j.out[1] = w.W4; j.N[1] = 2 * C; j.K[1] = C;
+    j.in[2] = p->conv5_w; j.out[2] = w.W5; j.N[2] = C; j.K[2] = C;
+    DCPT_TRY(launch_wpack_bf16(j, s));
+    DCPT_TRY(launch_ln_fwd_bf16(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
+    GemmNTB g{};
+    g.M = M; g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = w.W1; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIAS, s));
+    DwGeom dg{B, H, W, C};
+    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
+    DCPT_TRY(launch_dw_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
+    DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
+    // y = inp + (conv3(t2 * s) + b3) * beta: the per-image scale lives in the weights, one GEMM problem per image
+    j = WpackBJobs{};
+    j.n = 1;
+    j.in[0] = p->conv3_w; j.out[0] = w.W3s; j.N[0] = C; j.K[0] = C; j.kscale[0] = sv->s; j.nimg[0] = B;
+    DCPT_TRY(launch_wpack_bf16(j, s));
+    g = GemmNTB{};
+    g.M = P; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = w.W3s; g.N = C; g.C = sv->y; g.ldc = C; g.bias = p->conv3_b;
+    g.res = inp; g.ldres = C; g.cscale = p->beta;
+    g.nb = B; g.sA = (int64_t)P * C; g.sB = (int64_t)C * C; g.sC = (int64_t)P * C; g.sR = (int64_t)P * C;
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_RESID, s));
+    DCPT_TRY(launch_ln_fwd_bf16(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
+    g = GemmNTB{};
+    g.M = M; g.A = sv->xn2; g.lda = C; g.K = C; g.Bw = w.W4; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b; g.gate = sv->g;
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIASGATE, s));
+    g = GemmNTB{};
+    g.M = M; g.A = sv->g; g.lda = C; g.K = C; g.Bw = w.W5; g.N = C; g.C = out; g.ldc = C; g.bias = p->conv5_b; g.res = sv->y; g.ldres = C;
+    g.cscale = p->gamma;
+    return launch_gemm_nt_bf16(g, EB_RESID, s);
+}
+
+extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* gr, const uint16_t* inp,
+                                      const dcpt_nafblock_saved_bf16* sv, const uint16_t* dout, uint16_t* dinp, void* ws, size_t ws_bytes, int B,
+                                      int H, int W, int C, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(p && gr && inp && sv && dout && dinp, "nafblock_bwd_bf16: null argument");
+    DCPT_CHECK_ARG(shape_ok(B, H, W, C), "nafblock_bwd_bf16: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+    BwdWsB w;
+    const size_t need = bwd_layout(B, H, W, C, ws, ws_bytes, &w);
+    if (need > ws_bytes || ws == nullptr) {
+        dcpt_set_error("nafblock_bwd_bf16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DCPT_ERR_WS;
+    }
+    const int64_t M = (int64_t)B * H * W;
+    const int P = H * W;
+    const int C2 = 2 * C;
+    DwGeom dg{B, H, W, C};
+
+    // transposed (and gain-scaled) bf16 weights of the four dgrad GEMMs + the depthwise [9][2C] pack
+    WpackBJobs j{};
+    j.n = 4;
+    j.in[0] = p->conv5_w; j.out[0] = w.wT5; j.rs[0] = p->gamma; j.N[0] = C;  j.K[0] = C; j.transpose[0] = 1;
+    j.in[1] = p->conv4_w; j.out[1] = w.wT4; j.rs[1] = nullptr;  j.N[1] = C2; j.K[1] = C; j.transpose[1] = 1;
+    j.in[2] = p->conv3_w; j.out[2] = w.wT3; j.rs[2] = p->beta;  j.N[2] = C;  j.K[2] = C; j.transpose[2] = 1;
+    j.in[3] = p->conv1_w; j.out[3] = w.wT1; j.rs[3] = nullptr;  j.N[3] = C2; j.K[3] = C; j.transpose[3] = 1;
+    DCPT_TRY(launch_wpack_bf16(j, s));
+    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, C2, s));
+
+    Side* sd = side_for(s);
+    hipStream_t sw = side_stream(sd, s);
+    DCPT_TRY(side_fork(sd, 0, s));
+    GemmNTB g{};
+    // B1: dv = SimpleGate'(dout * gamma * W5; v)
+    g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = w.dv; g.ldc = C2; g.aux = sv->v;
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_SGBWD, s));
+    // B2: conv5 / gamma gradients
+    DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
+    DCPT_TRY(side_fork(sd, 1, s));
+    // B3: gradient of LN2's output
+    g = GemmNTB{};
+    g.M = M; g.A = w.dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = w.gln; g.ldc = C;
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    // B4: conv4 gradients
+    DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
+    // B5: dy = dout + LN2-backward
+    DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
+    DCPT_TRY(side_fork(sd, 2, s));
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    // B6: dts = d(t2 * s) (+ SCA's per-image channel sums out of the epilogue when an image is a whole number of 128-pixel tiles)
+    g = GemmNTB{};
+    g.M = M; g.A = w.dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = w.dts; g.ldc = C;
+    if (w.ds_fused) {
+        g.res = sv->t2; g.ldres = C; g.colpart = w.ds_part;
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_DOTCOL, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        DCPT_TRY(launch_sca_ds_part_bf16(w.dts, sv->t2, w.ds_part, B, C, P, w.ds_slices, s));
+    }
+    // B7: conv3 / beta gradients: G = sum_m dy[m][n] t2[m][k] s[img(m)][k]
+    {
+        GemmTNB t{};
+        t.X = w.dy; t.ldx = C; t.N = C; t.Y = sv->t2; t.ldy = C; t.K = C; t.M = M; t.slab = w.slab; t.colsum = w.colsum;
+        if (gemm_tn_bf16_plan_images(M, C, C, P, &t.splits, &t.rows_per_split) && (size_t)t.splits * C * C <= w.slab_elems &&
+            (size_t)t.splits * gemm_tn_bf16_tiles_k(C, C) * C <= w.colsum_elems) {
+            // every pixel chunk inside one image: plain operands, the scale weights the chunk slabs in the reducer
+            DCPT_TRY(launch_gemm_tn_bf16(t, sw));
+            DCPT_TRY(launch_wgrad_reduce_scaled(w.slab, w.colsum, t.splits, t.splits * gemm_tn_bf16_tiles_k(C, C), C, C, p->beta, p->conv3_w,
+                                                p->conv3_b, gr->conv3_w, gr->beta, gr->conv3_b, WR_PLAIN, sv->s, (int)(P / t.rows_per_split), sw));
+        } else {
+            DCPT_TRY(launch_scale_rows_bf16(sv->t2, sv->s, w.t2s, M, C, P, sw));
+            DCPT_TRY(wgrad_b(w.dy, C, w.t2s, C, M, w.slab, w.colsum, p->beta, p->conv3_w, p->conv3_b, gr->conv3_w, gr->beta, gr->conv3_b, sw));
+        }
+    }
+    // B8: SCA backward
+    DCPT_TRY(launch_sca_dpool(w.ds_part, w.ds_slices, p->sca_w, w.dpool, B, C, P, s));
+    // B9 / B10: SimpleGate + depthwise backward, da on chip
+    DCPT_TRY(launch_dw_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s));
+    DCPT_TRY(side_fork(sd, 3, s));
+    DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
+    // B11: gradient of LN1's output
+    g = GemmNTB{};
+    g.M = M; g.A = w.dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = w.gln; g.ldc = C;
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    // B12: conv1 gradients
+    DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
+    // B13: dinp = dy + LN1-backward
+    DCPT_TRY(launch_ln_bwd_bf16(w.gln, inp, sv->mu1, sv->rstd1, p->norm1_w, w.dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
+    DCPT_TRY(side_fork(sd, 5, s));
+    DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+    DCPT_TRY(side_join(sd, s));
+    return DCPT_OK;
+}
+
+extern "C" int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(x && y && n >= 0, "cast_f32_bf16: null argument");
+    return n == 0 ? DCPT_OK : launch_cast_f32_bf16(x, y, n, (hipStream_t)stream);
+}
+extern "C" int dcpt_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(x && y && n >= 0, "cast_bf16_f32: null argument");
+    return n == 0 ? DCPT_OK : launch_cast_bf16_f32(x, y, n, (hipStream_t)stream);
+}

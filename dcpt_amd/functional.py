@@ -139,6 +139,113 @@ def nafblock(inp: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor
     return _NAFBlockFn.apply(inp, *[params[k] for k in PARAM_FIELDS])
 
 
+# ------------------------------------------------------------------------------------------------
+# bf16-storage path (BASELINE.json configs[2]): activations / saved tensors torch.bfloat16 (channels_last), parameters fp32
+def _empty_nhwc_bf16(n, c, h, w, dev) -> torch.Tensor:
+    return torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=torch.bfloat16, device=dev)
+
+
+def _require_gpu_bf16(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.DcptHipError("dcpt_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.bfloat16:
+            raise _lib.DcptHipError(f"the bf16-storage path takes torch.bfloat16 activations (got {t.dtype})")
+
+
+class _NAFBlockBf16Fn(torch.autograd.Function):
+    """NAFBlock.forward (reference nafnet_arch.py:165-186) with bf16 storage -> dcpt_nafblock_fwd_bf16 / bwd_bf16."""
+
+    @staticmethod
+    def forward(ctx, inp, *params):
+        lib = _lib.load()
+        _require_gpu_bf16(inp)
+        _require_gpu(*params)
+        inp = _nhwc(inp)
+        params = tuple(_contig(p.detach()) for p in params)
+        B, Cc, H, W = inp.shape
+        if Cc % 8:
+            raise _lib.DcptHipError(f"the bf16-storage path needs channel counts that are multiples of 8 (got {Cc})")
+        dev = inp.device
+        M = B * H * W
+        out = _empty_nhwc_bf16(B, Cc, H, W, dev)
+        t1 = _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
+        v = _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
+        acts = torch.empty((5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp), LN2(y), SimpleGate(v)
+        stats = torch.empty((4, M), dtype=torch.float32, device=dev)
+        sca = torch.empty((2, B, Cc), dtype=torch.float32, device=dev)           # pooled, s
+        ps = NafBlockParams(*[p.data_ptr() for p in params])
+        sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(),
+                                    stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
+                                    acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
+        ws = _workspace(dev, lib.dcpt_nafblock_fwd_bf16_ws_bytes(B, H, W, Cc))
+        check(lib.dcpt_nafblock_fwd_bf16(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
+                                         B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd_bf16")
+        ctx.save_for_backward(inp, t1, v, acts, stats, sca, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        inp, t1, v, acts, stats, sca, *params = ctx.saved_tensors
+        dout = _nhwc(dout if dout.dtype == torch.bfloat16 else dout.to(torch.bfloat16))
+        B, Cc, H, W = inp.shape
+        dev = inp.device
+        grads = [torch.empty_like(p) for p in params]
+        dinp = _empty_nhwc_bf16(B, Cc, H, W, dev)
+        ps = NafBlockParams(*[p.data_ptr() for p in params])
+        gs = NafBlockGrads(*[g.data_ptr() for g in grads])
+        sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(),
+                                    stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
+                                    acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
+        ws = _workspace(dev, lib.dcpt_nafblock_bwd_bf16_ws_bytes(B, H, W, Cc))
+        check(lib.dcpt_nafblock_bwd_bf16(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(), dinp.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_nafblock_bwd_bf16")
+        return (dinp, *grads)
+
+
+def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """bf16 activations in / out, fp32 parameters (dict with the keys of _lib.PARAM_FIELDS)."""
+    return _NAFBlockBf16Fn.apply(inp, *[params[k] for k in PARAM_FIELDS])
+
+
+class _CastFn(torch.autograd.Function):
+    """edge of the bf16 path: fp32 -> bf16 (RNE) in forward, the bf16 gradient back to fp32 in backward (or the reverse)"""
+
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        lib = _lib.load()
+        ctx.to_bf16 = bool(to_bf16)
+        return _cast(lib, x, ctx.to_bf16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _cast(_lib.load(), g, not ctx.to_bf16), None
+
+
+def _cast(lib, x, to_bf16):
+    src, dst = (torch.float32, torch.bfloat16) if to_bf16 else (torch.bfloat16, torch.float32)
+    if x.dtype == dst:
+        return x
+    if not x.is_cuda or x.dtype != src:
+        raise _lib.DcptHipError(f"cast: expected a {src} device tensor, got {x.dtype} on {x.device}")
+    x = _nhwc(x) if x.dim() == 4 else _contig(x)
+    if x.numel() % 8:
+        raise _lib.DcptHipError("cast: element count must be a multiple of 8")
+    y = torch.empty_like(x, dtype=dst)   # preserves the (dense NHWC) strides
+    fn = lib.dcpt_cast_f32_bf16 if to_bf16 else lib.dcpt_cast_bf16_f32
+    check(fn(x.data_ptr(), y.data_ptr(), x.numel(), _stream(x.device)), "dcpt_cast")
+    return y
+
+
+def to_bf16(x):
+    return _CastFn.apply(x, True)
+
+
+def to_f32(x):
+    return _CastFn.apply(x, False)
+
+
 def nafblock_local(inp: torch.Tensor, params: Dict[str, torch.Tensor], k1: int, k2: int) -> torch.Tensor:
     """TLSC inference forward (reference nafnet_arch.py:277-288 + arch_util.py:313-455): SCA with a k1 x k2 local mean."""
     if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params.values())):

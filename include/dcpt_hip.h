@@ -101,6 +101,36 @@ int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* 
                       const dcpt_nafblock_saved* saved, const float* dout, float* dinp, void* ws, size_t ws_bytes,
                       int B, int H, int W, int C, dcpt_stream_t stream);
 
+/* ---- NAFBlock, bf16 storage (BASELINE.json configs[2]) --------------------------------------------------------------
+ * Same block (nafnet_arch.py:83-186), activations and saved tensors as bfloat16 (raw uint16_t, upper half of an fp32, stored
+ * round-to-nearest-even), fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 parameters / parameter gradients / LayerNorm
+ * statistics / reductions.  The reference has no reduced-precision mode (its AMP / TF32 switches are commented out,
+ * basicsr/test.py:26-27): this is new behaviour with its own tolerance (tests/test_gpu_bf16.py, oracle bf16 mode).
+ * C must be a multiple of 8 (16-byte rows), at most 1024.  dinp must NOT alias dout (weight-gradient GEMMs on the side
+ * stream still read dout when dinp is written). */
+typedef struct {
+    uint16_t* t1;   /* [M][2C] bf16 */
+    uint16_t* t2;   /* [M][C]  */
+    uint16_t* y;    /* [M][C]  */
+    uint16_t* v;    /* [M][2C] */
+    float* mu1; float* rstd1; float* mu2; float* rstd2;   /* [M] fp32 */
+    float* pooled;  /* [B][C] fp32 */
+    float* s;       /* [B][C] fp32 */
+    uint16_t* xn1;  /* [M][C]  LN1(inp) */
+    uint16_t* xn2;  /* [M][C]  LN2(y) */
+    uint16_t* g;    /* [M][C]  SimpleGate(v) */
+} dcpt_nafblock_saved_bf16;
+size_t dcpt_nafblock_fwd_bf16_ws_bytes(int B, int H, int W, int C);
+size_t dcpt_nafblock_bwd_bf16_ws_bytes(int B, int H, int W, int C);
+int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint16_t* inp, uint16_t* out, const dcpt_nafblock_saved_bf16* saved,
+                           void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
+int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* g, const uint16_t* inp,
+                           const dcpt_nafblock_saved_bf16* saved, const uint16_t* dout, uint16_t* dinp, void* ws, size_t ws_bytes,
+                           int B, int H, int W, int C, dcpt_stream_t stream);
+/* fp32 <-> bf16 (RNE) on n contiguous elements, n % 8 == 0: the edges of the bf16 path */
+int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream);
+int dcpt_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, dcpt_stream_t stream);
+
 /* TLSC variant (nafnet_arch.py:277-288 `NAFNet`, arch_util.py:313-455): inference-only forward where SCA's global
  * mean is a k1 x k2 local box mean (replicate-padded), i.e. a per-pixel attention map.  Callers use the plain
  * dcpt_nafblock_fwd when the window covers the whole map (arch_util.py:352-353). */

@@ -58,6 +58,60 @@ def nafblock(inp, P: dict, pre: str):
     return y + x * g("gamma")
 
 
+# ---- bf16-storage mode (BASELINE.json configs[2]) -----------------------------------------------------------------------
+# The reference has no reduced-precision arithmetic (AMP / TF32 are commented out, basicsr/test.py:26-27), so there is nothing
+# of the reference to pin this mode to beyond "close to fp32".  It restates nafblock() with a bf16 round-to-nearest-even at every
+# point where the HIP bf16 path (dcpt_amd/csrc/nafblock_bf16.hip) stores a tensor to HBM, everything else in fp32.
+class _Round(torch.autograd.Function):
+    """fwd / bwd flags: round the value in forward and / or the gradient in backward through bf16"""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.bfloat16().float() if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.bfloat16().float() if ctx.bwd else g), None, None
+
+
+def _rr(x):   # stored in bf16 in forward, its gradient is stored in bf16 in backward
+    return _Round.apply(x, True, True)
+
+
+def _rf(x):   # rounded in forward only (weight operand copies; SimpleGate(v))
+    return _Round.apply(x, True, False)
+
+
+def _rb(x):   # only its gradient is stored in bf16
+    return _Round.apply(x, False, True)
+
+
+def nafblock_bf16(inp, P: dict, pre: str):
+    """nafblock() with the HIP bf16 path's rounding points.  ``inp`` holds bf16-representable values; so does the result."""
+    g = lambda n: P[pre + n]
+    c = g("conv3.weight").shape[0]
+    c2 = 2 * c
+    inp = _rb(inp)                                                                  # dinp is stored in bf16
+    xn1 = _rr(layernorm2d(inp, g("norm1.weight"), g("norm1.bias")))
+    t1 = _rr(F.conv2d(xn1, _rf(g("conv1.weight")), g("conv1.bias")))
+    a = F.conv2d(t1, g("conv2.weight"), g("conv2.bias"), padding=1, groups=c2)     # depthwise: fp32 weights on the bf16 t1
+    t2u = simple_gate(a)
+    pooled = t2u.mean(dim=(2, 3))                                                    # pooling sums the unrounded gate outputs
+    t2 = _rf(t2u)                                                                    # (dt2 = dts * s + dpool stays on chip)
+    s = F.linear(pooled, g("sca.1.weight").flatten(1), g("sca.1.bias"))             # [B][C]
+    w3s = _rf(g("conv3.weight").flatten(1)[None] * s[:, None, :])                   # per-image weights W3[n][k] * s[b][k]
+    x3 = torch.einsum("bnk,bkhw->bnhw", w3s, _rb(t2)) + g("conv3.bias").view(1, -1, 1, 1)   # (dts is stored in bf16)
+    y = _rr(inp + x3 * g("beta"))
+    xn2 = _rr(layernorm2d(y, g("norm2.weight"), g("norm2.bias")))
+    vu = F.conv2d(xn2, _rf(g("conv4.weight")), g("conv4.bias"))
+    v = _rr(vu)
+    gate_val = simple_gate(vu).bfloat16().float()                                    # product of the UNROUNDED halves, rounded once
+    gate = gate_val.detach() + (simple_gate(v) - simple_gate(v).detach())            # backward uses the stored (rounded) v
+    x5 = F.conv2d(gate, _rf(g("conv5.weight")), g("conv5.bias"))
+    return _rr(y + x5 * g("gamma"))
+
+
 def pixel_shuffle2(x):
     """out[n, k, 2h+i, 2w+j] = in[n, 4k+2i+j, h, w] (torch.nn.PixelShuffle(2))."""
     n, c4, h, w = x.shape
