@@ -89,7 +89,16 @@ class NAFBlock(nn.Module):
             "beta": self.beta, "gamma": self.gamma,
         }
 
+    # bf16-storage mode (NAFNetBaseline.set_act_dtype): the block takes fp32 or bf16 activations and runs on the bf16 kernels;
+    # the LAST block of a group hands fp32 back, so forward hooks on ``decoder{i}`` / ``decoder{i}.0`` (the DCPT taps) and the
+    # fp32 layers between the groups see what they see in fp32 mode
+    act_bf16 = False
+    emit_f32 = True
+
     def forward(self, inp):
+        if self.act_bf16:
+            y = DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params())
+            return DF.to_f32(y) if self.emit_f32 else y
         pool = self.sca[0]
         if isinstance(pool, AvgPool2d) and pool.kernel_size is not None:
             k1, k2 = int(pool.kernel_size[0]), int(pool.kernel_size[1])
@@ -99,18 +108,7 @@ class NAFBlock(nn.Module):
 
 
 class _BlockGroup(nn.Sequential):
-    """A level's NAFBlocks (an ``nn.Sequential`` in the reference, so the state-dict keys and the forward hooks on
-    ``decoder{i}`` are unchanged).  With ``act_bf16`` the whole group runs on the bf16-storage kernels between two casts."""
-
-    act_bf16 = False
-
-    def forward(self, x):
-        if not self.act_bf16 or len(self) == 0:
-            return super().forward(x)
-        x = DF.to_bf16(x)
-        for blk in self:
-            x = DF.nafblock_bf16(x, blk.fused_params())
-        return DF.to_f32(x)
+    """A level's NAFBlocks (an ``nn.Sequential`` in the reference: same state-dict keys, same forward-hook targets)."""
 
 
 class _Down(nn.Conv2d):
@@ -161,7 +159,9 @@ class NAFNetBaseline(nn.Module):
         self.act_dtype = act_dtype
         for m in self.modules():
             if isinstance(m, _BlockGroup):
-                m.act_bf16 = act_dtype == "bf16"
+                for i, blk in enumerate(m):
+                    blk.act_bf16 = act_dtype == "bf16"
+                    blk.emit_f32 = i == len(m) - 1
 
     def _streams(self, n, device):
         while len(self._side_streams) < n:

@@ -2,7 +2,11 @@
 """Secondary workloads of BASELINE.json (configs[2..4]) on ONE MI355X -- evidence for DESIGN.md, not the driver's
 contract (that is bench.py).  Prints one JSON line per workload.
 
-    python bench_extra.py --workload dcpt|restormer|infer2k [--steps K] [--warmup W]
+    python bench_extra.py --workload dcpt|restormer|infer2k|naf [--dtype fp32|bf16] [--steps K] [--warmup W]
+
+``--dtype bf16`` (dcpt, naf): the NAFBlock groups run with bf16 storage / fp32 accumulate (act_dtype="bf16"); everything else
+(layers between the groups, the classifier head, parameters, optimizer) stays fp32.  Its lines carry BOTH rooflines: the bf16
+MFMA peak (2.5 PF dense) and the HBM roof with the bf16 algorithmic bytes -- in bf16 the blocks are HBM-bound.
 """
 from __future__ import annotations
 
@@ -32,7 +36,8 @@ def timed(fn, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k"])
+    ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k", "naf"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
@@ -43,13 +48,43 @@ def main():
     from dcpt_amd.keyed_init import fill_module_
 
     g = torch.Generator(device=dev).manual_seed(1234)
-    if args.workload == "dcpt":
+    bf = args.dtype == "bf16"
+    naf = dict(NAF, act_dtype=args.dtype)
+    # SURVEY 8d algorithmic HBM bytes of NAFNet-64 fwd+bwd per 256^2 image: 25 element passes over the blocks' sum c*P = 30.146 M
+    # (bf16: 2 B each) + 3 passes over the 40.4 M elements of the layers between the groups (fp32 in both modes)
+    naf_bytes = 25 * 30.146e6 * (2 if bf else 4) + 3 * 40.4e6 * 4
+    peak = 2.5e15 if bf else 157.3e12
+
+    def rooflines(flops, nbytes, dt):
+        return dict(alg_tflops=round(flops / dt / 1e12, 2), mfma_peak_tflops=peak / 1e12, mfma_frac=round(flops / dt / peak, 4),
+                    alg_gbytes=round(nbytes / 1e9, 2), hbm_frac=round(nbytes / dt / 8e12, 4),
+                    bound="hbm" if nbytes / 8e12 > flops / peak else "mfma",
+                    note="hbm_frac against the 8 TB/s spec roof; a streaming kernel reaches ~6.3 TB/s (0.79) on this part")
+
+    if args.workload == "naf":
+        # configs[1]'s network and batch, as a bf16-vs-fp32 comparison line (the fp32 headline is bench.py's, never this one)
+        B, S = args.batch or 32, args.size or 256
+        net = fill_module_(build_network(dict(type="NAFNetBaseline", **naf))).to(dev)
+        optm = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0, fused=True)
+        lq = torch.rand((B, 3, S, S), generator=g, device=dev)
+        gt = torch.rand((B, 3, S, S), generator=g, device=dev)
+
+        def step():
+            optm.zero_grad(set_to_none=True)
+            (net(lq) - gt).abs().mean().backward()
+            optm.step()
+
+        dt = timed(step, args.steps, args.warmup)
+        sc = B * (S / 256.0) ** 2
+        res = dict(workload=f"NAFNet-64 [1,1,1,28] fwd+L1+bwd+AdamW, B={B}, {S}x{S}, NAFBlock activations {args.dtype}",
+                   ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3), **rooflines(sc * 378.3e9, sc * naf_bytes, dt))
+    elif args.workload == "dcpt":
         # configs[2]: NAFNet-64 encoder + PromptIR_NoImg_DC head, 10 classes, one DCPT step (fp32 here; the reference has no AMP)
         B, S = args.batch or 32, args.size or 128
         from basicsr.models import build_model
 
         opt = dict(name="b", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
-                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", **NAF),
+                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", **naf),
                    network_dc=dict(type="PromptIR_NoImg_DC", feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10),
                    path=dict(), train=dict(pixel_opt=dict(type="L1Loss"), classify_opt=dict(type="CrossEntropyLoss"),
                                            optim_g=dict(type="AdamW", lr=1e-4, fused=True), optim_dc=dict(type="AdamW", lr=1e-4, fused=True)))
@@ -60,10 +95,21 @@ def main():
                 "dataset_idx": torch.randint(0, 10, (B,), generator=g, device=dev)}
         m.feed_data(data)
         dt = timed(lambda: m.optimize_parameters(1), args.steps, args.warmup)
-        flops = B * (S / 256.0) ** 2 * 1.315e12   # 1.315 TFLOP fwd+bwd per 256^2 image
-        res = dict(workload=f"DCPT step: NAFNet-64 x2 fwd + PromptIR_NoImg_DC head + bwd + 2x AdamW, B={B}, {S}x{S}, fp32",
-                   ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3),
-                   alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4), log=m.get_current_log())
+        sc = B * (S / 256.0) ** 2
+        flops = sc * 1.315e12   # 1.315 TFLOP fwd+bwd per 256^2 image (2 x 378.3 GF encoder + 558.9 GF head)
+        res = dict(workload=f"DCPT step: NAFNet-64 x2 fwd + PromptIR_NoImg_DC head + bwd + 2x AdamW, B={B}, {S}x{S}, "
+                            f"NAFBlock activations {args.dtype}, head fp32",
+                   ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3), log=m.get_current_log())
+        if bf:
+            # two rooflines for the mixed step: the encoder's flops on the bf16 pipe + the head's on the fp32 pipe (time bound),
+            # and the encoder's bf16 algorithmic bytes (the head's bytes are not in SURVEY 8d and are left out: a lower bound)
+            t_mfma = sc * (2 * 378.3e9 / 2.5e15 + 558.9e9 / 157.3e12)
+            t_hbm = sc * 2 * naf_bytes / 8e12
+            res.update(alg_tflops=round(flops / dt / 1e12, 2), mfma_time_bound_ms=round(t_mfma * 1e3, 2), mfma_frac=round(t_mfma / dt, 4),
+                       hbm_time_bound_ms_encoder_only=round(t_hbm * 1e3, 2), hbm_frac=round(t_hbm / dt, 4),
+                       note="fractions = time bound / measured step; encoder bf16 (2.5 PF, bf16 bytes), head fp32 (157.3 TF)")
+        else:
+            res.update(alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4))
     elif args.workload == "restormer":
         # configs[3]: Restormer defaults, 128x128, fwd + L1 + bwd + AdamW
         B, S = args.batch or 64, args.size or 128

@@ -239,11 +239,11 @@ def _cast(lib, x, to_bf16):
 
 
 def to_bf16(x):
-    return _CastFn.apply(x, True)
+    return x if x.dtype == torch.bfloat16 else _CastFn.apply(x, True)
 
 
 def to_f32(x):
-    return _CastFn.apply(x, False)
+    return x if x.dtype == torch.float32 else _CastFn.apply(x, False)
 
 
 def nafblock_local(inp: torch.Tensor, params: Dict[str, torch.Tensor], k1: int, k2: int) -> torch.Tensor:

@@ -124,3 +124,35 @@ def test_nafnet_bf16_blocks_in_network(dev):
     assert _rel(outs["bf16"][1], outs["fp32"][1]) <= 8e-2
     worst = max(_rel(outs["bf16"][2][k], outs["fp32"][2][k]) for k in outs["fp32"][2])
     assert worst <= 0.15, worst
+
+
+def test_dcpt_step_with_bf16_encoder(dev):
+    """DCPTModel.optimize_parameters (reference ...pretrain_model.py:133-169) with ``network_g.act_dtype: bf16``: the decoder taps
+    (hooks on ``decoder{i}.0``) still fire with fp32 tensors, the head and both optimizers run, and the losses stay close to the
+    fp32 step's."""
+    from basicsr.models import build_model
+    from dcpt_amd.keyed_init import keyed_state_dict
+    from oracle import dc_oracle as D
+
+    tiny = dict(img_channel=3, width=8, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 2], dec_blk_nums=[1, 1, 1, 1])
+    dc = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+    logs = {}
+    for dt in ("fp32", "bf16"):
+        opt = dict(name="t", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", act_dtype=dt, **tiny),
+                   network_dc=dict(type="PromptIR_NoImg_DC", **dc), path=dict(),
+                   train=dict(pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"),
+                              classify_opt=dict(type="CrossEntropyLoss", loss_weight=1.0),
+                              optim_g=dict(type="SGD", lr=0.0), optim_dc=dict(type="SGD", lr=0.0)))
+        m = build_model(opt)
+        m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**tiny), seed=0), strict=True)
+        m.net_dc.load_state_dict(keyed_state_dict(D.dc_param_shapes(**dc), seed=0), strict=True)
+        assert len(m.hooks) == 4
+        m.feed_data({"lq": keyed_input("dcpt.lq", (2, 3, 32, 32)), "gt": keyed_input("dcpt.gt", (2, 3, 32, 32)),
+                     "dataset_idx": torch.tensor([3, 8])})
+        m.optimize_parameters(1)
+        logs[dt] = dict(m.get_current_log())
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.net_g.parameters())
+        assert all(p.grad is not None for p in m.net_dc.parameters()) and m.hook_outputs == []
+    assert abs(logs["bf16"]["l_pix"] - logs["fp32"]["l_pix"]) <= 2e-2 * abs(logs["fp32"]["l_pix"]), logs
+    assert abs(logs["bf16"]["l_classify"] - logs["fp32"]["l_classify"]) <= 5e-2 * abs(logs["fp32"]["l_classify"]), logs
