@@ -318,6 +318,24 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": round(whole["mfma_frac"] * PEAK_F32_TFLOPS, 2),
                                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": whole["mfma_frac"], "traffic": None,
                                "whole_step": whole}
+        # Whole-step account of the DEFAULT command (two streams) from the committed rocprofv3 kernel trace: main-queue time split into
+        # MFMA kernels / bandwidth kernels / torch kernels / idle gaps (they sum to the traced step time), side-queue busy time and
+        # how much of it coincides with main-queue kernels.  It cannot be produced live (rocprofv3 wraps the process), so it is read
+        # from profiles/step_budget.json (tools/step_budget.py; `traced_ms_per_step` says which run it describes).
+        try:
+            with open(os.path.join(ROOT, "profiles", "step_budget.json")) as fh:
+                sb = json.load(fh)
+            res["roofline"]["step_budget"] = {
+                "traced_ms_per_step": sb["step_ms"],
+                "main_stream": {"mfma_kernels_ms": sb["main_mfma_ms"], "hbm_kernels_ms": sb["main_hbm_ms"], "torch_kernels_ms": sb["main_torch_ms"],
+                                "idle_ms": sb["main_idle_ms"], "sum_ms": sb["check_sum_ms"]},
+                "side_stream": {"busy_ms": sb["side_busy_ms"], "mfma_kernels_ms": sb["side_mfma_ms"], "overlapping_main_kernels_ms": sb["side_overlap_ms"],
+                                "in_main_idle_ms": sb["side_in_main_idle_ms"]},
+                "launches_per_step": {"main": sb["main_launches"], "side": sb["side_launches"]},
+                "source": sb.get("source", "profiles/step_budget.json"),
+            }
+        except (OSError, ValueError, KeyError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

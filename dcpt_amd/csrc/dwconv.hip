@@ -142,6 +142,11 @@ struct DwP {
     float* part;        // fwd: pool_part [B][NBLK][C]; bwd_b: wpart [B*NBLK][10][2C]
     int B, H, W, C;
     int Ctot;  // bwd_b / plain: total channel count of the depthwise conv
+    // fused backward, optional: per-pixel partials of  dt1 . u  and  dt1 . (t1 - cvec)  over this block's channel chunk,
+    // rowpart[pixel][gridDim.x][2] -- the two row sums of the LayerNorm backward downstream (gemm.h, E_LNBWD2)
+    float* rowpart;
+    const float* uvec;   // [2C]
+    const float* cvec;   // [2C]
 };
 
 __device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
@@ -371,6 +376,11 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
         sv = gld<VW>(p.simg + (int64_t)b * C + cg, true);
         dpv = gld<VW>(p.dpool + (int64_t)b * C + cg, true);
     }
+    vf<VW> uv = vz<VW>(), cv = vz<VW>();
+    if (p.rowpart && qok) {
+        uv = gld<VW>(p.uvec + co, true);
+        cv = gld<VW>(p.cvec + co, true);
+    }
     vf<VW> g[10];   // tap gradients (0..8) and bias gradient (9)
 #pragma unroll
     for (int t = 0; t < 10; ++t) g[t] = vz<VW>();
@@ -441,6 +451,19 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(const DwP p) {
         {
             const int y = rho - 1;   // complete now
             bstT<VW, ST>(rs_o, (ok && y >= h0 && y < h1) ? (uint32_t)(((y - rb) * p.W + x) * C2 + co) * ES : ROW_SENT, B0);
+            if (p.rowpart) {   // t1[y][x] is Tm[1] here (rows r-2 = y, r-1, r are in Tm, Tc, T)
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                VFOR {
+                    a1 = fmaf(B0.v[i_], uv.v[i_], a1);
+                    a2 = fmaf(B0.v[i_], Tm[1].v[i_] - cv.v[i_], a2);
+                }
+                if (!qok) a1 = a2 = 0.f;
+                a1 = group_sum(a1, mp.QB);   // the QB lanes of this pixel (one channel chunk)
+                a2 = group_sum(a2, mp.QB);
+                if (ql == 0 && x < p.W && y >= h0 && y < h1)
+                    *reinterpret_cast<float2*>(p.rowpart + ((((int64_t)b * p.H + y) * p.W + x) * gridDim.x + bk.x) * 2) = make_float2(a1, a2);
+            }
         }
         // ---- tap gradients: da[rho][x] with t1 rows rho-1 (Tm), rho (Tc), rho+1 (= row r, T) at columns x-1..x+1; rows of this
         //      block's range only, so that every pixel is counted once
@@ -619,11 +642,14 @@ int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2,
     return DCPT_OK;
 }
 
+int dw_fused_row_chunks(const DwGeom& g) { return dw_map(g.H, g.W, 2 * g.C / dw_fused_vw()).nqc; }
+
 int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
-                        float* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+                        float* dt1, float* wpart, const DwGeom& g, hipStream_t s, float* rowpart, const float* uvec, const float* cvec) {
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd: C=%d must be a multiple of 4", g.C);
     DwP p{};
     p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = dt1; p.part = wpart;
+    p.rowpart = rowpart; p.uvec = uvec; p.cvec = cvec;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
     const int vw = dw_fused_vw();
     const DwMap mp = dw_map(g.H, g.W, 2 * g.C / vw);

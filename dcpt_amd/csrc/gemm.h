@@ -9,7 +9,7 @@
 #include "dcpt_common.h"
 
 enum GemmALoad { A_PLAIN = 0, A_LN = 1, A_SCALE = 2, A_SG = 3, A_GATHER = 4, A_CONV3 = 5, A_LNBF = 6 };
-enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7, E_BIASGATE = 8, E_DOTCOL = 9, E_LNBWD = 10, E_RESIDLN = 11 };
+enum GemmEpi { E_PLAIN = 0, E_BIAS = 1, E_RESID = 2, E_SGBWD = 3, E_SCATTER = 4, E_SCATTER_ADD = 5, E_ADDSCALED = 6, E_MUL = 7, E_BIASGATE = 8, E_DOTCOL = 9, E_LNBWD = 10, E_RESIDLN = 11, E_LNBWD2 = 12 };
 
 struct GemmNT {
     const float* A;   // [M][lda]   (A_SG: 2K columns; A_GATHER: fine NHWC image, see g*)
@@ -46,6 +46,17 @@ struct GemmNT {
     float* ln_mu;
     float* ln_rstd;
     float ln_eps;
+    // E_LNBWD2 (any N): LayerNorm backward WITHOUT a row reduction in the epilogue.  The two row sums of the backward formula,
+    //   C s1 = sum_c g_c w_c  and  C s2 = sum_c g_c w_c xhat_c   (g = this GEMM's accumulator row = dZ W, Z = W (w * xhat + b) + bz),
+    // are linear in dZ:  C s1 = dZ . u,  C s2 = dZ . (Z - cvec)  with u_j = sum_c W[j][c] w_c,  cvec_j = bz_j + sum_c W[j][c] b_c,
+    // so whoever PRODUCED dZ (the SimpleGate-backward epilogue E_SGBWD, the fused depthwise backward) already left them as
+    // per-row partials rowpart[m][np][2] (np column chunks).  The epilogue is then elementwise:
+    //   C = rstd (g w - xhat s2 - s1) + aux,   colpart[m / 128][0][n] = sum_rows g xhat,  colpart[m / 128][1][n] = sum_rows g.
+    // E_SGBWD writes such partials when rowpart != null (np = its number of column tiles; uvec / cvec have 2N entries).
+    float* rowpart;
+    int rowparts;         // E_LNBWD2: np of the producer
+    const float* uvec;    // E_SGBWD with rowpart
+    const float* cvec;
     float* colpart;       // E_DOTCOL: C = acc as E_PLAIN AND colpart[m / 128][n] = sum over the tile's 128 rows of acc * res[m][n]
                           // (fixed order; SCA backward's per-image channel sums come out of the producing GEMM)
     float* gate;          // E_BIASGATE (N = 2*Ch, SimpleGate input): C = acc + bias as usual AND gate[m][c] = C[m][c] * C[m][Ch + c],
@@ -57,6 +68,8 @@ struct GemmNT {
 };
 
 int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t stream);
+// number of column tiles the launch of this problem uses (= row partials per row written by E_SGBWD with rowpart)
+int gemm_nt_tiles_n(const GemmNT& p, int aload, int epi);
 
 struct GemmTN {
     const float* X;  // [M][ldx]  -> rows of G (n index)

@@ -130,9 +130,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     }
     const rsrc_t rsC = make_rsrc(p.C + cbase);
     rsrc_t rsR = rsC, rsX = rsC;
-    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD || EK == E_RESIDLN) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD || EK == E_RESIDLN || EK == E_LNBWD2) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
     if constexpr (EK == E_RESIDLN) rsX = make_rsrc(p.ln_out + m0 * (int64_t)p.ldc);
-    if constexpr (EK == E_LNBWD) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
+    if constexpr (EK == E_LNBWD || EK == E_LNBWD2) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
     if constexpr (EK == E_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
     if constexpr (EK == E_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
     constexpr int HALF = (EK == E_SGBWD) ? 2 : 1;   // SGBWD needs two loads per row: do it in two halves
@@ -140,8 +140,18 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
     float4 dot = f4_zero();   // E_DOTCOL / E_LNBWD: this thread's part of the column sums
     float4 dot2 = f4_zero();  // E_LNBWD: second plane (sum of g)
     float4 lnw4 = f4_zero(), lnb4 = f4_zero();
-    if constexpr (EK == E_LNBWD || EK == E_RESIDLN) {
+    if constexpr (EK == E_LNBWD || EK == E_RESIDLN || EK == E_LNBWD2) {
         if (nok) lnw4 = ldg4(p.lnw + n);
+    }
+    // E_SGBWD with row partials: this thread's entries of u / cvec for both halves of the gate
+    float4 u_lo = f4_zero(), u_hi = f4_zero(), c_lo = f4_zero(), c_hi = f4_zero();
+    if constexpr (EK == E_SGBWD) {
+        if (p.rowpart && nok) {
+            u_lo = ldg4(p.uvec + n);
+            u_hi = ldg4(p.uvec + p.N + n);
+            c_lo = ldg4(p.cvec + n);
+            c_hi = ldg4(p.cvec + p.N + n);
+        }
     }
     if constexpr (EK == E_RESIDLN) {
         if (nok && p.lnb) lnb4 = ldg4(p.lnb + n);
@@ -162,9 +172,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                 if constexpr (EK == E_SCATTER_ADD) pre1[it] = buf_ld4(rsR, addr[it]);
             } else {
                 addr[it] = ok ? (uint32_t)rl * (uint32_t)p.ldc * 4u + coladd : ROW_SENT;
-                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD || EK == E_RESIDLN)
+                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL || EK == E_LNBWD || EK == E_RESIDLN || EK == E_LNBWD2)
                     pre1[it] = buf_ld4(rsR, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
-                if constexpr (EK == E_LNBWD) {
+                if constexpr (EK == E_LNBWD || EK == E_LNBWD2) {
                     if (p.aux) pre2[it] = buf_ld4(rsX, ok ? (uint32_t)rl * (uint32_t)ldres * 4u + coladd : ROW_SENT);
                 }
                 if constexpr (EK == E_SGBWD) {
@@ -214,6 +224,32 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
                     dot = f4_fma(v, xh, dot);
                     dot2 = f4_add(dot2, v);
                 }
+            } else if constexpr (EK == E_LNBWD2) {
+                // the row sums come from the producer of dZ: lane q of the row's lane group fetches partial q, the group adds them
+                const int64_t m = m0 + rl;
+                const bool rok = m < p.M;
+                const float mean = rok ? p.mu[m] : 0.f, rs = rok ? p.rstd[m] : 0.f;
+                float a1 = 0.f, a2 = 0.f;
+                if (rok && q < p.rowparts) {
+                    const float2 pr = *reinterpret_cast<const float2*>(p.rowpart + (m * p.rowparts + q) * 2);
+                    a1 = pr.x;
+                    a2 = pr.y;
+                }
+                const float invN = 1.0f / (float)p.N;
+                const float s1 = group_sum(a1, QP) * invN, s2 = group_sum(a2, QP) * invN;
+                const float4 xh = make_float4((pre1[it].x - mean) * rs, (pre1[it].y - mean) * rs, (pre1[it].z - mean) * rs,
+                                              (pre1[it].w - mean) * rs);
+                const float4 gw = f4_mul(v, lnw4);
+                float4 d;
+                d.x = rs * (gw.x - xh.x * s2 - s1);
+                d.y = rs * (gw.y - xh.y * s2 - s1);
+                d.z = rs * (gw.z - xh.z * s2 - s1);
+                d.w = rs * (gw.w - xh.w * s2 - s1);
+                buf_st4(rsC, addr[it], f4_add(d, pre2[it]));
+                if (rok && nok) {
+                    dot = f4_fma(v, xh, dot);
+                    dot2 = f4_add(dot2, v);
+                }
             } else if constexpr (EK == E_DOTCOL) {
                 buf_st4(rsC, addr[it], v);
                 dot = f4_fma(v, pre1[it], dot);   // rows past M loaded 0
@@ -228,14 +264,28 @@ __device__ __forceinline__ void epilogue_rows(const GemmNT& p, const float* __re
             } else if constexpr (EK == E_MUL) {
                 buf_st4(rsC, addr[it], f4_mul(f4_add(v, bias), pre1[it]));
             } else if constexpr (EK == E_SGBWD) {
-                buf_st4(rsC, addr[it], f4_mul(v, pre2[it]));
-                buf_st4(rsC, addr[it] + 4u * (uint32_t)p.N, f4_mul(v, pre1[it]));
+                const float4 d1 = f4_mul(v, pre2[it]), d2 = f4_mul(v, pre1[it]);   // gradients of the first / second half of the gate input
+                buf_st4(rsC, addr[it], d1);
+                buf_st4(rsC, addr[it] + 4u * (uint32_t)p.N, d2);
+                if (p.rowpart) {   // row partials of  dZ . u  and  dZ . (Z - cvec)  for the LayerNorm backward downstream (E_LNBWD2)
+                    const int64_t m = m0 + rl;
+                    const float4 z1 = make_float4(pre1[it].x - c_lo.x, pre1[it].y - c_lo.y, pre1[it].z - c_lo.z, pre1[it].w - c_lo.w);
+                    const float4 z2 = make_float4(pre2[it].x - c_hi.x, pre2[it].y - c_hi.y, pre2[it].z - c_hi.z, pre2[it].w - c_hi.w);
+                    float a1 = nok ? f4_sum(f4_mul(d1, u_lo)) + f4_sum(f4_mul(d2, u_hi)) : 0.f;
+                    float a2 = nok ? f4_sum(f4_mul(d1, z1)) + f4_sum(f4_mul(d2, z2)) : 0.f;
+                    a1 = group_sum(a1, QP);
+                    a2 = group_sum(a2, QP);
+                    if (q == 0 && m < p.M) {
+                        const int np = (p.N + BN - 1) / BN;
+                        *reinterpret_cast<float2*>(p.rowpart + (m * np + n0 / BN) * 2) = make_float2(a1, a2);
+                    }
+                }
             } else {  // E_SCATTER_ADD
                 buf_st4(rsC, addr[it], f4_add(v, pre1[it]));
             }
         }
     }
-    if constexpr (EK == E_LNBWD) {
+    if constexpr (EK == E_LNBWD || EK == E_LNBWD2) {
         // the two column-sum planes over the tile's rows, as for E_DOTCOL
         float* sm = const_cast<float*>(Cs);
         for (int pl = 0; pl < 2; ++pl) {
@@ -437,53 +487,52 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
     TL_STAMP(3)
 }
 
+// Tile width of a launch.  Row-spanning epilogues (E_LNBWD / E_RESIDLN) need the whole row in one tile.  Otherwise: 96-wide
+// tiles when they pad N less than 128-wide ones (Restormer's 96 / 192 / 288 / 576-channel layers); 128 x 64 tiles (48 KB of LDS:
+// three resident blocks per CU instead of two) whenever the grid is only a few rounds of the resident slots -- a grid of 580
+// 128 x 128 tiles is 1.13 rounds of 512 slots and runs as two, the same work as 1160 narrower tiles is 1.5 rounds of 768 slots,
+// and three co-resident blocks hide each other's prologue / epilogue better (measured: 2K tiled inference -9 %, the training
+// step -0.9 %: its 1024- and 2048-tile launches at the deepest level); grids of many rounds keep the wider tile (fewer LDS
+// reads per flop).
+int nt_pick_bn(const GemmNT& p, int epi) {
+    const bool gate = (epi == E_BIASGATE);
+    const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
+    if (epi == E_LNBWD || epi == E_RESIDLN) return p.N <= 64 ? 64 : 128;
+    static const int smallk = getenv("DCPT_NT_SMALLK") ? atoi(getenv("DCPT_NT_SMALLK")) : 0;
+    static const int use96 = getenv("DCPT_NT_96") ? atoi(getenv("DCPT_NT_96")) : 1;
+    static const int use64_below = getenv("DCPT_NT_64_BELOW") ? atoi(getenv("DCPT_NT_64_BELOW")) : 2100;
+    if (!gate && use96 && p.N > 64 && cdiv(p.N, 96) * 96 < cdiv(p.N, 128) * 128 && cdiv64(p.M, 128) * cdiv(p.N, 96) * nbatch > 256) return 96;
+    const int64_t tiles128 = cdiv64(p.M, 128) * (gate ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
+    if (p.N <= 64 || tiles128 * nbatch < use64_below || p.K <= smallk) return 64;
+    return 128;
+}
+
 template <int AK, int EK>
 int launch_cfg(const GemmNT& p, hipStream_t s) {
     const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     constexpr bool GATE = (EK == E_BIASGATE);
-    // 128 x 64 tiles when N is narrow
-    const int64_t tiles128 = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
-    if constexpr (EK == E_LNBWD || EK == E_RESIDLN) {   // the tile must span the whole row
-        if (p.N <= 64) {
-            gemm_nt_kernel<128, 64, 4, 1, AK, EK, 32><<<dim3((unsigned)cdiv64(p.M, 128), nbatch), dim3(256), 0, s>>>(p);
-        } else {
-            gemm_nt_kernel<128, 128, 2, 2, AK, EK, 32><<<dim3((unsigned)cdiv64(p.M, 128), nbatch), dim3(256), 0, s>>>(p);
-        }
-        DCPT_CHECK_LAUNCH("gemm_nt");
-        return DCPT_OK;
-    }
-    static const int smallk = getenv("DCPT_NT_SMALLK") ? atoi(getenv("DCPT_NT_SMALLK")) : 0;
-    static const int use96 = getenv("DCPT_NT_96") ? atoi(getenv("DCPT_NT_96")) : 1;
-    if constexpr (!GATE) {
-        // 96-wide tiles when they pad N less than 128-wide ones (Restormer's 96 / 192 / 288 / 576-channel layers)
-        if (use96 && p.N > 64 && cdiv(p.N, 96) * 96 < cdiv(p.N, 128) * 128 && cdiv64(p.M, 128) * cdiv(p.N, 96) * nbatch > 256) {
-            constexpr int BM = 128, BN = 96;
-            const int64_t tiles = cdiv64(p.M, BM) * cdiv(p.N, BN);
-            gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
-            DCPT_CHECK_LAUNCH("gemm_nt");
-            return DCPT_OK;
-        }
-    }
-    // 128 x 64 tiles (48 KB of LDS: three resident blocks per CU instead of two) whenever the grid is only a few rounds of
-    // the resident slots: a grid of 580 128 x 128 tiles is 1.13 rounds of 512 slots and runs as two, the same work as 1160
-    // narrower tiles is 1.5 rounds of 768 slots, and three co-resident blocks hide each other's prologue / epilogue better.
-    // Measured: 2K tiled inference -9 %, the training step -0.9 % (its 1024- and 2048-tile launches at the deepest level);
-    // grids of many rounds keep the wider tile (fewer LDS reads per flop).
-    static const int use64_below = getenv("DCPT_NT_64_BELOW") ? atoi(getenv("DCPT_NT_64_BELOW")) : 2100;
-    if (p.N <= 64 || tiles128 * nbatch < use64_below || p.K <= smallk) {
-        constexpr int BM = 128, BN = 64;
-        const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
-        gemm_nt_kernel<BM, BN, 4, 1, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
+    const int bn = nt_pick_bn(p, EK);
+    const int64_t tiles = cdiv64(p.M, 128) * (GATE ? cdiv(p.N / 2, bn / 2) : cdiv(p.N, bn));
+    const dim3 grid((unsigned)tiles, nbatch);
+    if (bn == 64) {
+        gemm_nt_kernel<128, 64, 4, 1, AK, EK, 32><<<grid, dim3(256), 0, s>>>(p);
+    } else if (bn == 96) {
+        if constexpr (!GATE && EK != E_LNBWD && EK != E_RESIDLN) gemm_nt_kernel<128, 96, 4, 1, AK, EK, 32><<<grid, dim3(256), 0, s>>>(p);
     } else {
-        constexpr int BM = 128, BN = 128;
-        const int64_t tiles = cdiv64(p.M, BM) * (GATE ? cdiv(p.N / 2, BN / 2) : cdiv(p.N, BN));
-        gemm_nt_kernel<BM, BN, 2, 2, AK, EK, 32><<<dim3((unsigned)tiles, nbatch), dim3(256), 0, s>>>(p);
+        gemm_nt_kernel<128, 128, 2, 2, AK, EK, 32><<<grid, dim3(256), 0, s>>>(p);
     }
     DCPT_CHECK_LAUNCH("gemm_nt");
     return DCPT_OK;
 }
 
 }  // namespace
+
+int gemm_nt_tiles_n(const GemmNT& pin, int aload, int epi) {
+    (void)aload;
+    GemmNT p = pin;
+    const int bn = nt_pick_bn(p, epi);
+    return epi == E_BIASGATE ? cdiv(p.N / 2, bn / 2) : cdiv(p.N, bn);
+}
 
 int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     GemmNT p = pin;
@@ -511,7 +560,11 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk * (aload == A_SG ? 2 : 1) + mn * (epi == E_SGBWD ? 4 : epi == E_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
     if (epi == E_RESID || epi == E_SCATTER_ADD || epi == E_DOTCOL) bytes += mn;
-    if (epi == E_LNBWD) bytes += 2 * mn;
+    if (epi == E_LNBWD || epi == E_LNBWD2) bytes += 2 * mn;
+    if (epi == E_LNBWD2)
+        DCPT_CHECK_ARG(p.colpart && p.res && p.mu && p.rstd && p.lnw && p.rowpart && p.rowparts >= 1 && p.rowparts <= 16 && p.N % 4 == 0 &&
+                           p.nb1 * p.nb2 == 1, "gemm_nt: LayerNorm-backward (row sums supplied) epilogue needs res / mu / rstd / lnw / colpart / rowpart, <= 16 row partials");
+    if (epi == E_SGBWD && p.rowpart) DCPT_CHECK_ARG(p.uvec && p.cvec, "gemm_nt: SimpleGate-backward row partials need uvec / cvec");
     if (epi == E_RESIDLN) bytes += 2 * mn;
     const double nbat = (double)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     ProfScope prof(s, PROF_NT + aload * 16 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * nbat, bytes * 4.0 * nbat);
@@ -536,6 +589,7 @@ int launch_gemm_nt(const GemmNT& pin, int aload, int epi, hipStream_t s) {
     CASE(A_PLAIN, E_BIASGATE)
     CASE(A_PLAIN, E_DOTCOL)
     CASE(A_PLAIN, E_LNBWD)
+    CASE(A_PLAIN, E_LNBWD2)
     CASE(A_SCALE, E_RESIDLN)
 #undef CASE
     dcpt_set_error("gemm_nt: unsupported loader/epilogue combination %d/%d", aload, epi);

@@ -37,8 +37,23 @@ int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2,
 // SimpleGate-backward + transposed depthwise + tap-gradient partials in one pass (da = gate-backward(dts * s + dpool) is never
 // written): dt1 and wpart[B*NBLKf][10][2C], NBLKf = dw_num_blocks_per_image_fused
 int dw_num_blocks_per_image_fused(const DwGeom& g);
+// optional rowpart[pixel][dw_fused_row_chunks][2]: per-pixel partials of dt1 . uvec and dt1 . (t1 - cvec) (gemm.h, E_LNBWD2)
+int dw_fused_row_chunks(const DwGeom& g);
 int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
-                        float* dt1, float* wpart, const DwGeom& g, hipStream_t s);
+                        float* dt1, float* wpart, const DwGeom& g, hipStream_t s, float* rowpart = nullptr, const float* uvec = nullptr,
+                        const float* cvec = nullptr);
+// LayerNorm-through-conv vectors of the row-sum identities (gemm.h, E_LNBWD2), for a 1x1 conv W [N2][C] (+ bias bz) applied to
+// LN(x) * w + b:   u[j] = sum_c W[j][c] w[c],   cvec[j] = bz[j] + sum_c W[j][c] b[c];   grid.y = job (two LayerNorms per block)
+struct LnVecJobs {
+    const float* W[2];
+    const float* bz[2];
+    const float* lnw[2];
+    const float* lnb[2];
+    float* u[2];
+    float* cvec[2];
+    int N2, C, n;
+};
+int launch_lnvec(const LnVecJobs& jobs, hipStream_t s);
 // dw2[ch*9+tap] and db2[ch] from wpart[R][10][C2]
 int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float* db2, hipStream_t s);
 

@@ -417,6 +417,33 @@ __global__ void wpack_multi_kernel(const WpackJobs jobs) {
     jobs.out[y][i] = rs ? v * rs[n] : v;
 }
 
+// one wave per output j: u[j] = W[j][:] . lnw,  cvec[j] = bz[j] + W[j][:] . lnb
+__global__ __launch_bounds__(256) void lnvec_kernel(const LnVecJobs jobs) {
+    const int y = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= jobs.N2) return;
+    const float* __restrict__ w = jobs.W[y] + (int64_t)j * jobs.C;
+    float a = 0.f, b = 0.f;
+    for (int c = 4 * lane; c < jobs.C; c += 256) {
+        const float4 wv = ldg4(w + c);
+        a += f4_sum(f4_mul(wv, ldg4(jobs.lnw[y] + c)));
+        b += f4_sum(f4_mul(wv, ldg4(jobs.lnb[y] + c)));
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        jobs.u[y][j] = a;
+        jobs.cvec[y][j] = b + (jobs.bz[y] ? jobs.bz[y][j] : 0.f);
+    }
+}
+
+int launch_lnvec(const LnVecJobs& jobs, hipStream_t s) {
+    DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= 2 && jobs.C % 4 == 0, "lnvec: bad job");
+    lnvec_kernel<<<dim3(cdiv(jobs.N2, 4), jobs.n), dim3(256), 0, s>>>(jobs);
+    DCPT_CHECK_LAUNCH("lnvec");
+    return DCPT_OK;
+}
+
 int launch_wpack_multi(const WpackJobs& jobs, hipStream_t s) {
     DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= WPACK_MAX_JOBS, "wpack_multi: %d jobs", jobs.n);
     int64_t mx = 0;

@@ -53,6 +53,9 @@ struct BwdWs {
     float *ds_part, *ds, *dpool;
     float* wpart;
     int ln_nblk, nblk_b;
+    // LayerNorm backward with supplied row sums (C > 128, gemm.h E_LNBWD2): u / cvec of conv4 o LN2 and conv1 o LN1, row partials
+    float *u4, *c4, *u1, *c1, *rowpart;
+    int rp_sg, rp_dw;   // partials per row written by the SimpleGate-backward GEMM / the fused depthwise backward
 };
 
 bool ln_in_epilogue(int C);
@@ -96,7 +99,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.ln_nblk = ln_bwd_num_blocks(M, C);
     {
         // LayerNorm column partials: [ln_nblk][3][C] from ln_bwd, or [M / 128 tiles][2][C] from the E_LNBWD GEMM epilogue
-        const size_t a1 = (size_t)w.ln_nblk * 3 * C, a2 = ln_in_epilogue(C) ? (size_t)cdiv64(M, 128) * 2 * C : 0;
+        const size_t a1 = (size_t)w.ln_nblk * 3 * C, a2 = (size_t)cdiv64(M, 128) * 2 * C;   // E_LNBWD / E_LNBWD2 tiles
         w.lnpart = a.get<float>(a1 > a2 ? a1 : a2);
         w.lnpart2 = a.get<float>(a1 > a2 ? a1 : a2);
     }
@@ -108,8 +111,27 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.dpool = a.get<float>((size_t)B * C);
     w.nblk_b = dw_num_blocks_per_image_fused(g);
     w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
+    w.u4 = a.get<float>((size_t)2 * C);
+    w.c4 = a.get<float>((size_t)2 * C);
+    w.u1 = a.get<float>((size_t)2 * C);
+    w.c1 = a.get<float>((size_t)2 * C);
+    w.rp_sg = cdiv(C, 64);   // upper bound over the tile widths the SimpleGate-backward launch may pick (64 / 96 / 128)
+    w.rp_dw = dw_fused_row_chunks(g);
+    w.rowpart = a.get<float>((size_t)M * (w.rp_sg > w.rp_dw ? w.rp_sg : w.rp_dw) * 2);
     if (out) *out = w;
     return a.off;
+}
+
+// Wide levels (C > 128): the LayerNorm backward's two row sums are linear in the gradient that enters the conv behind the
+// LayerNorm (dv for conv4 o LN2, dt1 for conv1 o LN1) -- gemm.h, E_LNBWD2 -- so the kernels that PRODUCE those gradients leave
+// them as per-row partials and the dgrad GEMM applies the LayerNorm backward elementwise in its epilogue: no separate
+// bandwidth kernel, the LayerNorm's incoming gradient is never written.
+// OFF by default (DCPT_LN_ROWSUMS=1 enables it): exact and 4 tensor passes lighter, but measured SLOWER in fp32 -- the step goes
+// from 120.7 to 124.4 ms, a level-3 block's backward from 1.95 to 2.09 ms: the wide levels' GEMMs are MFMA-bound, their
+// epilogues are exposed time, and the separate LayerNorm kernel was overlapping the side stream's weight-gradient GEMMs.
+bool ln_rowsums(int C, int rp_sg, int rp_dw) {
+    static const int on = getenv("DCPT_LN_ROWSUMS") ? atoi(getenv("DCPT_LN_ROWSUMS")) : 0;
+    return on && C > 128 && rp_sg <= 16 && rp_dw <= 16;
 }
 
 // Narrow levels (C <= 128: one GEMM tile spans all channels): LayerNorm backward runs inside the epilogue of the dgrad GEMM
@@ -230,10 +252,24 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     hipStream_t sw = side_stream(sd, s);   // stream of the weight-gradient GEMMs
     DCPT_TRY(side_fork(sd, 0, s));      // dout / saved activations / packed weights are ready
 
+    const bool lne = ln_in_epilogue(C);
+    const bool lrs = !lne && ln_rowsums(C, w.rp_sg, w.rp_dw);
+    if (lrs) {
+        LnVecJobs lj{};
+        lj.n = 2; lj.N2 = C2; lj.C = C;
+        lj.W[0] = p->conv4_w; lj.bz[0] = p->conv4_b; lj.lnw[0] = p->norm2_w; lj.lnb[0] = p->norm2_b; lj.u[0] = w.u4; lj.cvec[0] = w.c4;
+        lj.W[1] = p->conv1_w; lj.bz[1] = p->conv1_b; lj.lnw[1] = p->norm1_w; lj.lnb[1] = p->norm1_b; lj.u[1] = w.u1; lj.cvec[1] = w.c1;
+        DCPT_TRY(launch_lnvec(lj, s));
+    }
     GemmNT g{};
     GemmTN tp{};
-    // B1: dv = SG'(dout*gamma * W5; v)
+    // B1: dv = SG'(dout*gamma * W5; v)  (+ the row sums of LN2's backward, which are linear in dv)
     g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = dv; g.ldc = C2; g.aux = sv->v;
+    int rp_b1 = 0;
+    if (lrs) {
+        g.rowpart = w.rowpart; g.uvec = w.u4; g.cvec = w.c4;
+        rp_b1 = gemm_nt_tiles_n(g, A_PLAIN, E_SGBWD);
+    }
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SGBWD, s));
     // B2: conv5 / gamma gradients
     tp = GemmTN{};
@@ -242,12 +278,15 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(side_fork(sd, 1, s));      // dv
     // B3: grad w.r.t. LN2 output
     g = GemmNT{};
-    const bool lne = ln_in_epilogue(C);
     const int ln_tiles = (int)cdiv64(M, 128);
     g.M = M; g.A = dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = gln; g.ldc = C;
     if (lne) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv * W4^T)
         g.C = dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
         DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD, s));
+    } else if (lrs) {   // the same in one launch at any width: the row sums were left by B1
+        g.C = dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
+        g.rowpart = w.rowpart; g.rowparts = rp_b1;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD2, s));
     } else {
         DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     }
@@ -256,9 +295,9 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(wgrad(dv, C2, C2, sv->xn2, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
                    gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
-    if (!lne) DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
+    if (!lne && !lrs) DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 2, s));      // dy, LN2 partial sums
-    if (lne) DCPT_TRY(launch_colpart_reduce(w.lnpart, ln_tiles, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    if (lne || lrs) DCPT_TRY(launch_colpart_reduce(w.lnpart, ln_tiles, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     else DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2*s)
     // when an image is a whole number of 128-pixel GEMM tiles, SCA's ds[b][k] = sum_p dts * t2 comes out of this GEMM's epilogue
@@ -297,7 +336,8 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_sca_dpool(w.ds_part, ds_slices, p->sca_w, w.dpool, B, C, P, s));
     // B9/B10: SimpleGate + depthwise conv backward
     (void)da;   // the fused kernel keeps da on chip
-    DCPT_TRY(launch_dw_bwd_fused(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s));
+    // (wide levels: + the row sums of LN1's backward, linear in dt1; the LN2 partials in the same buffer were consumed by B3)
+    DCPT_TRY(launch_dw_bwd_fused(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s, lrs ? w.rowpart : nullptr, w.u1, w.c1));
     DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise and SCA partial sums
     DCPT_TRY(launch_sca_wgrad(w.ds_part, ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
@@ -307,6 +347,10 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     if (lne) {   // B11 + B13 in one launch: dinp = dy + LN1-backward(dt1 * W1^T)
         g.C = dinp; g.res = inp; g.ldres = C; g.aux = dy; g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.colpart = w.lnpart2;
         DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD, s));
+    } else if (lrs) {
+        g.C = dinp; g.res = inp; g.ldres = C; g.aux = dy; g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.colpart = w.lnpart2;
+        g.rowpart = w.rowpart; g.rowparts = w.rp_dw;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD2, s));
     } else {
         DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     }
@@ -315,9 +359,9 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(wgrad(dt1, C2, C2, sv->xn1, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
                    gr->conv1_b, sw));
     // B13: dinp = dy + LN1-backward
-    if (!lne) DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
+    if (!lne && !lrs) DCPT_TRY(launch_ln_bwd(gln, inp, sv->mu1, sv->rstd1, p->norm1_w, dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 5, s));      // LN1 partial sums
-    if (lne) DCPT_TRY(launch_colpart_reduce(w.lnpart2, ln_tiles, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+    if (lne || lrs) DCPT_TRY(launch_colpart_reduce(w.lnpart2, ln_tiles, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     else DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 3, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     DCPT_TRY(side_join(sd, s));      // the caller's stream continues only after every weight gradient is written
     return DCPT_OK;
