@@ -38,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k", "naf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--restormer-save", default="full", choices=["lean", "full"], help="what the Restormer halves keep for backward")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
@@ -113,6 +114,9 @@ def main():
     elif args.workload == "restormer":
         # configs[3]: Restormer defaults, 128x128, fwd + L1 + bwd + AdamW
         B, S = args.batch or 64, args.size or 128
+        from dcpt_amd import functional as DF
+
+        DF.set_restormer_save(args.restormer_save)
         net = fill_module_(build_network(dict(type="Restormer"))).to(dev)
         optm = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
         lq = torch.rand((B, 3, S, S), generator=g, device=dev)
@@ -125,7 +129,7 @@ def main():
 
         dt = timed(step, args.steps, args.warmup)
         flops = B * (S / 128.0) ** 2 * 232e9      # 77.45 GF fwd -> 232 GF fwd+bwd per 128^2 image
-        res = dict(workload=f"Restormer (dim 48, [4,6,6,8], BiasFree LN) fwd+L1+bwd+AdamW, B={B}, {S}x{S}, fp32",
+        res = dict(workload=f"Restormer (dim 48, [4,6,6,8], BiasFree LN) fwd+L1+bwd+AdamW, B={B}, {S}x{S}, fp32, saved tensors: {args.restormer_save}",
                    ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3),
                    alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4))
     else:

@@ -291,11 +291,13 @@ struct MdtaWs {
     float *dxn;                       // [M][c]
     float *dG, *dGT, *scr;            // [B*heads][ch][ch]
     float *scr2;                      // [3c] sink of the (non-existent) depthwise bias gradient
+    float *scr3;                      // [2M] sink of the statistics of a recomputed LayerNorm
     float *cqk;                       // [B][2c]
     float *dtpart;                    // [B*heads]
     float *slab;                      // weight-gradient slabs
     float *wpart;                     // dw partials
     float *lnpart;
+    float *r_xn, *r_qkv1, *r_out;     // lean mode: LN(x), qkv conv output, attn @ v recomputed here when the caller did not keep them
     int nblk_dw, splits_a, ln_nblk, nblk_dwb;
 };
 
@@ -308,6 +310,9 @@ size_t mdta_layout(int B, int H, int W, int c, int heads, int backward, void* ba
     w.splits_a = attn_splits(P, B * heads);
     w.w2p = a.get<float>((size_t)27 * c);
     w.gslab = a.get<float>((size_t)B * heads * w.splits_a * ch * ch);
+    w.r_xn = a.get<float>((size_t)M * c);
+    w.r_qkv1 = a.get<float>((size_t)M * 3 * c);
+    w.r_out = a.get<float>((size_t)M * c);
     if (!backward) {
         w.sqpart = a.get<float>((size_t)B * w.nblk_dw * 2 * c);
     } else {
@@ -321,6 +326,7 @@ size_t mdta_layout(int B, int H, int W, int c, int heads, int backward, void* ba
         w.dGT = a.get<float>((size_t)B * heads * ch * ch);
         w.scr = a.get<float>((size_t)B * heads * ch * ch);
         w.scr2 = a.get<float>((size_t)3 * c);
+        w.scr3 = a.get<float>((size_t)2 * M);
         w.cqk = a.get<float>((size_t)B * 2 * c);
         w.dtpart = a.get<float>((size_t)B * heads);
         int sp1, sp2;
@@ -349,6 +355,7 @@ struct GdfnWs {
     float *wT_out, *wT_in;         // backward: [hp][c], [c][2hp]
     float *dt, *da, *du, *dxn;     // [M][hp], [M][2hp], [M][2hp], [M][c]
     float *slab, *wpart, *lnpart, *gpad;
+    float *r_xn, *r_t;             // lean mode: LN(x) and gelu(x1) * x2 recomputed here when the caller did not keep them
     int ln_nblk, nblk_dwb;
 };
 
@@ -359,6 +366,8 @@ size_t gdfn_layout(int B, int H, int W, int c, int hp, int backward, void* base,
     w.wp_in = a.get<float>((size_t)2 * hp * c);
     w.w2p = a.get<float>((size_t)18 * hp);
     w.wp_out = a.get<float>((size_t)c * hp);
+    w.r_xn = a.get<float>((size_t)M * c);
+    w.r_t = a.get<float>((size_t)M * hp);
     if (backward) {
         w.wT_out = a.get<float>((size_t)hp * c);
         w.wT_in = a.get<float>((size_t)c * 2 * hp);
@@ -415,15 +424,18 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
     }
     const int64_t M = (int64_t)B * H * W;
     const int P = H * W, ch = C / heads, C3 = 3 * C;
-    DCPT_CHECK_ARG(sv->xn != nullptr, "mdta_fwd: saved.xn missing");
     // the normalised activations are materialised once (restormer_arch.py:40,59); the qkv conv and, in backward, its weight
-    // gradient then take them as plain operands (global -> LDS by DMA)
-    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, ln_eps, s));
+    // gradient then take them as plain operands (global -> LDS by DMA).  Lean mode (saved.xn / qkv1 / out_att null): they live in
+    // the workspace and the backward pass recomputes them (dcpt_hip.h).
+    float* xn = sv->xn ? sv->xn : w.r_xn;
+    float* qkv1 = sv->qkv1 ? sv->qkv1 : w.r_qkv1;
+    float* out_att = sv->out_att ? sv->out_att : w.r_out;
+    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, xn, sv->mu, sv->rstd, M, C, ln_eps, s));
     GemmNT g{};
-    g.M = M; g.A = sv->xn; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = sv->qkv1; g.ldc = C3;
+    g.M = M; g.A = xn; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = qkv1; g.ldc = C3;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     DCPT_TRY(launch_dw_pack_weights(p->dw_w, w.w2p, C3, s));
-    DCPT_TRY(launch_dw_plain_fwd(sv->qkv1, w.w2p, sv->qkv, w.sqpart, 2 * C, B, H, W, C3, s));
+    DCPT_TRY(launch_dw_plain_fwd(qkv1, w.w2p, sv->qkv, w.sqpart, 2 * C, B, H, W, C3, s));
     sq_norm_kernel<<<dim3(cdiv(B * 2 * C, 256)), dim3(256), 0, s>>>(w.sqpart, w.nblk_dw, sv->nrm, B, 2 * C);
     DCPT_CHECK_LAUNCH("sq_norm");
     // Gram matrices per (image, head)
@@ -444,13 +456,13 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
     DCPT_CHECK_LAUNCH("attn_finalize");
     // out_att[p][i] = sum_j attn[i][j] v[p][j]
     g = GemmNT{};
-    g.M = P; g.A = sv->qkv + 2 * C; g.lda = C3; g.K = ch; g.Bw = sv->attn; g.N = ch; g.C = sv->out_att; g.ldc = C;
+    g.M = P; g.A = sv->qkv + 2 * C; g.lda = C3; g.K = ch; g.Bw = sv->attn; g.N = ch; g.C = out_att; g.ldc = C;
     g.nb1 = B; g.nb2 = heads; g.sA1 = (int64_t)P * C3; g.sA2 = ch; g.sB1 = (int64_t)heads * ch * ch; g.sB2 = (int64_t)ch * ch;
     g.sC1 = (int64_t)P * C; g.sC2 = ch;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     // y = x + project_out(out_att)
     g = GemmNT{};
-    g.M = M; g.A = sv->out_att; g.lda = C; g.K = C; g.Bw = p->proj_w; g.N = C; g.C = y; g.ldc = C; g.res = x;
+    g.M = M; g.A = out_att; g.lda = C; g.K = C; g.Bw = p->proj_w; g.N = C; g.C = y; g.ldc = C; g.res = x;
     return launch_gemm_nt(g, A_PLAIN, E_RESID, s);
 }
 
@@ -479,11 +491,34 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     Side* sd = nullptr;
     hipStream_t sw = side_stream(sd, s);
     DCPT_TRY(side_fork(sd, 0, s));          // dy and the saved activations are ready
+    // lean mode: rebuild what the forward pass did not keep -- LN(x) (one bandwidth pass), the qkv conv output (the depthwise
+    // conv's tap gradients need it: one GEMM, +8 % of the block's flops) and attn @ v (a small batched GEMM)
+    const float* xn = sv->xn;
+    const float* qkv1 = sv->qkv1;
+    const float* out_att = sv->out_att;
+    if (!xn) {
+        DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, w.r_xn, w.scr3, w.scr3 + M, M, C, ln_eps, s));
+        xn = w.r_xn;
+    }
+    if (!qkv1) {
+        g.M = M; g.A = xn; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = w.r_qkv1; g.ldc = C3;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+        qkv1 = w.r_qkv1;
+        g = GemmNT{};
+    }
+    if (!out_att) {
+        g.M = P; g.A = sv->qkv + 2 * C; g.lda = C3; g.K = ch; g.Bw = sv->attn; g.N = ch; g.C = w.r_out; g.ldc = C;
+        g.nb1 = B; g.nb2 = heads; g.sA1 = (int64_t)P * C3; g.sA2 = ch; g.sB1 = (int64_t)heads * ch * ch; g.sB2 = (int64_t)ch * ch;
+        g.sC1 = (int64_t)P * C; g.sC2 = ch;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+        out_att = w.r_out;
+        g = GemmNT{};
+    }
     // B1: d_att = dy * Wproj ; dWproj = dy^T out_att
     DCPT_TRY(launch_wpack(p->proj_w, w.wT_proj, nullptr, C, C, WP_TRANSPOSE, s));
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT_proj; g.N = C; g.C = w.d_att; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(tn_reduce(dy, C, C, sv->out_att, C, C, A_PLAIN, tp, M, w.slab, gr->proj_w, sw));
+    DCPT_TRY(tn_reduce(dy, C, C, out_att, C, C, A_PLAIN, tp, M, w.slab, gr->proj_w, sw));
     // B2: dattn[i][j] = sum_p d_att[p][i] v[p][j]   (batched TN)
     GemmTN t{};
     t.M = P; t.X = w.d_att; t.ldx = C; t.N = ch; t.Y = sv->qkv + 2 * C; t.ldy = C3; t.K = ch;
@@ -520,7 +555,7 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_ADDSCALED, s));
     // B5: depthwise backward
     DCPT_TRY(launch_dw_pack_weights(p->dw_w, w.w2p, C3, s));
-    DCPT_TRY(launch_dw_generic_bwd(w.dqkv, sv->qkv1, w.w2p, w.dqkv1, w.wpart, B, H, W, C3, s));
+    DCPT_TRY(launch_dw_generic_bwd(w.dqkv, qkv1, w.w2p, w.dqkv1, w.wpart, B, H, W, C3, s));
     DCPT_TRY(side_fork(sd, 1, s));          // dqkv1, depthwise partial sums
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, C3, gr->dw_w, w.scr2 /*unused bias grad*/, sw));
     // B6: qkv 1x1
@@ -529,7 +564,7 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     g.M = M; g.A = w.dqkv1; g.lda = C3; g.K = C3; g.Bw = w.wT_qkv; g.N = C; g.C = w.dxn; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     tp = GemmTN{};
-    DCPT_TRY(tn_reduce(w.dqkv1, C3, C3, sv->xn, C, C, A_PLAIN, tp, M, w.slab, gr->qkv_w, sw));
+    DCPT_TRY(tn_reduce(w.dqkv1, C3, C3, xn, C, C, A_PLAIN, tp, M, w.slab, gr->qkv_w, sw));
     // B7: dx = dy + LN-backward
     DCPT_TRY(launch_ln_bwd_ex(w.dxn, x, sv->mu, sv->rstd, p->norm_w, dy, nullptr, nullptr, biasfree, dx, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 2, s));          // LayerNorm partial sums
@@ -562,14 +597,15 @@ extern "C" int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)18 * hp)), dim3(256), 0, s>>>(p->dw_w, w.w2p, C, hidden, hp, 1);
     gdfn_pack_kernel<<<dim3(grid_for((int64_t)C * hp)), dim3(256), 0, s>>>(p->out_w, w.wp_out, C, hidden, hp, 2);
     DCPT_CHECK_LAUNCH("gdfn_pack");
-    DCPT_CHECK_ARG(sv->xn != nullptr, "gdfn_fwd: saved.xn missing");
-    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, sv->xn, sv->mu, sv->rstd, M, C, ln_eps, s));
+    float* xn = sv->xn ? sv->xn : w.r_xn;   // lean mode: LN(x) and the gated product live in the workspace (recomputed in backward)
+    float* tg = sv->t ? sv->t : w.r_t;
+    DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, xn, sv->mu, sv->rstd, M, C, ln_eps, s));
     GemmNT g{};
-    g.M = M; g.A = sv->xn; g.lda = C; g.K = C; g.Bw = w.wp_in; g.N = 2 * hp; g.C = sv->u; g.ldc = 2 * hp;
+    g.M = M; g.A = xn; g.lda = C; g.K = C; g.Bw = w.wp_in; g.N = 2 * hp; g.C = sv->u; g.ldc = 2 * hp;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, sv->t, B, H, W, hp, s));
+    DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, tg, B, H, W, hp, s));
     g = GemmNT{};
-    g.M = M; g.A = sv->t; g.lda = hp; g.K = hp; g.Bw = w.wp_out; g.N = C; g.C = y; g.ldc = C; g.res = x;
+    g.M = M; g.A = tg; g.lda = hp; g.K = hp; g.Bw = w.wp_out; g.N = C; g.C = y; g.ldc = C; g.res = x;
     return launch_gemm_nt(g, A_PLAIN, E_RESID, s);
 }
 
@@ -601,10 +637,20 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
     Side* sd = nullptr;                     // see dcpt_mdta_bwd: no side stream for the Restormer blocks
     hipStream_t sw = side_stream(sd, s);
     DCPT_TRY(side_fork(sd, 0, s));          // dy and the saved activations are ready
+    const float* xn = sv->xn;
+    const float* tg = sv->t;
+    if (!xn) {   // lean mode: rebuild LN(x) (statistics discarded into du, which is written later) and gelu(x1) * x2
+        DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, w.r_xn, w.du, w.du + M, M, C, ln_eps, s));
+        xn = w.r_xn;
+    }
+    if (!tg) {
+        DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, w.r_t, B, H, W, hp, s));
+        tg = w.r_t;
+    }
     // dt = dy * Wout ; dWout = dy^T t
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT_out; g.N = hp; g.C = w.dt; g.ldc = hp;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(tn_reduce(dy, C, C, sv->t, hp, hp, A_PLAIN, tp, M, w.slab, g_out, sw));
+    DCPT_TRY(tn_reduce(dy, C, C, tg, hp, hp, A_PLAIN, tp, M, w.slab, g_out, sw));
     gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, sw>>>(g_out, gr->out_w, C, hidden, hp, 2);
     DCPT_CHECK_LAUNCH("gdfn_unpack_out");
     // gate backward, depthwise backward
@@ -619,7 +665,7 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
     g.M = M; g.A = w.du; g.lda = 2 * hp; g.K = 2 * hp; g.Bw = w.wT_in; g.N = C; g.C = w.dxn; g.ldc = C;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     tp = GemmTN{};
-    DCPT_TRY(tn_reduce(w.du, 2 * hp, 2 * hp, sv->xn, C, C, A_PLAIN, tp, M, w.slab, g_in, sw));
+    DCPT_TRY(tn_reduce(w.du, 2 * hp, 2 * hp, xn, C, C, A_PLAIN, tp, M, w.slab, g_in, sw));
     gdfn_unpack_kernel<<<dim3(grid_for((int64_t)2 * hidden * C)), dim3(256), 0, sw>>>(g_in, gr->in_w, C, hidden, hp, 0);
     DCPT_CHECK_LAUNCH("gdfn_unpack_in");
     DCPT_TRY(launch_ln_bwd_ex(w.dxn, x, sv->mu, sv->rstd, p->norm_w, dy, nullptr, nullptr, biasfree, dx, w.lnpart, w.ln_nblk, M, C, s));

@@ -178,3 +178,38 @@ def test_directional_derivative_full_size(dev):
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert abs(analytic) > 1e-4, analytic
     assert abs(numeric - analytic) <= 3e-2 * abs(analytic), (numeric, analytic, float(loss))
+
+
+def test_lean_saved_tensors_equal_full(dev):
+    """LEAN mode (DCPT_RESTORMER_SAVE=lean: LN(x), the qkv conv output, attn @ v and the GDFN gate product are recomputed in backward instead of
+    kept) gives bit-identical outputs and gradients to FULL mode -- the recomputation runs the same kernels on the same inputs --
+    and keeps fewer bytes alive between forward and backward."""
+    from basicsr.archs import build_network
+    from dcpt_amd import functional as DF
+
+    shapes = {k: tuple(v.shape) for k, v in build_network(dict(type="Restormer", **R_CFG)).state_dict().items()}
+    sd = keyed_state_dict(shapes, seed=0)
+    x = keyed_input("lean.x", (2, 3, 32, 32)).to(dev)
+    res = {}
+    prev = DF.set_restormer_save("full")
+    try:
+        for mode in ("full", "lean"):
+            DF.set_restormer_save(mode)
+            net = build_network(dict(type="Restormer", **R_CFG))
+            net.load_state_dict(sd, strict=True)
+            net = net.to(dev)
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            y = net(x)
+            torch.cuda.synchronize()
+            held = torch.cuda.memory_allocated() - base
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}, held)
+            del net, y
+    finally:
+        DF.set_restormer_save(prev)
+    assert torch.equal(res["full"][0], res["lean"][0])
+    for k in res["full"][1]:
+        assert torch.equal(res["full"][1][k], res["lean"][1][k]), k
+    assert res["lean"][2] < 0.7 * res["full"][2], (res["lean"][2], res["full"][2])
