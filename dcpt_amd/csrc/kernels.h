@@ -57,6 +57,11 @@ int launch_lnvec(const LnVecJobs& jobs, hipStream_t s);
 // dw2[ch*9+tap] and db2[ch] from wpart[R][10][C2]
 int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float* db2, hipStream_t s);
 
+// dwring.hip: the same forward on an LDS-DMA row ring (fp32 / bf16 storage); pool_part[B][dw_ring_num_blocks_per_image][C]
+bool dw_ring_usable(const DwGeom& g, int elem_bytes);
+int dw_ring_num_blocks_per_image(const DwGeom& g, int elem_bytes);
+int launch_dw_ring_fwd_f32(const float* t1, const float* w2p, const float* b2, float* t2, float* pool_part, const DwGeom& g, hipStream_t s);
+
 // generic depthwise pieces (Restormer): w2p is the [9][Ctot] packed weight (launch_dw_pack_weights)
 int dw_num_blocks_generic(int B, int H, int W, int Ctot);
 // t[M][Ch] = gelu(dw(u)[:, :Ch]) * dw(u)[:, Ch:]   (u has 2*Ch channels, no bias)

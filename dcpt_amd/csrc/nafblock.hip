@@ -31,7 +31,7 @@ struct FwdWs {
 size_t fwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWs* out) {
     WsAlloc a(base, base ? bytes : (size_t)-1);
     DwGeom g{B, H, W, C};
-    const int nblk = dw_num_blocks_per_image(g);
+    const int nblk = dw_ring_usable(g, 4) ? dw_ring_num_blocks_per_image(g, 4) : dw_num_blocks_per_image(g);
     float* w2p = a.get<float>((size_t)9 * 2 * C);
     float* pp = a.get<float>((size_t)B * nblk * C);
     if (out) {
@@ -187,7 +187,8 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     // t2 = SG(dw(t1)+b2) and pooling partials
     DwGeom dg{B, H, W, C};
     DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
-    DCPT_TRY(launch_dw_fwd(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
+    if (dw_ring_usable(dg, 4)) DCPT_TRY(launch_dw_ring_fwd_f32(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
+    else DCPT_TRY(launch_dw_fwd(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
     // y = inp + (conv3(t2*s)+b3)*beta
     g = GemmNT{};

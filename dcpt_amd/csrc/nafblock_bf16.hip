@@ -33,7 +33,7 @@ size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* 
     WsAlloc a(base, base ? bytes : (size_t)-1);
     DwGeom g{B, H, W, C};
     FwdWsB w{};
-    w.nblk_pool = dw_num_blocks_per_image_bf16(g);
+    w.nblk_pool = dw_ring_usable(g, 2) ? dw_ring_num_blocks_per_image(g, 2) : dw_num_blocks_per_image_bf16(g);
     w.w2p = a.get<float>((size_t)18 * C);
     w.pool_part = a.get<float>((size_t)B * w.nblk_pool * C);
     w.W1 = a.get<bf16_t>((size_t)2 * C * C);
@@ -149,7 +149,8 @@ extern "C" int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint1
     DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIAS, s));
     DwGeom dg{B, H, W, C};
     DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
-    DCPT_TRY(launch_dw_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
+    if (dw_ring_usable(dg, 2)) DCPT_TRY(launch_dw_ring_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
+    else DCPT_TRY(launch_dw_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
     // y = inp + (conv3(t2 * s) + b3) * beta: the per-image scale lives in the weights, one GEMM problem per image
     j = WpackBJobs{};
