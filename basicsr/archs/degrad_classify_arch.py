@@ -7,6 +7,10 @@ embedding of ``lq``, so its feature maps start at half the image resolution).  E
 autograd node backed by ``dcpt_conv_ln_fwd/bwd`` (1x1 and dense 3x3 convolutions run as fp32 MFMA GEMMs, the 3x3
 as an implicit GEMM), the downsample layers by ``dcpt_conv1x1_pool_relu_*``, the softmax feature mixing by
 ``dcpt_mix_*`` and the head by ``dcpt_meanpool_fc_*``.  Child modules only own the parameters.
+
+``act_dtype="bf16"`` (an extension; the reference computes in fp32 only): the bottleneck groups and the downsample layers run on
+the bf16-storage kernels (``dcpt_conv_ln_*_bf16``, ``dcpt_conv1x1_pool_relu_*_bf16``: bf16 activations, fp32 parameters and
+accumulation); the mixing step and mean + Linear stay fp32 behind casts.  Needs feature_dims that are multiples of 8.
 """
 from __future__ import annotations
 
@@ -38,6 +42,8 @@ class Conv2d(nn.Conv2d):
         self.norm = norm
 
     def fused(self, x, res=None, relu=True):
+        if x.dtype == torch.bfloat16:
+            return DF.conv_ln_bf16(x, self.weight, self.norm.weight, self.norm.bias, res, relu)
         return DF.conv_ln(x, self.weight, self.norm.weight, self.norm.bias, res, relu)
 
 
@@ -68,6 +74,8 @@ class _Downsample(nn.Sequential):
     """Conv2d(1x1, bias=False) -> MaxPool2d(2,2) -> ReLU as one op (reference :596-602)."""
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16:
+            return DF.conv1x1_pool_relu_bf16(x, self[0].weight)
         return DF.conv1x1_pool_relu(x, self[0].weight)
 
 
@@ -89,23 +97,36 @@ class _DCHead(nn.Module):
         self.mixing_weights = nn.Parameter(torch.ones(len(self.bottleneck_layers)), requires_grad=True)
         self.fc = nn.Linear(last, num_classes)
 
+    act_dtype = "fp32"
+
+    def _set_act_dtype(self, act_dtype):
+        if act_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"act_dtype must be 'fp32' or 'bf16', got {act_dtype!r}")
+        if act_dtype == "bf16" and any(d % 8 for d in self.feature_dims):
+            raise ValueError("act_dtype='bf16' needs feature_dims that are multiples of 8")
+        self.act_dtype = act_dtype
+
     def _run_stages(self, x, features):
+        bf = self.act_dtype == "bf16"
         for i, feature in enumerate(features):
-            x = DF.mix(x, feature, self.mixing_weights, i)
+            x = DF.mix(None if x is None else DF.to_f32(x), DF.to_f32(feature), self.mixing_weights, i)   # fp32: one pass per stage
+            if bf:
+                x = DF.to_bf16(x)
             x = self.bottleneck_layers[i](x)
             x = self.downsample_layers[i](x)
         x = self.last_stage(x)
-        return DF.meanpool_fc(x, self.fc.weight, self.fc.bias)
+        return DF.meanpool_fc(DF.to_f32(x), self.fc.weight, self.fc.bias)
 
 
 @ARCH_REGISTRY.register()
 class PromptIR_NoImg_DC(_DCHead):
-    def __init__(self, feature_dims, num_res_blocks=2, num_classes=3, downsample=False):
+    def __init__(self, feature_dims, num_res_blocks=2, num_classes=3, downsample=False, act_dtype="fp32"):
         super().__init__()
         if downsample:
             raise NotImplementedError("downsample=True (token inputs) is not on the DCPT path")
         self.downsample = downsample
         self._build_stages(feature_dims, num_res_blocks, num_classes)
+        self._set_act_dtype(act_dtype)
 
     def forward(self, lq, features):
         """``lq`` is accepted and ignored, exactly like the reference (:621)."""

@@ -38,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k", "naf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--head-dtype", default=None, choices=["fp32", "bf16"], help="dcpt: classifier-head activations (default: --dtype)")
     ap.add_argument("--restormer-save", default="full", choices=["lean", "full"], help="what the Restormer halves keep for backward")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -86,7 +87,8 @@ def main():
 
         opt = dict(name="b", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
                    hook_names="decoder", network_g=dict(type="NAFNetBaseline", **naf),
-                   network_dc=dict(type="PromptIR_NoImg_DC", feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10),
+                   network_dc=dict(type="PromptIR_NoImg_DC", feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10,
+                                   act_dtype=args.head_dtype or args.dtype),
                    path=dict(), train=dict(pixel_opt=dict(type="L1Loss"), classify_opt=dict(type="CrossEntropyLoss"),
                                            optim_g=dict(type="AdamW", lr=1e-4, fused=True), optim_dc=dict(type="AdamW", lr=1e-4, fused=True)))
         m = build_model(opt)
@@ -99,16 +101,17 @@ def main():
         sc = B * (S / 256.0) ** 2
         flops = sc * 1.315e12   # 1.315 TFLOP fwd+bwd per 256^2 image (2 x 378.3 GF encoder + 558.9 GF head)
         res = dict(workload=f"DCPT step: NAFNet-64 x2 fwd + PromptIR_NoImg_DC head + bwd + 2x AdamW, B={B}, {S}x{S}, "
-                            f"NAFBlock activations {args.dtype}, head fp32",
+                            f"NAFBlock activations {args.dtype}, head {args.head_dtype or args.dtype}",
                    ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3), log=m.get_current_log())
         if bf:
             # two rooflines for the mixed step: the encoder's flops on the bf16 pipe + the head's on the fp32 pipe (time bound),
             # and the encoder's bf16 algorithmic bytes (the head's bytes are not in SURVEY 8d and are left out: a lower bound)
-            t_mfma = sc * (2 * 378.3e9 / 2.5e15 + 558.9e9 / 157.3e12)
+            head_peak = 2.5e15 if (args.head_dtype or args.dtype) == "bf16" else 157.3e12
+            t_mfma = sc * (2 * 378.3e9 / 2.5e15 + 558.9e9 / head_peak)
             t_hbm = sc * 2 * naf_bytes / 8e12
             res.update(alg_tflops=round(flops / dt / 1e12, 2), mfma_time_bound_ms=round(t_mfma * 1e3, 2), mfma_frac=round(t_mfma / dt, 4),
                        hbm_time_bound_ms_encoder_only=round(t_hbm * 1e3, 2), hbm_frac=round(t_hbm / dt, 4),
-                       note="fractions = time bound / measured step; encoder bf16 (2.5 PF, bf16 bytes), head fp32 (157.3 TF)")
+                       note="fractions = time bound / measured step; encoder bf16 (2.5 PF, bf16 bytes), head on its own pipe's peak")
         else:
             res.update(alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4))
     elif args.workload == "restormer":

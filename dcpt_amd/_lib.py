@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 _lock = threading.Lock()
 
@@ -91,6 +91,15 @@ SIGNATURES = {
                                       f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_cast_f32_bf16": (cint, [f32p, f32p, i64, stream_t]),
     "dcpt_cast_bf16_f32": (cint, [f32p, f32p, i64, stream_t]),
+    "dcpt_conv_ln_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint, cint]),
+    "dcpt_conv_ln_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, cint, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint,
+                                     cint, cint, cint, stream_t]),
+    "dcpt_conv_ln_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz,
+                                     cint, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv1x1_pool_relu_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
+    "dcpt_conv1x1_pool_relu_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv1x1_pool_relu_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,
+                                               stream_t]),
     "dcpt_nafblock_local_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
     "dcpt_nafblock_local_fwd": (cint, [C.POINTER(NafBlockParams), f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint,
                                        stream_t]),

@@ -85,6 +85,9 @@ struct GemmNTB {
     // grid.y = nb independent problems (one per image): element offsets b * s?
     int nb;
     int64_t sA, sB, sC, sR;
+    // conv3 != 0: implicit GEMM of a dense 3x3 (zero pad 1): A is the NHWC image [.][gH][gW][gC], K = 9 * gC, column index
+    // = tap * gC + ch, tap = 3 ky + kx  <->  pixel (h + ky - 1, w + kx - 1); gC % 8 == 0 (a 16-byte chunk never straddles taps)
+    int conv3, gH, gW, gC;
 };
 int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
 
@@ -99,6 +102,8 @@ struct GemmTNB {
     int N, K, ldx, ldy;
     int splits;
     int64_t rows_per_split;
+    // yconv != 0: Y is gathered like GemmNTB's conv3 operand (weight gradient of a dense 3x3): K = 9 * gC
+    int yconv, gH, gW, gC;
 };
 int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s);
 int gemm_tn_bf16_tiles_k(int N, int K);

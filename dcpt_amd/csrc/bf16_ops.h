@@ -9,11 +9,18 @@ int ln_bwd_bf16_num_blocks(int64_t M, int C);
 // part: [nblk][2][C] fp32 (0: sum gy*xhat -> dweight, 1: sum gy -> dbias); reduce with launch_colpart_reduce(part, nblk, 2, C, ...)
 int launch_ln_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* dres, bf16_t* dx,
                        float* part, int nblk, int64_t M, int C, hipStream_t s);
+// channels-first LayerNorm of the classifier head with its fused tail / head: y = [relu](LN(x) * w + b [+ res]);
+// backward: gy masked by (ymask > 0) (and copied to gmasked for the shortcut branch) before the LayerNorm backward
+int launch_ln_act_fwd_bf16(const bf16_t* x, const float* w, const float* b, const bf16_t* res, int relu, bf16_t* y, float* mu, float* rstd,
+                           int64_t M, int C, float eps, hipStream_t s);
+int launch_ln_act_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* ymask,
+                           bf16_t* gmasked, bf16_t* dx, float* part, int nblk, int64_t M, int C, hipStream_t s);
 int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
 
 constexpr int WPACKB_MAX_JOBS = 8;
-struct WpackBJobs {   // job j: in [N][K] fp32 ->  transpose ? out[k][n] = in[n][k] * rs[n]  :  out[img][n][k] = in[n][k] * kscale[img][k]
+struct WpackBJobs {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
+                      // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
     const float* in[WPACKB_MAX_JOBS];
     bf16_t* out[WPACKB_MAX_JOBS];
     const float* rs[WPACKB_MAX_JOBS];

@@ -34,7 +34,7 @@ __host__ __device__ inline int lnb_group(int C) {
 template <int NQ>
 __global__ __launch_bounds__(256) void ln_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                           bf16_t* __restrict__ y, float* __restrict__ mu, float* __restrict__ rstd, int64_t M,
-                                                          int C, float eps, int G) {
+                                                          int C, float eps, int G, const bf16_t* __restrict__ res, int relu) {
     const int tid = threadIdx.x, gpb = 256 / G, lig = tid % G, nq = C / 8;
     f8 ww[NQ], bb[NQ];
 #pragma unroll
@@ -79,7 +79,13 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_kernel(const bf16_t* __restri
         for (int i = 0; i < NQ; ++i) {
             const int q = lig + i * G;
             const f8 r8 = f8{make_float4(rs, rs, rs, rs), make_float4(rs, rs, rs, rs)};
-            st8(yr + 8 * q, valid && q < nq, f8_fma(f8_mul(v[i], r8), ww[i], bb[i]));
+            f8 o = f8_fma(f8_mul(v[i], r8), ww[i], bb[i]);
+            if (res) o = f8_add(o, ld8(res + (valid ? row : 0) * (int64_t)C + 8 * q, valid && q < nq));   // channels-first LN + shortcut
+            if (relu) {
+                o.lo = make_float4(fmaxf(o.lo.x, 0.f), fmaxf(o.lo.y, 0.f), fmaxf(o.lo.z, 0.f), fmaxf(o.lo.w, 0.f));
+                o.hi = make_float4(fmaxf(o.hi.x, 0.f), fmaxf(o.hi.y, 0.f), fmaxf(o.hi.z, 0.f), fmaxf(o.hi.w, 0.f));
+            }
+            st8(yr + 8 * q, valid && q < nq, o);
         }
     }
 }
@@ -89,7 +95,8 @@ template <int NQ>
 __global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ mu,
                                                           const float* __restrict__ rstd, const float* __restrict__ w,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ part,
-                                                          int64_t M, int C, int G, int64_t iters) {
+                                                          int64_t M, int C, int G, int64_t iters, const bf16_t* __restrict__ ymask,
+                                                          bf16_t* __restrict__ gmasked) {
     __shared__ float red[2][256 * 8 * NQ];
     const int tid = threadIdx.x, gpb = 256 / G, gid = tid / G, lig = tid % G, nq = C / 8;
     f8 ww[NQ], aw[NQ], ab[NQ];
@@ -113,6 +120,14 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const bf16_t* __restri
             const int q = lig + i * G;
             const bool ok = valid && q < nq;
             g[i] = ld8(gy + ro + 8 * q, ok);
+            if (ymask) {   // ReLU behind the LayerNorm: the gradient passes where the (post-ReLU) output is > 0
+                const f8 ym = ld8(ymask + ro + 8 * q, ok);
+                g[i].lo = make_float4(ym.lo.x > 0.f ? g[i].lo.x : 0.f, ym.lo.y > 0.f ? g[i].lo.y : 0.f, ym.lo.z > 0.f ? g[i].lo.z : 0.f,
+                                      ym.lo.w > 0.f ? g[i].lo.w : 0.f);
+                g[i].hi = make_float4(ym.hi.x > 0.f ? g[i].hi.x : 0.f, ym.hi.y > 0.f ? g[i].hi.y : 0.f, ym.hi.z > 0.f ? g[i].hi.z : 0.f,
+                                      ym.hi.w > 0.f ? g[i].hi.w : 0.f);
+            }
+            if (gmasked) st8(gmasked + ro + 8 * q, ok, g[i]);   // the shortcut branch receives the masked gradient
             const f8 xv = ld8(x + ro + 8 * q, ok);
             dr[i] = dres ? ld8(dres + ro + 8 * q, ok) : f8_zero();
             xh[i].lo = make_float4((xv.lo.x - mean) * rs, (xv.lo.y - mean) * rs, (xv.lo.z - mean) * rs, (xv.lo.w - mean) * rs);
@@ -202,9 +217,19 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobs jobs) 
         const int64_t img = i / ((int64_t)N * K);
         const int64_t e = i % ((int64_t)N * K);
         float v;
-        if (jobs.transpose[j]) {   // out[k][n] = in[n][k] * rs[n]
+        if (jobs.transpose[j] == 1) {   // out[k][n] = in[n][k] * rs[n]
             const int k = (int)(e / N), n = (int)(e % N);
             v = in[(int64_t)n * K + k] * (rs ? rs[n] : 1.f);
+        } else if (jobs.transpose[j] == 2) {   // dense 3x3, N = Co, K = 9 Ci: out[oc][tap * Ci + ic] = in[(oc * Ci + ic) * 9 + tap]
+            const int Ci = K / 9;
+            const int oc = (int)(e / K), r = (int)(e % K);
+            const int tap = r / Ci, ic = r % Ci;
+            v = in[((int64_t)oc * Ci + ic) * 9 + tap];
+        } else if (jobs.transpose[j] == 3) {   // its transposed conv: out[ic][tap * Co + oc] = in[(oc * Ci + ic) * 9 + 8 - tap]
+            const int Ci = K / 9, Co = N;
+            const int ic = (int)(e / (9 * Co)), r = (int)(e % (9 * Co));
+            const int tap = r / Co, oc = r % Co;
+            v = in[((int64_t)oc * Ci + ic) * 9 + (8 - tap)];
         } else {                   // out[img][n][k] = in[n][k] * kscale[img][k]
             const int k = (int)(e % K);
             v = in[e] * (ks ? ks[img * K + k] : 1.f);
@@ -294,9 +319,21 @@ int launch_ln_fwd_bf16(const bf16_t* x, const float* w, const float* b, bf16_t* 
     const int G = lnb_group(C), gpb = 256 / G;
     int64_t nb = cdiv64(M, gpb);
     if (nb > 8192) nb = 8192;
-    if (C / 8 <= G) ln_fwd_bf16_kernel<1><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G);
-    else ln_fwd_bf16_kernel<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G);
+    if (C / 8 <= G) ln_fwd_bf16_kernel<1><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G, nullptr, 0);
+    else ln_fwd_bf16_kernel<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G, nullptr, 0);
     DCPT_CHECK_LAUNCH("ln_fwd_bf16");
+    return DCPT_OK;
+}
+
+int launch_ln_act_fwd_bf16(const bf16_t* x, const float* w, const float* b, const bf16_t* res, int relu, bf16_t* y, float* mu, float* rstd,
+                           int64_t M, int C, float eps, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_act_fwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
+    const int G = lnb_group(C), gpb = 256 / G;
+    int64_t nb = cdiv64(M, gpb);
+    if (nb > 8192) nb = 8192;
+    if (C / 8 <= G) ln_fwd_bf16_kernel<1><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G, res, relu);
+    else ln_fwd_bf16_kernel<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(x, w, b, y, mu, rstd, M, C, eps, G, res, relu);
+    DCPT_CHECK_LAUNCH("ln_act_fwd_bf16");
     return DCPT_OK;
 }
 
@@ -305,9 +342,20 @@ int launch_ln_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const
     DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_bwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
     const int G = lnb_group(C), gpb = 256 / G;
     const int64_t iters = cdiv64(M, (int64_t)nblk * gpb);
-    if (C / 8 <= G) ln_bwd_bf16_kernel<1><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, dres, dx, part, M, C, G, iters);
-    else ln_bwd_bf16_kernel<2><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, dres, dx, part, M, C, G, iters);
+    if (C / 8 <= G) ln_bwd_bf16_kernel<1><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, dres, dx, part, M, C, G, iters, nullptr, nullptr);
+    else ln_bwd_bf16_kernel<2><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, dres, dx, part, M, C, G, iters, nullptr, nullptr);
     DCPT_CHECK_LAUNCH("ln_bwd_bf16");
+    return DCPT_OK;
+}
+
+int launch_ln_act_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* ymask,
+                           bf16_t* gmasked, bf16_t* dx, float* part, int nblk, int64_t M, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_act_bwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
+    const int G = lnb_group(C), gpb = 256 / G;
+    const int64_t iters = cdiv64(M, (int64_t)nblk * gpb);
+    if (C / 8 <= G) ln_bwd_bf16_kernel<1><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, nullptr, dx, part, M, C, G, iters, ymask, gmasked);
+    else ln_bwd_bf16_kernel<2><<<dim3(nblk), dim3(256), 0, s>>>(gy, x, mu, rstd, w, nullptr, dx, part, M, C, G, iters, ymask, gmasked);
+    DCPT_CHECK_LAUNCH("ln_act_bwd_bf16");
     return DCPT_OK;
 }
 

@@ -125,7 +125,7 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EK>
+template <int BM, int BN, int WM, int WN, int EK, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
     static_assert(WM * WN == 4, "4 waves");
     GemmNTB p = pin;
@@ -155,16 +155,32 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
     const int64_t m0 = (int64_t)(lin / tilesN) * BM;
     const int n0 = (lin % tilesN) * (GATE ? BN / 2 : BN);
 
-    const i32x4 rsA = make_rsrc_dma(p.A + (m0 < p.M ? m0 : 0) * (int64_t)p.lda);
+    // conv3: the window starts one image row + one pixel before the tile's first pixel (clipped at the tensor start)
+    int64_t apix0 = (m0 < p.M ? m0 : 0);
+    if constexpr (CONV) {
+        apix0 -= p.gW + 1;
+        if (apix0 < 0) apix0 = 0;
+    }
+    const i32x4 rsA = make_rsrc_dma(p.A + apix0 * (int64_t)(CONV ? p.gC : p.lda));
     const i32x4 rsB = make_rsrc_dma(p.Bw + (GATE ? 0 : (int64_t)n0 * p.K));
     // staging map: thread -> row (tid >> 3) + 32 * pass, LDS slot tid & 7 = logical 16-byte chunk slot ^ ((row >> 1) & 7)
     const int lrow = tid >> 3;
     const int lk = 8 * ((tid & 7) ^ ((tid >> 4) & 7));   // first k element of this thread's chunk inside a k-tile
     uint32_t aoff[A_IT], boff[B_IT];
+    int ah[A_IT], aw[A_IT];   // conv3: pixel coordinates of this thread's rows
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int r = lrow + 32 * i;
-        aoff[i] = (m0 + r < p.M) ? ((uint32_t)r * (uint32_t)p.lda + (uint32_t)lk) * 2u : ROW_SENT;
+        if constexpr (CONV) {
+            const int64_t m = m0 + r;
+            const bool ok = m < p.M;
+            const int64_t mm = ok ? m : 0;
+            aw[i] = (int)(mm % p.gW);
+            ah[i] = ok ? (int)((mm / p.gW) % p.gH) : -100000;   // invalid row: every tap out of bounds
+            aoff[i] = (uint32_t)((mm - apix0) * p.gC) * 2u;
+        } else {
+            aoff[i] = (m0 + r < p.M) ? ((uint32_t)r * (uint32_t)p.lda + (uint32_t)lk) * 2u : ROW_SENT;
+        }
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -183,8 +199,21 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
         const uint32_t ksent = (kt * KT + lk < p.K) ? 0u : COL_SENT;   // ragged K: only the last k-tile (K % 8 == 0)
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) dma16(rsB, lds_b + buf * B_BYTES + i * 4096, boff[i] + ksent, (uint32_t)kt * 128u);
+        if constexpr (CONV) {
+            const int k = kt * KT + lk;
+            const int tap = k / p.gC, ch = k - tap * p.gC;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int shift = ((ky - 1) * p.gW + (kx - 1)) * p.gC + ch;   // elements, relative to the row's own pixel
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) dma16(rsA, lds_a + buf * A_BYTES + i * 4096, aoff[i] + ksent, (uint32_t)kt * 128u);
+            for (int i = 0; i < A_IT; ++i) {
+                const int hh = ah[i] + ky - 1, ww = aw[i] + kx - 1;
+                const bool ok = k < p.K && hh >= 0 && hh < p.gH && ww >= 0 && ww < p.gW;
+                dma16(rsA, lds_a + buf * A_BYTES + i * 4096, ok ? aoff[i] + (uint32_t)(shift * 2) : COL_SENT, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) dma16(rsA, lds_a + buf * A_BYTES + i * 4096, aoff[i] + ksent, (uint32_t)kt * 128u);
+        }
     };
 
     floatx16 acc[TM][TN];
@@ -249,6 +278,14 @@ int launch_nt(const GemmNTB& p, hipStream_t s) {
     constexpr bool GATE = (EK == EB_BIASGATE);
     const unsigned nb = (unsigned)(p.nb > 0 ? p.nb : 1);
     const int ncols = GATE ? p.N / 2 : p.N;
+    if constexpr (EK == EB_PLAIN) {
+        if (p.conv3) {
+            if (ncols <= 64) gemm_nt_bf16_kernel<128, 64, 4, 1, EK, true><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 64)), nb), dim3(256), 0, s>>>(p);
+            else gemm_nt_bf16_kernel<128, 128, 2, 2, EK, true><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 128)), nb), dim3(256), 0, s>>>(p);
+            DCPT_CHECK_LAUNCH("gemm_nt_bf16 conv3");
+            return DCPT_OK;
+        }
+    }
     if (ncols <= (GATE ? 32 : 64)) {
         const int64_t tiles = cdiv64(p.M, 128) * cdiv(ncols, GATE ? 32 : 64);
         gemm_nt_bf16_kernel<128, 64, 4, 1, EK><<<dim3((unsigned)tiles, nb), dim3(256), 0, s>>>(p);
@@ -283,7 +320,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int mrow, i
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int BN, int BKo, int WN, int WK>
+template <int BN, int BKo, int WN, int WK, bool YCONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
     static_assert(WN * WK == 4, "4 waves");
     constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
@@ -307,12 +344,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
     if (mend > p.M) mend = p.M;
     const int64_t mw = mbeg < p.M ? mbeg : 0;
     const i32x4 rsX = make_rsrc_dma(p.X + mw * (int64_t)p.ldx);
-    const i32x4 rsY = make_rsrc_dma(p.Y + mw * (int64_t)p.ldy);
+    int64_t ypix0 = mw;   // gathered Y: the window starts one image row + one pixel before the chunk (clipped at the tensor start)
+    if constexpr (YCONV) {
+        ypix0 -= p.gW + 1;
+        if (ypix0 < 0) ypix0 = 0;
+    }
+    const i32x4 rsY = make_rsrc_dma(p.Y + ypix0 * (int64_t)(YCONV ? p.gC : p.ldy));
 
     // staging: pass i, thread tid writes tile bytes [4096 i + 16 tid, +16): row = (256 i + tid) / chunks-per-row, chunk POSITION
     // cp = (256 i + tid) % chunks-per-row, which holds source chunk cp ^ swz(row)
     int xrow[X_IT], yrow[Y_IT];
     uint32_t xfix[X_IT], yfix[Y_IT];
+    int yky[Y_IT], ykx[Y_IT];   // gathered Y: the tap of this thread's chunk in pass i (fixed for the whole launch)
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
         const int e = 256 * i + tid;
@@ -325,7 +368,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
         const int e = 256 * i + tid;
         yrow[i] = e / YCH;
         const int c = (e % YCH) ^ tn_swz<BKo>(yrow[i]);
-        yfix[i] = (k0 + 8 * c < p.K) ? ((uint32_t)yrow[i] * (uint32_t)p.ldy + (uint32_t)(k0 + 8 * c)) * 2u : COL_SENT;
+        if constexpr (YCONV) {
+            const int k = k0 + 8 * c;
+            const int tap = k / p.gC, ch = k - tap * p.gC;
+            yky[i] = tap / 3;
+            ykx[i] = tap - 3 * yky[i];
+            // offset of (tap, ch) relative to the row's own pixel, in elements (may be negative: added to the pixel offset below)
+            yfix[i] = (k < p.K) ? (uint32_t)(((yky[i] - 1) * p.gW + (ykx[i] - 1)) * p.gC + ch) : COL_SENT;
+        } else {
+            yfix[i] = (k0 + 8 * c < p.K) ? ((uint32_t)yrow[i] * (uint32_t)p.ldy + (uint32_t)(k0 + 8 * c)) * 2u : COL_SENT;
+        }
     }
     const uint32_t lds_x = lds_addr(reinterpret_cast<const float*>(&Xs[0][0])) + wave * 1024;
     const uint32_t lds_y = lds_addr(reinterpret_cast<const float*>(&Ys[0][0])) + wave * 1024;
@@ -335,9 +387,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
 #pragma unroll
         for (int i = 0; i < X_IT; ++i)
             dma16(rsX, lds_x + buf * XB + i * 4096, (xrow[i] < left) ? xfix[i] : ROW_SENT, step * (uint32_t)p.ldx * 2u);
+        if constexpr (YCONV) {
 #pragma unroll
-        for (int i = 0; i < Y_IT; ++i)
-            dma16(rsY, lds_y + buf * YB + i * 4096, (yrow[i] < left) ? yfix[i] : ROW_SENT, step * (uint32_t)p.ldy * 2u);
+            for (int i = 0; i < Y_IT; ++i) {
+                const int64_t m = mt + yrow[i];
+                const int w = (int)(m % p.gW), h = (int)((m / p.gW) % p.gH);
+                const int hh = h + yky[i] - 1, ww = w + ykx[i] - 1;
+                const bool ok = yrow[i] < left && yfix[i] != COL_SENT && hh >= 0 && hh < p.gH && ww >= 0 && ww < p.gW;
+                dma16(rsY, lds_y + buf * YB + i * 4096, ok ? (uint32_t)(((int64_t)(m - ypix0) * p.gC + (int)yfix[i]) * 2) : ROW_SENT, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < Y_IT; ++i)
+                dma16(rsY, lds_y + buf * YB + i * 4096, (yrow[i] < left) ? yfix[i] : ROW_SENT, step * (uint32_t)p.ldy * 2u);
+        }
     };
 
     floatx16 acc[TN][TK];
@@ -416,6 +479,9 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     DCPT_CHECK_ARG(p.A && p.Bw && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt_bf16: null operand or empty problem");
     DCPT_CHECK_ARG(p.K % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldc % 8 == 0 && p.ldres % 8 == 0,
                    "gemm_nt_bf16: K=%d, N=%d and the row strides must be multiples of 8 (16-byte rows)", p.K, p.N);
+    if (p.conv3)
+        DCPT_CHECK_ARG(epi == EB_PLAIN && p.gC % 8 == 0 && p.K == 9 * p.gC && p.nb == 1 && (double)(130 + 2 * p.gW + 2) * p.gC * 2.0 < 1.0e9,
+                       "gemm_nt_bf16: conv3 needs the plain epilogue, K == 9 * gC, gC %% 8 == 0");
     DCPT_CHECK_ARG(p.K < (1 << 20) && p.N < (1 << 20) && p.lda < (1 << 20) && p.ldc < (1 << 20) && (double)p.N * p.K * 2.0 < 1.0e9,
                    "gemm_nt_bf16: K/N/row strides out of the 32-bit window range");
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 32) < (1ll << 31), "gemm_nt_bf16: grid too large");
@@ -481,12 +547,21 @@ int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s) {
     DCPT_CHECK_ARG(p.splits >= 1 && p.splits <= 65535 && p.rows_per_split >= 1, "gemm_tn_bf16: bad split plan");
     DCPT_CHECK_ARG((double)(p.rows_per_split + 64) * (double)(p.ldx > p.ldy ? p.ldx : p.ldy) * 2.0 < 1.0e9 && (double)p.N * p.K < 2.0e8,
                    "gemm_tn_bf16: pixel chunk or slab too large for 32-bit window offsets");
+    if (p.yconv)
+        DCPT_CHECK_ARG(p.gC % 8 == 0 && p.K == 9 * p.gC && p.colsum == nullptr && (double)(p.rows_per_split + 66 + 2 * p.gW) * p.gC * 2.0 < 1.0e9,
+                       "gemm_tn_bf16: gathered Y needs K == 9 * gC, gC %% 8 == 0, no column sums");
     const double bytes = ((double)p.M * p.N + (double)p.M * p.K) * 2.0 + (double)p.splits * p.N * p.K * 4.0;
     ProfScope prof(s, PROF_TN + 256, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K, bytes);
     int bn, bk;
     tn_shape(p.N, p.K, &bn, &bk);
     const int tiles = cdiv(p.N, bn) * cdiv(p.K, bk);
     const dim3 grid((unsigned)(tiles * p.splits));
+    if (p.yconv) {
+        if (bn == 64) gemm_tn_bf16_kernel<64, 128, 1, 4, true><<<grid, dim3(256), 0, s>>>(p);   // (K = 9 gC >= 72: the 128-wide k tile)
+        else gemm_tn_bf16_kernel<128, 128, 2, 2, true><<<grid, dim3(256), 0, s>>>(p);
+        DCPT_CHECK_LAUNCH("gemm_tn_bf16 conv3");
+        return DCPT_OK;
+    }
     if (bn == 64 && bk == 64) gemm_tn_bf16_kernel<64, 64, 2, 2><<<grid, dim3(256), 0, s>>>(p);
     else if (bk == 64) gemm_tn_bf16_kernel<128, 64, 4, 1><<<grid, dim3(256), 0, s>>>(p);
     else if (bn == 64) gemm_tn_bf16_kernel<64, 128, 1, 4><<<grid, dim3(256), 0, s>>>(p);

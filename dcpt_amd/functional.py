@@ -564,6 +564,97 @@ def conv_ln(x, weight, lnw, lnb, res=None, relu=True):
     return _ConvLNFn.apply(x, weight, lnw, lnb, res, relu)
 
 
+class _ConvLNBf16Fn(torch.autograd.Function):
+    """_ConvLNFn with bf16 activations (dcpt_conv_ln_fwd_bf16 / bwd_bf16): x, res, z, y and their gradients bf16; parameters fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, lnw, lnb, res, relu):
+        lib = _lib.load()
+        _require_gpu_bf16(x, *([] if res is None else [res]))
+        _require_gpu(weight, lnw, lnb)
+        x = _nhwc(x)
+        res_ = None if res is None else _nhwc(res)
+        w_, lw, lb = _contig(weight.detach()), _contig(lnw.detach()), _contig(lnb.detach())
+        B, Cin, H, W = x.shape
+        Cout, ks = w_.shape[0], w_.shape[2]
+        dev = x.device
+        z = _empty_nhwc_bf16(B, Cout, H, W, dev)
+        y = _empty_nhwc_bf16(B, Cout, H, W, dev)
+        stats = torch.empty((2, B * H * W), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.dcpt_conv_ln_bf16_ws_bytes(B, H, W, Cin, Cout, ks, 0))
+        check(lib.dcpt_conv_ln_fwd_bf16(x.data_ptr(), w_.data_ptr(), lw.data_ptr(), lb.data_ptr(), _p(res_), int(bool(relu)),
+                                        z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                                        ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)), "dcpt_conv_ln_fwd_bf16")
+        ctx.save_for_backward(x, w_, lw, z, y, stats)
+        ctx.relu, ctx.has_res = bool(relu), res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_, lw, z, y, stats = ctx.saved_tensors
+        dy = _nhwc(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16))
+        B, Cin, H, W = x.shape
+        Cout, ks = w_.shape[0], w_.shape[2]
+        dev = x.device
+        dx = _empty_nhwc_bf16(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        dlw, dlb = torch.empty_like(lw), torch.empty_like(lw)
+        dres = _empty_nhwc_bf16(B, Cout, H, W, dev) if ctx.has_res else None
+        ws = _workspace(dev, lib.dcpt_conv_ln_bf16_ws_bytes(B, H, W, Cin, Cout, ks, 1))
+        check(lib.dcpt_conv_ln_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), lw.data_ptr(), z.data_ptr(), y.data_ptr(),
+                                        stats[0].data_ptr(), stats[1].data_ptr(), dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(),
+                                        dlb.data_ptr(), _p(dres), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks,
+                                        int(ctx.relu), _stream(dev)), "dcpt_conv_ln_bwd_bf16")
+        return dx, dw, dlw, dlb, dres, None
+
+
+def conv_ln_bf16(x, weight, lnw, lnb, res=None, relu=True):
+    return _ConvLNBf16Fn.apply(x, weight, lnw, lnb, res, relu)
+
+
+class _ConvPoolReluBf16Fn(torch.autograd.Function):
+    """_ConvPoolReluFn with bf16 activations."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        _require_gpu_bf16(x)
+        _require_gpu(weight)
+        x = _nhwc(x)
+        w_ = _contig(weight.detach())
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        z = _empty_nhwc_bf16(B, Cout, H, W, dev)
+        y = _empty_nhwc_bf16(B, Cout, H // 2, W // 2, dev)
+        ws = _workspace(dev, lib.dcpt_conv1x1_pool_relu_bf16_ws_bytes(B, H, W, Cin, Cout, 0))
+        check(lib.dcpt_conv1x1_pool_relu_fwd_bf16(x.data_ptr(), w_.data_ptr(), z.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv1x1_pool_relu_fwd_bf16")
+        ctx.save_for_backward(x, w_, z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_, z = ctx.saved_tensors
+        dy = _nhwc(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16))
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        dx = _empty_nhwc_bf16(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        ws = _workspace(dev, lib.dcpt_conv1x1_pool_relu_bf16_ws_bytes(B, H, W, Cin, Cout, 1))
+        check(lib.dcpt_conv1x1_pool_relu_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), z.data_ptr(), dx.data_ptr(),
+                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, _stream(dev)),
+              "dcpt_conv1x1_pool_relu_bwd_bf16")
+        return dx, dw
+
+
+def conv1x1_pool_relu_bf16(x, weight):
+    return _ConvPoolReluBf16Fn.apply(x, weight)
+
+
 class _PatchUnfoldFn(torch.autograd.Function):
     """NCHW image -> patch rows (B, Kp, Ho, Wo) in NHWC memory, last real column = 1 (carries the conv bias);
     the unfolding half of PromptIR_DC.conv_embed (degrad_classify_arch.py:491-494)."""

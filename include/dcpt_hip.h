@@ -131,6 +131,23 @@ int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_gr
 int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream);
 int dcpt_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, dcpt_stream_t stream);
 
+/* ---- classifier head, bf16 storage: the conv -> channels-first LayerNorm -> [+shortcut] -> [ReLU] groups and the
+ * conv1x1 -> MaxPool2d(2,2) -> ReLU downsamples of degrad_classify_arch.py (:69-103, :227-243, :596-602) with bf16 activations
+ * (x, z = conv output, y and their gradients), fp32 parameters / gradients / statistics; same argument meaning as dcpt_conv_ln_* and
+ * dcpt_conv1x1_pool_relu_* below.  Channel counts must be multiples of 8, Cout <= 1024. */
+size_t dcpt_conv_ln_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int backward);
+int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const float* lnw, const float* lnb, const uint16_t* res, int relu, uint16_t* z,
+                          uint16_t* y, float* mu, float* rstd, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize,
+                          dcpt_stream_t stream);
+int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
+                          const float* mu, const float* rstd, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres, void* ws,
+                          size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream);
+size_t dcpt_conv1x1_pool_relu_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward);
+int dcpt_conv1x1_pool_relu_fwd_bf16(const uint16_t* x, const float* w, uint16_t* z, uint16_t* y, void* ws, size_t ws_bytes, int B, int H, int W,
+                                    int Cin, int Cout, dcpt_stream_t stream);
+int dcpt_conv1x1_pool_relu_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const uint16_t* z, uint16_t* dx, float* dw, void* ws,
+                                    size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+
 /* TLSC variant (nafnet_arch.py:277-288 `NAFNet`, arch_util.py:313-455): inference-only forward where SCA's global
  * mean is a k1 x k2 local box mean (replicate-padded), i.e. a per-pixel attention map.  Callers use the plain
  * dcpt_nafblock_fwd when the window covers the whole map (arch_util.py:352-353). */

@@ -44,6 +44,43 @@ def dc_forward(features, P, x0=0):
     return F.linear(x, P["fc.weight"], P["fc.bias"])
 
 
+# ---- bf16-storage mode of the head (dcpt_amd/csrc/dchead_bf16.hip): fp32 arithmetic, a bf16 round-to-nearest-even wherever the HIP
+# path stores an activation (conv output z, LayerNorm-group output y, the stage input after mixing) or its gradient; weights are
+# rounded as GEMM operands only.  The reference has no such mode (basicsr/test.py:26-27); pinned to the fp32 head by tolerance.
+def _round_ops():
+    from oracle.nafnet_oracle import _rf, _rr
+
+    return _rr, _rf
+
+
+def bottleneck_bf16(x, P, pre):
+    rr, rf = _round_ops()
+    g = lambda n: P[pre + n]
+    z = rr(F.conv2d(x, rf(g("conv1.weight"))))
+    out = rr(F.relu(layernorm_cf(z, g("conv1.norm.weight"), g("conv1.norm.bias"))))
+    z = rr(F.conv2d(out, rf(g("conv2.weight")), padding=1))
+    out = rr(F.relu(layernorm_cf(z, g("conv2.norm.weight"), g("conv2.norm.bias"))))
+    z = rr(F.conv2d(out, rf(g("conv3.weight"))))
+    return rr(F.relu(layernorm_cf(z, g("conv3.norm.weight"), g("conv3.norm.bias")) + x))
+
+
+def dc_forward_bf16(features, P):
+    rr, rf = _round_ops()
+    mix = torch.softmax(P["mixing_weights"], dim=0)
+    nblk = len({k.split(".")[2] for k in P if k.startswith("bottleneck_layers.0.")})
+    x = 0
+    for i, f in enumerate(features):
+        x = rr(x + mix[i] * f)                     # the mixing runs in fp32, its result enters the stage as bf16
+        for b in range(nblk):
+            x = bottleneck_bf16(x, P, f"bottleneck_layers.{i}.{b}.")
+        z = rr(F.conv2d(x, rf(P[f"downsample_layers.{i}.0.weight"])))
+        x = rr(F.relu(F.max_pool2d(z, 2, 2)))
+    for b in range(len({k.split(".")[1] for k in P if k.startswith("last_stage.")})):
+        x = bottleneck_bf16(x, P, f"last_stage.{b}.")
+    x = x.mean(dim=[-1, -2])
+    return F.linear(x, P["fc.weight"], P["fc.bias"])
+
+
 def dc_img_forward(lq, features, P):
     """PromptIR_DC.forward (:546-555): lq_feats = LayerNorm(Conv2d(3, dim0, 7, stride 2, pad 3)(lq)) (:491-494), then the
     same stages as above starting from lq_feats (features[0] lives at half the image resolution)."""

@@ -13,6 +13,7 @@ relative, and a block stores ~10 tensors in a chain.
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from dcpt_amd.keyed_init import keyed_input, keyed_tensor
 from oracle import nafnet_oracle as O
@@ -156,3 +157,169 @@ def test_dcpt_step_with_bf16_encoder(dev):
         assert all(p.grad is not None for p in m.net_dc.parameters()) and m.hook_outputs == []
     assert abs(logs["bf16"]["l_pix"] - logs["fp32"]["l_pix"]) <= 2e-2 * abs(logs["fp32"]["l_pix"]), logs
     assert abs(logs["bf16"]["l_classify"] - logs["fp32"]["l_classify"]) <= 5e-2 * abs(logs["fp32"]["l_classify"]), logs
+
+
+# ---- classifier head in bf16 storage ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,use_res,relu", [(2, 16, 32, 9, 7, 1, False, True), (2, 64, 64, 8, 8, 3, False, True),
+                                                            (1, 128, 128, 16, 16, 3, True, True), (2, 64, 32, 6, 10, 1, True, False),
+                                                            (3, 256, 256, 8, 6, 3, False, False)])
+def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
+    """conv (1x1 | dense 3x3 as implicit GEMM) -> channels-first LayerNorm -> [+res] -> [ReLU] with bf16 activations vs the same
+    chain in fp32 with a bf16 rounding at the two stored tensors (degrad_classify_arch.py:69-103,227-243)."""
+    from dcpt_amd import functional as DF
+    from oracle import dc_oracle as D
+    from oracle.nafnet_oracle import _rb, _rf, _rr
+
+    tag = f"cl.{Cin}.{Cout}.{H}x{W}.{ks}."
+    w = keyed_tensor(tag + "conv.weight", (Cout, Cin, ks, ks))
+    lw, lb = keyed_tensor(tag + "norm.weight", (Cout,)), keyed_tensor(tag + "norm.bias", (Cout,))
+    x = keyed_input(tag + "x", (B, Cin, H, W), lo=-1.5, hi=1.5).bfloat16().float()
+    res = keyed_input(tag + "res", (B, Cout, H, W), lo=-1, hi=1).bfloat16().float() if use_res else None
+    gw = keyed_input(tag + "gw", (B, Cout, H, W), lo=-1, hi=1).bfloat16().float()
+
+    def oracle(bf):
+        ps = [t.clone().requires_grad_(True) for t in (w, lw, lb)]
+        xr = x.clone().requires_grad_(True)
+        rr_ = res.clone().requires_grad_(True) if use_res else None
+        if bf:
+            z = _rr(F.conv2d(_rb(xr), _rf(ps[0]), padding=ks // 2))
+        else:
+            z = F.conv2d(xr, ps[0], padding=ks // 2)
+        y = D.layernorm_cf(z, ps[1], ps[2])
+        if use_res:
+            y = y + (_rb(rr_) if bf else rr_)
+        if relu:
+            y = F.relu(y)
+        if bf:
+            y = _rr(y)
+        (y * gw).sum().backward()
+        return y.detach(), xr.grad, [p.grad for p in ps], (rr_.grad if use_res else None)
+
+    yb, dxb, gb, drb = oracle(True)
+    yf, dxf, gf, drf = oracle(False)
+    xd = x.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pd = [t.to(dev).requires_grad_(True) for t in (w, lw, lb)]
+    rd = res.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True) if use_res else None
+    yd = DF.conv_ln_bf16(xd, pd[0], pd[1], pd[2], rd, relu)
+    yd.backward(gw.to(dev).bfloat16())
+    torch.cuda.synchronize()
+    errs = {"y": _rel(yd, yb), "dx": _rel(xd.grad, dxb), "dw": _rel(pd[0].grad, gb[0]), "dlnw": _rel(pd[1].grad, gb[1]), "dlnb": _rel(pd[2].grad, gb[2])}
+    if use_res:
+        errs["dres"] = _rel(rd.grad, drb)
+    bad = {k: v for k, v in errs.items() if not np.isfinite(v) or v > 2e-2}
+    assert not bad, f"vs bf16-mode oracle: {bad} (all { {k: round(v, 4) for k, v in errs.items()} })"
+    # vs fp32: a sanity bound only -- ReLU masks of values that round across zero flip whole gradient entries
+    assert _rel(yd, yf) <= 4e-2 and _rel(xd.grad, dxf) <= 0.15 and _rel(pd[0].grad, gf[0]) <= 0.15
+
+
+def test_dc_head_bf16_oracle(dev):
+    """PromptIR_NoImg_DC(act_dtype='bf16') (reference degrad_classify_arch.py:558-641) vs the oracle's bf16 mode of the head and,
+    loosely, vs the fp32 head: logits, feature gradients, every parameter gradient."""
+    from basicsr.archs import build_network
+    from dcpt_amd.keyed_init import keyed_state_dict
+    from oracle import dc_oracle as D
+
+    cfg = dict(feature_dims=[32, 64, 128], num_res_blocks=2, num_classes=10)
+    sd = keyed_state_dict(D.dc_param_shapes(**cfg), seed=0)
+    feats = [keyed_input("dcb.f0", (2, 32, 32, 24), lo=-1, hi=1), keyed_input("dcb.f1", (2, 64, 16, 12), lo=-1, hi=1),
+             keyed_input("dcb.f2", (2, 128, 8, 6), lo=-1, hi=1)]
+    labels = torch.tensor([3, 8])
+
+    def oracle(fn):
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        fs = [f.clone().requires_grad_(True) for f in feats]
+        logits = fn(fs, P)
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+        return logits.detach(), [f.grad for f in fs], {k: v.grad for k, v in P.items()}
+
+    lb, fb, gb = oracle(D.dc_forward_bf16)
+    lf, ff, gf = oracle(D.dc_forward)
+    net = build_network(dict(type="PromptIR_NoImg_DC", act_dtype="bf16", **cfg))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    fd = [f.to(dev).requires_grad_(True) for f in feats]
+    logits = net(None, fd)
+    assert logits.dtype == torch.float32 and logits.shape == (2, 10)
+    torch.nn.functional.cross_entropy(logits, labels.to(dev)).backward()
+    torch.cuda.synchronize()
+    assert _rel(logits, lb) <= 2e-2, _rel(logits, lb)
+    assert _rel(logits, lf) <= 5e-2
+    # Gradients.  This head is 27 conv -> LN -> ReLU groups and 3 max-pools deep and, with keyed random weights, chaotic: a value that
+    # rounds across zero (or a pool maximum that changes place) switches a whole path on or off.  The bf16-mode ORACLE itself is
+    # 19-31 % (relative L2) away from the fp32 oracle in the feature gradients, and a 1e-3 input perturbation moves the fp32
+    # gradients by 2 %.  Two bf16 evaluations that differ in summation order are therefore expected to be about as far from each
+    # other as bf16 is from fp32; the parity claims are the per-op tests above (<= 2e-2) and the logits, and here the HIP path only
+    # has to sit inside that noise: err(HIP, bf16 oracle) <= 1.5 * err(bf16 oracle, fp32 oracle) + 0.02 for every tensor.
+
+    def l2(a, b):
+        a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+    params = dict(net.named_parameters())
+    bad = {}
+    for i in range(3):
+        e, noise = l2(fd[i].grad, fb[i]), l2(fb[i], ff[i])
+        if not np.isfinite(e) or e > 1.5 * noise + 0.02:
+            bad[f"feature{i}"] = (e, noise)
+    for k in gb:
+        e, noise = l2(params[k].grad, gb[k]), l2(gb[k], gf[k])
+        if not np.isfinite(e) or e > 1.5 * noise + 0.02:
+            bad[k] = (e, noise)
+    assert not bad, f"(error vs bf16 oracle, bf16-vs-fp32 noise): {bad}"
+    # the parameters next to the loss see little of that amplification: these are checked tightly
+    for k in ("fc.weight", "fc.bias", "last_stage.1.conv3.weight", "last_stage.1.conv3.norm.weight"):
+        assert l2(params[k].grad, gb[k]) <= 3e-2, (k, l2(params[k].grad, gb[k]))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 32, 64, 8, 12), (1, 64, 64, 16, 16), (3, 16, 8, 6, 4)])
+def test_conv1x1_pool_relu_bf16_oracle(dev, B, Cin, Cout, H, W):
+    """conv1x1 -> MaxPool2d(2,2) -> ReLU with bf16 activations (degrad_classify_arch.py:596-602) vs fp32 arithmetic with bf16 rounding
+    of the stored conv output and of the pooled output."""
+    from dcpt_amd import functional as DF
+    from oracle.nafnet_oracle import _rb, _rf, _rr
+
+    tag = f"pr.{Cin}.{Cout}.{H}x{W}."
+    w = keyed_tensor(tag + "conv.weight", (Cout, Cin, 1, 1))
+    x = keyed_input(tag + "x", (B, Cin, H, W), lo=-1.5, hi=1.5).bfloat16().float()
+    gw = keyed_input(tag + "gw", (B, Cout, H // 2, W // 2), lo=-1, hi=1).bfloat16().float()
+    wr, xr = w.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    z = _rr(F.conv2d(_rb(xr), _rf(wr)))
+    y = _rr(F.relu(F.max_pool2d(z, 2, 2)))
+    (y * gw).sum().backward()
+    xd = x.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    yd = DF.conv1x1_pool_relu_bf16(xd, wd)
+    yd.backward(gw.to(dev).bfloat16())
+    torch.cuda.synchronize()
+    errs = {"y": _rel(yd, y), "dx": _rel(xd.grad, xr.grad), "dw": _rel(wd.grad, wr.grad)}
+    bad = {k: v for k, v in errs.items() if not np.isfinite(v) or v > 2e-2}
+    assert not bad, errs
+
+
+def test_dcpt_step_all_bf16(dev):
+    """DCPT step with the bf16 encoder AND the bf16 head (feature_dims multiples of 8): runs, finite, losses near the fp32 step's."""
+    from basicsr.models import build_model
+    from dcpt_amd.keyed_init import keyed_state_dict
+    from oracle import dc_oracle as D
+
+    enc = dict(img_channel=3, width=8, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 2], dec_blk_nums=[1, 1, 1, 1])
+    dc = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
+    logs = {}
+    for dt in ("fp32", "bf16"):
+        opt = dict(name="t", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", act_dtype=dt, **enc),
+                   network_dc=dict(type="PromptIR_NoImg_DC", act_dtype=dt, **dc), path=dict(),
+                   train=dict(pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"),
+                              classify_opt=dict(type="CrossEntropyLoss", loss_weight=1.0),
+                              optim_g=dict(type="SGD", lr=0.0), optim_dc=dict(type="SGD", lr=0.0)))
+        m = build_model(opt)
+        m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**enc), seed=0), strict=True)
+        m.net_dc.load_state_dict(keyed_state_dict(D.dc_param_shapes(**dc), seed=0), strict=True)
+        m.feed_data({"lq": keyed_input("dcpt.lq", (2, 3, 32, 32)), "gt": keyed_input("dcpt.gt", (2, 3, 32, 32)),
+                     "dataset_idx": torch.tensor([3, 8])})
+        m.optimize_parameters(1)
+        logs[dt] = dict(m.get_current_log())
+        for net in (m.net_g, m.net_dc):
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    assert abs(logs["bf16"]["l_pix"] - logs["fp32"]["l_pix"]) <= 2e-2 * abs(logs["fp32"]["l_pix"]), logs
+    assert abs(logs["bf16"]["l_classify"] - logs["fp32"]["l_classify"]) <= 8e-2 * abs(logs["fp32"]["l_classify"]), logs
