@@ -66,7 +66,7 @@ __device__ __forceinline__ float f8_sum(f8 a) { return f4_sum(a.lo) + f4_sum(a.h
 #endif
 
 // ---- launchers of the bf16 kernels (gemm_bf16.hip, bf16_ops.hip) ----------------------------------------------------------
-enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5 };
+enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5, EB_LNBWD2 = 6 };
 
 // C[m][n] = sum_k A[m][k] * Bw[n][k]  on v_mfma_f32_32x32x16_bf16; A, Bw, C, res, aux, gate bf16; bias / cscale / colpart fp32.
 struct GemmNTB {
@@ -82,6 +82,15 @@ struct GemmNTB {
     const bf16_t* aux;      // EB_SGBWD: v [M][2N]:  C[:, n] = acc * v[:, N + n],  C[:, N + n] = acc * v[:, n]
     bf16_t* gate;           // EB_BIASGATE (N = 2 Ch): C = acc + bias AND gate[m][c] = C[m][c] * C[m][Ch + c]   ([M][Ch])
     float* colpart;         // EB_DOTCOL
+    // LayerNorm backward with the row sums supplied by the producer of dZ (gemm.h, E_LNBWD2 -- in bf16 the GEMMs have MFMA slack,
+    // so this is a pure saving of two tensor passes and one launch per LayerNorm):
+    //   EB_SGBWD with rowpart != null also writes rowpart[m][np][2] = per-tile partials of  dZ . uvec  and  dZ . (Z - cvec)
+    //   (np = column tiles of the launch, Z = aux, uvec / cvec fp32 [2N]);
+    //   EB_LNBWD2:  C = rstd (g w - xhat s2 - s1) + aux,  xhat from res (the LayerNorm input), s1 / s2 = sum of the `rowparts`
+    //   partials / N;  colpart[m / 128][0][n] = sum_rows g xhat,  colpart[m / 128][1][n] = sum_rows g.
+    float* rowpart;
+    int rowparts;
+    const float *uvec, *cvec, *mu, *rstd, *lnw;
     // grid.y = nb independent problems (one per image): element offsets b * s?
     int nb;
     int64_t sA, sB, sC, sR;
@@ -90,6 +99,7 @@ struct GemmNTB {
     int conv3, gH, gW, gC;
 };
 int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
+int gemm_nt_bf16_tiles_n(const GemmNTB& p, int epi);   // column tiles of the launch (row partials per row written by EB_SGBWD)
 
 // G[n][k] = sum_m X[m][n] * Y[m][k]  (weight gradients): X, Y bf16 row-major, fp32 slabs [splits][N][K] + column sums of X as in
 // the fp32 TN kernel (gemm.h); operands are transposed on the way out of LDS by ds_read_b64_tr_b16.

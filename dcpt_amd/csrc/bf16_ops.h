@@ -36,7 +36,9 @@ int launch_sca_ds_part_bf16(const bf16_t* dts, const bf16_t* t2, float* ds_part,
 int dw_num_blocks_per_image_bf16(const DwGeom& g);
 int dw_num_blocks_per_image_fused_bf16(const DwGeom& g);
 int launch_dw_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s);
+int dw_fused_row_chunks_bf16(const DwGeom& g);
 int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
-                             bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s);
+                             bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s, float* rowpart = nullptr, const float* uvec = nullptr,
+                             const float* cvec = nullptr);
 // dwring.hip
 int launch_dw_ring_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s);

@@ -677,12 +677,15 @@ int launch_dw_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16
 int dw_num_blocks_per_image_bf16(const DwGeom& g) { return nblk_for(g, g.C / 4); }
 int dw_num_blocks_per_image_fused_bf16(const DwGeom& g) { return nblk_for(g, 2 * g.C / 4); }
 
+int dw_fused_row_chunks_bf16(const DwGeom& g) { return dw_map(g.H, g.W, 2 * g.C / 4).nqc; }
+
 int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
-                             bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+                             bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s, float* rowpart, const float* uvec, const float* cvec) {
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd_bf16: C=%d must be a multiple of 4", g.C);
     DwP p{};
     p.in0 = reinterpret_cast<const float*>(t1); p.in1 = reinterpret_cast<const float*>(dts); p.w2p = w2p; p.b2 = b2; p.simg = simg;
     p.dpool = dpool; p.out = reinterpret_cast<float*>(dt1); p.part = wpart;
+    p.rowpart = rowpart; p.uvec = uvec; p.cvec = cvec;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C;
     const DwMap mp = dw_map(g.H, g.W, 2 * g.C / 4);
     const int nblk = nblk_for(g, 2 * g.C / 4);

@@ -50,10 +50,22 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
     }
     const rsrc_t rsC = make_rsrc(p.C + m0 * (int64_t)p.ldc);
     rsrc_t rsR = rsC, rsX = rsC;
-    if constexpr (EK == EB_RESID || EK == EB_DOTCOL) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == EB_RESID || EK == EB_DOTCOL || EK == EB_LNBWD2) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
+    if constexpr (EK == EB_LNBWD2) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
     if constexpr (EK == EB_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
     if constexpr (GATE) rsX = make_rsrc(p.gate + m0 * (int64_t)Ch);
-    f8 dot = f8_zero();
+    f8 dot = f8_zero(), dot2 = f8_zero(), lnw8 = f8_zero(), u_lo = f8_zero(), u_hi = f8_zero(), c_lo = f8_zero(), c_hi = f8_zero();
+    if constexpr (EK == EB_LNBWD2) {
+        if (nok) lnw8 = f8_ld(p.lnw + n);
+    }
+    if constexpr (EK == EB_SGBWD) {
+        if (p.rowpart && nok) {
+            u_lo = f8_ld(p.uvec + n);
+            u_hi = f8_ld(p.uvec + p.N + n);
+            c_lo = f8_ld(p.cvec + n);
+            c_hi = f8_ld(p.cvec + p.N + n);
+        }
+    }
     constexpr int HALF = (EK == EB_SGBWD) ? 2 : 1;   // two 16-byte loads per row: prefetch in two halves (registers)
     constexpr int ITH = IT / HALF;
 #pragma unroll
@@ -65,8 +77,11 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
             const bool ok = (m0 + rl < p.M) && nok;
             pre1[it] = f8_zero();
             pre2[it] = f8_zero();
-            if constexpr (EK == EB_RESID || EK == EB_DOTCOL)
+            if constexpr (EK == EB_RESID || EK == EB_DOTCOL || EK == EB_LNBWD2)
                 pre1[it] = bbuf_ld8(rsR, ok ? ((uint32_t)rl * (uint32_t)ldres + (uint32_t)n) * 2u : ROW_SENT);
+            if constexpr (EK == EB_LNBWD2) {
+                if (p.aux) pre2[it] = bbuf_ld8(rsX, ok ? ((uint32_t)rl * (uint32_t)ldres + (uint32_t)n) * 2u : ROW_SENT);
+            }
             if constexpr (EK == EB_SGBWD) {
                 const uint32_t xo = ok ? ((uint32_t)rl * (uint32_t)p.N * 2u + (uint32_t)n) * 2u : ROW_SENT;
                 pre1[it] = bbuf_ld8(rsX, xo);
@@ -97,11 +112,73 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
             } else if constexpr (EK == EB_RESID) {
                 bbuf_st8(rsC, o, f8_fma(f8_add(v, bias), cs, pre1[it]));
             } else if constexpr (EK == EB_SGBWD) {
-                bbuf_st8(rsC, o, f8_mul(v, pre2[it]));
-                bbuf_st8(rsC, o + 2u * (uint32_t)p.N, f8_mul(v, pre1[it]));
+                const f8 d1 = f8_mul(v, pre2[it]), d2 = f8_mul(v, pre1[it]);
+                bbuf_st8(rsC, o, d1);
+                bbuf_st8(rsC, o + 2u * (uint32_t)p.N, d2);
+                if (p.rowpart) {
+                    const int64_t m = m0 + rl;
+                    f8 z1, z2;
+                    z1.lo = make_float4(pre1[it].lo.x - c_lo.lo.x, pre1[it].lo.y - c_lo.lo.y, pre1[it].lo.z - c_lo.lo.z, pre1[it].lo.w - c_lo.lo.w);
+                    z1.hi = make_float4(pre1[it].hi.x - c_lo.hi.x, pre1[it].hi.y - c_lo.hi.y, pre1[it].hi.z - c_lo.hi.z, pre1[it].hi.w - c_lo.hi.w);
+                    z2.lo = make_float4(pre2[it].lo.x - c_hi.lo.x, pre2[it].lo.y - c_hi.lo.y, pre2[it].lo.z - c_hi.lo.z, pre2[it].lo.w - c_hi.lo.w);
+                    z2.hi = make_float4(pre2[it].hi.x - c_hi.hi.x, pre2[it].hi.y - c_hi.hi.y, pre2[it].hi.z - c_hi.hi.z, pre2[it].hi.w - c_hi.hi.w);
+                    float a1 = nok ? f8_sum(f8_mul(d1, u_lo)) + f8_sum(f8_mul(d2, u_hi)) : 0.f;
+                    float a2 = nok ? f8_sum(f8_mul(d1, z1)) + f8_sum(f8_mul(d2, z2)) : 0.f;
+                    a1 = group_sum(a1, Q);
+                    a2 = group_sum(a2, Q);
+                    if (q == 0 && m < p.M) {
+                        const int np = (p.N + BN - 1) / BN;
+                        *reinterpret_cast<float2*>(p.rowpart + (m * np + n0 / BN) * 2) = make_float2(a1, a2);
+                    }
+                }
+            } else if constexpr (EK == EB_LNBWD2) {
+                const int64_t m = m0 + rl;
+                const bool rok = m < p.M;
+                const float mean = rok ? p.mu[m] : 0.f, rs = rok ? p.rstd[m] : 0.f;
+                float a1 = 0.f, a2 = 0.f;
+                if (rok && q < p.rowparts) {
+                    const float2 pr = *reinterpret_cast<const float2*>(p.rowpart + (m * p.rowparts + q) * 2);
+                    a1 = pr.x;
+                    a2 = pr.y;
+                }
+                const float invN = 1.0f / (float)p.N;
+                const float s1 = group_sum(a1, Q) * invN, s2 = group_sum(a2, Q) * invN;
+                f8 xh, d;
+                xh.lo = make_float4((pre1[it].lo.x - mean) * rs, (pre1[it].lo.y - mean) * rs, (pre1[it].lo.z - mean) * rs, (pre1[it].lo.w - mean) * rs);
+                xh.hi = make_float4((pre1[it].hi.x - mean) * rs, (pre1[it].hi.y - mean) * rs, (pre1[it].hi.z - mean) * rs, (pre1[it].hi.w - mean) * rs);
+                const f8 gw = f8_mul(v, lnw8);
+                d.lo = make_float4(rs * (gw.lo.x - xh.lo.x * s2 - s1), rs * (gw.lo.y - xh.lo.y * s2 - s1), rs * (gw.lo.z - xh.lo.z * s2 - s1),
+                                   rs * (gw.lo.w - xh.lo.w * s2 - s1));
+                d.hi = make_float4(rs * (gw.hi.x - xh.hi.x * s2 - s1), rs * (gw.hi.y - xh.hi.y * s2 - s1), rs * (gw.hi.z - xh.hi.z * s2 - s1),
+                                   rs * (gw.hi.w - xh.hi.w * s2 - s1));
+                bbuf_st8(rsC, o, f8_add(d, pre2[it]));
+                if (rok && nok) {
+                    dot = f8_fma(v, xh, dot);
+                    dot2 = f8_add(dot2, v);
+                }
             } else {   // EB_DOTCOL
                 bbuf_st8(rsC, o, v);
                 dot = f8_fma(v, pre1[it], dot);   // rows past M loaded 0
+            }
+        }
+    }
+    if constexpr (EK == EB_LNBWD2) {
+        // the two column-sum planes (-> LayerNorm weight / bias gradients) over the tile's rows, as for EB_DOTCOL
+        for (int pl = 0; pl < 2; ++pl) {
+            __syncthreads();
+            *reinterpret_cast<float4*>(&Cs[r0 * BN + 8 * q]) = pl == 0 ? dot.lo : dot2.lo;
+            *reinterpret_cast<float4*>(&Cs[r0 * BN + 8 * q + 4]) = pl == 0 ? dot.hi : dot2.hi;
+            __syncthreads();
+            if (r0 == 0 && nok) {
+                float4 a = *reinterpret_cast<const float4*>(&Cs[8 * q]), b = *reinterpret_cast<const float4*>(&Cs[8 * q + 4]);
+#pragma unroll
+                for (int g = 1; g < RPP; ++g) {
+                    a = f4_add(a, *reinterpret_cast<const float4*>(&Cs[g * BN + 8 * q]));
+                    b = f4_add(b, *reinterpret_cast<const float4*>(&Cs[g * BN + 8 * q + 4]));
+                }
+                float* dst = p.colpart + ((m0 / BM) * 2 + pl) * (int64_t)p.N + n;
+                stg4(dst, a);
+                stg4(dst + 4, b);
             }
         }
     }
@@ -488,10 +565,14 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     if (epi == EB_BIASGATE) DCPT_CHECK_ARG(p.gate && p.N % 16 == 0, "gemm_nt_bf16: gate epilogue needs gate != null, N %% 16 == 0");
     if (epi == EB_DOTCOL) DCPT_CHECK_ARG(p.colpart && p.res && p.nb == 1, "gemm_nt_bf16: column-dot epilogue needs colpart and res");
     if (epi == EB_RESID) DCPT_CHECK_ARG(p.res, "gemm_nt_bf16: residual epilogue needs res");
-    if (epi == EB_SGBWD) DCPT_CHECK_ARG(p.aux && p.ldc == 2 * p.N, "gemm_nt_bf16: SimpleGate-backward epilogue needs aux and ldc == 2N");
+    if (epi == EB_SGBWD) DCPT_CHECK_ARG(p.aux && p.ldc == 2 * p.N && (!p.rowpart || (p.uvec && p.cvec)), "gemm_nt_bf16: SimpleGate-backward epilogue needs aux and ldc == 2N");
+    if (epi == EB_LNBWD2)
+        DCPT_CHECK_ARG(p.res && p.mu && p.rstd && p.lnw && p.colpart && p.rowpart && p.rowparts >= 1 && p.rowparts <= 8 && p.nb == 1,
+                       "gemm_nt_bf16: LayerNorm-backward epilogue needs res / mu / rstd / lnw / colpart / rowpart (<= 8 partials per row)");
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk + mn * (epi == EB_SGBWD ? 4 : epi == EB_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
     if (epi == EB_RESID || epi == EB_DOTCOL) bytes += mn;
+    if (epi == EB_LNBWD2) bytes += 2 * mn;
     ProfScope prof(s, PROF_NT + 256 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * p.nb, bytes * 2.0 * p.nb);
     switch (epi) {
         case EB_PLAIN: return launch_nt<EB_PLAIN>(p, s);
@@ -500,9 +581,16 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
         case EB_SGBWD: return launch_nt<EB_SGBWD>(p, s);
         case EB_BIASGATE: return launch_nt<EB_BIASGATE>(p, s);
         case EB_DOTCOL: return launch_nt<EB_DOTCOL>(p, s);
+        case EB_LNBWD2: return launch_nt<EB_LNBWD2>(p, s);
     }
     dcpt_set_error("gemm_nt_bf16: unknown epilogue %d", epi);
     return DCPT_ERR_ARG;
+}
+
+int gemm_nt_bf16_tiles_n(const GemmNTB& p, int epi) {
+    const bool gate = epi == EB_BIASGATE;
+    const int ncols = gate ? p.N / 2 : p.N;
+    return ncols <= (gate ? 32 : 64) ? cdiv(ncols, gate ? 32 : 64) : cdiv(ncols, gate ? 64 : 128);
 }
 
 int gemm_tn_bf16_tiles_k(int N, int K) {

@@ -52,6 +52,7 @@ struct LnVecJobs {
     float* u[2];
     float* cvec[2];
     int N2, C, n;
+    int round_bf16;   // the bf16 path: W enters as its bf16-rounded GEMM operand copy
 };
 int launch_lnvec(const LnVecJobs& jobs, hipStream_t s);
 // dw2[ch*9+tap] and db2[ch] from wpart[R][10][C2]

@@ -425,7 +425,15 @@ __global__ __launch_bounds__(256) void lnvec_kernel(const LnVecJobs jobs) {
     const float* __restrict__ w = jobs.W[y] + (int64_t)j * jobs.C;
     float a = 0.f, b = 0.f;
     for (int c = 4 * lane; c < jobs.C; c += 256) {
-        const float4 wv = ldg4(w + c);
+        float4 wv = ldg4(w + c);
+        if (jobs.round_bf16) {   // round-to-nearest-even to bf16, as the operand pack does
+            auto r = [](float x) {
+                uint32_t u = __builtin_bit_cast(uint32_t, x);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                return __builtin_bit_cast(float, u & 0xffff0000u);
+            };
+            wv = make_float4(r(wv.x), r(wv.y), r(wv.z), r(wv.w));
+        }
         a += f4_sum(f4_mul(wv, ldg4(jobs.lnw[y] + c)));
         b += f4_sum(f4_mul(wv, ldg4(jobs.lnb[y] + c)));
     }

@@ -54,6 +54,10 @@ struct BwdWsB {
     float *ds_part, *ds, *dpool, *wpart;
     int ln_nblk, nblk_b, ds_slices;
     bool ds_fused;
+    // LayerNorm backward inside the dgrad GEMM epilogues (row sums supplied by the producers of dv / dt1: bf16.h EB_LNBWD2)
+    float *u4, *c4, *u1, *c1, *rowpart;
+    int rp_sg, rp_dw;
+    bool lrs;
 };
 
 size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* out) {
@@ -98,6 +102,30 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
     w.dpool = a.get<float>((size_t)B * C);
     w.nblk_b = dw_num_blocks_per_image_fused_bf16(g);
     w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
+    w.u4 = a.get<float>((size_t)2 * C);
+    w.c4 = a.get<float>((size_t)2 * C);
+    w.u1 = a.get<float>((size_t)2 * C);
+    w.c1 = a.get<float>((size_t)2 * C);
+    {
+        GemmNTB q{};
+        q.N = C;
+        w.rp_sg = gemm_nt_bf16_tiles_n(q, EB_SGBWD);
+    }
+    w.rp_dw = dw_fused_row_chunks_bf16(g);
+    // OFF by default: exact and 4 tensor passes lighter, but measured slower at EVERY level also in bf16 (same box, A/B: level-0
+    // backward 2.68 vs 2.47 ms, level 3 0.64 vs 0.60 ms, the NAFNet-64 step 53.2 vs 51.3 ms).  A GEMM whose epilogue moves more bytes
+    // than its k-loop runs at ~3 TB/s -- its loads are not overlapped across tiles -- while the separate LayerNorm kernel streams
+    // at 5.3 TB/s; the two passes it saves do not pay for that.
+    static const int on = getenv("DCPT_LN_ROWSUMS_BF16") ? atoi(getenv("DCPT_LN_ROWSUMS_BF16")) : 0;
+    w.lrs = on && w.rp_sg <= 8 && w.rp_dw <= 8;
+    w.rowpart = a.get<float>((size_t)M * (w.rp_sg > w.rp_dw ? w.rp_sg : w.rp_dw) * 2);
+    {   // the GEMM-epilogue form of the LayerNorm column partials: [M / 128 tiles][2][C]
+        const size_t need = (size_t)cdiv64(M, 128) * 2 * C;
+        if (need > (size_t)w.ln_nblk * 2 * C) {
+            w.lnpart = a.get<float>(need);
+            w.lnpart2 = a.get<float>(need);
+        }
+    }
     if (out) *out = w;
     return a.off;
 }
@@ -199,12 +227,23 @@ extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_
     DCPT_TRY(launch_wpack_bf16(j, s));
     DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, C2, s));
 
+    const int ln_tiles = (int)cdiv64(M, 128);
+    if (w.lrs) {   // u = W w_ln, c = b_conv + W b_ln for conv4 o LN2 and conv1 o LN1 (fp32; gemm.h E_LNBWD2)
+        LnVecJobs lj{};
+        lj.n = 2; lj.N2 = C2; lj.C = C; lj.round_bf16 = 1;
+        lj.W[0] = p->conv4_w; lj.bz[0] = p->conv4_b; lj.lnw[0] = p->norm2_w; lj.lnb[0] = p->norm2_b; lj.u[0] = w.u4; lj.cvec[0] = w.c4;
+        lj.W[1] = p->conv1_w; lj.bz[1] = p->conv1_b; lj.lnw[1] = p->norm1_w; lj.lnb[1] = p->norm1_b; lj.u[1] = w.u1; lj.cvec[1] = w.c1;
+        DCPT_TRY(launch_lnvec(lj, s));
+    }
     Side* sd = side_for(s);
     hipStream_t sw = side_stream(sd, s);
     DCPT_TRY(side_fork(sd, 0, s));
     GemmNTB g{};
-    // B1: dv = SimpleGate'(dout * gamma * W5; v)
+    // B1: dv = SimpleGate'(dout * gamma * W5; v)   (+ the row sums of LN2's backward, linear in dv)
     g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = w.dv; g.ldc = C2; g.aux = sv->v;
+    if (w.lrs) {
+        g.rowpart = w.rowpart; g.uvec = w.u4; g.cvec = w.c4;
+    }
     DCPT_TRY(launch_gemm_nt_bf16(g, EB_SGBWD, s));
     // B2: conv5 / gamma gradients
     DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
@@ -212,13 +251,19 @@ extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_
     // B3: gradient of LN2's output
     g = GemmNTB{};
     g.M = M; g.A = w.dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = w.gln; g.ldc = C;
-    DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    if (w.lrs) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv W4^T), the LayerNorm's incoming gradient is never written
+        g.C = w.dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
+        g.rowpart = w.rowpart; g.rowparts = w.rp_sg;
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_LNBWD2, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    }
     // B4: conv4 gradients
     DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
-    DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
+    if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 2, s));
-    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2 * s) (+ SCA's per-image channel sums out of the epilogue when an image is a whole number of 128-pixel tiles)
     g = GemmNTB{};
     g.M = M; g.A = w.dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = w.dts; g.ldc = C;
@@ -247,20 +292,27 @@ extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_
     // B8: SCA backward
     DCPT_TRY(launch_sca_dpool(w.ds_part, w.ds_slices, p->sca_w, w.dpool, B, C, P, s));
     // B9 / B10: SimpleGate + depthwise backward, da on chip
-    DCPT_TRY(launch_dw_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s));
+    DCPT_TRY(launch_dw_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s, w.lrs ? w.rowpart : nullptr, w.u1,
+                                      w.c1));
     DCPT_TRY(side_fork(sd, 3, s));
     DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
     // B11: gradient of LN1's output
     g = GemmNTB{};
     g.M = M; g.A = w.dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = w.gln; g.ldc = C;
-    DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    if (w.lrs) {   // B11 + B13: dinp = dy + LN1-backward(dt1 W1^T)
+        g.C = dinp; g.res = inp; g.ldres = C; g.aux = w.dy; g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.colpart = w.lnpart2;
+        g.rowpart = w.rowpart; g.rowparts = w.rp_dw;
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_LNBWD2, s));
+    } else {
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    }
     // B12: conv1 gradients
     DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
     // B13: dinp = dy + LN1-backward
-    DCPT_TRY(launch_ln_bwd_bf16(w.gln, inp, sv->mu1, sv->rstd1, p->norm1_w, w.dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
+    if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, inp, sv->mu1, sv->rstd1, p->norm1_w, w.dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 5, s));
-    DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+    DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     DCPT_TRY(side_join(sd, s));
     return DCPT_OK;
 }
