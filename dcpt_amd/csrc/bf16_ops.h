@@ -42,3 +42,5 @@ int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w
                              const float* cvec = nullptr);
 // dwring.hip
 int launch_dw_ring_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s);
+int launch_dw_ring_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                                  bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s);

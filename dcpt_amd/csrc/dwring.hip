@@ -253,6 +253,390 @@ int launch_fwd(const void* t1, const float* w2p, const float* b2, void* t2, floa
     return DCPT_OK;
 }
 
+
+// ---- fused SimpleGate + depthwise BACKWARD on the row ring ------------------------------------------------------------------
+// Same math as dw_bwd_fused_kernel (dwconv.hip):  a = dw3x3(t1) + b2 (recomputed),  dt2 = dts * s + dpool,  da_1 = dt2 * a_2,
+// da_2 = dt2 * a_1,  dt1 = dw3x3^T(da),  per-block partial sums of the tap / bias gradients.  The register version recomputes a
+// at three columns per thread (5 overlapping global loads of t1 and 3 of dts per pixel: it takes 826 / 790 us at level 0 in
+// fp32 / bf16 -- the same time for half the bytes, i.e. it is instruction-bound).  Here every quantity is computed ONCE:
+//   * t1 row r and dts row r-1 arrive by LDS-DMA in ring slot (it % R), R - 2 rows ahead;
+//   * a thread owns TWO channels of BOTH gate halves at TWO adjacent pixels: it completes a[r-1] from the running forward-conv
+//     accumulators, forms da[r-1] at its two pixels (both halves are in the thread, no lane exchange), accumulates the 2 x 9 tap
+//     gradients against the three t1 rows it holds (two in registers, one just read), and parks da in an LDS exchange row;
+//   * one iteration later (after the iteration's single barrier) it reads its left / right neighbours' da from the exchange row
+//     and advances the transposed-conv accumulators; dt1 row r-3 is complete and stored.
+// Column tiles: with one tile per image row (MULTI = 0) the neighbours outside the image are zeros; with several (MULTI = 1) a
+// tile computes da at PB columns and owns the PB - 2 interior ones (the edge columns are recomputed by the neighbouring tile), so
+// nothing crosses blocks.  LDS planes are split by column parity so that the PP pixel-pair groups of a wave read consecutive
+// 8-byte (fp32) / 4-byte (bf16) runs: conflict-free for every LP.
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2 v2z() {
+    v2 z;
+    z.x = 0.f;
+    z.y = 0.f;
+    return z;
+}
+
+template <typename ST>
+__device__ __forceinline__ v2 lds_pair(const unsigned char* p) {   // two consecutive channels
+    if constexpr (sizeof(ST) == 4) {
+        return *reinterpret_cast<const v2*>(p);
+    } else {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        v2 r;
+        r.x = bf_lo(w);
+        r.y = bf_hi(w);
+        return r;
+    }
+}
+
+#ifndef DWRB_R32
+#define DWRB_R32 5
+#endif
+#ifndef DWRB_R16
+#define DWRB_R16 7
+#endif
+// ring slots of the backward kernel (fp32 / bf16): the row in use + R - 2 in flight + the one being refilled.  vmcnt also counts the
+// dt1 stores, so the ring depth has to cover the store acknowledgement latency as well; two blocks per CU must fit the 160 KiB.
+
+struct DwrBP {
+    const void* t1;     // [M][2C]
+    const void* dts;    // [M][C]
+    const float* w2p;   // [9][2C]
+    const float* b2;    // [2C] or null
+    const float* simg;  // [B][C] or null (= 1)
+    const float* dpool; // [B][C] (with simg)
+    void* dt1;          // [M][2C]
+    float* part;        // [B][gridDim.y][10][2C]
+    int B, H, W, C;
+    int nwc;            // column tiles
+};
+
+template <typename ST, int LP, int MULTI>
+__global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
+    constexpr int ES = sizeof(ST), PBY = 2 * ES, R = ES == 4 ? DWRB_R32 : DWRB_R16;
+    constexpr int NDT = ES / 2;                    // t1 DMAs per wave and row (4 planes x 256 runs x PBY bytes = NDT x 4 KiB)
+    constexpr int NCH = 256 / LP;                  // pixel pairs per plane
+    constexpr int PP = NCH - MULTI, PB = 2 * PP;   // pixel-pair groups that work / da columns of the tile
+    constexpr int NC = PB + 2 * MULTI;             // t1 columns in a slot
+    constexpr int UPH = LP * PBY / 16;             // 16-byte DMA units per (pixel, half) run
+    constexpr int BLK = LP * PBY, PLANE = NCH * BLK;
+    constexpr int TBYTES = 4 * PLANE, SLOT = TBYTES + 4096;
+    constexpr int XBLK = LP * 8, XPLANE = NCH * XBLK, XSLOT = 4 * XPLANE;
+    constexpr int XOFF = R * SLOT, ZOFF = XOFF + 2 * XSLOT;
+    static_assert(TBYTES == NDT * 4096 && UPH >= 1 && 2 * NCH * BLK <= 4096, "slot geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ZOFF + 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, PH = C / 2;
+    const int nrp = gridDim.y / p.nwc, rpp = (p.H + nrp - 1) / nrp;
+    const int wc = blockIdx.y % p.nwc, rp = blockIdx.y / p.nwc, b = blockIdx.z;
+    const int h0 = rp * rpp, h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
+    const int x0 = MULTI ? wc * (PB - 2) - 1 : 0;   // image column of da column 0
+    const int xs = x0 - MULTI;                      // image column of t1 slot column 0
+    const int piece0 = blockIdx.x * LP;
+    const int g = tid % LP, pp = tid / LP;
+    const bool act = pp < PP;
+    const bool gok = act && piece0 + g < PH;
+    const int c1 = (piece0 + g) * 2, c2 = C + c1;
+
+    // ---- per-thread constants (consumed before the first DMA: the compiler's vmcnt bookkeeping does not see the DMAs)
+    v2 w[2][9], bias[2], sv, dpv;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        w[0][t] = gok ? *reinterpret_cast<const v2*>(p.w2p + t * 2 * C + c1) : v2z();
+        w[1][t] = gok ? *reinterpret_cast<const v2*>(p.w2p + t * 2 * C + c2) : v2z();
+    }
+    bias[0] = (gok && p.b2) ? *reinterpret_cast<const v2*>(p.b2 + c1) : v2z();
+    bias[1] = (gok && p.b2) ? *reinterpret_cast<const v2*>(p.b2 + c2) : v2z();
+    sv.x = sv.y = 1.f;
+    dpv = v2z();
+    if (gok && p.simg) {
+        sv = *reinterpret_cast<const v2*>(p.simg + (int64_t)b * C + c1);
+        dpv = *reinterpret_cast<const v2*>(p.dpool + (int64_t)b * C + c1);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(w[0][t]), "v"(w[1][t]));
+    asm volatile("" ::"v"(bias[0]), "v"(bias[1]), "v"(sv), "v"(dpv));
+    wait_vm<0>();
+
+    // ---- DMA map of this lane
+    const int rb = h0 - 2 > 0 ? h0 - 2 : 0;   // first image row the windows reach
+    const i32x4 rs_t = make_rsrc_dma((const ST*)p.t1 + ((int64_t)b * p.H + rb) * p.W * 2 * C);
+    const i32x4 rs_d = make_rsrc_dma((const ST*)p.dts + ((int64_t)b * p.H + rb) * p.W * C);
+    uint32_t colo[NDT], cold;
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) {
+        const int e = (j * 4 + wave) * 64 + lane;
+        const int blk = e / UPH, unit = e % UPH;
+        const int plane = blk / NCH, idx = blk % NCH;
+        const int lc = idx * 2 + (plane >> 1), h = plane & 1;
+        const int x = xs + lc, cb = piece0 * PBY + unit * 16;
+        const bool ok = lc < NC && x >= 0 && x < p.W && cb < C * ES;
+        colo[j] = ok ? (uint32_t)((x * 2 * C + h * C) * ES + cb) : COL_SENT;
+    }
+    {
+        const int e = wave * 64 + lane;
+        const int blk = e / UPH, unit = e % UPH;
+        const int o = blk / NCH, ppx = blk % NCH;
+        const int px = 2 * ppx + o, x = x0 + px, cb = piece0 * PBY + unit * 16;
+        const bool ok = blk < 2 * NCH && px < PB && x >= 0 && x < p.W && cb < C * ES;
+        cold = ok ? (uint32_t)(x * C * ES + cb) : COL_SENT;
+    }
+    const uint32_t lds0 = lds_addr(reinterpret_cast<const float*>(smem));
+    const uint32_t rowT = (uint32_t)p.W * 2u * (uint32_t)C * ES, rowD = (uint32_t)p.W * (uint32_t)C * ES;
+    auto issue = [&](int r, int slot) {   // t1 row r and dts row r - 1 (rows that are not needed or do not exist: zeros)
+        const bool tok = r >= 0 && r < p.H && r <= h1 + 1;
+        const int rd = r - 1;
+        const bool dok = rd >= 0 && rd >= h0 - 1 && rd < p.H && rd <= h1;
+        const uint32_t ro = tok ? (uint32_t)(r - rb) * rowT : 0u, rod = dok ? (uint32_t)(rd - rb) * rowD : 0u;
+#pragma unroll
+        for (int j = 0; j < NDT; ++j)
+            dma16(rs_t, lds0 + slot * SLOT + ((j * 4 + wave) * 64) * 16, (tok && colo[j] != COL_SENT) ? ro + colo[j] : ROW_SENT, 0);
+        dma16(rs_d, lds0 + slot * SLOT + TBYTES + (wave * 64) * 16, (dok && cold != COL_SENT) ? rod + cold : ROW_SENT, 0);
+    };
+
+    // ---- this thread's LDS addresses
+    //  t1 column j (image column xa - 1 + j, xa = x0 + 2 pp): slot column lc = MULTI + 2 pp - 1 + j -> plane (lc & 1) * 2 + h, index lc >> 1
+    const int tb = pp * BLK + g * PBY;
+    const bool z0 = !MULTI && pp == 0, z3 = !MULTI && pp == PP - 1;
+    constexpr int TJ0 = MULTI ? 0 : 2 * PLANE - BLK, TJ1 = MULTI ? 2 * PLANE : 0, TJ2 = MULTI ? BLK : 2 * PLANE,
+                  TJ3 = MULTI ? 2 * PLANE + BLK : BLK;
+    const int db = TBYTES + pp * BLK + g * PBY;                                  // dts pixel o: + o * PLANE
+    const int xb = pp * XBLK + g * 8;                                            // own da (o, h): + (o * 2 + h) * XPLANE
+    const bool zl = pp == 0, zr = pp + 1 >= NCH;
+    const unsigned char* zero = smem + ZOFF;
+    // zero the exchange rows (every column has an owner among the 256 threads) and the zero cell
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<v2*>(smem + XOFF + k * XSLOT + q * XPLANE + xb) = v2z();
+    if (tid < 4) reinterpret_cast<float*>(smem + ZOFF)[tid] = 0.f;
+
+    // ---- output columns
+    const int xa = x0 + 2 * pp;
+    bool oval[2];
+    uint32_t ocol[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int x = xa + o, lcol = 2 * pp + o;
+        oval[o] = gok && x >= 0 && x < p.W && (!MULTI || (lcol >= 1 && lcol <= PB - 2));
+        ocol[o] = oval[o] ? (uint32_t)((x * 2 * C + c1) * ES) : COL_SENT;
+    }
+    bool pval[2];   // the pixel exists (da is defined)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) pval[o] = gok && xa + o >= 0 && xa + o < p.W;
+    const rsrc_t rs_o = make_rsrc((ST*)p.dt1 + ((int64_t)b * p.H + rb) * p.W * 2 * C);
+
+    v2 a0[2][2], a1[2][2], B0[2][2], B1[2][2], daP[2][2], T1[2][4], T2[2][4], gr[2][10];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) a0[o][h] = a1[o][h] = B0[o][h] = B1[o][h] = daP[o][h] = v2z();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T1[h][j] = T2[h][j] = v2z();
+#pragma unroll
+        for (int t = 0; t < 10; ++t) gr[h][t] = v2z();
+    }
+
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) issue(h0 - 2 + k, k);
+    const int niter = h1 > h0 ? h1 - h0 + 5 : 0;
+    for (int it = 0; it < niter; ++it) {
+        const int r = h0 - 2 + it;
+#ifdef DWR_SAFE
+        wait_vm<0>();
+#else
+        if (it < R - 1) wait_vm<(R - 2) * (NDT + 1)>();
+        else wait_vm<4 + (R - 2) * (NDT + 5)>();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(r + R - 1, (it + R - 1) % R);
+        const unsigned char* sl = smem + (it % R) * SLOT;
+        // ---- t1 row r at columns xa-1 .. xa+2, dts row r-1 at xa, xa+1
+        v2 T[2][4], D[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            T[h][0] = lds_pair<ST>(z0 ? zero : sl + tb + TJ0 + h * PLANE);
+            T[h][1] = lds_pair<ST>(sl + tb + TJ1 + h * PLANE);
+            T[h][2] = lds_pair<ST>(sl + tb + TJ2 + h * PLANE);
+            T[h][3] = lds_pair<ST>(z3 ? zero : sl + tb + TJ3 + h * PLANE);
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) D[o] = lds_pair<ST>(sl + db + o * PLANE);
+        // ---- neighbours' da of row rho' = r - 2 (written in the previous iteration)
+        const unsigned char* xr = smem + XOFF + ((it + 1) & 1) * XSLOT + xb;
+        v2 X[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            X[h][0] = *reinterpret_cast<const v2*>(zl ? zero : xr + (2 + h) * XPLANE - XBLK);
+            X[h][1] = daP[0][h];
+            X[h][2] = daP[1][h];
+            X[h][3] = *reinterpret_cast<const v2*>(zr ? zero : xr + h * XPLANE + XBLK);
+        }
+        // ---- forward conv: row r completes a[r-1] (kernel row 2), feeds a[r] (row 1), starts a[r+1] (row 0)
+        const int rho = r - 1;
+        const bool rho_ok = rho >= 0 && rho < p.H && rho >= h0 - 1 && rho <= h1;
+        v2 da[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            v2 f[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f[h] = fma2(w[h][6], T[h][o], fma2(w[h][7], T[h][o + 1], fma2(w[h][8], T[h][o + 2], a0[o][h]))) + bias[h];
+                a0[o][h] = fma2(w[h][3], T[h][o], fma2(w[h][4], T[h][o + 1], fma2(w[h][5], T[h][o + 2], a1[o][h])));
+                a1[o][h] = fma2(w[h][0], T[h][o], fma2(w[h][1], T[h][o + 1], w[h][2] * T[h][o + 2]));
+            }
+            const v2 dt2 = fma2(D[o], sv, dpv);
+            const bool pin = rho_ok && pval[o];
+            da[o][0] = pin ? dt2 * f[1] : v2z();
+            da[o][1] = pin ? dt2 * f[0] : v2z();
+        }
+        unsigned char* xw = smem + XOFF + (it & 1) * XSLOT + xb;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) *reinterpret_cast<v2*>(xw + (o * 2 + h) * XPLANE) = da[o][h];
+        // ---- tap gradients of row rho: da[rho][x] with t1 rows rho-1 (T2), rho (T1), rho+1 (T) at columns x-1..x+1
+        if (rho >= h0 && rho < h1) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2 d = oval[o] ? da[o][h] : v2z();
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        gr[h][0 * 3 + kx] = fma2(d, T2[h][o + kx], gr[h][0 * 3 + kx]);
+                        gr[h][1 * 3 + kx] = fma2(d, T1[h][o + kx], gr[h][1 * 3 + kx]);
+                        gr[h][2 * 3 + kx] = fma2(d, T[h][o + kx], gr[h][2 * 3 + kx]);
+                    }
+                    gr[h][9] += d;
+                }
+        }
+        // ---- transposed conv with da row rho' = r - 2: completes dt1 row r - 3;  da[.][x - 1 + j] <-> kx = 2 - j
+        const int y = r - 3;
+        const bool yok = y >= h0 && y < h1;
+        const uint32_t yo = yok ? (uint32_t)(y - rb) * rowT : ROW_SENT;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const v2 out = fma2(w[h][2], X[h][o], fma2(w[h][1], X[h][o + 1], fma2(w[h][0], X[h][o + 2], B0[o][h])));
+                B0[o][h] = fma2(w[h][5], X[h][o], fma2(w[h][4], X[h][o + 1], fma2(w[h][3], X[h][o + 2], B1[o][h])));
+                B1[o][h] = fma2(w[h][8], X[h][o], fma2(w[h][7], X[h][o + 1], w[h][6] * X[h][o + 2]));
+                const uint32_t off = (yok && ocol[o] != COL_SENT) ? yo + ocol[o] + (uint32_t)(h * C * ES) : ROW_SENT;
+                if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, out), rs_o, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(bf_pack(out.x, out.y), rs_o, off, 0, 0);
+            }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) daP[o][h] = da[o][h];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T2[h][j] = T1[h][j];
+                T1[h][j] = T[h][j];
+            }
+    }
+    wait_vm<0>();
+    __syncthreads();
+    // ---- per-block partial sums of the tap / bias gradients: the PP pixel-pair groups of a channel pair through LDS, fixed order
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) *reinterpret_cast<v2*>(red + tid * 40 + (h * 10 + t) * 2) = gr[h][t];
+    __syncthreads();
+    float* dst = p.part + ((int64_t)b * gridDim.y + blockIdx.y) * 10 * 2 * C;
+    for (int idx = tid; idx < LP * 40; idx += 256) {
+        const int gg = idx / 40, k = idx % 40;
+        if (piece0 + gg >= PH) continue;
+        float s = 0.f;
+        for (int q = 0; q < PP; ++q) s += red[(q * LP + gg) * 40 + k];
+        const int h = k / 20, t = (k % 20) / 2, i = k & 1;
+        dst[t * 2 * C + h * C + (piece0 + gg) * 2 + i] = s;
+    }
+}
+
+
+struct DwrBGeom {
+    int LP, multi, nqc, nwc, nrp;
+};
+
+DwrBGeom dwr_bwd_geom(const DwGeom& g) {
+    DwrBGeom d;
+    const int PH = g.C / 2;
+    int cap = 8;
+    while (cap < PH && cap < 32) cap <<= 1;
+    static const int force_lp = getenv("DCPT_DWR_BWD_LP") ? atoi(getenv("DCPT_DWR_BWD_LP")) : 0;   // experiments
+    static const int force_multi = getenv("DCPT_DWR_BWD_MULTI") ? atoi(getenv("DCPT_DWR_BWD_MULTI")) : -1;
+    int lp = g.W <= 16 ? 32 : g.W <= 32 ? 16 : g.W <= 64 ? 8 : 0;
+    d.multi = lp == 0;
+    if (lp == 0) lp = 16;
+    if (lp > cap) lp = cap;
+    if (force_lp == 8 || force_lp == 16 || force_lp == 32) lp = force_lp;
+    if (force_multi == 1) d.multi = 1;
+    if (!d.multi && 2 * (256 / lp) < g.W) d.multi = 1;
+    d.LP = lp;
+    d.nqc = cdiv(PH, lp);
+    const int PB = 2 * (256 / lp - d.multi);
+    d.nwc = d.multi ? cdiv(g.W, PB - 2) : 1;
+    // row parts: two blocks are resident per CU (512 slots); a grid of 1.25 rounds costs two, so aim at >= 1024 blocks while a part
+    // keeps >= 32 rows (it runs 5 extra iterations).  Measured at B = 32: level 0 647 -> 554 us (fp32), 614 -> 518 (bf16) with 2 parts.
+    int64_t nrp = cdiv64(1024, (int64_t)g.B * d.nqc * d.nwc);
+    const int64_t maxp = g.H / 32 > 0 ? g.H / 32 : 1;
+    if (nrp > maxp) nrp = maxp;
+    if (nrp < 1) nrp = 1;
+    static const int force_nrp = getenv("DCPT_DWR_BWD_NRP") ? atoi(getenv("DCPT_DWR_BWD_NRP")) : 0;
+    if (force_nrp > 0) nrp = force_nrp < g.H ? force_nrp : g.H;
+    d.nrp = (int)nrp;
+    return d;
+}
+
+bool dwr_bwd_enabled() {
+    static const int on = getenv("DCPT_DW_RING_BWD") ? atoi(getenv("DCPT_DW_RING_BWD")) : 1;
+    return on != 0;
+}
+
+template <typename ST>
+int launch_bwd(const void* dts, const void* t1, const float* w2p, const float* b2, const float* simg, const float* dpool, void* dt1,
+               float* wpart, const DwGeom& g, hipStream_t s) {
+    const DwrBGeom d = dwr_bwd_geom(g);
+    DwrBP p{};
+    p.t1 = t1; p.dts = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.dt1 = dt1; p.part = wpart;
+    p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.nwc = d.nwc;
+    DCPT_CHECK_ARG(((double)cdiv(g.H, d.nrp) + 6.0) * g.W * 2.0 * g.C * sizeof(ST) < 1.0e9, "depthwise ring: a row range exceeds the 32-bit window");
+    const dim3 grid(d.nqc, d.nwc * d.nrp, g.B), blk(256);
+#define DWRB(LP_, MU_) dwr_bwd_fused_kernel<ST, LP_, MU_><<<grid, blk, 0, s>>>(p)
+    if (d.multi) {
+        if (d.LP == 8) DWRB(8, 1);
+        else if (d.LP == 16) DWRB(16, 1);
+        else DWRB(32, 1);
+    } else {
+        if (d.LP == 8) DWRB(8, 0);
+        else if (d.LP == 16) DWRB(16, 0);
+        else DWRB(32, 0);
+    }
+#undef DWRB
+    DCPT_CHECK_LAUNCH("dwr_bwd_fused");
+    static const bool dbg = getenv("DCPT_DWR_DEBUG") != nullptr;
+    if (dbg) {
+        int n16 = -1, n8 = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, dwr_bwd_fused_kernel<ST, 16, 1>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, dwr_bwd_fused_kernel<ST, 16, 0>, 256, 0);
+        fprintf(stderr, "dwr_bwd es=%d LP=%d multi=%d grid=(%d,%d,%d) occupancy(blocks/CU) multi %d single %d\n", (int)sizeof(ST), d.LP, d.multi, d.nqc,
+                d.nwc * d.nrp, g.B, n16, n8);
+    }
+    return DCPT_OK;
+}
+
 }  // namespace
 
 bool dw_ring_usable(const DwGeom& g, int es) { return dwr_enabled() && g.B <= 65535 && (g.C * es) % 16 == 0 && g.W >= 1; }
@@ -265,4 +649,19 @@ int launch_dw_ring_fwd_f32(const float* t1, const float* w2p, const float* b2, f
 }
 int launch_dw_ring_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s) {
     return launch_fwd<bf16_t>(t1, w2p, b2, t2, pool_part, g, s);
+}
+
+// fused SimpleGate + depthwise backward on the ring; wpart[B][dw_ring_bwd_num_blocks_per_image][10][2C]
+bool dw_ring_bwd_usable(const DwGeom& g, int es) { return dwr_bwd_enabled() && g.B <= 65535 && (g.C * es) % 16 == 0 && g.C % 2 == 0 && g.W >= 1; }
+int dw_ring_bwd_num_blocks_per_image(const DwGeom& g) {
+    const DwrBGeom d = dwr_bwd_geom(g);
+    return d.nwc * d.nrp;
+}
+int launch_dw_ring_bwd_fused_f32(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                                 float* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+    return launch_bwd<float>(dts, t1, w2p, b2, simg, dpool, dt1, wpart, g, s);
+}
+int launch_dw_ring_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                                  bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+    return launch_bwd<bf16_t>(dts, t1, w2p, b2, simg, dpool, dt1, wpart, g, s);
 }

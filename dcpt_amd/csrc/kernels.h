@@ -62,6 +62,11 @@ int launch_dw_wgrad_reduce(const float* wpart, int R, int C2, float* dw2, float*
 bool dw_ring_usable(const DwGeom& g, int elem_bytes);
 int dw_ring_num_blocks_per_image(const DwGeom& g, int elem_bytes);
 int launch_dw_ring_fwd_f32(const float* t1, const float* w2p, const float* b2, float* t2, float* pool_part, const DwGeom& g, hipStream_t s);
+// launch_dw_bwd_fused on the ring (no row partials); wpart[B][dw_ring_bwd_num_blocks_per_image][10][2C]
+bool dw_ring_bwd_usable(const DwGeom& g, int elem_bytes);
+int dw_ring_bwd_num_blocks_per_image(const DwGeom& g);
+int launch_dw_ring_bwd_fused_f32(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
+                                 float* dt1, float* wpart, const DwGeom& g, hipStream_t s);
 
 // generic depthwise pieces (Restormer): w2p is the [9][Ctot] packed weight (launch_dw_pack_weights)
 int dw_num_blocks_generic(int B, int H, int W, int Ctot);

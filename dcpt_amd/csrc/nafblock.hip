@@ -109,7 +109,10 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     }
     w.ds = a.get<float>((size_t)B * C);
     w.dpool = a.get<float>((size_t)B * C);
-    w.nblk_b = dw_num_blocks_per_image_fused(g);
+    {   // tap-gradient partials of the fused depthwise backward: the ring kernel's or the register kernel's block count
+        const int n1 = dw_num_blocks_per_image_fused(g), n2 = dw_ring_bwd_usable(g, 4) ? dw_ring_bwd_num_blocks_per_image(g) : 0;
+        w.nblk_b = n1 > n2 ? n1 : n2;
+    }
     w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
     w.u4 = a.get<float>((size_t)2 * C);
     w.c4 = a.get<float>((size_t)2 * C);
@@ -338,10 +341,13 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     // B9/B10: SimpleGate + depthwise conv backward
     (void)da;   // the fused kernel keeps da on chip
     // (wide levels: + the row sums of LN1's backward, linear in dt1; the LN2 partials in the same buffer were consumed by B3)
-    DCPT_TRY(launch_dw_bwd_fused(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s, lrs ? w.rowpart : nullptr, w.u1, w.c1));
+    const bool ring_b = !lrs && dw_ring_bwd_usable(dg, 4);   // dwring.hip: every quantity computed once, rows by LDS-DMA
+    const int nblk_b = ring_b ? dw_ring_bwd_num_blocks_per_image(dg) : dw_num_blocks_per_image_fused(dg);
+    if (ring_b) DCPT_TRY(launch_dw_ring_bwd_fused_f32(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s));
+    else DCPT_TRY(launch_dw_bwd_fused(dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, dt1, w.wpart, dg, s, lrs ? w.rowpart : nullptr, w.u1, w.c1));
     DCPT_TRY(side_fork(sd, 3, s));      // dt1, depthwise and SCA partial sums
     DCPT_TRY(launch_sca_wgrad(w.ds_part, ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
     // B11: grad w.r.t. LN1 output
     g = GemmNT{};
     g.M = M; g.A = dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = gln; g.ldc = C;

@@ -100,7 +100,10 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
     w.ds_part = a.get<float>((size_t)B * w.ds_slices * C);
     w.ds = a.get<float>((size_t)B * C);
     w.dpool = a.get<float>((size_t)B * C);
-    w.nblk_b = dw_num_blocks_per_image_fused_bf16(g);
+    {
+        const int n1 = dw_num_blocks_per_image_fused_bf16(g), n2 = dw_ring_bwd_usable(g, 2) ? dw_ring_bwd_num_blocks_per_image(g) : 0;
+        w.nblk_b = n1 > n2 ? n1 : n2;
+    }
     w.wpart = a.get<float>((size_t)B * w.nblk_b * 10 * 2 * C);
     w.u4 = a.get<float>((size_t)2 * C);
     w.c4 = a.get<float>((size_t)2 * C);
@@ -292,11 +295,15 @@ extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_
     // B8: SCA backward
     DCPT_TRY(launch_sca_dpool(w.ds_part, w.ds_slices, p->sca_w, w.dpool, B, C, P, s));
     // B9 / B10: SimpleGate + depthwise backward, da on chip
-    DCPT_TRY(launch_dw_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s, w.lrs ? w.rowpart : nullptr, w.u1,
-                                      w.c1));
+    const bool ring_b = !w.lrs && dw_ring_bwd_usable(dg, 2);
+    const int nblk_b = ring_b ? dw_ring_bwd_num_blocks_per_image(dg) : dw_num_blocks_per_image_fused_bf16(dg);
+    if (ring_b) DCPT_TRY(launch_dw_ring_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s));
+    else
+        DCPT_TRY(launch_dw_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s, w.lrs ? w.rowpart : nullptr, w.u1,
+                                          w.c1));
     DCPT_TRY(side_fork(sd, 3, s));
     DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
     // B11: gradient of LN1's output
     g = GemmNTB{};
     g.M = M; g.A = w.dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = w.gln; g.ldc = C;

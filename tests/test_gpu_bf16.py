@@ -62,7 +62,9 @@ def test_cast_roundtrip(dev):
 # C = 64 / P = 1024: the fused SCA sums (P % 128 == 0) and image-aligned conv3 weight gradient; (2, 16, 6, 10): ragged tiles,
 # C < one MFMA tile; (3, 24, 5, 7): odd image, three images; C = 128 / 512 / 1024: two GEMM column tiles, multi-k-tile loops,
 # two LayerNorm chunks per lane
-@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8)])
+# (1, 16, 11, 70) / (1, 24, 6, 50) / (1, 8, 70, 9): the depthwise ring kernels' multi-column-tile, 8-piece and two-row-part tilings
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8),
+                                   (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9)])
 def test_nafblock_bf16_oracle(dev, shape):
     from dcpt_amd import functional as DF
 

@@ -115,7 +115,10 @@ def test_nafblock_golden(dev, golden_dir, c):
         check("grad " + k, grads[k], g["g." + k], 1e-4)
 
 
-@pytest.mark.parametrize("B,c,H,W", [(1, 8, 5, 7), (3, 24, 9, 4), (2, 128, 12, 20), (1, 512, 8, 8), (2, 32, 33, 17)])
+# the last three shapes walk the depthwise ring kernels' other tilings (dwring.hip): several column tiles with recomputed edge
+# columns (W > 64), the 8-piece single tile (32 < W <= 64), and two row parts (H >= 64 with few blocks)
+@pytest.mark.parametrize("B,c,H,W", [(1, 8, 5, 7), (3, 24, 9, 4), (2, 128, 12, 20), (1, 512, 8, 8), (2, 32, 33, 17),
+                                     (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9)])
 def test_nafblock_oracle(dev, B, c, H, W):
     P = block_params(c, f"ob{c}.")
     x = keyed_input(f"ob{c}.x", (B, c, H, W), lo=-1.0, hi=1.0)
