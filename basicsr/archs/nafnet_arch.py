@@ -10,9 +10,11 @@ pass, SCA / residual scales / SimpleGate in GEMM epilogues)
 blocks are ``dcpt_conv3x3_*``, ``dcpt_down2x2_*`` and ``dcpt_up_ps_*``.  Feature maps are channels_last
 (NHWC) tensors.
 
-``act_dtype="bf16"`` (an extension; the reference computes in fp32 only) runs every NAFBlock group with
-bfloat16 activations / saved tensors and fp32 accumulation (``dcpt_nafblock_fwd_bf16/bwd_bf16``); the
-layers between the groups and all parameters stay fp32, with one cast kernel at each group edge.
+``act_dtype="bf16"`` (an extension; the reference computes in fp32 only) keeps every feature map in bfloat16
+storage from the intro conv's output to the ending conv's input -- NAFBlocks (``dcpt_nafblock_fwd_bf16/bwd_bf16``)
+and the layers between them (``dcpt_conv3x3_in/out_*_bf16``, ``dcpt_down2x2_*_bf16``, ``dcpt_up_ps_*_bf16``) -- with
+fp32 accumulation; images, all parameters and their gradients stay fp32 and there are no cast kernels.  Needs
+``width % 8 == 0``; forward hooks on the block groups see bf16 feature maps.
 
 The child ``nn.Conv2d`` / ``LayerNorm2d`` modules below only OWN the parameters (for state-dict and
 optimizer compatibility); they are never called on the fused path.
@@ -93,12 +95,10 @@ class NAFBlock(nn.Module):
     # the LAST block of a group hands fp32 back, so forward hooks on ``decoder{i}`` / ``decoder{i}.0`` (the DCPT taps) and the
     # fp32 layers between the groups see what they see in fp32 mode
     act_bf16 = False
-    emit_f32 = True
 
     def forward(self, inp):
-        if self.act_bf16:
-            y = DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params())
-            return DF.to_f32(y) if self.emit_f32 else y
+        if self.act_bf16:   # bf16 in / out (an fp32 input -- a block used on its own -- is cast once)
+            return DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params())
         pool = self.sca[0]
         if isinstance(pool, AvgPool2d) and pool.kernel_size is not None:
             k1, k2 = int(pool.kernel_size[0]), int(pool.kernel_size[1])
@@ -156,12 +156,12 @@ class NAFNetBaseline(nn.Module):
 
     def set_act_dtype(self, act_dtype):
         """'fp32' (the reference's arithmetic) or 'bf16' (bf16 storage of the NAFBlock activations, fp32 accumulate)"""
+        if act_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"act_dtype must be 'fp32' or 'bf16', got {act_dtype!r}")
         self.act_dtype = act_dtype
         for m in self.modules():
-            if isinstance(m, _BlockGroup):
-                for i, blk in enumerate(m):
-                    blk.act_bf16 = act_dtype == "bf16"
-                    blk.emit_f32 = i == len(m) - 1
+            if isinstance(m, NAFBlock):
+                m.act_bf16 = act_dtype == "bf16"
 
     def _streams(self, n, device):
         while len(self._side_streams) < n:
@@ -187,7 +187,9 @@ class NAFNetBaseline(nn.Module):
         return self._forward_impl(inp, hook)
 
     def _forward_impl(self, inp, hook=False):
-        x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias)
+        # bf16 storage: the intro conv emits bf16 features and every layer up to the ending conv's input stays bf16 (forward hooks on
+        # the block groups then see bf16 feature maps; the classifier head takes either dtype)
+        x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias, out_bf16=self.act_dtype == "bf16")
         encs = []
         for encoder, down in zip(self.encoders, self.downs):
             x = encoder(x)

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 _lock = threading.Lock()
 
@@ -100,6 +100,16 @@ SIGNATURES = {
     "dcpt_conv1x1_pool_relu_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv1x1_pool_relu_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,
                                                stream_t]),
+    "dcpt_conv3x3_in_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_in_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_out_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv3x3_out_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_down2x2_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_down2x2_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_down2x2_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_up_ps_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_up_ps_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_up_ps_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_nafblock_local_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
     "dcpt_nafblock_local_fwd": (cint, [C.POINTER(NafBlockParams), f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint,
                                        stream_t]),

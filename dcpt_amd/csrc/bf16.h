@@ -66,7 +66,7 @@ __device__ __forceinline__ float f8_sum(f8 a) { return f4_sum(a.lo) + f4_sum(a.h
 #endif
 
 // ---- launchers of the bf16 kernels (gemm_bf16.hip, bf16_ops.hip) ----------------------------------------------------------
-enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5, EB_LNBWD2 = 6 };
+enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5, EB_LNBWD2 = 6, EB_SCATTER = 7, EB_SCATTER_ADD = 8 };
 
 // C[m][n] = sum_k A[m][k] * Bw[n][k]  on v_mfma_f32_32x32x16_bf16; A, Bw, C, res, aux, gate bf16; bias / cscale / colpart fp32.
 struct GemmNTB {
@@ -97,6 +97,11 @@ struct GemmNTB {
     // conv3 != 0: implicit GEMM of a dense 3x3 (zero pad 1): A is the NHWC image [.][gH][gW][gC], K = 9 * gC, column index
     // = tap * gC + ch, tap = 3 ky + kx  <->  pixel (h + ky - 1, w + kx - 1); gC % 8 == 0 (a 16-byte chunk never straddles taps)
     int conv3, gH, gW, gC;
+    // gather2 != 0 (the 2x2 stride-2 conv and the pixel-shuffle backward, as gemm.h's A_GATHER): A is the FINE NHWC image
+    // [.][2 gH][2 gW][gC], a row is a coarse pixel (b, h, w) of the gH x gW grid, K = 4 * gC, column (2 i + j) * gC + ch  <->  fine
+    // pixel (2 h + i, 2 w + j), channel ch.  EB_SCATTER / EB_SCATTER_ADD: C (and res) are such a fine image, N = 4 * gC, the same
+    // column map; the adding form computes C = acc + res.   gC % 8 == 0.
+    int gather2;
 };
 int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
 int gemm_nt_bf16_tiles_n(const GemmNTB& p, int epi);   // column tiles of the launch (row partials per row written by EB_SGBWD)
@@ -113,7 +118,9 @@ struct GemmTNB {
     int splits;
     int64_t rows_per_split;
     // yconv != 0: Y is gathered like GemmNTB's conv3 operand (weight gradient of a dense 3x3): K = 9 * gC
+    // xg2 / yg2 != 0: X / Y is the fine image gathered in 2x2 cells like GemmNTB's gather2 operand (N resp. K = 4 * gC)
     int yconv, gH, gW, gC;
+    int xg2, yg2;
 };
 int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s);
 int gemm_tn_bf16_tiles_k(int N, int K);

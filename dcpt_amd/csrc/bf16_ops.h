@@ -21,6 +21,7 @@ int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
 constexpr int WPACKB_MAX_JOBS = 8;
 struct WpackBJobs {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
                       // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
+                      // 4 / 5 / 6 / 7: misc.hip's WP_DOWN / WP_DOWN_T / WP_UP / WP_UP_T (2x2 stride-2 conv, 1x1 conv + PixelShuffle(2))
     const float* in[WPACKB_MAX_JOBS];
     bf16_t* out[WPACKB_MAX_JOBS];
     const float* rs[WPACKB_MAX_JOBS];
@@ -44,3 +45,10 @@ int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w
 int launch_dw_ring_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s);
 int launch_dw_ring_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                                   bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s);
+
+// conv3x3.hip: the network-edge 3x3 convs with the feature side in bf16 storage
+int launch_conv3x3_s2b_bf16(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cs, int Cb, int wmode, hipStream_t s);
+int launch_conv3x3_b2s_bf16(const bf16_t* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W, int Cs, int Cb,
+                            int wmode, hipStream_t s);
+int launch_conv3x3_wgrad_bf16(const bf16_t* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H, int W, int Cs,
+                              int Cb, int omode, hipStream_t s);

@@ -230,6 +230,26 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobs jobs) 
             const int ic = (int)(e / (9 * Co)), r = (int)(e % (9 * Co));
             const int tap = r / Co, oc = r % Co;
             v = in[((int64_t)oc * Ci + ic) * 9 + (8 - tap)];
+        } else if (jobs.transpose[j] == 4) {   // 2x2 stride-2 conv (misc.hip WP_DOWN): out[oc][ij * C + ic] = in[oc][ic][ij], K = 4 C
+            const int Cc = K / 4;
+            const int oc = (int)(e / K), r = (int)(e % K);
+            const int ij = r / Cc, ic = r % Cc;
+            v = in[((int64_t)oc * Cc + ic) * 4 + ij];
+        } else if (jobs.transpose[j] == 5) {   // WP_DOWN_T: out[ij * C + ic][oc]
+            const int Cc = K / 4;
+            const int r = (int)(e / N), oc = (int)(e % N);
+            const int ij = r / Cc, ic = r % Cc;
+            v = in[((int64_t)oc * Cc + ic) * 4 + ij];
+        } else if (jobs.transpose[j] == 6) {   // WP_UP (1x1 conv + PixelShuffle(2)): out[ij * G + kk][ic] = in[4 kk + ij][ic], G = N / 4
+            const int G = N / 4;
+            const int r = (int)(e / K), ic = (int)(e % K);
+            const int ij = r / G, kk = r % G;
+            v = in[(int64_t)(4 * kk + ij) * K + ic];
+        } else if (jobs.transpose[j] == 7) {   // WP_UP_T: out[ic][ij * G + kk] = in[4 kk + ij][ic]
+            const int G = N / 4;
+            const int ic = (int)(e / N), r = (int)(e % N);
+            const int ij = r / G, kk = r % G;
+            v = in[(int64_t)(4 * kk + ij) * K + ic];
         } else {                   // out[img][n][k] = in[n][k] * kscale[img][k]
             const int k = (int)(e % K);
             v = in[e] * (ks ? ks[img * K + k] : 1.f);

@@ -3,12 +3,26 @@
 // <= 4 channels, so these are bandwidth-bound direct convolutions on the VALU (K = 27 is far too
 // small for MFMA).  The image side stays NCHW-contiguous: the layout change to/from NHWC is fused
 // into these kernels, so no separate permute pass ever touches the big tensors.
+#include "bf16.h"
+#include "bf16_ops.h"
 #include "bufops.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int MAXCS = 4;
+
+// the big (NHWC feature) side is fp32 or bf16 storage (ST = float / bf16_t); offsets are in bytes
+template <typename ST>
+__device__ __forceinline__ float4 big_ld4(rsrc_t r, uint32_t off) {
+    if constexpr (sizeof(ST) == 4) return buf_ld4(r, off);
+    else return bbuf_ld4(r, off);
+}
+template <typename ST>
+__device__ __forceinline__ void big_st4(rsrc_t r, uint32_t off, float4 v) {
+    if constexpr (sizeof(ST) == 4) buf_st4(r, off, v);
+    else bbuf_st4(r, off, v);
+}
 constexpr int WGRAD_BLOCKS = 768;   // weight-gradient kernel: one resident round (3 blocks/CU), few partial rows to reduce
 
 // All three kernels share one shape: a thread owns one channel quad of the big side and one pixel column, keeps its
@@ -61,10 +75,11 @@ __device__ __forceinline__ EdgeBlk edge_block(const EdgeMap& m, int H, int W, in
 
 // small -> big:  y[p][c] = sum_{s,tap} x[p+off(tap)][s] * W(c,s,tap) (+bias[c])      x NCHW [B][CS][H][W], y NHWC
 // wmode 0: W = w[c][s][tap] (intro forward);  wmode 1: W = w[s][c][8-tap] (ending dgrad)
-template <int CS>
+template <int CS, typename ST = float>
 __global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                          const float* __restrict__ bias, ST* __restrict__ y, int B, int H,
                                                           int W, int Cb, int wmode) {
+    constexpr uint32_t ES = sizeof(ST);
     const EdgeMap m = edge_map(B, H, W, Cb);
     const EdgeBlk k = edge_block(m, H, W, Cb);
     float4 wv[CS * 9];
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restric
             a2 = f4_fma(wv[s * 9 + 0], l4, f4_fma(wv[s * 9 + 1], c4, f4_fma(wv[s * 9 + 2], r4, a2)));   // ky = 0 -> row r+1
         }
         const int yo = r - 1;
-        buf_st4(rs_y, (k.ok && yo >= k.y0) ? ((uint32_t)((yo - k.y0) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT, f4_add(a0, bv));
+        big_st4<ST>(rs_y, (k.ok && yo >= k.y0) ? ((uint32_t)((yo - k.y0) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * ES : ROW_SENT, f4_add(a0, bv));
         a0 = a1;
         a1 = a2;
     }
@@ -109,8 +124,8 @@ __global__ __launch_bounds__(256) void conv3x3_s2b_kernel(const float* __restric
 
 // big -> small:  y[p][s] = sum_{c,tap} x[p+off(tap)][c] * W(s,c,tap) (+bias[s]) (+res[p][s])     x NHWC, y/res NCHW [B][CS][H][W]
 // wmode 0: W = w[s][c][tap] (ending forward);  wmode 1: W = w[c][s][8-tap] (intro dgrad).  One wave holds all quads of a pixel.
-template <int CS>
-__global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int CS, typename ST = float>
+__global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const ST* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ res,
                                                           float* __restrict__ y, int B, int H, int W, int Cb, int wmode) {
     const EdgeMap m = edge_map(B, H, W, Cb);
@@ -136,14 +151,15 @@ __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const float* __restric
     const rsrc_t rs_y = make_rsrc(y + (int64_t)k.b * CS * H * W);
     const rsrc_t rs_r = make_rsrc(res ? res + (int64_t)k.b * CS * H * W : y);
     const uint32_t cl = (k.ok && k.x > 0) ? 0u : COL_SENT, cc = k.ok ? 0u : COL_SENT, cr = (k.ok && k.x + 1 < W) ? 0u : COL_SENT;
-    const uint32_t st = 4u * (uint32_t)Cb;
+    constexpr uint32_t ES = sizeof(ST);
+    const uint32_t st = ES * (uint32_t)Cb;
     const int ql = threadIdx.x % m.QB;
     float a0[CS], a1[CS];
 #pragma unroll
     for (int s = 0; s < CS; ++s) a0[s] = a1[s] = 0.f;
     for (int r = k.y0 - 1; r <= k.y1; ++r) {
-        const uint32_t o = (r >= 0 && r < H) ? ((uint32_t)((r - rb) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT;
-        const float4 xl = buf_ld4(rs_x, (o - st) | cl), xc = buf_ld4(rs_x, o | cc), xr = buf_ld4(rs_x, (o + st) | cr);
+        const uint32_t o = (r >= 0 && r < H) ? ((uint32_t)((r - rb) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * ES : ROW_SENT;
+        const float4 xl = big_ld4<ST>(rs_x, (o - st) | cl), xc = big_ld4<ST>(rs_x, o | cc), xr = big_ld4<ST>(rs_x, (o + st) | cr);
         float a2[CS];
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
@@ -174,8 +190,8 @@ __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const float* __restric
 
 // Weight gradient partials: acc[s*9+tap] (float4 over 4 big channels) += big[p][4q..] * small[p+off][s]
 // block partials [nblk][CS*9+1][Cb] (last row: column sum of big), nblk = conv3x3_wgrad_num_blocks()
-template <int CS>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ big, const float* __restrict__ small,
+template <int CS, typename ST = float>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const ST* __restrict__ big, const float* __restrict__ small,
                                                             float* __restrict__ part, int B, int H, int W, int Cb) {
     __shared__ float4 red[256];
     const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
     load_row(k.y0, 1);
     for (int r = k.y0; r < k.y1; ++r) {
         load_row(r + 1, 2);
-        const float4 g = buf_ld4(rs_g, k.ok ? ((uint32_t)((r - k.y0) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * 4u : ROW_SENT);
+        const float4 g = big_ld4<ST>(rs_g, k.ok ? ((uint32_t)((r - k.y0) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * (uint32_t)sizeof(ST) : ROW_SENT);
         acc[CS * 9] = f4_add(acc[CS * 9], g);
 #pragma unroll
         for (int s = 0; s < CS; ++s)
@@ -331,6 +347,33 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float* __re
         else KERNEL<4><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);                  \
     } while (0)
 
+#define EDGE_GO_B(KERNEL, ...)                                                            \
+    do {                                                                                  \
+        const EdgeMap m = edge_map(B, H, W, Cb);                                          \
+        const dim3 grid(m.nqc * m.nwc, m.strips, B);                                      \
+        if (Cs == 1) KERNEL<1, bf16_t><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);           \
+        else if (Cs == 2) KERNEL<2, bf16_t><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);      \
+        else if (Cs == 3) KERNEL<3, bf16_t><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);      \
+        else KERNEL<4, bf16_t><<<grid, dim3(256), 0, s>>>(__VA_ARGS__);                   \
+    } while (0)
+
+// the same three kernels with the feature side in bf16 storage (image side, weights, partial sums fp32)
+int launch_conv3x3_s2b_bf16(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cs, int Cb, int wmode,
+                            hipStream_t s) {
+    EDGE_CHECK("conv3x3_s2b_bf16", 2048);
+    EDGE_GO_B(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
+    DCPT_CHECK_LAUNCH("conv3x3_s2b_bf16");
+    return DCPT_OK;
+}
+int launch_conv3x3_b2s_bf16(const bf16_t* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W, int Cs, int Cb,
+                            int wmode, hipStream_t s) {
+    EDGE_CHECK("conv3x3_b2s_bf16", 2048);
+    DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s_bf16: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
+    EDGE_GO_B(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
+    DCPT_CHECK_LAUNCH("conv3x3_b2s_bf16");
+    return DCPT_OK;
+}
+
 int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cs, int Cb,
                        int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_s2b", 2048);
@@ -351,6 +394,24 @@ int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const 
 int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb) {
     const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
     return B * m.strips * m.nwc;
+}
+
+int launch_conv3x3_wgrad_bf16(const bf16_t* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H, int W, int Cs,
+                              int Cb, int omode, hipStream_t s) {
+    EDGE_CHECK("conv3x3_wgrad_bf16", WGRAD_BLOCKS);
+    DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad_bf16: nblk mismatch");
+    {
+        const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
+        const dim3 grid(m.nqc * m.nwc, m.strips, B);
+        if (Cs == 1) conv3x3_wgrad_kernel<1, bf16_t><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+        else if (Cs == 2) conv3x3_wgrad_kernel<2, bf16_t><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+        else if (Cs == 3) conv3x3_wgrad_kernel<3, bf16_t><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+        else conv3x3_wgrad_kernel<4, bf16_t><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
+    }
+    DCPT_CHECK_LAUNCH("conv3x3_wgrad_bf16");
+    conv3x3_wgrad_reduce_kernel<<<dim3(cdiv(Cb, 16), Cs * 9 + 1), dim3(256), 0, s>>>(part, nblk, Cs, Cb, dW, bsum, omode);
+    DCPT_CHECK_LAUNCH("conv3x3_wgrad_reduce");
+    return DCPT_OK;
 }
 
 int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H,

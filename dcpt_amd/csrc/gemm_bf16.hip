@@ -22,6 +22,16 @@ namespace {
 
 constexpr int KT = 64;          // k elements per NT tile (128 bytes per row)
 
+// first element of the fine pixel (2h, 2w) that coarse pixel m = (b, h, w) of a gH x gW grid maps to (fine image 2gH x 2gW x gC)
+template <typename P>
+__device__ __forceinline__ int64_t fine_elem(const P& p, int64_t m) {
+    const int w = (int)(m % p.gW);
+    const int64_t t = m / p.gW;
+    const int h = (int)(t % p.gH);
+    const int64_t b = t / p.gH;
+    return ((b * (2 * p.gH) + 2 * h) * (int64_t)(2 * p.gW) + 2 * w) * p.gC;
+}
+
 template <int EK, int BM, int BN>
 __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ Cs, int64_t m0, int n0, int tid) {
     constexpr bool GATE = (EK == EB_BIASGATE);
@@ -48,8 +58,18 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
     if constexpr (EK == EB_RESID) {
         if (p.cscale && nok) cs = f8_ld(p.cscale + n);
     }
-    const rsrc_t rsC = make_rsrc(p.C + m0 * (int64_t)p.ldc);
+    constexpr bool SCAT = (EK == EB_SCATTER || EK == EB_SCATTER_ADD);
+    int64_t cbase = m0 * (int64_t)p.ldc;
+    uint32_t coladd = 0;   // SCAT: byte offset of this thread's 8 columns (one (i, j) cell, 8 channels) relative to the row's fine pixel
+    if constexpr (SCAT) {
+        cbase = fine_elem(p, m0 < p.M ? m0 : 0);
+        const int nn = nok ? n : 0;
+        const int ij = nn / p.gC, ch = nn - ij * p.gC;
+        coladd = (uint32_t)((((ij >> 1) * (2 * p.gW) + (ij & 1)) * p.gC + ch) * 2);
+    }
+    const rsrc_t rsC = make_rsrc(p.C + cbase);
     rsrc_t rsR = rsC, rsX = rsC;
+    if constexpr (EK == EB_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
     if constexpr (EK == EB_RESID || EK == EB_DOTCOL || EK == EB_LNBWD2) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
     if constexpr (EK == EB_LNBWD2) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
     if constexpr (EK == EB_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
@@ -79,6 +99,7 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
             pre2[it] = f8_zero();
             if constexpr (EK == EB_RESID || EK == EB_DOTCOL || EK == EB_LNBWD2)
                 pre1[it] = bbuf_ld8(rsR, ok ? ((uint32_t)rl * (uint32_t)ldres + (uint32_t)n) * 2u : ROW_SENT);
+            if constexpr (EK == EB_SCATTER_ADD) pre1[it] = bbuf_ld8(rsR, ok ? (uint32_t)((fine_elem(p, m0 + rl) - cbase) * 2) + coladd : ROW_SENT);
             if constexpr (EK == EB_LNBWD2) {
                 if (p.aux) pre2[it] = bbuf_ld8(rsX, ok ? ((uint32_t)rl * (uint32_t)ldres + (uint32_t)n) * 2u : ROW_SENT);
             }
@@ -92,7 +113,8 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
         for (int it = 0; it < ITH; ++it) {
             const int rl = r0 + (hh * ITH + it) * RPP;
             const bool ok = (m0 + rl < p.M) && nok;
-            const uint32_t o = ok ? ((uint32_t)rl * (uint32_t)p.ldc + (uint32_t)n) * 2u : ROW_SENT;
+            uint32_t o = ok ? ((uint32_t)rl * (uint32_t)p.ldc + (uint32_t)n) * 2u : ROW_SENT;
+            if constexpr (SCAT) o = ok ? (uint32_t)((fine_elem(p, m0 + rl) - cbase) * 2) + coladd : ROW_SENT;
             f8 v;
             v.lo = *reinterpret_cast<const float4*>(&Cs[rl * BN + 8 * q]);
             v.hi = *reinterpret_cast<const float4*>(&Cs[rl * BN + 8 * q + 4]);
@@ -105,8 +127,10 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
                 bbuf_st8(rsC, o, v);
                 bbuf_st8(rsC, o + 2u * (uint32_t)Ch, v2);
                 bbuf_st8(rsX, ok ? ((uint32_t)rl * (uint32_t)Ch + (uint32_t)n) * 2u : ROW_SENT, f8_mul(v, v2));
-            } else if constexpr (EK == EB_PLAIN) {
+            } else if constexpr (EK == EB_PLAIN || EK == EB_SCATTER) {
                 bbuf_st8(rsC, o, v);
+            } else if constexpr (EK == EB_SCATTER_ADD) {
+                bbuf_st8(rsC, o, f8_add(v, pre1[it]));
             } else if constexpr (EK == EB_BIAS) {
                 bbuf_st8(rsC, o, f8_add(v, bias));
             } else if constexpr (EK == EB_RESID) {
@@ -202,9 +226,10 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EK, bool CONV = false>
+template <int BM, int BN, int WM, int WN, int EK, int AM = 0>   // AM: 0 plain A, 1 implicit 3x3 (conv3), 2 gathered 2x2 cells (gather2)
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
     static_assert(WM * WN == 4, "4 waves");
+    constexpr bool CONV = AM == 1, GATH = AM == 2;
     GemmNTB p = pin;
     if (gridDim.y > 1) {
         const int64_t b = blockIdx.y;
@@ -238,7 +263,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
         apix0 -= p.gW + 1;
         if (apix0 < 0) apix0 = 0;
     }
-    const i32x4 rsA = make_rsrc_dma(p.A + apix0 * (int64_t)(CONV ? p.gC : p.lda));
+    if constexpr (GATH) apix0 = fine_elem(p, apix0);   // (elements, not pixels)
+    const i32x4 rsA = make_rsrc_dma(p.A + (GATH ? apix0 : apix0 * (int64_t)(CONV ? p.gC : p.lda)));
     const i32x4 rsB = make_rsrc_dma(p.Bw + (GATE ? 0 : (int64_t)n0 * p.K));
     // staging map: thread -> row (tid >> 3) + 32 * pass, LDS slot tid & 7 = logical 16-byte chunk slot ^ ((row >> 1) & 7)
     const int lrow = tid >> 3;
@@ -255,6 +281,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
             aw[i] = (int)(mm % p.gW);
             ah[i] = ok ? (int)((mm / p.gW) % p.gH) : -100000;   // invalid row: every tap out of bounds
             aoff[i] = (uint32_t)((mm - apix0) * p.gC) * 2u;
+        } else if constexpr (GATH) {
+            aoff[i] = (m0 + r < p.M) ? (uint32_t)((fine_elem(p, m0 + r) - apix0) * 2) : ROW_SENT;
         } else {
             aoff[i] = (m0 + r < p.M) ? ((uint32_t)r * (uint32_t)p.lda + (uint32_t)lk) * 2u : ROW_SENT;
         }
@@ -287,6 +315,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
                 const bool ok = k < p.K && hh >= 0 && hh < p.gH && ww >= 0 && ww < p.gW;
                 dma16(rsA, lds_a + buf * A_BYTES + i * 4096, ok ? aoff[i] + (uint32_t)(shift * 2) : COL_SENT, 0);
             }
+        } else if constexpr (GATH) {
+            const int k = kt * KT + lk;
+            const int ij = k / p.gC, ch = k - ij * p.gC;
+            const uint32_t shift = (k < p.K) ? (uint32_t)((((ij >> 1) * (2 * p.gW) + (ij & 1)) * p.gC + ch) * 2) : COL_SENT;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) dma16(rsA, lds_a + buf * A_BYTES + i * 4096, aoff[i] + shift, 0);
         } else {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) dma16(rsA, lds_a + buf * A_BYTES + i * 4096, aoff[i] + ksent, (uint32_t)kt * 128u);
@@ -357,9 +391,17 @@ int launch_nt(const GemmNTB& p, hipStream_t s) {
     const int ncols = GATE ? p.N / 2 : p.N;
     if constexpr (EK == EB_PLAIN) {
         if (p.conv3) {
-            if (ncols <= 64) gemm_nt_bf16_kernel<128, 64, 4, 1, EK, true><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 64)), nb), dim3(256), 0, s>>>(p);
-            else gemm_nt_bf16_kernel<128, 128, 2, 2, EK, true><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 128)), nb), dim3(256), 0, s>>>(p);
+            if (ncols <= 64) gemm_nt_bf16_kernel<128, 64, 4, 1, EK, 1><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 64)), nb), dim3(256), 0, s>>>(p);
+            else gemm_nt_bf16_kernel<128, 128, 2, 2, EK, 1><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 128)), nb), dim3(256), 0, s>>>(p);
             DCPT_CHECK_LAUNCH("gemm_nt_bf16 conv3");
+            return DCPT_OK;
+        }
+    }
+    if constexpr (EK == EB_PLAIN || EK == EB_BIAS) {
+        if (p.gather2) {
+            if (ncols <= 64) gemm_nt_bf16_kernel<128, 64, 4, 1, EK, 2><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 64)), nb), dim3(256), 0, s>>>(p);
+            else gemm_nt_bf16_kernel<128, 128, 2, 2, EK, 2><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 128)), nb), dim3(256), 0, s>>>(p);
+            DCPT_CHECK_LAUNCH("gemm_nt_bf16 gather2");
             return DCPT_OK;
         }
     }
@@ -397,9 +439,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int mrow, i
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int BN, int BKo, int WN, int WK, bool YCONV = false>
+template <int BN, int BKo, int WN, int WK, int YM = 0, bool XG = false>   // YM: 0 plain Y, 1 implicit 3x3 (yconv), 2 gathered 2x2 cells (yg2); XG: xg2
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
     static_assert(WN * WK == 4, "4 waves");
+    constexpr bool YCONV = YM == 1, YG = YM == 2;
     constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
     constexpr int XB = BRB * BN * 2, YB = BRB * BKo * 2;     // bytes per tile
     constexpr int X_IT = XB / 4096, Y_IT = YB / 4096;        // 256 threads x 16 bytes per pass
@@ -420,13 +463,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
     int64_t mend = mbeg + p.rows_per_split;
     if (mend > p.M) mend = p.M;
     const int64_t mw = mbeg < p.M ? mbeg : 0;
-    const i32x4 rsX = make_rsrc_dma(p.X + mw * (int64_t)p.ldx);
+    const int64_t xbase = XG ? fine_elem(p, mw) : mw * (int64_t)p.ldx;   // elements
+    const i32x4 rsX = make_rsrc_dma(p.X + xbase);
     int64_t ypix0 = mw;   // gathered Y: the window starts one image row + one pixel before the chunk (clipped at the tensor start)
     if constexpr (YCONV) {
         ypix0 -= p.gW + 1;
         if (ypix0 < 0) ypix0 = 0;
     }
-    const i32x4 rsY = make_rsrc_dma(p.Y + ypix0 * (int64_t)(YCONV ? p.gC : p.ldy));
+    const int64_t ybase = YG ? fine_elem(p, mw) : ypix0 * (int64_t)(YCONV ? p.gC : p.ldy);
+    const i32x4 rsY = make_rsrc_dma(p.Y + ybase);
 
     // staging: pass i, thread tid writes tile bytes [4096 i + 16 tid, +16): row = (256 i + tid) / chunks-per-row, chunk POSITION
     // cp = (256 i + tid) % chunks-per-row, which holds source chunk cp ^ swz(row)
@@ -438,7 +483,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
         const int e = 256 * i + tid;
         xrow[i] = e / XCH;
         const int c = (e % XCH) ^ tn_swz<BN>(xrow[i]);
-        xfix[i] = (n0 + 8 * c < p.N) ? ((uint32_t)xrow[i] * (uint32_t)p.ldx + (uint32_t)(n0 + 8 * c)) * 2u : COL_SENT;
+        if constexpr (XG) {   // element offset of the chunk's (i, j) cell and channel relative to the row's fine pixel
+            const int col = n0 + 8 * c, ij = col / p.gC, ch = col - ij * p.gC;
+            xfix[i] = (col < p.N) ? (uint32_t)(((ij >> 1) * (2 * p.gW) + (ij & 1)) * p.gC + ch) : COL_SENT;
+        } else {
+            xfix[i] = (n0 + 8 * c < p.N) ? ((uint32_t)xrow[i] * (uint32_t)p.ldx + (uint32_t)(n0 + 8 * c)) * 2u : COL_SENT;
+        }
     }
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
@@ -452,6 +502,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
             ykx[i] = tap - 3 * yky[i];
             // offset of (tap, ch) relative to the row's own pixel, in elements (may be negative: added to the pixel offset below)
             yfix[i] = (k < p.K) ? (uint32_t)(((yky[i] - 1) * p.gW + (ykx[i] - 1)) * p.gC + ch) : COL_SENT;
+        } else if constexpr (YG) {
+            const int col = k0 + 8 * c, ij = col / p.gC, ch = col - ij * p.gC;
+            yfix[i] = (col < p.K) ? (uint32_t)(((ij >> 1) * (2 * p.gW) + (ij & 1)) * p.gC + ch) : COL_SENT;
         } else {
             yfix[i] = (k0 + 8 * c < p.K) ? ((uint32_t)yrow[i] * (uint32_t)p.ldy + (uint32_t)(k0 + 8 * c)) * 2u : COL_SENT;
         }
@@ -461,10 +514,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTNB p) {
     auto gload = [&](int64_t mt, int buf) {
         const int left = (int)(mend - mt);
         const uint32_t step = (uint32_t)(mt - mbeg);
+        if constexpr (XG) {
 #pragma unroll
-        for (int i = 0; i < X_IT; ++i)
-            dma16(rsX, lds_x + buf * XB + i * 4096, (xrow[i] < left) ? xfix[i] : ROW_SENT, step * (uint32_t)p.ldx * 2u);
-        if constexpr (YCONV) {
+            for (int i = 0; i < X_IT; ++i) {
+                const bool ok = xrow[i] < left && xfix[i] != COL_SENT;
+                dma16(rsX, lds_x + buf * XB + i * 4096, ok ? (uint32_t)((fine_elem(p, mt + xrow[i]) - xbase + xfix[i]) * 2) : ROW_SENT, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < X_IT; ++i)
+                dma16(rsX, lds_x + buf * XB + i * 4096, (xrow[i] < left) ? xfix[i] : ROW_SENT, step * (uint32_t)p.ldx * 2u);
+        }
+        if constexpr (YG) {
+#pragma unroll
+            for (int i = 0; i < Y_IT; ++i) {
+                const bool ok = yrow[i] < left && yfix[i] != COL_SENT;
+                dma16(rsY, lds_y + buf * YB + i * 4096, ok ? (uint32_t)((fine_elem(p, mt + yrow[i]) - ybase + yfix[i]) * 2) : ROW_SENT, 0);
+            }
+        } else if constexpr (YCONV) {
 #pragma unroll
             for (int i = 0; i < Y_IT; ++i) {
                 const int64_t m = mt + yrow[i];
@@ -559,6 +626,14 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     if (p.conv3)
         DCPT_CHECK_ARG(epi == EB_PLAIN && p.gC % 8 == 0 && p.K == 9 * p.gC && p.nb == 1 && (double)(130 + 2 * p.gW + 2) * p.gC * 2.0 < 1.0e9,
                        "gemm_nt_bf16: conv3 needs the plain epilogue, K == 9 * gC, gC %% 8 == 0");
+    if (p.gather2)
+        DCPT_CHECK_ARG((epi == EB_PLAIN || epi == EB_BIAS) && !p.conv3 && p.gC % 8 == 0 && p.K == 4 * p.gC && p.nb == 1 &&
+                           (double)(130 + 2 * p.gW) * 4.0 * p.gC * 2.0 < 1.0e9,
+                       "gemm_nt_bf16: gather2 needs the plain / bias epilogue, K == 4 * gC, gC %% 8 == 0");
+    if (epi == EB_SCATTER || epi == EB_SCATTER_ADD)
+        DCPT_CHECK_ARG(p.gC % 8 == 0 && p.N == 4 * p.gC && p.nb == 1 && !p.conv3 && !p.gather2 && (epi == EB_SCATTER || p.res) &&
+                           (double)(130 + 2 * p.gW) * 4.0 * p.gC * 2.0 < 1.0e9,
+                       "gemm_nt_bf16: scatter epilogue needs N == 4 * gC, gC %% 8 == 0 (and res for the adding form)");
     DCPT_CHECK_ARG(p.K < (1 << 20) && p.N < (1 << 20) && p.lda < (1 << 20) && p.ldc < (1 << 20) && (double)p.N * p.K * 2.0 < 1.0e9,
                    "gemm_nt_bf16: K/N/row strides out of the 32-bit window range");
     DCPT_CHECK_ARG(cdiv64(p.M, 128) * cdiv(p.N, 32) < (1ll << 31), "gemm_nt_bf16: grid too large");
@@ -571,7 +646,7 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
                        "gemm_nt_bf16: LayerNorm-backward epilogue needs res / mu / rstd / lnw / colpart / rowpart (<= 8 partials per row)");
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk + mn * (epi == EB_SGBWD ? 4 : epi == EB_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
-    if (epi == EB_RESID || epi == EB_DOTCOL) bytes += mn;
+    if (epi == EB_RESID || epi == EB_DOTCOL || epi == EB_SCATTER_ADD) bytes += mn;
     if (epi == EB_LNBWD2) bytes += 2 * mn;
     ProfScope prof(s, PROF_NT + 256 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * p.nb, bytes * 2.0 * p.nb);
     switch (epi) {
@@ -582,6 +657,8 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
         case EB_BIASGATE: return launch_nt<EB_BIASGATE>(p, s);
         case EB_DOTCOL: return launch_nt<EB_DOTCOL>(p, s);
         case EB_LNBWD2: return launch_nt<EB_LNBWD2>(p, s);
+        case EB_SCATTER: return launch_nt<EB_SCATTER>(p, s);
+        case EB_SCATTER_ADD: return launch_nt<EB_SCATTER_ADD>(p, s);
     }
     dcpt_set_error("gemm_nt_bf16: unknown epilogue %d", epi);
     return DCPT_ERR_ARG;
@@ -638,6 +715,10 @@ int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s) {
     if (p.yconv)
         DCPT_CHECK_ARG(p.gC % 8 == 0 && p.K == 9 * p.gC && p.colsum == nullptr && (double)(p.rows_per_split + 66 + 2 * p.gW) * p.gC * 2.0 < 1.0e9,
                        "gemm_tn_bf16: gathered Y needs K == 9 * gC, gC %% 8 == 0, no column sums");
+    if (p.xg2 || p.yg2)
+        DCPT_CHECK_ARG(!(p.xg2 && p.yg2) && !p.yconv && p.gC % 8 == 0 && (p.xg2 ? p.N : p.K) == 4 * p.gC && (!p.xg2 || p.colsum == nullptr) &&
+                           (double)(p.rows_per_split + 66 + 2 * p.gW) * 4.0 * p.gC * 2.0 < 1.0e9,
+                       "gemm_tn_bf16: a gathered operand needs 4 * gC columns, gC %% 8 == 0 (and no column sums of a gathered X)");
     const double bytes = ((double)p.M * p.N + (double)p.M * p.K) * 2.0 + (double)p.splits * p.N * p.K * 4.0;
     ProfScope prof(s, PROF_TN + 256, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K, bytes);
     int bn, bk;
@@ -645,9 +726,23 @@ int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s) {
     const int tiles = cdiv(p.N, bn) * cdiv(p.K, bk);
     const dim3 grid((unsigned)(tiles * p.splits));
     if (p.yconv) {
-        if (bn == 64) gemm_tn_bf16_kernel<64, 128, 1, 4, true><<<grid, dim3(256), 0, s>>>(p);   // (K = 9 gC >= 72: the 128-wide k tile)
-        else gemm_tn_bf16_kernel<128, 128, 2, 2, true><<<grid, dim3(256), 0, s>>>(p);
+        if (bn == 64) gemm_tn_bf16_kernel<64, 128, 1, 4, 1><<<grid, dim3(256), 0, s>>>(p);   // (K = 9 gC >= 72: the 128-wide k tile)
+        else gemm_tn_bf16_kernel<128, 128, 2, 2, 1><<<grid, dim3(256), 0, s>>>(p);
         DCPT_CHECK_LAUNCH("gemm_tn_bf16 conv3");
+        return DCPT_OK;
+    }
+    if (p.yg2 || p.xg2) {   // N resp. K = 4 gC >= 32 on the gathered side
+#define TNG(BN_, BK_, WN_, WK_)                                                                         \
+    do {                                                                                                \
+        if (p.yg2) gemm_tn_bf16_kernel<BN_, BK_, WN_, WK_, 2, false><<<grid, dim3(256), 0, s>>>(p);     \
+        else gemm_tn_bf16_kernel<BN_, BK_, WN_, WK_, 0, true><<<grid, dim3(256), 0, s>>>(p);           \
+    } while (0)
+        if (bn == 64 && bk == 64) TNG(64, 64, 2, 2);
+        else if (bk == 64) TNG(128, 64, 4, 1);
+        else if (bn == 64) TNG(64, 128, 1, 4);
+        else TNG(128, 128, 2, 2);
+#undef TNG
+        DCPT_CHECK_LAUNCH("gemm_tn_bf16 gather2");
         return DCPT_OK;
     }
     if (bn == 64 && bk == 64) gemm_tn_bf16_kernel<64, 64, 2, 2><<<grid, dim3(256), 0, s>>>(p);

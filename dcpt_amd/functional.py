@@ -380,11 +380,88 @@ class _EndingFn(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
 
 
-def conv3x3_in(x, weight, bias):
-    return _IntroFn.apply(x, weight, bias)
+class _IntroBf16Fn(torch.autograd.Function):
+    """_IntroFn with the feature side in bf16 storage (edge_bf16.hip): fp32 image in, bf16 NHWC features out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _require_gpu(x, weight, bias)
+        x = _contig(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        y = _empty_nhwc_bf16(B, Cout, H, W, x.device)
+        check(lib.dcpt_conv3x3_in_fwd_bf16(x.data_ptr(), w_.data_ptr(), _p(b_), y.data_ptr(), B, H, W, Cin, Cout, _stream(x.device)),
+              "dcpt_conv3x3_in_fwd_bf16")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        _require_gpu_bf16(dy)
+        dy = _nhwc(dy)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        dw = torch.empty_like(w_)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = _workspace(dev, lib.dcpt_conv3x3_in_bwd_ws_bytes(B, H, W, Cin, Cout))
+        check(lib.dcpt_conv3x3_in_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv3x3_in_bwd_bf16")
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+class _EndingBf16Fn(torch.autograd.Function):
+    """_EndingFn with bf16 NHWC features in, fp32 image (+ residual image) out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res):
+        lib = _lib.load()
+        _require_gpu_bf16(x)
+        _require_gpu(weight, bias, res)
+        x = _nhwc(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        res_ = None if res is None else _contig(res)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        check(lib.dcpt_conv3x3_out_fwd_bf16(x.data_ptr(), w_.data_ptr(), _p(b_), _p(res_), y.data_ptr(), B, H, W, Cin, Cout,
+                                            _stream(x.device)), "dcpt_conv3x3_out_fwd_bf16")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias = bias is not None
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        dy = _contig(dy)
+        B, Cin, H, W = x.shape
+        Cout = w_.shape[0]
+        dev = x.device
+        dx = _empty_nhwc_bf16(B, Cin, H, W, dev)
+        dw = torch.empty_like(w_)
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.dcpt_conv3x3_out_bwd_ws_bytes(B, H, W, Cin, Cout))
+        check(lib.dcpt_conv3x3_out_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv3x3_out_bwd_bf16")
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
+
+
+def conv3x3_in(x, weight, bias, out_bf16=False):
+    """3x3 conv image -> features; ``out_bf16``: emit bf16-storage features (the first layer of the bf16 path)"""
+    return _IntroBf16Fn.apply(x, weight, bias) if out_bf16 else _IntroFn.apply(x, weight, bias)
 
 
 def conv3x3_out(x, weight, bias, res=None):
+    if x.dtype == torch.bfloat16:
+        return _EndingBf16Fn.apply(x, weight, bias, res)
     return _EndingFn.apply(x, weight, bias, res)
 
 
@@ -463,11 +540,87 @@ class _UpFn(torch.autograd.Function):
         return dx, dw, (dy if ctx.has_skip else None)
 
 
+class _DownBf16Fn(torch.autograd.Function):
+    """_DownFn in bf16 storage (edge_bf16.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _require_gpu_bf16(x)
+        _require_gpu(weight, bias)
+        x = _nhwc(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        B, Cc, H, W = x.shape
+        if H % 2 or W % 2:
+            raise ValueError(f"down2x2: H={H}, W={W} must be even")
+        y = _empty_nhwc_bf16(B, 2 * Cc, H // 2, W // 2, x.device)
+        ws = _workspace(x.device, lib.dcpt_down2x2_bf16_ws_bytes(B, H, W, Cc, 0))
+        check(lib.dcpt_down2x2_fwd_bf16(x.data_ptr(), w_.data_ptr(), _p(b_), y.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc,
+                                        _stream(x.device)), "dcpt_down2x2_fwd_bf16")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        _require_gpu_bf16(dy)
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = _empty_nhwc_bf16(B, Cc, H, W, dev)
+        dw = torch.empty_like(w_)
+        db = torch.empty((2 * Cc,), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.dcpt_down2x2_bf16_ws_bytes(B, H, W, Cc, 1))
+        check(lib.dcpt_down2x2_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_down2x2_bwd_bf16")
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+class _UpBf16Fn(torch.autograd.Function):
+    """_UpFn in bf16 storage (edge_bf16.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, skip):
+        lib = _lib.load()
+        _require_gpu_bf16(x, *([] if skip is None else [skip]))
+        _require_gpu(weight)
+        x = _nhwc(x)
+        w_ = _contig(weight.detach())
+        skip_ = None if skip is None else _nhwc(skip)
+        B, Cc, H, W = x.shape
+        y = _empty_nhwc_bf16(B, Cc // 2, 2 * H, 2 * W, x.device)
+        ws = _workspace(x.device, lib.dcpt_up_ps_bf16_ws_bytes(B, H, W, Cc, 0))
+        check(lib.dcpt_up_ps_fwd_bf16(x.data_ptr(), w_.data_ptr(), _p(skip_), y.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc,
+                                      _stream(x.device)), "dcpt_up_ps_fwd_bf16")
+        ctx.save_for_backward(x, w_)
+        ctx.has_skip = skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        _require_gpu_bf16(dy)
+        dy = _nhwc(dy)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = _empty_nhwc_bf16(B, Cc, H, W, dev)
+        dw = torch.empty_like(w_)
+        ws = _workspace(dev, lib.dcpt_up_ps_bf16_ws_bytes(B, H, W, Cc, 1))
+        check(lib.dcpt_up_ps_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W,
+                                      Cc, _stream(dev)), "dcpt_up_ps_bwd_bf16")
+        return dx, dw, (dy if ctx.has_skip else None)
+
+
 def down2x2(x, weight, bias):
-    return _DownFn.apply(x, weight, bias)
+    return _DownBf16Fn.apply(x, weight, bias) if x.dtype == torch.bfloat16 else _DownFn.apply(x, weight, bias)
 
 
 def up_ps(x, weight, skip=None):
+    if x.dtype == torch.bfloat16:
+        return _UpBf16Fn.apply(x, weight, skip)
     return _UpFn.apply(x, weight, skip)
 
 

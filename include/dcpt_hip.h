@@ -131,6 +131,30 @@ int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_gr
 int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream);
 int dcpt_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, dcpt_stream_t stream);
 
+/* ---- the layers between the NAFBlock groups, bf16 storage (edge_bf16.hip): same algorithms and argument meaning as
+ * dcpt_conv3x3_in / _out, dcpt_down2x2 and dcpt_up_ps below (reference basicsr/archs/nafnet_arch.py:202-219, :230, :238-242,
+ * :252-272); feature maps (NHWC) and their gradients are bf16, the 3-channel images (NCHW), weights, biases and all parameter
+ * gradients fp32.  With these a NAFNet in bf16 storage has no cast kernels between its layers.  down: C % 8 == 0; up: C % 16 == 0.
+ * Workspaces: dcpt_conv3x3_in_bwd_ws_bytes / dcpt_conv3x3_out_bwd_ws_bytes (unchanged), dcpt_down2x2_bf16_ws_bytes, dcpt_up_ps_bf16_ws_bytes. */
+int dcpt_conv3x3_in_fwd_bf16(const float* x, const float* w, const float* bias, uint16_t* y, int B, int H, int W, int Cin, int Cout,
+                             dcpt_stream_t stream);
+int dcpt_conv3x3_in_bwd_bf16(const uint16_t* dy, const float* x, const float* w, float* dx /* may be NULL */, float* dw, float* dbias, void* ws,
+                             size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+int dcpt_conv3x3_out_fwd_bf16(const uint16_t* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W, int Cin,
+                              int Cout, dcpt_stream_t stream);
+int dcpt_conv3x3_out_bwd_bf16(const float* dy, const uint16_t* x, const float* w, uint16_t* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                              int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+size_t dcpt_down2x2_bf16_ws_bytes(int B, int H, int W, int C, int backward);
+int dcpt_down2x2_fwd_bf16(const uint16_t* x, const float* w, const float* bias, uint16_t* y, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                          dcpt_stream_t stream);
+int dcpt_down2x2_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, uint16_t* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                          int B, int H, int W, int C, dcpt_stream_t stream);
+size_t dcpt_up_ps_bf16_ws_bytes(int B, int H, int W, int C, int backward);
+int dcpt_up_ps_fwd_bf16(const uint16_t* x, const float* w, const uint16_t* skip /* may be NULL */, uint16_t* y, void* ws, size_t ws_bytes, int B,
+                        int H, int W, int C, dcpt_stream_t stream);
+int dcpt_up_ps_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, uint16_t* dx, float* dw, void* ws, size_t ws_bytes, int B, int H,
+                        int W, int C, dcpt_stream_t stream);
+
 /* ---- classifier head, bf16 storage: the conv -> channels-first LayerNorm -> [+shortcut] -> [ReLU] groups and the
  * conv1x1 -> MaxPool2d(2,2) -> ReLU downsamples of degrad_classify_arch.py (:69-103, :227-243, :596-602) with bf16 activations
  * (x, z = conv output, y and their gradients), fp32 parameters / gradients / statistics; same argument meaning as dcpt_conv_ln_* and

@@ -164,6 +164,50 @@ def nafnet_forward(inp, P: dict, hook: bool = False):
     return x, taps
 
 
+# ---- bf16-storage mode of the layers between the block groups (dcpt_amd/csrc/edge_bf16.hip) ------------------------------------
+# Feature maps and their gradients are stored in bf16 (rounded once, on store), GEMM weight operands are bf16 copies, the two
+# 3-channel convs (direct VALU kernels) use the fp32 weights; images, biases, all parameter gradients fp32.
+def intro_bf16(inp, w, b):
+    return _rr(F.conv2d(inp, w, b, padding=1))
+
+
+def ending_bf16(x, w, b, inp):
+    return F.conv2d(_rb(x), w, b, padding=1) + inp
+
+
+def down_bf16(x, w, b):
+    return _rr(F.conv2d(_rb(x), _rf(w), b, stride=2))
+
+
+def up_bf16(x, w, skip):
+    y = pixel_shuffle2(F.conv2d(_rb(x), _rf(w)))
+    return _rr(y + skip if skip is not None else y)
+
+
+def nafnet_forward_bf16(inp, P: dict, hook: bool = False):
+    """nafnet_forward() in bf16 storage end to end (NAFNetBaseline(act_dtype="bf16")): same return convention."""
+    enc_nums, mid_num, dec_nums = nafnet_cfg_from_params(P)
+    x = intro_bf16(inp, P["intro.weight"], P["intro.bias"])
+    encs = []
+    for i, nb in enumerate(enc_nums):
+        for j in range(nb):
+            x = nafblock_bf16(x, P, f"encoders.{i}.{j}.")
+        x = _rb(x)   # the group output feeds the down conv AND the skip: autograd adds the two bf16 gradients into a bf16 tensor
+        encs.append(x)
+        x = down_bf16(x, P[f"downs.{i}.weight"], P[f"downs.{i}.bias"])
+    for j in range(mid_num):
+        x = nafblock_bf16(x, P, f"middle_blks.{j}.")
+    taps = []
+    for i, nb in enumerate(dec_nums):
+        x = up_bf16(x, P[f"ups.{i}.0.weight"], encs[len(encs) - 1 - i])
+        for j in range(nb):
+            x = nafblock_bf16(x, P, f"decoder{i}.{j}.")
+        taps.append(x)
+    if hook:
+        return None, taps
+    return ending_bf16(x, P["ending.weight"], P["ending.bias"], inp), taps
+
+
 def nafnet_param_shapes(img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=(), dec_blk_nums=()):
     """State-dict key -> shape, in the reference's registration order
     (nafnet_arch.py:200-248; NAFBlock.__init__ :84-163)."""

@@ -101,14 +101,101 @@ def test_nafblock_bf16_oracle(dev, shape):
         assert _rel(Pd[k].grad, gf[name]) <= 6e-2, (k, _rel(Pd[k].grad, gf[name]))
 
 
-def test_nafnet_bf16_blocks_in_network(dev):
-    """``act_dtype='bf16'`` NAFNetBaseline: same state dict, block groups on the bf16 kernels between casts, hooks still fire with
-    fp32 group outputs; the network output stays close to the fp32 network's (tiny net, 9 blocks)."""
+def _bf(t):
+    return t.bfloat16().float()
+
+
+# down: C = 8 / 24 (one ragged k-tile, N < a tile) / 64 / 256 (multi k-tile, two column tiles); odd coarse grids
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 4, 6), (1, 64, 16, 16), (3, 24, 2, 10), (1, 256, 8, 4), (2, 16, 10, 14)])
+def test_down_up_bf16_oracle(dev, B, C, H, W):
+    """Conv2d(C, 2C, 2, 2) and Conv2d(C, 2C, 1) + PixelShuffle(2) + skip (reference nafnet_arch.py:230, :238-242, :264-265) in bf16
+    storage vs the oracle's bf16 mode (fp32 arithmetic, bf16 rounding of the stored tensors and of the weight operand)."""
+    from dcpt_amd import functional as DF
+
+    x = _bf(keyed_input("bd.x", (B, C, H, W), lo=-1, hi=1))
+    w = keyed_tensor("bd.downs.weight", (2 * C, C, 2, 2))
+    b = keyed_tensor("bd.downs.bias", (2 * C,))
+    go = _bf(keyed_input("bd.go", (B, 2 * C, H // 2, W // 2), lo=-1, hi=1))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = O.down_bf16(xr, wr, br)
+    yr.backward(go)
+    xg = x.to(dev).bfloat16().requires_grad_(True)
+    wg, bg = (t.to(dev).requires_grad_(True) for t in (w, b))
+    y = DF.down2x2(xg, wg, bg)
+    assert y.dtype == torch.bfloat16
+    y.backward(go.to(dev).bfloat16())
+    errs = {"y": _rel(y, yr), "dx": _rel(xg.grad, xr.grad), "dw": _rel(wg.grad, wr.grad), "db": _rel(bg.grad, br.grad)}
+    assert xg.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
+    assert all(np.isfinite(v) and v <= 1e-2 for v in errs.values()), ("down", errs)
+
+    if C % 16:
+        return
+    wu = keyed_tensor("bu.ups.weight", (2 * C, C, 1, 1))
+    skip = _bf(keyed_input("bu.skip", (B, C // 2, 2 * H, 2 * W), lo=-1, hi=1))
+    go2 = _bf(keyed_input("bu.go", (B, C // 2, 2 * H, 2 * W), lo=-1, hi=1))
+    xr, wr, sr = (t.clone().requires_grad_(True) for t in (x, wu, skip))
+    yr = O.up_bf16(xr, wr, sr)
+    yr.backward(go2)
+    xg, sg = (t.to(dev).bfloat16().requires_grad_(True) for t in (x, skip))
+    wg = wu.to(dev).requires_grad_(True)
+    y = DF.up_ps(xg, wg, sg)
+    assert y.dtype == torch.bfloat16
+    y.backward(go2.to(dev).bfloat16())
+    errs = {"y": _rel(y, yr), "dx": _rel(xg.grad, xr.grad), "dw": _rel(wg.grad, wr.grad), "dskip": _rel(sg.grad, sr.grad)}
+    assert all(np.isfinite(v) and v <= 1e-2 for v in errs.values()), ("up", errs)
+    # no skip
+    xr2, wr2 = x.clone().requires_grad_(True), wu.clone().requires_grad_(True)
+    yr2 = O.up_bf16(xr2, wr2, None)
+    y2 = DF.up_ps(x.to(dev).bfloat16(), wu.to(dev), None)
+    assert _rel(y2, yr2) <= 1e-2
+
+
+@pytest.mark.parametrize("B,Cs,Cb,H,W", [(2, 3, 8, 6, 10), (1, 3, 64, 16, 16), (2, 1, 16, 5, 5), (1, 4, 32, 7, 3)])
+def test_edge_convs_bf16_oracle(dev, B, Cs, Cb, H, W):
+    """intro (image -> bf16 features) and ending (bf16 features -> image + residual) 3x3 convs (reference nafnet_arch.py:202-219)."""
+    from dcpt_amd import functional as DF
+
+    img = keyed_input("be.img", (B, Cs, H, W), lo=-1, hi=1)
+    w = keyed_tensor("be.intro.weight", (Cb, Cs, 3, 3))
+    b = keyed_tensor("be.intro.bias", (Cb,))
+    go = _bf(keyed_input("be.go", (B, Cb, H, W), lo=-1, hi=1))
+    ir, wr, br = (t.clone().requires_grad_(True) for t in (img, w, b))
+    yr = O.intro_bf16(ir, wr, br)
+    yr.backward(go)
+    ig, wg, bg = (t.to(dev).requires_grad_(True) for t in (img, w, b))
+    y = DF.conv3x3_in(ig, wg, bg, out_bf16=True)
+    assert y.dtype == torch.bfloat16
+    y.backward(go.to(dev).bfloat16())
+    errs = {"y": _rel(y, yr), "dimg": _rel(ig.grad, ir.grad), "dw": _rel(wg.grad, wr.grad), "db": _rel(bg.grad, br.grad)}
+    assert all(np.isfinite(v) and v <= 1e-2 for v in errs.values()), ("intro", errs)
+
+    feat = _bf(keyed_input("be.feat", (B, Cb, H, W), lo=-1, hi=1))
+    w2 = keyed_tensor("be.ending.weight", (Cs, Cb, 3, 3))
+    b2 = keyed_tensor("be.ending.bias", (Cs,))
+    go2 = keyed_input("be.go2", (B, Cs, H, W), lo=-1, hi=1)
+    fr, wr, br, rr = (t.clone().requires_grad_(True) for t in (feat, w2, b2, img))
+    yr = O.ending_bf16(fr, wr, br, rr)
+    yr.backward(go2)
+    fg = feat.to(dev).bfloat16().requires_grad_(True)
+    wg, bg, rg = (t.to(dev).requires_grad_(True) for t in (w2, b2, img))
+    y = DF.conv3x3_out(fg, wg, bg, rg)
+    assert y.dtype == torch.float32
+    y.backward(go2.to(dev))
+    errs = {"y": _rel(y, yr), "dx": _rel(fg.grad, fr.grad), "dw": _rel(wg.grad, wr.grad), "db": _rel(bg.grad, br.grad), "dres": _rel(rg.grad, rr.grad)}
+    assert fg.grad.dtype == torch.bfloat16
+    assert all(np.isfinite(v) and v <= 1e-2 for v in errs.values()), ("ending", errs)
+
+
+def test_nafnet_bf16_end_to_end(dev):
+    """``act_dtype='bf16'`` NAFNetBaseline: same state dict; every feature map from the intro conv's output to the ending conv's input
+    is bf16 (hooks on the decoder groups see bf16 taps, no cast kernels); output, input gradient and parameter gradients against
+    the oracle's bf16-mode network (oracle/nafnet_oracle.py::nafnet_forward_bf16) and, as a sanity bound, the fp32 network."""
     from basicsr.archs import build_network
     from dcpt_amd.keyed_init import keyed_state_dict
 
     cfg = dict(img_channel=3, width=8, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 2], dec_blk_nums=[1, 1, 1, 1])
     sd = keyed_state_dict(O.nafnet_param_shapes(**cfg), seed=0)
+    x0 = keyed_input("bfnet.x", (2, 3, 32, 32))
     outs = {}
     for dt in ("fp32", "bf16"):
         net = build_network(dict(type="NAFNetBaseline", act_dtype=dt, **cfg))
@@ -116,13 +203,26 @@ def test_nafnet_bf16_blocks_in_network(dev):
         net = net.to(dev)
         taps = []
         hooks = [getattr(net, f"decoder{i}").register_forward_hook(lambda m, i, o: taps.append(o)) for i in range(4)]
-        x = keyed_input("bfnet.x", (2, 3, 32, 32)).to(dev).requires_grad_(True)
+        x = x0.to(dev).requires_grad_(True)
         y = net(x)
+        assert y.dtype == torch.float32
         y.square().mean().backward()
-        assert len(taps) == 4 and all(t.dtype == torch.float32 for t in taps)
-        outs[dt] = (y.detach(), x.grad.detach(), {k: p.grad.detach() for k, p in net.named_parameters()})
+        assert len(taps) == 4 and all(t.dtype == (torch.float32 if dt == "fp32" else torch.bfloat16) for t in taps)
+        outs[dt] = (y.detach(), x.grad.detach(), {k: p.grad.detach() for k, p in net.named_parameters()}, [t.detach() for t in taps])
         for h in hooks:
             h.remove()
+    # bf16-mode oracle
+    Pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x0.clone().requires_grad_(True)
+    yo, taps_o = O.nafnet_forward_bf16(xr, Pr)
+    yo.square().mean().backward()
+    assert _rel(outs["bf16"][0], yo) <= 1.5e-2, _rel(outs["bf16"][0], yo)
+    for t, to in zip(outs["bf16"][3], taps_o):
+        assert _rel(t, to) <= 2e-2, _rel(t, to)
+    assert _rel(outs["bf16"][1], xr.grad) <= 4e-2, _rel(outs["bf16"][1], xr.grad)
+    worst = max((_rel(outs["bf16"][2][k], Pr[k].grad), k) for k in Pr)
+    assert worst[0] <= 6e-2, worst
+    # sanity: how far bf16 storage moves the result
     assert _rel(outs["bf16"][0], outs["fp32"][0]) <= 3e-2
     assert _rel(outs["bf16"][1], outs["fp32"][1]) <= 8e-2
     worst = max(_rel(outs["bf16"][2][k], outs["fp32"][2][k]) for k in outs["fp32"][2])
