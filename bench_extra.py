@@ -53,8 +53,8 @@ def main():
     bf = args.dtype == "bf16"
     naf = dict(NAF, act_dtype=args.dtype)
     # SURVEY 8d algorithmic HBM bytes of NAFNet-64 fwd+bwd per 256^2 image: 25 element passes over the blocks' sum c*P = 30.146 M
-    # (bf16: 2 B each) + 3 passes over the 40.4 M elements of the layers between the groups (fp32 in both modes)
-    naf_bytes = 25 * 30.146e6 * (2 if bf else 4) + 3 * 40.4e6 * 4
+    # + 3 passes over the 40.4 M elements of the layers between the groups; 4 B per element in fp32, 2 B in bf16 storage (end to end)
+    naf_bytes = (25 * 30.146e6 + 3 * 40.4e6) * (2 if bf else 4)
     peak = 2.5e15 if bf else 157.3e12
 
     def rooflines(flops, nbytes, dt):
@@ -78,7 +78,7 @@ def main():
 
         dt = timed(step, args.steps, args.warmup)
         sc = B * (S / 256.0) ** 2
-        res = dict(workload=f"NAFNet-64 [1,1,1,28] fwd+L1+bwd+AdamW, B={B}, {S}x{S}, NAFBlock activations {args.dtype}",
+        res = dict(workload=f"NAFNet-64 [1,1,1,28] fwd+L1+bwd+AdamW, B={B}, {S}x{S}, feature maps {args.dtype}",
                    ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3), **rooflines(sc * 378.3e9, sc * naf_bytes, dt))
     elif args.workload == "dcpt":
         # configs[2]: NAFNet-64 encoder + PromptIR_NoImg_DC head, 10 classes, one DCPT step (fp32 here; the reference has no AMP)
@@ -101,7 +101,7 @@ def main():
         sc = B * (S / 256.0) ** 2
         flops = sc * 1.315e12   # 1.315 TFLOP fwd+bwd per 256^2 image (2 x 378.3 GF encoder + 558.9 GF head)
         res = dict(workload=f"DCPT step: NAFNet-64 x2 fwd + PromptIR_NoImg_DC head + bwd + 2x AdamW, B={B}, {S}x{S}, "
-                            f"NAFBlock activations {args.dtype}, head {args.head_dtype or args.dtype}",
+                            f"encoder feature maps {args.dtype}, head {args.head_dtype or args.dtype}",
                    ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3), log=m.get_current_log())
         if bf:
             # two rooflines for the mixed step: the encoder's flops on the bf16 pipe + the head's on the fp32 pipe (time bound),

@@ -242,11 +242,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    constexpr int SM_BYTES = 2 * (A_BYTES + B_BYTES);
+#ifndef NTB_STAGES
+#define NTB_STAGES 2
+#endif
+    constexpr int ST = NTB_STAGES;   // k-tiles resident in LDS: the one in use + ST - 1 in flight
+    constexpr int SM_BYTES = ST * (A_BYTES + B_BYTES);
     static_assert(SM_BYTES >= BM * BN * 4, "epilogue staging does not fit");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
-    unsigned char* const As0 = smem;                 // [2][A_BYTES]
-    unsigned char* const Bs0 = smem + 2 * A_BYTES;   // [2][B_BYTES]
+    unsigned char* const As0 = smem;                  // [ST][A_BYTES]
+    unsigned char* const Bs0 = smem + ST * A_BYTES;   // [ST][B_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,8 +340,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (p.K + KT - 1) / KT;
-    gload(0, 0);
-    dma_wait_all();
+    // prologue: ST - 1 k-tiles in flight (tiles past the end are issued too -- their offsets are out of range, they land as zeros --
+    // so that the counted waits below see a fixed number of DMAs per k-tile)
+#pragma unroll
+    for (int q = 0; q < ST - 1; ++q) gload(q, q);
+    if constexpr (ST == 2) dma_wait_all();
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (A_IT + B_IT)) : "memory");
     __syncthreads();
     const int fi = ((lane & 31) >> 1) & 7, fh = lane >> 5;
     const int a_row = (wm * TM * 32 + (lane & 31)) * 128;
@@ -346,8 +354,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) slot[j] = ((2 * j + fh) ^ fi) * 16;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1, buf ^ 1);
+        const int buf = kt % ST;
+        if constexpr (ST == 2) {
+            if (kt + 1 < nkt) gload(kt + 1, buf ^ 1);
+        } else {
+            gload(kt + ST - 1, (kt + ST - 1) % ST);   // refills the buffer read in iteration kt - 1 (published free by the last barrier)
+        }
         const unsigned char* as = As0 + buf * A_BYTES + a_row;
         const unsigned char* bs = Bs0 + buf * B_BYTES + b_row;
 #pragma unroll
@@ -362,7 +374,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[jn], acc[i][jn], 0, 0, 0);
         }
-        dma_wait_all();
+        if constexpr (ST == 2) dma_wait_all();
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (A_IT + B_IT)) : "memory");   // k-tile kt + 1 has landed
+        __syncthreads();
+    }
+    if constexpr (ST > 2) {
+        dma_wait_all();   // the zero tiles past the end, before the staging area is reused
         __syncthreads();
     }
 
