@@ -53,12 +53,30 @@ __device__ __forceinline__ pv<8 / sizeof(ST)> lds_piece(const unsigned char* p) 
     return r;
 }
 
+// gelu(a) = a Phi(a) and its derivative Phi(a) + a phi(a) from ONE exponential, branch-free: erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, i.e. below fp32 resolution of Phi; ocml's erff is ~50 instructions with divergent branches and made the
+// GELU-gate loop 2.3x the SimpleGate one), e = exp(-a^2 / 2) is shared by the erf tail and the density term.
+__device__ __forceinline__ void dwr_gelu_both(float a, float& g, float& gd) {
+    const float ax = fabsf(a) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float e = __expf(-ax * ax);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, a));
+    g = a * cdf;
+    gd = fmaf(a * 0.39894228040143268f, e, cdf);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename ST>
+// GATE: 0 SimpleGate (a_1 + b_1)(a_2 + b_2) + pooling partials (NAFNet), 1 gelu(a_1) a_2 (Restormer GDFN, restormer_arch.py:75-92).
+// (A gate-less mode for Restormer's qkv depthwise conv was measured slower than the register kernel, 221 vs 191 us per launch, and
+// is not kept.)
+template <typename ST, int GATE = 0>
 __global__ __launch_bounds__(256) void dwr_gate_fwd_kernel(const DwrP p) {
     constexpr int ES = sizeof(ST), VW = 8 / ES, R = RING;
+    constexpr int NST = 2;   // output stores per thread and row
     __shared__ __attribute__((aligned(16))) unsigned char ring[R * SLOT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(256) void dwr_gate_fwd_kernel(const DwrP p) {
         wait_vm<0>();
 #else
         if (it < R - 1) wait_vm<3 * (R - 2)>();                 // no / fewer stores issued yet: conservative count
-        else wait_vm<3 * (R - 2) + 2 * (R - 1)>();
+        else wait_vm<3 * (R - 2) + NST * (R - 1)>();
 #endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -173,7 +191,13 @@ __global__ __launch_bounds__(256) void dwr_gate_fwd_kernel(const DwrP p) {
                 a0[o][1].v[i] = fmaf(w2[3].v[i], l2, fmaf(w2[4].v[i], m2, fmaf(w2[5].v[i], r2, a1[o][1].v[i])));
                 a1[o][0].v[i] = fmaf(w1[0].v[i], l1, fmaf(w1[1].v[i], m1, w1[2].v[i] * r1));
                 a1[o][1].v[i] = fmaf(w2[0].v[i], l2, fmaf(w2[1].v[i], m2, w2[2].v[i] * r2));
-                t.v[i] = (f1 + bias1.v[i]) * (f2 + bias2.v[i]);
+                if constexpr (GATE == 0) {
+                    t.v[i] = (f1 + bias1.v[i]) * (f2 + bias2.v[i]);
+                } else {
+                    float gv, gd;
+                    dwr_gelu_both(f1 + bias1.v[i], gv, gd);
+                    t.v[i] = gv * (f2 + bias2.v[i]);
+                }
             }
             const bool ok = yok && (o == 0 ? ok0 : ok1);
             const uint32_t off = ok ? (uint32_t)(((y - rb) * p.W + xa + o) * C + c1) * ES : ROW_SENT;
@@ -201,15 +225,15 @@ __global__ __launch_bounds__(256) void dwr_gate_fwd_kernel(const DwrP p) {
         for (int i = 0; i < VW; ++i) red[tid * VW + i] = pool.v[i];
         __syncthreads();
         if (pp == 0 && gok) {
-            float s[VW];
+            float sres[VW];
 #pragma unroll
-            for (int i = 0; i < VW; ++i) s[i] = red[g * VW + i];
+            for (int i = 0; i < VW; ++i) sres[i] = red[g * VW + i];
             for (int k = 1; k < PP; ++k)
 #pragma unroll
-                for (int i = 0; i < VW; ++i) s[i] += red[(k * LP + g) * VW + i];
+                for (int i = 0; i < VW; ++i) sres[i] += red[(k * LP + g) * VW + i];
             float* dst = p.part + ((int64_t)b * gridDim.y + blockIdx.y) * C + c1;
 #pragma unroll
-            for (int i = 0; i < VW; ++i) dst[i] = s[i];
+            for (int i = 0; i < VW; ++i) dst[i] = sres[i];
         }
     }
 }
@@ -241,14 +265,14 @@ bool dwr_enabled() {
     return on != 0;
 }
 
-template <typename ST>
+template <typename ST, int GATE = 0>
 int launch_fwd(const void* t1, const float* w2p, const float* b2, void* t2, float* pool_part, const DwGeom& g, hipStream_t s) {
     const DwrGeom d = dwr_geom(g, (int)sizeof(ST));
     DwrP p{};
     p.in = t1; p.w2p = w2p; p.b2 = b2; p.out = t2; p.part = pool_part;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.LP = d.LP; p.nwc = d.nwc;
     DCPT_CHECK_ARG(((double)cdiv(g.H, d.nrp) + 4.0) * g.W * 2.0 * g.C * sizeof(ST) < 1.0e9, "depthwise ring: a row range exceeds the 32-bit window");
-    dwr_gate_fwd_kernel<ST><<<dim3(d.nqc, d.nwc * d.nrp, g.B), dim3(256), 0, s>>>(p);
+    dwr_gate_fwd_kernel<ST, GATE><<<dim3(d.nqc, d.nwc * d.nrp, g.B), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("dwr_gate_fwd");
     return DCPT_OK;
 }
@@ -313,19 +337,26 @@ struct DwrBP {
     int nwc;            // column tiles
 };
 
-template <typename ST, int LP, int MULTI>
+// GATE: 0 SimpleGate a_1 a_2 (+ bias, SCA scale / pooled gradient; NAFNet), 1 gelu(a_1) a_2 with the exact erf GELU (Restormer GDFN,
+// reference restormer_arch.py:75-92), 2 no gate at all: `dts` is the gradient of the conv output itself over all 2C channels and
+// nothing is recomputed (the qkv depthwise conv of Restormer's MDTA, :108-145) -- the kernel is then the transposed conv + the tap
+// gradients on the ring.
+template <typename ST, int LP, int MULTI, int GATE = 0>
 __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
-    constexpr int ES = sizeof(ST), PBY = 2 * ES, R = ES == 4 ? DWRB_R32 : DWRB_R16;
+    constexpr int ES = sizeof(ST), PBY = 2 * ES;
+    constexpr int R = GATE == 2 ? 3 : (ES == 4 ? DWRB_R32 : DWRB_R16);   // (GATE 2: 16-KB slots, three keep two blocks per CU)
+    constexpr int DD = GATE == 2 ? 2 : 1;          // gate halves carried by the dts rows
+    constexpr int NDD = (DD * ES + 3) / 4;         // dts DMAs per wave and row (DD x 2 planes x 256 runs x PBY bytes)
     constexpr int NDT = ES / 2;                    // t1 DMAs per wave and row (4 planes x 256 runs x PBY bytes = NDT x 4 KiB)
     constexpr int NCH = 256 / LP;                  // pixel pairs per plane
     constexpr int PP = NCH - MULTI, PB = 2 * PP;   // pixel-pair groups that work / da columns of the tile
     constexpr int NC = PB + 2 * MULTI;             // t1 columns in a slot
     constexpr int UPH = LP * PBY / 16;             // 16-byte DMA units per (pixel, half) run
     constexpr int BLK = LP * PBY, PLANE = NCH * BLK;
-    constexpr int TBYTES = 4 * PLANE, SLOT = TBYTES + 4096;
+    constexpr int TBYTES = 4 * PLANE, SLOT = TBYTES + NDD * 4096;
     constexpr int XBLK = LP * 8, XPLANE = NCH * XBLK, XSLOT = 4 * XPLANE;
     constexpr int XOFF = R * SLOT, ZOFF = XOFF + 2 * XSLOT;
-    static_assert(TBYTES == NDT * 4096 && UPH >= 1 && 2 * NCH * BLK <= 4096, "slot geometry");
+    static_assert(TBYTES == NDT * 4096 && UPH >= 1 && DD * 2 * NCH * BLK <= NDD * 4096, "slot geometry");
     __shared__ __attribute__((aligned(16))) unsigned char smem[ZOFF + 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,8 +395,8 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
     // ---- DMA map of this lane
     const int rb = h0 - 2 > 0 ? h0 - 2 : 0;   // first image row the windows reach
     const i32x4 rs_t = make_rsrc_dma((const ST*)p.t1 + ((int64_t)b * p.H + rb) * p.W * 2 * C);
-    const i32x4 rs_d = make_rsrc_dma((const ST*)p.dts + ((int64_t)b * p.H + rb) * p.W * C);
-    uint32_t colo[NDT], cold;
+    const i32x4 rs_d = make_rsrc_dma((const ST*)p.dts + ((int64_t)b * p.H + rb) * p.W * (DD * C));
+    uint32_t colo[NDT], cold[NDD];
 #pragma unroll
     for (int j = 0; j < NDT; ++j) {
         const int e = (j * 4 + wave) * 64 + lane;
@@ -376,16 +407,18 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         const bool ok = lc < NC && x >= 0 && x < p.W && cb < C * ES;
         colo[j] = ok ? (uint32_t)((x * 2 * C + h * C) * ES + cb) : COL_SENT;
     }
-    {
-        const int e = wave * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NDD; ++j) {   // dts planes: (half, pixel parity) -> (hd * 2 + o) * NCH + pixel pair
+        const int e = (j * 4 + wave) * 64 + lane;
         const int blk = e / UPH, unit = e % UPH;
-        const int o = blk / NCH, ppx = blk % NCH;
+        const int plane = blk / NCH, ppx = blk % NCH;
+        const int hd = plane >> 1, o = plane & 1;
         const int px = 2 * ppx + o, x = x0 + px, cb = piece0 * PBY + unit * 16;
-        const bool ok = blk < 2 * NCH && px < PB && x >= 0 && x < p.W && cb < C * ES;
-        cold = ok ? (uint32_t)(x * C * ES + cb) : COL_SENT;
+        const bool ok = plane < 2 * DD && px < PB && x >= 0 && x < p.W && cb < C * ES;
+        cold[j] = ok ? (uint32_t)((x * DD * C + hd * C) * ES + cb) : COL_SENT;
     }
     const uint32_t lds0 = lds_addr(reinterpret_cast<const float*>(smem));
-    const uint32_t rowT = (uint32_t)p.W * 2u * (uint32_t)C * ES, rowD = (uint32_t)p.W * (uint32_t)C * ES;
+    const uint32_t rowT = (uint32_t)p.W * 2u * (uint32_t)C * ES, rowD = (uint32_t)p.W * (uint32_t)(DD * C) * ES;
     auto issue = [&](int r, int slot) {   // t1 row r and dts row r - 1 (rows that are not needed or do not exist: zeros)
         const bool tok = r >= 0 && r < p.H && r <= h1 + 1;
         const int rd = r - 1;
@@ -394,7 +427,9 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
 #pragma unroll
         for (int j = 0; j < NDT; ++j)
             dma16(rs_t, lds0 + slot * SLOT + ((j * 4 + wave) * 64) * 16, (tok && colo[j] != COL_SENT) ? ro + colo[j] : ROW_SENT, 0);
-        dma16(rs_d, lds0 + slot * SLOT + TBYTES + (wave * 64) * 16, (dok && cold != COL_SENT) ? rod + cold : ROW_SENT, 0);
+#pragma unroll
+        for (int j = 0; j < NDD; ++j)
+            dma16(rs_d, lds0 + slot * SLOT + TBYTES + ((j * 4 + wave) * 64) * 16, (dok && cold[j] != COL_SENT) ? rod + cold[j] : ROW_SENT, 0);
     };
 
     // ---- this thread's LDS addresses
@@ -403,7 +438,7 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
     const bool z0 = !MULTI && pp == 0, z3 = !MULTI && pp == PP - 1;
     constexpr int TJ0 = MULTI ? 0 : 2 * PLANE - BLK, TJ1 = MULTI ? 2 * PLANE : 0, TJ2 = MULTI ? BLK : 2 * PLANE,
                   TJ3 = MULTI ? 2 * PLANE + BLK : BLK;
-    const int db = TBYTES + pp * BLK + g * PBY;                                  // dts pixel o: + o * PLANE
+    const int db = TBYTES + pp * BLK + g * PBY;                                  // dts (half hd, pixel o): + (hd * 2 + o) * PLANE
     const int xb = pp * XBLK + g * 8;                                            // own da (o, h): + (o * 2 + h) * XPLANE
     const bool zl = pp == 0, zr = pp + 1 >= NCH;
     const unsigned char* zero = smem + ZOFF;
@@ -450,8 +485,8 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
 #ifdef DWR_SAFE
         wait_vm<0>();
 #else
-        if (it < R - 1) wait_vm<(R - 2) * (NDT + 1)>();
-        else wait_vm<4 + (R - 2) * (NDT + 5)>();
+        if (it < R - 1) wait_vm<(R - 2) * (NDT + NDD)>();
+        else wait_vm<4 + (R - 2) * (NDT + NDD + 4)>();
 #endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -459,7 +494,7 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         issue(r + R - 1, (it + R - 1) % R);
         const unsigned char* sl = smem + (it % R) * SLOT;
         // ---- t1 row r at columns xa-1 .. xa+2, dts row r-1 at xa, xa+1
-        v2 T[2][4], D[2];
+        v2 T[2][4], D[2][DD];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             T[h][0] = lds_pair<ST>(z0 ? zero : sl + tb + TJ0 + h * PLANE);
@@ -468,7 +503,9 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
             T[h][3] = lds_pair<ST>(z3 ? zero : sl + tb + TJ3 + h * PLANE);
         }
 #pragma unroll
-        for (int o = 0; o < 2; ++o) D[o] = lds_pair<ST>(sl + db + o * PLANE);
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int hd = 0; hd < DD; ++hd) D[o][hd] = lds_pair<ST>(sl + db + (hd * 2 + o) * PLANE);
         // ---- neighbours' da of row rho' = r - 2 (written in the previous iteration)
         const unsigned char* xr = smem + XOFF + ((it + 1) & 1) * XSLOT + xb;
         v2 X[2][4];
@@ -485,17 +522,33 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         v2 da[2][2];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            v2 f[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f[h] = fma2(w[h][6], T[h][o], fma2(w[h][7], T[h][o + 1], fma2(w[h][8], T[h][o + 2], a0[o][h]))) + bias[h];
-                a0[o][h] = fma2(w[h][3], T[h][o], fma2(w[h][4], T[h][o + 1], fma2(w[h][5], T[h][o + 2], a1[o][h])));
-                a1[o][h] = fma2(w[h][0], T[h][o], fma2(w[h][1], T[h][o + 1], w[h][2] * T[h][o + 2]));
-            }
-            const v2 dt2 = fma2(D[o], sv, dpv);
             const bool pin = rho_ok && pval[o];
-            da[o][0] = pin ? dt2 * f[1] : v2z();
-            da[o][1] = pin ? dt2 * f[0] : v2z();
+            if constexpr (GATE == 2) {
+                da[o][0] = pin ? D[o][0] : v2z();
+                da[o][1] = pin ? D[o][1] : v2z();
+            } else {
+                v2 f[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f[h] = fma2(w[h][6], T[h][o], fma2(w[h][7], T[h][o + 1], fma2(w[h][8], T[h][o + 2], a0[o][h]))) + bias[h];
+                    a0[o][h] = fma2(w[h][3], T[h][o], fma2(w[h][4], T[h][o + 1], fma2(w[h][5], T[h][o + 2], a1[o][h])));
+                    a1[o][h] = fma2(w[h][0], T[h][o], fma2(w[h][1], T[h][o + 1], w[h][2] * T[h][o + 2]));
+                }
+                if constexpr (GATE == 0) {
+                    const v2 dt2 = fma2(D[o][0], sv, dpv);
+                    da[o][0] = pin ? dt2 * f[1] : v2z();
+                    da[o][1] = pin ? dt2 * f[0] : v2z();
+                } else {   // t = gelu(a_1) a_2:  da_1 = dt a_2 gelu'(a_1),  da_2 = dt gelu(a_1)
+                    float g0, d0, g1, d1;
+                    dwr_gelu_both(f[0].x, g0, d0);
+                    dwr_gelu_both(f[0].y, g1, d1);
+                    v2 gd, gv;
+                    gv.x = g0; gv.y = g1;
+                    gd.x = d0; gd.y = d1;
+                    da[o][0] = pin ? D[o][0] * f[1] * gd : v2z();
+                    da[o][1] = pin ? D[o][0] * gv : v2z();
+                }
+            }
         }
         unsigned char* xw = smem + XOFF + (it & 1) * XSLOT + xb;
 #pragma unroll
@@ -605,7 +658,7 @@ bool dwr_bwd_enabled() {
     return on != 0;
 }
 
-template <typename ST>
+template <typename ST, int GATE = 0>
 int launch_bwd(const void* dts, const void* t1, const float* w2p, const float* b2, const float* simg, const float* dpool, void* dt1,
                float* wpart, const DwGeom& g, hipStream_t s) {
     const DwrBGeom d = dwr_bwd_geom(g);
@@ -614,7 +667,7 @@ int launch_bwd(const void* dts, const void* t1, const float* w2p, const float* b
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.nwc = d.nwc;
     DCPT_CHECK_ARG(((double)cdiv(g.H, d.nrp) + 6.0) * g.W * 2.0 * g.C * sizeof(ST) < 1.0e9, "depthwise ring: a row range exceeds the 32-bit window");
     const dim3 grid(d.nqc, d.nwc * d.nrp, g.B), blk(256);
-#define DWRB(LP_, MU_) dwr_bwd_fused_kernel<ST, LP_, MU_><<<grid, blk, 0, s>>>(p)
+#define DWRB(LP_, MU_) dwr_bwd_fused_kernel<ST, LP_, MU_, GATE><<<grid, blk, 0, s>>>(p)
     if (d.multi) {
         if (d.LP == 8) DWRB(8, 1);
         else if (d.LP == 16) DWRB(16, 1);
@@ -629,9 +682,9 @@ int launch_bwd(const void* dts, const void* t1, const float* w2p, const float* b
     static const bool dbg = getenv("DCPT_DWR_DEBUG") != nullptr;
     if (dbg) {
         int n16 = -1, n8 = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, dwr_bwd_fused_kernel<ST, 16, 1>, 256, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, dwr_bwd_fused_kernel<ST, 16, 0>, 256, 0);
-        fprintf(stderr, "dwr_bwd es=%d LP=%d multi=%d grid=(%d,%d,%d) occupancy(blocks/CU) multi %d single %d\n", (int)sizeof(ST), d.LP, d.multi, d.nqc,
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, dwr_bwd_fused_kernel<ST, 16, 1, GATE>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, dwr_bwd_fused_kernel<ST, 16, 0, GATE>, 256, 0);
+        fprintf(stderr, "dwr_bwd gate=%d es=%d LP=%d multi=%d grid=(%d,%d,%d) occupancy(blocks/CU) multi %d single %d\n", GATE, (int)sizeof(ST), d.LP, d.multi, d.nqc,
                 d.nwc * d.nrp, g.B, n16, n8);
     }
     return DCPT_OK;
@@ -664,4 +717,22 @@ int launch_dw_ring_bwd_fused_f32(const float* dts, const float* t1, const float*
 int launch_dw_ring_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                                   bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
     return launch_bwd<bf16_t>(dts, t1, w2p, b2, simg, dpool, dt1, wpart, g, s);
+}
+
+// Restormer (fp32): GDFN gate backward gelu(a_1) a_2 fused with the transposed conv and the tap gradients (u [M][2 Ch], dt [M][Ch]),
+// and the plain depthwise backward dx = dw^T(dy) + tap gradients over Ctot channels (Ctot % 8 == 0); wpart as above with C = Ch / Ctot / 2
+int launch_dw_ring_bwd_gelu_f32(const float* dt, const float* u, const float* w2p, float* du, float* wpart, int B, int H, int W, int Ch, hipStream_t s) {
+    const DwGeom g{B, H, W, Ch};
+    return launch_bwd<float, 1>(dt, u, w2p, nullptr, nullptr, nullptr, du, wpart, g, s);
+}
+int launch_dw_ring_bwd_plain_f32(const float* dy, const float* x, const float* w2p, float* dx, float* wpart, int B, int H, int W, int Ctot, hipStream_t s) {
+    DCPT_CHECK_ARG(Ctot % 8 == 0, "depthwise ring: Ctot=%d must be a multiple of 8", Ctot);
+    const DwGeom g{B, H, W, Ctot / 2};
+    return launch_bwd<float, 2>(dy, x, w2p, nullptr, nullptr, nullptr, dx, wpart, g, s);
+}
+
+// Restormer GDFN forward on the ring (fp32): t [M][Ch] = gelu(dw(u)[:, :Ch]) * dw(u)[:, Ch:]
+int launch_dw_ring_gelu_fwd_f32(const float* u, const float* w2p, float* t, int B, int H, int W, int Ch, hipStream_t s) {
+    const DwGeom g{B, H, W, Ch};
+    return launch_fwd<float, 1>(u, w2p, nullptr, t, nullptr, g, s);
 }

@@ -17,6 +17,11 @@
 
 namespace {
 
+// depthwise backward on the ring kernels (dwring.hip) when the channel count allows it (Ctot % 8 == 0); DCPT_DW_RING_BWD=0 disables
+bool dwf_ring(int B, int H, int W, int Ctot) { return Ctot % 8 == 0 && dw_ring_usable(DwGeom{B, H, W, Ctot / 2}, 4); }
+bool dwb_ring(int B, int H, int W, int Ctot) { return Ctot % 8 == 0 && dw_ring_bwd_usable(DwGeom{B, H, W, Ctot / 2}, 4); }
+
+
 constexpr float NORM_EPS = 1e-12f;  // F.normalize eps
 
 // nrm[b][c2] = max(sqrt(sum_blk part[b][blk][c2]), eps)
@@ -336,6 +341,10 @@ size_t mdta_layout(int B, int H, int W, int c, int heads, int backward, void* ba
         const size_t s1 = (size_t)sp1 * 3 * c * c, s2 = (size_t)sp2 * c * c;
         w.slab = a.get<float>(s1 > s2 ? s1 : s2);
         w.nblk_dwb = dw_num_blocks_generic(B, H, W, 3 * c);
+        if (dwb_ring(B, H, W, 3 * c)) {
+            const int nr = dw_ring_bwd_num_blocks_per_image(DwGeom{B, H, W, 3 * c / 2});
+            if (nr > w.nblk_dwb) w.nblk_dwb = nr;
+        }
         w.wpart = a.get<float>((size_t)B * w.nblk_dwb * 10 * 3 * c);
         w.ln_nblk = ln_bwd_num_blocks(M, c);
         w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * c);
@@ -382,6 +391,10 @@ size_t gdfn_layout(int B, int H, int W, int c, int hp, int backward, void* base,
         const size_t s1 = (size_t)sp1 * 2 * hp * c, s2 = (size_t)sp2 * c * hp;
         w.slab = a.get<float>(s1 > s2 ? s1 : s2);
         w.nblk_dwb = dw_num_blocks_generic(B, H, W, 2 * hp);
+        if (dwb_ring(B, H, W, 2 * hp)) {
+            const int nr = dw_ring_bwd_num_blocks_per_image(DwGeom{B, H, W, hp});
+            if (nr > w.nblk_dwb) w.nblk_dwb = nr;
+        }
         w.wpart = a.get<float>((size_t)B * w.nblk_dwb * 10 * 2 * hp);
         w.ln_nblk = ln_bwd_num_blocks(M, c);
         w.lnpart = a.get<float>((size_t)w.ln_nblk * 3 * c);
@@ -435,6 +448,8 @@ extern "C" int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y
     g.M = M; g.A = xn; g.lda = C; g.K = C; g.Bw = p->qkv_w; g.N = C3; g.C = qkv1; g.ldc = C3;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
     DCPT_TRY(launch_dw_pack_weights(p->dw_w, w.w2p, C3, s));
+    // (the register kernel: the ring form of this plain conv measured slower, 221 vs 191 us per launch -- with 3c / 2 = 72..576
+    // channels per half its 128-byte runs are not line-aligned)
     DCPT_TRY(launch_dw_plain_fwd(qkv1, w.w2p, sv->qkv, w.sqpart, 2 * C, B, H, W, C3, s));
     sq_norm_kernel<<<dim3(cdiv(B * 2 * C, 256)), dim3(256), 0, s>>>(w.sqpart, w.nblk_dw, sv->nrm, B, 2 * C);
     DCPT_CHECK_LAUNCH("sq_norm");
@@ -555,9 +570,15 @@ extern "C" int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_g
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_ADDSCALED, s));
     // B5: depthwise backward
     DCPT_TRY(launch_dw_pack_weights(p->dw_w, w.w2p, C3, s));
-    DCPT_TRY(launch_dw_generic_bwd(w.dqkv, qkv1, w.w2p, w.dqkv1, w.wpart, B, H, W, C3, s));
+    int nblk_dwb = dw_num_blocks_generic(B, H, W, C3);
+    if (dwb_ring(B, H, W, C3)) {   // transposed conv + tap gradients on the LDS-DMA row ring (dwring.hip)
+        nblk_dwb = dw_ring_bwd_num_blocks_per_image(DwGeom{B, H, W, C3 / 2});
+        DCPT_TRY(launch_dw_ring_bwd_plain_f32(w.dqkv, qkv1, w.w2p, w.dqkv1, w.wpart, B, H, W, C3, s));
+    } else {
+        DCPT_TRY(launch_dw_generic_bwd(w.dqkv, qkv1, w.w2p, w.dqkv1, w.wpart, B, H, W, C3, s));
+    }
     DCPT_TRY(side_fork(sd, 1, s));          // dqkv1, depthwise partial sums
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, C3, gr->dw_w, w.scr2 /*unused bias grad*/, sw));
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_dwb, C3, gr->dw_w, w.scr2 /*unused bias grad*/, sw));
     // B6: qkv 1x1
     DCPT_TRY(launch_wpack(p->qkv_w, w.wT_qkv, nullptr, C3, C, WP_TRANSPOSE, s));
     g = GemmNT{};
@@ -603,7 +624,8 @@ extern "C" int dcpt_gdfn_fwd(const dcpt_gdfn_params* p, const float* x, float* y
     GemmNT g{};
     g.M = M; g.A = xn; g.lda = C; g.K = C; g.Bw = w.wp_in; g.N = 2 * hp; g.C = sv->u; g.ldc = 2 * hp;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, tg, B, H, W, hp, s));
+    if (dwf_ring(B, H, W, 2 * hp)) DCPT_TRY(launch_dw_ring_gelu_fwd_f32(sv->u, w.w2p, tg, B, H, W, hp, s));
+    else DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, tg, B, H, W, hp, s));
     g = GemmNT{};
     g.M = M; g.A = tg; g.lda = hp; g.K = hp; g.Bw = w.wp_out; g.N = C; g.C = y; g.ldc = C; g.res = x;
     return launch_gemm_nt(g, A_PLAIN, E_RESID, s);
@@ -644,7 +666,8 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
         xn = w.r_xn;
     }
     if (!tg) {
-        DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, w.r_t, B, H, W, hp, s));
+        if (dwf_ring(B, H, W, 2 * hp)) DCPT_TRY(launch_dw_ring_gelu_fwd_f32(sv->u, w.w2p, w.r_t, B, H, W, hp, s));
+        else DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, w.r_t, B, H, W, hp, s));
         tg = w.r_t;
     }
     // dt = dy * Wout ; dWout = dy^T t
@@ -654,10 +677,16 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
     gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, sw>>>(g_out, gr->out_w, C, hidden, hp, 2);
     DCPT_CHECK_LAUNCH("gdfn_unpack_out");
     // gate backward, depthwise backward
-    DCPT_TRY(launch_dw_gelu_bwd_a(w.dt, sv->u, w.w2p, w.da, B, H, W, hp, s));
-    DCPT_TRY(launch_dw_generic_bwd(w.da, sv->u, w.w2p, w.du, w.wpart, B, H, W, 2 * hp, s));
+    int nblk_dwb = dw_num_blocks_generic(B, H, W, 2 * hp);
+    if (dwb_ring(B, H, W, 2 * hp)) {   // one pass on the row ring: the gate's da never goes to memory
+        nblk_dwb = dw_ring_bwd_num_blocks_per_image(DwGeom{B, H, W, hp});
+        DCPT_TRY(launch_dw_ring_bwd_gelu_f32(w.dt, sv->u, w.w2p, w.du, w.wpart, B, H, W, hp, s));
+    } else {
+        DCPT_TRY(launch_dw_gelu_bwd_a(w.dt, sv->u, w.w2p, w.da, B, H, W, hp, s));
+        DCPT_TRY(launch_dw_generic_bwd(w.da, sv->u, w.w2p, w.du, w.wpart, B, H, W, 2 * hp, s));
+    }
     DCPT_TRY(side_fork(sd, 1, s));          // du, depthwise partial sums (dt is dead from here on)
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * w.nblk_dwb, 2 * hp, g_in, w.dt /*unused bias grad*/, sw));
+    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_dwb, 2 * hp, g_in, w.dt /*unused bias grad*/, sw));
     gdfn_unpack_kernel<<<dim3(grid_for((int64_t)2 * hidden * 9)), dim3(256), 0, sw>>>(g_in, gr->dw_w, C, hidden, hp, 1);
     DCPT_CHECK_LAUNCH("gdfn_unpack_dw");
     // project_in
