@@ -295,7 +295,8 @@ int dcpt_mdta_fwd(const dcpt_mdta_params* p, const float* x, float* y, const dcp
 int dcpt_mdta_bwd(const dcpt_mdta_params* p, const dcpt_mdta_params_grads* g, const float* x, const dcpt_mdta_saved* saved,
                   const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int H, int W, int C, int heads, int flags,
                   dcpt_stream_t stream);
-/* GDFN half (:75-100):  y = x + project_out(gelu(x1) * x2), (x1,x2) = dwconv(project_in(LN(x))).chunk(2); exact erf GELU.
+/* GDFN half (:75-100):  y = x + project_out(gelu(x1) * x2), (x1,x2) = dwconv(project_in(LN(x))).chunk(2); the erf GELU of
+ * torch.nn.functional.gelu (not the tanh form), evaluated branch-free with |error| <= 5e-7 absolute (Abramowitz-Stegun 7.1.26).
  * hidden = int(C * ffn_expansion_factor) may be any positive integer (padded to a multiple of 4 internally).
  * flags: DCPT_LN_BIASFREE | DCPT_LN_EPS_1E5 as for dcpt_mdta_fwd. */
 typedef struct {
