@@ -212,6 +212,23 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobs jobs) 
     const float* __restrict__ ks = jobs.kscale[j];
     const int N = jobs.N[j], K = jobs.K[j], nimg = jobs.nimg[j] > 0 ? jobs.nimg[j] : 1;
     const int64_t total = (int64_t)nimg * N * K;
+    if (jobs.transpose[j] == 0 && K % 8 == 0) {   // the big one (per-image scaled weights, nimg * N * K elements): 8 per thread, 16-byte stores
+        const int64_t nk = (int64_t)N * K;
+        for (int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x; i8 * 8 < total; i8 += (int64_t)gridDim.x * 256) {
+            const int64_t i = i8 * 8;
+            const int64_t img = i / nk, e = i - img * nk;
+            const int k = (int)(e % K);
+            f8 v = f8_ld(in + e);
+            if (ks) v = f8_mul(v, f8_ld(ks + img * K + k));
+            u32x4 o;
+            o.x = bf_pack(v.lo.x, v.lo.y);
+            o.y = bf_pack(v.lo.z, v.lo.w);
+            o.z = bf_pack(v.hi.x, v.hi.y);
+            o.w = bf_pack(v.hi.z, v.hi.w);
+            *reinterpret_cast<u32x4*>(out + i) = o;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         // i indexes the OUTPUT
         const int64_t img = i / ((int64_t)N * K);
