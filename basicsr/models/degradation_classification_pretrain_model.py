@@ -43,6 +43,7 @@ class DCPTModel(BaseModel):
                                   self.opt["path"].get(f"param_key_{tag}", "params"), self.opt.get("remove_norm", False))
         self.hook_outputs = []
         self.hooks = []
+        self.batched_encoder_passes = bool((opt.get("train") or {}).get("batched_encoder_passes", True))
         if self.is_train:
             self.init_training_settings()
 
@@ -102,12 +103,28 @@ class DCPTModel(BaseModel):
     def optimize_parameters(self, current_iter):
         loss_dict = OrderedDict()
         l_total = 0
+        taps = None
         if not self.freeze_encoder:
             self.net_g.train()
             self.net_dc.eval()
             self.optimizer_g.zero_grad()
             recon_in = self.lq if self.recon_on_lq else self.gt
-            pix_output = self.net_g(recon_in, hook=False)
+            if self.batched_encoder_passes and recon_in.shape == self.lq.shape:
+                # The reference runs the encoder twice per step (reconstruction input, then the degraded image for the taps).  Every
+                # encoder op is per-sample, so ONE pass over the two batches stacked gives the same activations and -- the weight
+                # gradients being sums over samples -- the same gradients up to fp32 summation order, with half the launches, one
+                # weight-gradient GEMM per layer instead of two and no gradient-accumulation adds (train.batched_encoder_passes: false
+                # restores the two passes).  DCTModel reconstructs from lq itself: one pass over the batch serves both.
+                nb = self.lq.shape[0]
+                self.hook_outputs = []
+                if self.recon_on_lq:
+                    pix_output = self.net_g(self.lq, hook=False)
+                    taps = self.hook_outputs
+                else:
+                    pix_output = self.net_g(torch.cat([recon_in, self.lq], 0), hook=False)[:nb]
+                    taps = [t[nb:] for t in self.hook_outputs]
+            else:
+                pix_output = self.net_g(recon_in, hook=False)
             self.hook_outputs = []  # drop the taps recorded by the reconstruction forward
             if self.cri_pixel:
                 l_pix = self.cri_pixel(pix_output, self.gt)
@@ -115,7 +132,9 @@ class DCPTModel(BaseModel):
                 loss_dict["l_pix"] = l_pix
         self.net_dc.train()
         self.optimizer_dc.zero_grad()
-        if self.freeze_encoder:
+        if taps is not None:
+            self.hook_outputs = taps
+        elif self.freeze_encoder:
             self.net_g.eval()
             self.hook_outputs = []
             with torch.no_grad():

@@ -99,6 +99,34 @@ def test_variants_vs_oracle(model_type, recon_on_lq, freeze):
     assert m.cls_output.shape == (2, 10)
 
 
+@pytest.mark.parametrize("model_type", ["DCPTModel", "DCTModel"])
+def test_batched_encoder_pass_equals_two_passes(model_type):
+    """train.batched_encoder_passes (default on): one encoder pass over [reconstruction input; lq] instead of the reference's two
+    passes -- same losses, logits and gradients up to fp32 summation order (the golden / oracle tests above run the batched form
+    against the real reference; this one pins the two forms of THIS repo to each other)."""
+    res = {}
+    for batched in (True, False):
+        from basicsr.models import build_model
+
+        opt = _opt(model_type)
+        opt["train"]["batched_encoder_passes"] = batched
+        m = build_model(opt)
+        m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0), strict=True)
+        m.net_dc.load_state_dict(keyed_state_dict(D.dc_param_shapes(**DC_CFG), seed=0), strict=True)
+        assert m.batched_encoder_passes is batched
+        _feed(m)
+        m.optimize_parameters(1)
+        log = m.get_current_log()
+        res[batched] = (log, m.cls_output.cpu(), {"g." + k: p.grad.cpu() for k, p in m.net_g.named_parameters()} |
+                        {"dc." + k: p.grad.cpu() for k, p in m.net_dc.named_parameters()})
+        assert m.hook_outputs == []
+    (la, ca, ga), (lb, cb, gb) = res[True], res[False]
+    assert abs(la["l_pix"] - lb["l_pix"]) < 1e-6 and abs(la["l_classify"] - lb["l_classify"]) < 1e-5
+    assert float((ca - cb).abs().max()) <= 1e-5 * float(cb.abs().max())
+    for k in gb:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * max(1e-7, float(gb[k].abs().max())), k
+
+
 # ------------------------------------------------------------------------------------------------
 DIST_G = dict(dim=16, num_blocks=[4, 6, 6, 1], num_refinement_blocks=1, heads=[1, 2, 4, 8])
 DIST_DC = dict(feature_dims=[32, 32, 64], num_res_blocks=1, num_classes=5)
