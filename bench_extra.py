@@ -4,9 +4,10 @@ contract (that is bench.py).  Prints one JSON line per workload.
 
     python bench_extra.py --workload dcpt|restormer|infer2k|naf [--dtype fp32|bf16] [--steps K] [--warmup W]
 
-``--dtype bf16`` (dcpt, naf): the NAFBlock groups run with bf16 storage / fp32 accumulate (act_dtype="bf16"); everything else
-(layers between the groups, the classifier head, parameters, optimizer) stays fp32.  Its lines carry BOTH rooflines: the bf16
-MFMA peak (2.5 PF dense) and the HBM roof with the bf16 algorithmic bytes -- in bf16 the blocks are HBM-bound.
+``--dtype bf16`` (dcpt, naf, infer2k): every feature map of the encoder in bf16 storage with fp32 accumulation (act_dtype="bf16";
+dcpt: the classifier head too unless --head-dtype fp32); images, parameters and the optimizer stay fp32.  Its lines carry BOTH
+rooflines: the bf16 MFMA peak (2.5 PF dense) and the HBM roof with the bf16 algorithmic bytes -- in bf16 the network is HBM-bound
+(SURVEY 8d).
 """
 from __future__ import annotations
 
@@ -141,7 +142,7 @@ def main():
         from basicsr.models import build_model
 
         opt = dict(name="b", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
-                   network_g=dict(type="NAFNetBaseline", window_size=16, **NAF), path=dict(), tile=dict(infer_size=512, tile_pad=16),
+                   network_g=dict(type="NAFNetBaseline", window_size=16, **naf), path=dict(), tile=dict(infer_size=512, tile_pad=16),
                    val=dict(save_img=False))
         m = build_model(opt)
         fill_module_(m.net_g)
@@ -155,9 +156,9 @@ def main():
 
         dt = timed(run, args.steps, args.warmup)
         flops = (S / 256.0) ** 2 * 126.11e9 * (544 / 512.0) ** 2
-        res = dict(workload=f"NAFNet-64 tiled inference, {S}x{S}, test_tile infer_size 512 / tile_pad 16, fp32",
+        res = dict(workload=f"NAFNet-64 tiled inference, {S}x{S}, test_tile infer_size 512 / tile_pad 16, feature maps {args.dtype}",
                    ms_per_image=round(dt * 1e3, 2), megapixels_per_s=round(S * S / 1e6 / dt, 3),
-                   alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4))
+                   alg_tflops=round(flops / dt / 1e12, 2), mfma_peak_tflops=peak / 1e12, mfma_frac=round(flops / dt / peak, 4))
     res["peak_mem_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
     print(json.dumps(res), flush=True)
 

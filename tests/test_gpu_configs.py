@@ -245,3 +245,32 @@ def test_psnr_gate_hip_vs_oracle(dev):
         assert (h8 != o8).mean() < 2e-3, f"image {i}: {(h8 != o8).mean():.2e} of the uint8 pixels differ"
     assert worst_p <= 0.01, f"PSNR differs by {worst_p:.4f} dB"
     assert worst_s <= 1e-4, f"SSIM differs by {worst_s:.2e}"
+
+
+def test_psnr_bf16_storage_vs_fp32(dev):
+    """How far bf16 STORAGE (act_dtype="bf16", an extension; the reference has no reduced precision) moves the acceptance metric: the
+    same restoration-like NAFNet-64 and synthetic pairs as above, PSNR of the bf16-storage output against the fp32 HIP output's PSNR.
+    Not a parity claim (the <= 0.01 dB gate is the fp32 path's, above) -- a measured bound for the mode's documentation."""
+    from basicsr.archs import build_network
+    from basicsr.metrics import calculate_psnr
+
+    sd = keyed_state_dict(O.nafnet_param_shapes(**FULL), seed=0)
+    sd = {k: (v * 0.01 if k.startswith("ending.") else v) for k, v in sd.items()}
+    nets = {}
+    for dt in ("fp32", "bf16"):
+        net = build_network(dict(type="NAFNetBaseline", act_dtype=dt, **FULL))
+        net.load_state_dict(sd, strict=True)
+        nets[dt] = net.to(dev).eval()
+    worst = 0.0
+    kw = dict(crop_border=0, test_y_channel=False, image_range=255.0)
+    f = lambda t: t.clamp(0, 1).cpu().numpy()   # noqa: E731
+    for i in range(4):
+        gt, lq = _smooth_pair(i)
+        with torch.no_grad():
+            o32, o16 = nets["fp32"](lq[None].to(dev)), nets["bf16"](lq[None].to(dev))
+        assert o16.dtype == torch.float32
+        p32, p16 = calculate_psnr(f(o32), f(gt[None]), **kw), calculate_psnr(f(o16), f(gt[None]), **kw)
+        worst = max(worst, abs(p32 - p16))
+    print(f"bf16 storage moves PSNR by at most {worst:.4f} dB on these pairs")
+    assert worst <= 0.02, f"PSNR differs by {worst:.4f} dB"   # measured: 0.0010 dB
+
