@@ -142,7 +142,11 @@ class SRModel(BaseModel):
     def test_tile(self):
         """independent ``infer_size`` tiles with ``tile_pad`` context, centre pasted back (sr_model.py:273-361).
         Same tiles, same arithmetic as the reference's loop; tiles of equal padded shape (interior / edge / corner
-        classes) are stacked into one batch per class so the GPU sees a few large launches instead of many 1-image ones."""
+        classes) are stacked into one batch per class so the GPU sees a few large launches instead of many 1-image ones.
+
+        ``tile.shard_across_ranks: true`` under a distributed launch (tiles are independent): batch number i goes to rank
+        i % world_size, every rank pastes its tiles into a zero image and ONE reduce(SUM, dst=0) assembles the result on rank 0 -- the
+        only exchange step of this path (the reference evaluates on rank 0 alone, sr_model.py:375-377)."""
         net = self._net()
         net.eval()
         size, pad, sc = self.opt["tile"]["infer_size"], self.opt["tile"]["tile_pad"], self.opt.get("scale", 1)
@@ -157,8 +161,14 @@ class SRModel(BaseModel):
                 xp0, yp0 = max(x0 - pad, 0), max(y0 - pad, 0)
                 xp1, yp1 = min(x1 + pad, width), min(y1 + pad, height)
                 groups.setdefault((yp1 - yp0, xp1 - xp0), []).append((x0, y0, x1, y1, xp0, yp0, xp1, yp1))
+        shard = self._tile_shard()
+        world, rank = (self.opt["world_size"], self.opt["rank"]) if shard else (1, 0)
+        nbatch = 0
         for tiles in groups.values():
             for i in range(0, len(tiles), max(1, max_batch // b)):
+                nbatch += 1
+                if (nbatch - 1) % world != rank:
+                    continue
                 chunk = tiles[i:i + max(1, max_batch // b)]
                 inp = torch.cat([self.lq[:, :, t[5]:t[7], t[4]:t[6]] for t in chunk], 0)
                 with torch.no_grad():
@@ -167,8 +177,16 @@ class SRModel(BaseModel):
                     ox, oy = (x0 - xp0) * sc, (y0 - yp0) * sc
                     self.output[:, :, y0 * sc:y1 * sc, x0 * sc:x1 * sc] = \
                         out[j * b:(j + 1) * b, :, oy:oy + (y1 - y0) * sc, ox:ox + (x1 - x0) * sc]
+        if shard:
+            import torch.distributed as dist
+
+            dist.reduce(self.output, dst=0, op=dist.ReduceOp.SUM)   # disjoint tiles: the sum is the assembled image (valid on rank 0)
         if net is self.net_g:
             net.train()
+
+    def _tile_shard(self):
+        return bool(self.opt.get("dist")) and self.opt.get("world_size", 1) > 1 and "tile" in self.opt and \
+            bool(self.opt["tile"].get("shard_across_ranks", False))
 
     def get_current_visuals(self):
         out = OrderedDict(lq=self.lq.detach().cpu(), result=self.output.detach().cpu())
@@ -177,7 +195,7 @@ class SRModel(BaseModel):
         return out
 
     def dist_validation(self, dataloader, current_iter, tb_logger, save_img, clamp=True):
-        if self.opt["rank"] == 0:
+        if self.opt["rank"] == 0 or self._tile_shard():   # sharded tiles: every rank computes its tiles, rank 0 scores
             return self.nondist_validation(dataloader, current_iter, tb_logger, save_img, clamp)
 
     def nondist_validation(self, dataloader, current_iter, tb_logger, save_img, clamp=True):
@@ -193,6 +211,11 @@ class SRModel(BaseModel):
             else:
                 self.test()
             self.post_test()
+            if self.opt.get("rank", 0) != 0:   # (tile-sharded validation: only rank 0 holds the assembled image)
+                del self.lq, self.output
+                if hasattr(self, "gt"):
+                    del self.gt
+                continue
             vis = self.get_current_visuals()
             result = vis["result"].clamp(0, 1) if clamp else vis["result"]   # reference sr_model.py:408-413
             if save_img:
@@ -216,6 +239,8 @@ class SRModel(BaseModel):
         for m in results:
             results[m] /= max(1, n)
         self.metric_results = results
+        if self.opt.get("rank", 0) != 0:
+            return results
         log = f"Validation {name}\n" + "".join(f"\t # {m}: {v:.4f}\n" for m, v in results.items())
         get_root_logger().info(log)
         if tb_logger:
