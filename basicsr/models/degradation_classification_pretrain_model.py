@@ -7,7 +7,11 @@ One step = encoder forward on the clean image (pixel loss), encoder forward on t
 forward hooks on the decoder groups, classifier head on the tapped features (classification loss), ONE
 backward through head -> taps -> encoder (twice), two optimizer steps.  Under DDP every fused block returns
 all its gradients at once, so the bucketed RCCL all-reduce overlaps the remaining backward kernels; a
-bucket is only complete after BOTH uses of each encoder weight have back-propagated."""
+bucket is only complete after BOTH uses of each encoder weight have back-propagated.
+
+By default (``train.batched_encoder_passes: true``) the two encoder forwards of a step run as ONE pass over the two batches stacked
+(every encoder op is per-sample): same losses, logits and gradients up to fp32 summation order, half the launches, one
+weight-gradient GEMM per layer; ``false`` runs the reference's two passes literally."""
 from __future__ import annotations
 
 from collections import OrderedDict
