@@ -229,6 +229,49 @@ def test_nafnet_bf16_end_to_end(dev):
     assert worst <= 0.15, worst
 
 
+def test_nafnet_bf16_full_size_properties(dev):
+    """Size-independent properties of the bf16-storage network at BASELINE.json's size (NAFNet-64 [1,1,1,28], 256 x 256): images are
+    independent (a batch of two copies gives two identical outputs, equal to the single-image output), the output stays within bf16
+    noise of the fp32 network's, and along a random direction the loss moves as the back-propagated gradient predicts."""
+    from basicsr.archs import build_network
+    from dcpt_amd.keyed_init import fill_module_
+
+    cfg = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1])
+    nets = {dt: fill_module_(build_network(dict(type="NAFNetBaseline", act_dtype=dt, **cfg)), seed=0).to(dev) for dt in ("fp32", "bf16")}
+    x1 = keyed_input("bffull.x", (1, 3, 256, 256)).to(dev)
+    with torch.no_grad():
+        y1 = nets["bf16"](x1)
+        y2 = nets["bf16"](torch.cat([x1, x1], 0))
+        yf = nets["fp32"](x1)
+    assert torch.equal(y2[0], y2[1])
+    assert _rel(y2[0:1], y1) <= 1e-6     # forward is per-image: no reduction crosses the batch
+    assert _rel(y1, yf) <= 6e-2, _rel(y1, yf)   # 36 blocks deep with keyed (untrained) weights: measured 3.2e-2 of the output range
+    # directional derivative at B = 8: <grad, d> against a central difference of the loss
+    net = nets["bf16"]
+    x = keyed_input("bffull.xb", (8, 3, 256, 256)).to(dev)
+    tgt = keyed_input("bffull.t", (8, 3, 256, 256)).to(dev)
+    loss = lambda: (net(x) - tgt).square().mean()   # noqa: E731
+    for p in net.parameters():
+        p.grad = None
+    l0 = loss()
+    l0.backward()
+    g = torch.Generator(device=dev).manual_seed(7)
+    ps = [p for p in net.parameters()]
+    ds = [torch.randn(p.shape, generator=g, device=dev) * p.detach().abs().mean().clamp_min(1e-3) for p in ps]
+    pred = sum(float((p.grad.double() * d.double()).sum()) for p, d in zip(ps, ds))
+    eps = 2e-2   # (bf16 storage: the loss itself carries ~1e-3 relative rounding noise, so the step has to be larger than in fp32)
+    vals = []
+    with torch.no_grad():
+        for sgn in (1.0, -1.0):
+            for p, d in zip(ps, ds):
+                p.add_(d, alpha=sgn * eps)
+            vals.append(float(loss()))
+            for p, d in zip(ps, ds):
+                p.add_(d, alpha=-sgn * eps)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert np.isfinite(fd) and abs(fd - pred) <= 0.1 * max(abs(fd), abs(pred)), (fd, pred)
+
+
 def test_dcpt_step_with_bf16_encoder(dev):
     """DCPTModel.optimize_parameters (reference ...pretrain_model.py:133-169) with ``network_g.act_dtype: bf16``: the decoder taps
     (hooks on ``decoder{i}.0``) still fire with fp32 tensors, the head and both optimizers run, and the losses stay close to the
