@@ -97,13 +97,15 @@ class NAFBlock(nn.Module):
     act_bf16 = False
 
     def forward(self, inp):
-        if self.act_bf16:   # bf16 in / out (an fp32 input -- a block used on its own -- is cast once)
-            return DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params())
         pool = self.sca[0]
         if isinstance(pool, AvgPool2d) and pool.kernel_size is not None:
             k1, k2 = int(pool.kernel_size[0]), int(pool.kernel_size[1])
             if not (k1 >= inp.shape[-2] and k2 >= inp.shape[-1]):  # arch_util.py:352-353: window covers the map -> global mean
+                if self.act_bf16:
+                    raise NotImplementedError("the TLSC (local-mean SCA) block is fp32 only: build NAFNet with act_dtype='fp32'")
                 return DF.nafblock_local(inp, self.fused_params(), k1, k2)
+        if self.act_bf16:   # bf16 in / out (an fp32 input -- a block used on its own -- is cast once)
+            return DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params())
         return DF.nafblock(inp, self.fused_params())
 
 

@@ -460,8 +460,15 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         ocol[o] = oval[o] ? (uint32_t)((x * 2 * C + c1) * ES) : COL_SENT;
     }
     bool pval[2];   // the pixel exists (da is defined)
+    v2 svo[2], dpo[2];   // SCA scale / pooled gradient of this thread's two pixels, zero where the pixel does not exist
+    v2 gmask[2];         // 1 where the pixel's tap gradients are this tile's to count (MULTI: not the recomputed edge columns)
 #pragma unroll
-    for (int o = 0; o < 2; ++o) pval[o] = gok && xa + o >= 0 && xa + o < p.W;
+    for (int o = 0; o < 2; ++o) {
+        pval[o] = gok && xa + o >= 0 && xa + o < p.W;
+        svo[o] = pval[o] ? sv : v2z();
+        dpo[o] = pval[o] ? dpv : v2z();
+        gmask[o].x = gmask[o].y = oval[o] ? 1.f : 0.f;
+    }
     const rsrc_t rs_o = make_rsrc((ST*)p.dt1 + ((int64_t)b * p.H + rb) * p.W * 2 * C);
 
     v2 a0[2][2], a1[2][2], B0[2][2], B1[2][2], daP[2][2], T1[2][4], T2[2][4], gr[2][10];
@@ -519,6 +526,8 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         // ---- forward conv: row r completes a[r-1] (kernel row 2), feeds a[r] (row 1), starts a[r+1] (row 0)
         const int rho = r - 1;
         const bool rho_ok = rho >= 0 && rho < p.H && rho >= h0 - 1 && rho <= h1;
+        v2 rmask;   // (uniform) 1 on the rows whose da exists
+        rmask.x = rmask.y = rho_ok ? 1.f : 0.f;
         v2 da[2][2];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -535,9 +544,10 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
                     a1[o][h] = fma2(w[h][0], T[h][o], fma2(w[h][1], T[h][o + 1], w[h][2] * T[h][o + 2]));
                 }
                 if constexpr (GATE == 0) {
-                    const v2 dt2 = fma2(D[o][0], sv, dpv);
-                    da[o][0] = pin ? dt2 * f[1] : v2z();
-                    da[o][1] = pin ? dt2 * f[0] : v2z();
+                    // (pixel / row validity is folded into svo / dpo / rmask: dt2 is exactly 0 where da must be, and f is finite)
+                    const v2 dt2 = fma2(D[o][0], svo[o], dpo[o] * rmask);
+                    da[o][0] = dt2 * f[1];
+                    da[o][1] = dt2 * f[0];
                 } else {   // t = gelu(a_1) a_2:  da_1 = dt a_2 gelu'(a_1),  da_2 = dt gelu(a_1)
                     float g0, d0, g1, d1;
                     dwr_gelu_both(f[0].x, g0, d0);
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
             for (int o = 0; o < 2; ++o)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const v2 d = oval[o] ? da[o][h] : v2z();
+                    const v2 d = MULTI ? da[o][h] * gmask[o] : da[o][h];   // (one tile per row: da is already 0 wherever it must not count)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         gr[h][0 * 3 + kx] = fma2(d, T2[h][o + kx], gr[h][0 * 3 + kx]);
