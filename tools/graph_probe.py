@@ -9,7 +9,8 @@ from dcpt_amd.keyed_init import fill_module_
 CFG = dict(img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1])
 dev = torch.device('cuda:0')
 lib = _lib.load()
-net = build_network(dict(type="NAFNetBaseline", **CFG)); fill_module_(net, seed=0); net = net.to(dev)
+ACT = sys.argv[1] if len(sys.argv) > 1 else "fp32"   # python tools/graph_probe.py [bf16]
+net = build_network(dict(type="NAFNetBaseline", act_dtype=ACT, **CFG)); fill_module_(net, seed=0); net = net.to(dev)
 opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0, fused=True, capturable=True)
 lq = torch.rand((32, 3, 256, 256), device=dev); gt = torch.rand((32, 3, 256, 256), device=dev)
 def step():
