@@ -125,8 +125,10 @@ class DCPTModel(BaseModel):
                     pix_output = self.net_g(self.lq, hook=False)
                     taps = self.hook_outputs
                 else:
-                    pix_output = self.net_g(torch.cat([recon_in, self.lq], 0), hook=False)[:nb]
-                    taps = [t[nb:] for t in self.hook_outputs]
+                    from dcpt_amd.functional import take_batch   # (stride-preserving slice gradients: no NCHW round trips)
+
+                    pix_output = take_batch(self.net_g(torch.cat([recon_in, self.lq], 0), hook=False), 0, nb)
+                    taps = [take_batch(t, nb, 2 * nb) for t in self.hook_outputs]
             else:
                 pix_output = self.net_g(recon_in, hook=False)
             self.hook_outputs = []  # drop the taps recorded by the reconstruction forward

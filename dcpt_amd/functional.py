@@ -264,6 +264,35 @@ def nafblock_local(inp: torch.Tensor, params: Dict[str, torch.Tensor], k1: int, 
 
 
 # ------------------------------------------------------------------------------------------------
+class _TakeBatchFn(torch.autograd.Function):
+    """x[lo:hi] along the batch axis as a view; the backward builds the zero-padded gradient WITH THE INPUT'S STRIDES (torch's own
+    slice backward allocates it NCHW-contiguous, which costs two layout conversions of the whole feature map per use for NHWC
+    tensors: one into the NCHW buffer and one back when the producing block reads it)."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.meta = (tuple(x.shape), tuple(x.stride()), x.dtype, x.device, int(lo), int(hi))
+        return x[lo:hi]
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, stride, dtype, dev, lo, hi = ctx.meta
+        dense = torch.empty(shape, dtype=dtype, device=dev).stride() == stride or len(shape) != 4
+        out = torch.empty_strided(shape, stride, dtype=dtype, device=dev) if not dense else torch.empty(shape, dtype=dtype, device=dev)
+        if lo > 0:
+            out[:lo].zero_()
+        if hi < shape[0]:
+            out[hi:].zero_()
+        out[lo:hi].copy_(g)
+        return out, None, None
+
+
+def take_batch(x, lo, hi):
+    """samples lo..hi-1 of a batch (a view in forward, a stride-preserving zero-padded gradient in backward)"""
+    return _TakeBatchFn.apply(x, lo, hi)
+
+
+# ------------------------------------------------------------------------------------------------
 class _LayerNorm2dFn(torch.autograd.Function):
     """reference nafnet_arch.py:25-53 (LayerNormFunction)."""
 
