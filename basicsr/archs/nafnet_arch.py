@@ -91,9 +91,8 @@ class NAFBlock(nn.Module):
             "beta": self.beta, "gamma": self.gamma,
         }
 
-    # bf16-storage mode (NAFNetBaseline.set_act_dtype): the block takes fp32 or bf16 activations and runs on the bf16 kernels;
-    # the LAST block of a group hands fp32 back, so forward hooks on ``decoder{i}`` / ``decoder{i}.0`` (the DCPT taps) and the
-    # fp32 layers between the groups see what they see in fp32 mode
+    # bf16-storage mode (NAFNetBaseline.set_act_dtype): the block runs on the bf16 kernels and hands bf16 on -- the layers between
+    # the groups and the forward hooks on ``decoder{i}`` (the DCPT taps) see bf16 feature maps (module docstring)
     act_bf16 = False
 
     def forward(self, inp):
@@ -149,46 +148,22 @@ class NAFNetBaseline(nn.Module):
             chan //= 2
             setattr(self, f"decoder{i}", _BlockGroup(*[NAFBlock(chan) for _ in range(num)]))
         self._n_dec = len(dec_blk_nums)
+        self._width = width
         self.set_act_dtype(act_dtype)
-        # >1: the batch is processed as that many sub-batches on separate HIP streams, so the HBM-bound kernels of one
-        # sub-batch (LayerNorm, depthwise conv, reductions) overlap the MFMA-bound GEMMs of the other (same arithmetic,
-        # same results; autograd replays each sub-batch's backward on its own stream)
-        self.stream_chunks = 1
-        self._side_streams = []
 
     def set_act_dtype(self, act_dtype):
         """'fp32' (the reference's arithmetic) or 'bf16' (bf16 storage of the NAFBlock activations, fp32 accumulate)"""
         if act_dtype not in ("fp32", "bf16"):
             raise ValueError(f"act_dtype must be 'fp32' or 'bf16', got {act_dtype!r}")
+        if act_dtype == "bf16" and self._width % 8:
+            # 16-byte bf16 rows at every level (the up layers' 2c -> c/2 PixelShuffle cells included: c = width * 2^k)
+            raise ValueError(f"act_dtype='bf16' needs width % 8 == 0 (16-byte bf16 channel vectors), got width={self._width}")
         self.act_dtype = act_dtype
         for m in self.modules():
             if isinstance(m, NAFBlock):
                 m.act_bf16 = act_dtype == "bf16"
 
-    def _streams(self, n, device):
-        while len(self._side_streams) < n:
-            self._side_streams.append(torch.cuda.Stream(device=device))
-        return self._side_streams[:n]
-
     def forward(self, inp, hook=False):
-        n = int(getattr(self, "stream_chunks", 1))
-        if n > 1 and not hook and inp.is_cuda and inp.shape[0] >= n:
-            cur = torch.cuda.current_stream(inp.device)
-            streams = self._streams(n, inp.device)
-            outs = []
-            for ch, st in zip(inp.chunk(n, 0), streams):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    ch.record_stream(st)
-                    o = self._forward_impl(ch, False)
-                o.record_stream(cur)
-                outs.append(o)
-            for st in streams:
-                cur.wait_stream(st)
-            return torch.cat(outs, 0)
-        return self._forward_impl(inp, hook)
-
-    def _forward_impl(self, inp, hook=False):
         # bf16 storage: the intro conv emits bf16 features and every layer up to the ending conv's input stays bf16 (forward hooks on
         # the block groups then see bf16 feature maps; the classifier head takes either dtype)
         x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias, out_bf16=self.act_dtype == "bf16")

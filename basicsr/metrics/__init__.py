@@ -11,8 +11,16 @@ optionally reduced to BT.601 luma, compared in float64 and averaged over the bat
 Extension kept for callers that already hold quantised images: ``input_order`` "HWC" / "CHW" takes ONE image whose values are
 already in [0, image_range] (no scaling, no rounding).
 
-PSNR is pinned against the reference function itself (tests/golden/metrics.npz, oracle/make_golden.py::gen_metrics); SSIM needs
-cv2.filter2D / getGaussianKernel, which cannot be imported here, so it is pinned against an independent scipy implementation."""
+PSNR is pinned against the reference function itself (tests/golden/metrics.npz, oracle/make_golden.py::gen_metrics: the reference's
+``calculate_psnr`` only needs ``cv2.cvtColor``'s channel flip, which a three-line module object provides).
+
+SSIM stays RESTATEMENT-ONLY, deliberately: the arithmetic of the reference's ``_ssim`` (:483-512) lives in ``cv2.getGaussianKernel``
+and ``cv2.filter2D``, and cv2 is not installed in the build image.  Running the reference function would therefore mean running it
+on stand-ins for those two OpenCV routines written here -- the result would pin this file against its own author's reading of
+OpenCV, not against the reference, so no such fixture is committed.  What is checked instead: ``calculate_ssim`` against an
+independently written scipy implementation of the published formula (11 x 11 Gaussian, sigma 1.5, "valid" window, C1 = (0.01 L)^2,
+C2 = (0.03 L)^2, float64; tests/test_plumbing_cpu.py::test_metrics_match_independent_implementations), and the acceptance gate of
+``north_star`` is stated in PSNR (<= 0.01 dB), which IS pinned."""
 from copy import deepcopy
 
 import numpy as np

@@ -64,7 +64,7 @@ class DCDistModel(SRModel):
         if self.ema_decay > 0:
             get_root_logger().info(f"Use Exponential Moving Average with decay: {self.ema_decay}")
             self.net_g_ema = build_network(self.opt["network_g"]).to(self.device)
-            self._init_ema()
+            self._init_ema(only_if_checkpoint_has_ema=True)   # the reference's DCDist model always starts from model_ema(0)
             self.net_g_ema.eval()
         self.hook_outputs, self.hooks = [], []
         hook_names = self.opt.get("hook_names", None)

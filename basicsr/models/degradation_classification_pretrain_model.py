@@ -128,6 +128,10 @@ class DCPTModel(BaseModel):
                     from dcpt_amd.functional import take_batch   # (stride-preserving slice gradients: no NCHW round trips)
 
                     pix_output = take_batch(self.net_g(torch.cat([recon_in, self.lq], 0), hook=False), 0, nb)
+                    # one stacked forward must have fired every hook exactly once, on the full 2B batch
+                    if len(self.hook_outputs) != len(self.hooks) or any(t.shape[0] != 2 * nb for t in self.hook_outputs):
+                        raise RuntimeError(f"batched encoder pass: expected {len(self.hooks)} taps of batch {2 * nb}, got "
+                                           f"{[tuple(t.shape) for t in self.hook_outputs]}")
                     taps = [take_batch(t, nb, 2 * nb) for t in self.hook_outputs]
             else:
                 pix_output = self.net_g(recon_in, hook=False)

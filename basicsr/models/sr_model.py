@@ -63,12 +63,17 @@ class SRModel(BaseModel):
         if train_opt.get("scheduler"):
             self.setup_schedulers()
 
-    def _init_ema(self):
+    def _init_ema(self, only_if_checkpoint_has_ema=False):
         """reference sr_model.py:70-79: with a pretrained / resumed network the EMA copy is loaded from the checkpoint's
         ``params_ema`` (load_network falls back to ``params`` when the key is missing) so that a restart keeps the EMA
-        history; only a fresh start copies net_g."""
+        history; only a fresh start copies net_g.  ``only_if_checkpoint_has_ema`` (DCDistModel, whose reference always starts the
+        EMA as a copy of net_g -- which also keeps ``remove_norm`` / ``param_key_g`` consistent between the two): load only when
+        the file really holds ``params_ema`` (a resumed run), copy net_g otherwise."""
         load_path = self.opt["path"].get("pretrain_network_g", None)
         if load_path is not None and osp.exists(load_path):
+            if only_if_checkpoint_has_ema and "params_ema" not in torch.load(load_path, map_location="cpu"):
+                self.model_ema(0)
+                return
             self.load_network(self.net_g_ema, load_path, self.opt["path"].get("strict_load_g", True), "params_ema")
         else:
             self.model_ema(0)
@@ -115,6 +120,40 @@ class SRModel(BaseModel):
         net.eval()
         with torch.no_grad():
             self.output = net(self.lq)
+        if was_training and net is self.net_g:
+            net.train()
+
+    def test_selfensemble(self):
+        """x8 geometric self-ensemble (reference sr_model.py:187-232; selected by ``ensemble: true`` at the top of the options,
+        :398): the input under the 8 elements of the dihedral group (built as the reference builds its list: width flip "v", height
+        flip "h", transpose "t", each applied to everything before it), the network on each, every output mapped back and the 8
+        results averaged.  The flips / transposes stay on the device (the reference goes through numpy), and augmentations of
+        equal shape run as one batch (the network is per-sample): 1 launch sequence for a square image, 2 otherwise."""
+        tf = {"v": lambda t: t.flip(-1), "h": lambda t: t.flip(-2), "t": lambda t: t.transpose(-1, -2)}
+        lq_list = [self.lq]
+        for op in ("v", "h", "t"):
+            lq_list.extend([tf[op](t).contiguous() for t in lq_list])
+        net = self._net()
+        was_training = net.training
+        net.eval()
+        b = self.lq.shape[0]
+        out_list = [None] * 8
+        by_shape = {}
+        for i, a in enumerate(lq_list):
+            by_shape.setdefault(tuple(a.shape), []).append(i)
+        with torch.no_grad():
+            for idx in by_shape.values():
+                out = net(torch.cat([lq_list[i] for i in idx], 0))
+                for j, i in enumerate(idx):
+                    out_list[i] = out[j * b:(j + 1) * b]
+        for i in range(8):   # undo in the reverse order of application (reference :218-226)
+            if i > 3:
+                out_list[i] = tf["t"](out_list[i])
+            if i % 4 > 1:
+                out_list[i] = tf["h"](out_list[i])
+            if (i % 4) % 2 == 1:
+                out_list[i] = tf["v"](out_list[i])
+        self.output = torch.stack(out_list, 0).mean(dim=0)
         if was_training and net is self.net_g:
             net.train()
 
@@ -205,9 +244,19 @@ class SRModel(BaseModel):
         n = 0
         for val_data in dataloader:
             self.feed_data(val_data)
+            if self._tile_shard():
+                # every rank built its own loader: a stochastic val set (sigma_type random / choice draws from Python's global
+                # ``random``) could hand the ranks differently-noised inputs -- rank 0's sample is the one that is scored
+                import torch.distributed as dist
+
+                dist.broadcast(self.lq, src=0)
+                if hasattr(self, "gt"):
+                    dist.broadcast(self.gt, src=0)
             self.pre_test()
             if "tile" in self.opt:
                 self.test_tile()
+            elif self.opt.get("ensemble"):   # reference sr_model.py:396-399 (tile takes precedence)
+                self.test_selfensemble()
             else:
                 self.test()
             self.post_test()
@@ -217,7 +266,7 @@ class SRModel(BaseModel):
                     del self.gt
                 continue
             vis = self.get_current_visuals()
-            result = vis["result"].clamp(0, 1) if clamp else vis["result"]   # reference sr_model.py:408-413
+            result = vis["result"].clamp(0, 1) if clamp else torch.nan_to_num(vis["result"], nan=0.0)   # reference sr_model.py:408-413, :432-436
             if save_img:
                 import os
 

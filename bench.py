@@ -83,6 +83,63 @@ def cpu_baseline(seconds_budget: float = 25.0):
     }
 
 
+def lib_digest():
+    """sha256 over dcpt_amd/csrc + the header + the flags that libdcpt_hip.so was built from (dcpt_amd/build.py)"""
+    try:
+        with open(os.path.join(ROOT, "dcpt_amd", "lib", "libdcpt_hip.digest")) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
+def secondary_dcpt_bf16(dev, steps=5, warmup=3):
+    """BASELINE.json configs[2] at its own dtype and size, timed by the run that prints the line: one DCPT pre-training step
+    (reference ...pretrain_model.py:133-169: encoder on the clean and on the degraded batch, classifier head on the decoder taps,
+    one backward, two AdamW updates) with NAFNet-64 + PromptIR_NoImg_DC([64,128,256,512]), 10 classes, B = 32, encoder AND head in
+    bf16 storage (fp32 accumulate, fp32 parameters / optimizer), at 128 x 128 and 256 x 256.  Never the headline."""
+    from basicsr.models import build_model
+    from dcpt_amd.keyed_init import fill_module_
+
+    out = {}
+    naf_bytes_bf16 = (25 * 30.146e6 + 3 * 40.4e6) * 2   # SURVEY 8d element passes per 256^2 image, 2 B each
+    for S in (128, 256):
+        B = 32
+        opt = dict(name="b", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", act_dtype="bf16", **CFG),
+                   network_dc=dict(type="PromptIR_NoImg_DC", feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10, act_dtype="bf16"),
+                   path=dict(), train=dict(pixel_opt=dict(type="L1Loss"), classify_opt=dict(type="CrossEntropyLoss"),
+                                           optim_g=dict(type="AdamW", lr=1e-4, fused=True), optim_dc=dict(type="AdamW", lr=1e-4, fused=True)))
+        m = build_model(opt)
+        fill_module_(m.net_g)
+        fill_module_(m.net_dc)
+        g = torch.Generator(device=dev).manual_seed(4321)
+        m.feed_data({"lq": torch.rand((B, 3, S, S), generator=g, device=dev), "gt": torch.rand((B, 3, S, S), generator=g, device=dev),
+                     "dataset_idx": torch.randint(0, 10, (B,), generator=g, device=dev)})
+        for _ in range(warmup):
+            m.optimize_parameters(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.optimize_parameters(1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        sc = B * (S / 256.0) ** 2
+        flops = sc * 1.315e12          # SURVEY 8d: 2 x 378.3 GF (encoder, fwd+bwd) + 558.9 GF (head) per 256^2 image
+        log = m.get_current_log()
+        out[f"dcpt_all_bf16_{S}"] = {
+            "workload": f"DCPT step (BASELINE.json configs[2]): NAFNet-64 x2 fwd + PromptIR_NoImg_DC([64,128,256,512]) head + bwd + 2x AdamW, "
+                        f"B={B}, {S}x{S}, encoder and head feature maps bf16 (fp32 accumulate / parameters)",
+            "ms_per_step": round(dt * 1e3, 2), "megapixels_per_s": round(B * S * S / 1e6 / dt, 3), "steps": steps, "warmup": warmup,
+            "alg_tflops": round(flops / dt / 1e12, 2), "mfma_frac": round(flops / dt / 2.5e15, 4),
+            "hbm_frac": round(sc * 2 * naf_bytes_bf16 / dt / (PEAK_HBM_TBS * 1e12), 4),
+            "hbm_frac_note": "encoder's algorithmic bf16 bytes only (SURVEY 8d has no byte count for the head): a lower bound",
+            "l_pix": round(float(log["l_pix"]), 6), "l_classify": round(float(log["l_classify"]), 6),
+        }
+        del m
+        torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(n: int) -> None:
     """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run, one process per GPU."""
     import socket
@@ -110,9 +167,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (the metric is quoted at 32)")
-    ap.add_argument("--chunks", type=int, default=1, help="sub-batches on separate HIP streams inside the model forward")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even with one rank (path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 DCPT steps (configs[2]) timed after the headline region")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--side-stream", type=int, default=1, help="0: keep the weight-gradient GEMMs on the main stream")
     ap.add_argument("--iso-steps", type=int, default=3, help="steps of the serialized per-kernel timing pass (0 = skip)")
@@ -155,7 +212,6 @@ def main():
     net = build_network(dict(type="NAFNetBaseline", **CFG))
     fill_module_(net, seed=0)
     net = net.to(dev)
-    net.stream_chunks = args.chunks
     model = net
     if use_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -265,7 +321,7 @@ def main():
                 "workload": "NAFNet-width64 enc[1,1,1,28] mid1 dec[1,1,1,1] fwd+L1+bwd(+all-reduce)+AdamW, 256x256, fp32 "
                             "(BASELINE.json configs[1])",
                 "per_gpu_batch": args.batch, "global_batch": world * args.batch, "image": [SIZE, SIZE],
-                "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "loss": round(loss_val, 6), "stream_chunks": args.chunks,
+                "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "loss": round(loss_val, 6),
                 "wgrad_side_stream": bool(args.side_stream),
             },
         }
@@ -278,20 +334,22 @@ def main():
             top = prof_rows[0]
             ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
             # HBM bytes per launch of that kernel from the committed PMC passes (cannot be read live): see the file's "source"
-            traffic, traffic_src = None, None
+            # (`traffic_stale`: the file was made from a different build of libdcpt_hip.so than the one running now -- digests differ)
+            traffic, traffic_src, traffic_stale = None, None, None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                     pmc = json.load(fh)
                 if top["kernel"] in pmc["kernels"]:
                     traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
                     traffic_src = "profiles/pmc_traffic.json (rocprofv3 PMC passes of an earlier run of this command)"
+                    traffic_stale = pmc.get("lib_digest") is None or pmc.get("lib_digest") != lib_digest()
             except (OSError, ValueError, KeyError):
                 pass
             gemm_ms = sum(r["ms"] for r in prof_rows)
             res["roofline"] = {
                 "bound": "mfma", "kernel": top["kernel"], "MNK": [top["M"], top["N"], top["K"]],
                 "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "launches": top["launches"], "avg_launch_us": round(top["ms"] * 1e3 / max(1, top["launches"]), 2),
                 "alg_flops_per_launch": round(top["flops"] / max(1, top["launches"])),
                 "alg_bytes_per_launch": round(top["bytes"] / max(1, top["launches"])),
@@ -333,9 +391,15 @@ def main():
                                 "in_main_idle_ms": sb["side_in_main_idle_ms"]},
                 "launches_per_step": {"main": sb["main_launches"], "side": sb["side_launches"]},
                 "source": sb.get("source", "profiles/step_budget.json"),
+                "stale": sb.get("lib_digest") is None or sb.get("lib_digest") != lib_digest(),
             }
         except (OSError, ValueError, KeyError):
             pass
+        res["lib_digest"] = lib_digest()
+        if world == 1 and not args.no_secondary:
+            del net, model, opt, lq, gt, loss
+            torch.cuda.empty_cache()
+            res["secondary"] = secondary_dcpt_bf16(dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

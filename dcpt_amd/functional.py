@@ -277,8 +277,13 @@ class _TakeBatchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         shape, stride, dtype, dev, lo, hi = ctx.meta
-        dense = torch.empty(shape, dtype=dtype, device=dev).stride() == stride or len(shape) != 4
-        out = torch.empty_strided(shape, stride, dtype=dtype, device=dev) if not dense else torch.empty(shape, dtype=dtype, device=dev)
+        # the input's own strides when they describe a dense, non-overlapping layout (contiguous or channels_last: sorted by
+        # stride, the strides telescope over the sizes); anything else (expanded / overlapping views) gets a contiguous gradient.
+        # Computed arithmetically -- no throw-away allocation of the feature map's size.
+        keep, run = len(shape) == 4, 1
+        for st, sz in sorted((st, sz) for st, sz in zip(stride, shape) if sz > 1):
+            keep, run = keep and st == run, run * sz
+        out = torch.empty_strided(shape, stride, dtype=dtype, device=dev) if keep else torch.empty(shape, dtype=dtype, device=dev)
         if lo > 0:
             out[:lo].zero_()
         if hi < shape[0]:

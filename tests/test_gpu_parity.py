@@ -366,25 +366,6 @@ def test_nafnet_local_tlsc_golden(dev, golden_dir):
         net(x.requires_grad_(True))
 
 
-def test_stream_chunks_same_result(dev):
-    """Two sub-batches on two HIP streams give the same output and gradients as the single-stream pass."""
-    net = _build_net(TINY, dev)
-    x = keyed_input("sc.x", (4, 3, 32, 32)).to(dev)
-    gw = keyed_input("sc.gw", (4, 3, 32, 32), lo=-1, hi=1).to(dev)
-    res = []
-    for n in (1, 2):
-        net.stream_chunks = n
-        net.zero_grad(set_to_none=True)
-        y = net(x)
-        (y * gw).sum().backward()
-        torch.cuda.synchronize()
-        res.append((y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
-    net.stream_chunks = 1
-    assert torch.equal(res[0][0], res[1][0])
-    for k in res[0][1]:
-        check("grad " + k, res[1][1][k], res[0][1][k], 1e-5)
-
-
 def test_tiled_inference_matches_per_tile_loop(dev):
     """SRModel.test_tile (batched by tile shape) == the reference's one-tile-at-a-time loop (sr_model.py:273-361)."""
     from basicsr.models import build_model

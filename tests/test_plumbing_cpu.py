@@ -481,3 +481,161 @@ def test_denoise_dataset_noise_matches_reference(tmp_path):
     assert np.array_equal(s["lq"].permute(1, 2, 0).numpy(), ref)
     with pytest.raises(FileNotFoundError):
         build_dataset(dict(common, phase="train", dataroot_gt=str(tmp_path / "missing")))
+
+
+# ------------------------------------------------------------------------------------------------
+@ARCH_REGISTRY.register()
+class _TestHookEnc(nn.Module):
+    """a two-group encoder with ``decoder{i}`` block groups (hook targets ``decoder{i}.0``) and the reference's ``hook`` contract"""
+
+    def __init__(self, img_channel=3, width=4):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.intro = nn.Conv2d(img_channel, width, 3, padding=1)
+        self.decoder0 = nn.Sequential(nn.Conv2d(width, width, 3, padding=1))
+        self.decoder1 = nn.Sequential(nn.Conv2d(width, width, 1))
+        self.ending = nn.Conv2d(width, img_channel, 3, padding=1)
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+
+    def forward(self, x, hook=False):
+        f = self.decoder1(torch.tanh(self.decoder0(self.intro(x))))
+        return None if hook else self.ending(f) + x
+
+
+@ARCH_REGISTRY.register()
+class _TestHead(nn.Module):
+    """(lq, taps) -> logits like PromptIR_NoImg_DC: ignores lq, mean-pools every tap"""
+
+    def __init__(self, width=4, num_classes=5, n_taps=2):
+        super().__init__()
+        self.fc = nn.Linear(width * n_taps, num_classes)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(4)
+            self.fc.weight.copy_(torch.randn(self.fc.weight.shape, generator=g))
+            self.fc.bias.zero_()
+
+    def forward(self, lq, feats):
+        return self.fc(torch.cat([f.float().mean(dim=(2, 3)) for f in feats], 1))
+
+
+def _dcpt_opt(**over):
+    opt = dict(name="t", model_type="DCPTModel", scale=1, num_gpu=0, dist=False, rank=0, world_size=1, is_train=True, hook_names="decoder",
+               network_g=dict(type="_TestHookEnc"), network_dc=dict(type="_TestHead"), path=dict(),
+               train=dict(pixel_opt=dict(type="L1Loss", loss_weight=1.0, reduction="mean"), classify_opt=dict(type="CrossEntropyLoss", loss_weight=1.0),
+                          optim_g=dict(type="SGD", lr=0.0), optim_dc=dict(type="SGD", lr=0.0)))
+    opt.update(over)
+    return opt
+
+
+def _dcpt_data(rank):
+    g = torch.Generator().manual_seed(200 + rank)
+    return {"lq": torch.rand(2, 3, 12, 12, generator=g), "gt": torch.rand(2, 3, 12, 12, generator=g), "dataset_idx": torch.randint(0, 5, (2,), generator=g)}
+
+
+def _dcpt_ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import tests.test_plumbing_cpu  # noqa: F401
+    from basicsr.models import build_model
+
+    m = build_model(_dcpt_opt(dist=True, rank=rank, world_size=world))
+    assert m.batched_encoder_passes and len(m.hooks) == 2
+    m.feed_data(_dcpt_data(rank))
+    m.optimize_parameters(1)
+    grads = torch.cat([p.grad.flatten() for net in (m.net_g, m.net_dc) for p in net.parameters()])
+    torch.save({"grads": grads, "log": dict(m.get_current_log())}, os.path.join(out, f"d{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_dcpt_step_batched_encoder_pass_gloo(tmp_path):
+    """The default DCPT step (``train.batched_encoder_passes``: ONE stacked encoder forward serves the reconstruction and the taps)
+    under DistributedDataParallel with world_size 2: both ranks end with the mean of the two ranks' gradients of the REFERENCE's
+    two-pass step (...pretrain_model.py:133-169), the hooks fire once per rank and step, losses are averaged on rank 0."""
+    import torch.multiprocessing as mp
+
+    from basicsr.models import build_model
+
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_dcpt_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"d{i}.pt")) for i in range(2))
+    assert torch.allclose(r0["grads"], r1["grads"], atol=1e-7)
+    local, logs = [], []
+    for rank in range(2):
+        opt = _dcpt_opt()
+        opt["train"]["batched_encoder_passes"] = False   # the reference's literal two encoder passes, one process
+        m = build_model(opt)
+        assert not m.batched_encoder_passes
+        m.feed_data(_dcpt_data(rank))
+        m.optimize_parameters(1)
+        local.append(torch.cat([p.grad.flatten() for net in (m.net_g, m.net_dc) for p in net.parameters()]))
+        logs.append(m.get_current_log())
+    assert float(local[0].abs().max()) > 1e-3
+    assert torch.allclose(r0["grads"], (local[0] + local[1]) / 2, atol=2e-6)
+    for k in ("l_pix", "l_classify"):
+        assert abs(r0["log"][k] - (logs[0][k] + logs[1][k]) / 2) < 1e-6
+
+
+def test_batched_encoder_pass_detects_split_forward():
+    """A net_g that fires its hooks more than once per forward (e.g. one that splits the batch internally) must not silently feed the
+    head mis-sliced taps."""
+    from basicsr.models import build_model
+
+    m = build_model(_dcpt_opt())
+    inner = m.net_g.forward
+    m.net_g.forward = lambda x, hook=False: torch.cat([inner(c, hook) for c in x.chunk(2, 0)], 0)
+    m.feed_data(_dcpt_data(0))
+    with pytest.raises(RuntimeError, match="batched encoder pass"):
+        m.optimize_parameters(1)
+
+
+def test_selfensemble_matches_reference_construction():
+    """SRModel.test_selfensemble (reference sr_model.py:187-232) == the reference's own list construction done with numpy: 8
+    augmentations (v, h, t applied cumulatively), network on each, inverse transforms in the reference's order, mean -- on a
+    non-square image (transposed augmentations have the other shape) -- and ``ensemble: true`` routes validation through it."""
+    from basicsr.models import build_model
+
+    m = build_model(_opt(network_g=dict(type="_TestConvArch"), ensemble=True))
+    lq = torch.rand(2, 3, 10, 14, generator=torch.Generator().manual_seed(9))
+    m.feed_data({"lq": lq})
+    m.test_selfensemble()
+    assert m.output.shape == lq.shape
+
+    def tf(v, op):   # the reference's _transform, on numpy
+        a = v.numpy()
+        a = a[..., ::-1] if op == "v" else a[..., ::-1, :] if op == "h" else a.transpose((0, 1, 3, 2))
+        return torch.from_numpy(a.copy())
+
+    lst = [lq]
+    for op in "vht":
+        lst.extend([tf(t, op) for t in lst])
+    with torch.no_grad():
+        outs = [m.net_g(a) for a in lst]
+    for i in range(8):
+        if i > 3:
+            outs[i] = tf(outs[i], "t")
+        if i % 4 > 1:
+            outs[i] = tf(outs[i], "h")
+        if (i % 4) % 2 == 1:
+            outs[i] = tf(outs[i], "v")
+    want = torch.cat([o.unsqueeze(0) for o in outs], 0).mean(dim=0)
+    assert torch.allclose(m.output, want, atol=1e-6)
+    m.test()
+    assert not torch.allclose(m.output, want, atol=1e-4)   # the conv is not flip-symmetric: the ensemble really differs
+
+    class _Loader(list):
+        dataset = type("D", (), {"opt": {"name": "v"}})()
+
+    one = lq[:1]
+    res_e = m.nondist_validation(_Loader([{"lq": one, "gt": (one * 0.9), "lq_path": ["a.png"]}]), 1, None, False)
+    m2 = build_model(_opt(network_g=dict(type="_TestConvArch")))
+    res_p = m2.nondist_validation(_Loader([{"lq": one, "gt": (one * 0.9), "lq_path": ["a.png"]}]), 1, None, False)
+    m.feed_data({"lq": one})
+    m.test_selfensemble()
+    from basicsr.metrics import calculate_psnr
+    direct = calculate_psnr(m.output.clamp(0, 1).numpy(), (one * 0.9).numpy(), crop_border=0, test_y_channel=False)
+    assert abs(res_e["psnr"] - direct) < 1e-9 and abs(res_e["psnr"] - res_p["psnr"]) > 1e-6

@@ -37,7 +37,13 @@ for sym, d in rows.items():
         continue   # two tile shapes of one class: keep the one with more launches (the level-3 blocks)
     out[name] = dict(hbm_bytes_per_launch=round(rd + wr), read_bytes=round(rd), write_bytes=round(wr), symbol=sym,
                      launches_used=vals['FETCH_SIZE'][1], median_us=round(vals['FETCH_SIZE'][2], 1))
-json.dump({"source": __doc__.strip() + f"  Raw passes: {os.path.basename(root)}.", "kernels": out},
+try:
+    dig = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dcpt_amd", "lib", "libdcpt_hip.digest")).read().strip()
+except OSError:
+    dig = None
+# lib_digest: the build of libdcpt_hip.so that was profiled (run this tool with the same tree); bench.py flags the figures stale when
+# the running library's digest differs
+json.dump({"source": __doc__.strip() + f"  Raw passes: {os.path.basename(root)}.", "lib_digest": dig, "kernels": out},
           open('profiles/pmc_traffic.json', 'w'), indent=1)
 for k, v in out.items():
     print(k, v)

@@ -1,7 +1,7 @@
 """Account for one training step of the DEFAULT bench command (two streams) from a rocprofv3 --kernel-trace CSV:
 
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d <dir> -o bench -- \
-        python <repo>/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-prof
+        python <repo>/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-prof
     python tools/step_budget.py <dir>/**/bench_kernel_trace.csv [--json out.json]
 
 A step period is delimited by consecutive launches of a kernel that runs once per step (the ending convolution's forward).  For every complete step:
@@ -117,7 +117,12 @@ def main():
     for t in avg["top_kernels"]:
         print(f"  {t['ms_per_step']:8.3f} ms  x{t['launches_per_step']:6.1f}  {t['kernel']}")
     if out_json:
-        avg["source"] = "rocprofv3 --kernel-trace of `python bench.py --steps K --warmup W --no-cpu-baseline --no-prof` (default two-stream configuration); tools/step_budget.py"
+        avg["source"] = "rocprofv3 --kernel-trace of `python bench.py --steps K --warmup W --no-cpu-baseline --no-secondary --no-prof` (default two-stream configuration); tools/step_budget.py"
+        import os
+        try:   # the build that was traced (bench.py marks the account stale when the running library differs)
+            avg["lib_digest"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dcpt_amd", "lib", "libdcpt_hip.digest")).read().strip()
+        except OSError:
+            avg["lib_digest"] = None
         json.dump(avg, open(out_json, "w"), indent=1)
 
 
