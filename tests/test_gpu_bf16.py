@@ -496,27 +496,39 @@ def test_dcpt_step_all_bf16_full_size(dev):
     """BASELINE.json configs[2] as it is quoted: `DCPTModel.optimize_parameters` (reference ...pretrain_model.py:133-169) with
     NAFNet-64 [1,1,1,28] + `PromptIR_NoImg_DC([64,128,256,512])`, B = 32, 128 x 128, encoder AND head in bf16 storage.
     (1) l_pix / l_classify of the bf16 step against the fp32 HIP step on the same batch (the fp32 step is pinned to the reference by
-    test_dcpt_step_golden and, at this size, by test_dcpt_step_full_size_directional_derivative);  (2) the gradients the bf16 step
-    leaves in `.grad` of BOTH networks, contracted with a random direction, against the central difference of the bf16 step's own
-    loss evaluated by forward passes (the step is larger than in fp32: the bf16 loss carries ~1e-3 of rounding noise)."""
+    test_dcpt_step_golden and, at this size, by test_dcpt_step_full_size_directional_derivative);
+    (2) the gradients the bf16 step leaves in `.grad` against the fp32 step's: cosine similarity per network;
+    (3) a central difference of the bf16 step's own loss (forward passes only) along the normalised gradient direction, with a step
+    sized for a ~2 % change of the loss -- the bf16 loss carries ~1e-3 of rounding noise, so a random direction with an fp32-sized
+    step measures that noise, not the slope (measured: 0.32 against an analytic 1.94 at eps = 1e-2)."""
     B, S = 32, 128
     gen = torch.Generator().manual_seed(21)
     gt = torch.rand((B, 3, S, S), generator=gen)
     lq = (gt + 0.1 * torch.randn((B, 3, S, S), generator=gen)).clamp(0, 1)
     labels = torch.randint(0, 10, (B,), generator=gen)
-    logs = {}
+    logs, grads = {}, {}
     for dt in ("fp32", "bf16"):
         m = _dcpt_full(dt)
         assert len(m.hooks) == 4
         m.feed_data({"lq": lq, "gt": gt, "dataset_idx": labels})
         m.optimize_parameters(1)
         logs[dt] = dict(m.get_current_log())
+        grads[dt] = {tag: torch.cat([p.grad.detach().double().flatten() for p in net.parameters()])
+                     for tag, net in (("g", m.net_g), ("dc", m.net_dc))}
         if dt == "fp32":
             del m
             torch.cuda.empty_cache()
     print("DCPT full size, fp32 vs all-bf16 losses:", logs)
-    assert abs(logs["bf16"]["l_pix"] - logs["fp32"]["l_pix"]) <= 2e-2 * abs(logs["fp32"]["l_pix"]), logs
-    assert abs(logs["bf16"]["l_classify"] - logs["fp32"]["l_classify"]) <= 8e-2 * abs(logs["fp32"]["l_classify"]), logs
+    # measured on MI355X: l_pix 25.6468 vs 25.6386 (3e-4), l_classify 7.8643 vs 7.8603 (5e-4)
+    assert abs(logs["bf16"]["l_pix"] - logs["fp32"]["l_pix"]) <= 3e-3 * abs(logs["fp32"]["l_pix"]), logs
+    assert abs(logs["bf16"]["l_classify"] - logs["fp32"]["l_classify"]) <= 5e-3 * abs(logs["fp32"]["l_classify"]), logs
+    cos = {}
+    for tag in ("g", "dc"):
+        a, b = grads["bf16"][tag], grads["fp32"][tag]
+        assert bool(torch.isfinite(a).all())
+        cos[tag] = float((a * b).sum() / (a.norm() * b.norm()))
+        print(f"gradient of net_{tag}: cosine(bf16, fp32) = {cos[tag]:.5f}, norm ratio {float(a.norm() / b.norm()):.4f}")
+    assert cos["g"] >= 0.998 and cos["dc"] >= 0.999, cos   # measured 0.99955 / 0.99994
 
     def losses():
         with torch.no_grad():
@@ -533,22 +545,22 @@ def test_dcpt_step_all_bf16_full_size(dev):
     lp, lc = losses()
     assert abs(lp - logs["bf16"]["l_pix"]) <= 1e-3 * max(1.0, abs(lp)) and abs(lc - logs["bf16"]["l_classify"]) <= 2e-3 * max(1.0, abs(lc)), (lp, lc, logs)
     params = [p for p in m.net_g.parameters()] + [p for p in m.net_dc.parameters()]
-    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
-    dirs = [torch.randn(p.shape, generator=gen).to(dev) * p.detach().abs().mean().clamp_min(1e-3) for p in params]
-    analytic = float(sum((p.grad.double() * d.double()).sum() for p, d in zip(params, dirs)))
-    eps = 1e-2
-    vals = []
-    with torch.no_grad():
-        for sign in (+1.0, -1.0):
-            for p, d in zip(params, dirs):
-                p.add_(d, alpha=sign * eps)
-            vals.append(sum(losses()))
-            for p, d in zip(params, dirs):
-                p.sub_(d, alpha=sign * eps)
-    numeric = (vals[0] - vals[1]) / (2 * eps)
-    print(f"DCPT all-bf16 full size: analytic {analytic:.6f}, central difference {numeric:.6f}")
-    assert abs(analytic) > 1e-3, analytic
-    assert abs(numeric - analytic) <= 0.1 * abs(analytic), (numeric, analytic, lp, lc)
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)))
+    dirs = [p.grad.detach() / gnorm for p in params]          # unit vector along the analytic gradient
+    analytic = gnorm                                          # <grad, dir>
+    for frac in (0.02, 0.05):
+        eps = frac * (lp + lc) / gnorm                        # loss changes by ~frac per side
+        vals = []
+        with torch.no_grad():
+            for sign in (+1.0, -1.0):
+                for p, d in zip(params, dirs):
+                    p.add_(d, alpha=sign * eps)
+                vals.append(sum(losses()))
+                for p, d in zip(params, dirs):
+                    p.sub_(d, alpha=sign * eps)
+        numeric = (vals[0] - vals[1]) / (2 * eps)
+        print(f"DCPT all-bf16 full size: |grad| {analytic:.5f}, central difference along it {numeric:.5f} (step {eps:.3e}, loss {lp + lc:.4f} -> {vals})")
+    assert abs(numeric - analytic) <= 0.04 * abs(analytic), (numeric, analytic, lp, lc)   # measured 0.2 % / 0.9 % at the two steps
 
 
 def _denoise_batch(i, dev, B=8, S=128):
@@ -596,6 +608,7 @@ def test_bf16_training_trajectory_tracks_fp32(dev):
           f"bf16 {psnr['bf16']:.2f} dB (noisy input {psnr['in']:.2f} dB)")
     assert curves["fp32"][-10:].mean() < 0.5 * curves["fp32"][:3].mean()
     assert psnr["fp32"] > psnr["in"] + 6.0 and psnr["bf16"] > psnr["in"] + 6.0, psnr
+    # measured on MI355X: final-10 ratio 1.049, worst 5-iteration ratio 1.051, held-out PSNR 31.72 (fp32) / 31.29 dB (bf16), input 20.28
     assert abs(tail - 1.0) <= 0.08, tail
-    assert ratio.max() <= 1.30, ratio.max()
-    assert abs(psnr["fp32"] - psnr["bf16"]) <= 0.5, psnr
+    assert ratio.max() <= 1.15, ratio.max()
+    assert abs(psnr["fp32"] - psnr["bf16"]) <= 0.6, psnr

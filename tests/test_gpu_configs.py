@@ -275,7 +275,7 @@ def test_psnr_gate_hip_vs_oracle(dev, trained_denoiser):
         assert (h8 != o8).mean() < 2e-3, f"image {i}: {(h8 != o8).mean():.2e} of the uint8 pixels differ"
     print(f"trained NAFNet-64: PSNR gain over the noisy input {min(gains):.2f}..{max(gains):.2f} dB; HIP vs oracle |dPSNR| <= {worst_p:.5f} dB, "
           f"|dSSIM| <= {worst_s:.2e}")
-    assert min(gains) > 6.0, gains   # the gate is taken on a network that restores (noisy input ~20.3 dB)
+    assert min(gains) > 12.0, gains   # the gate is taken on a network that restores (measured: +18.2..18.4 dB over the noisy input)
     assert worst_p <= 0.01, f"PSNR differs by {worst_p:.4f} dB"
     assert worst_s <= 1e-4, f"SSIM differs by {worst_s:.2e}"
 
@@ -303,4 +303,4 @@ def test_psnr_bf16_storage_vs_fp32(dev, trained_denoiser):
         p32, p16 = calculate_psnr(f(o32), f(gt[None]), **kw), calculate_psnr(f(o16), f(gt[None]), **kw)
         worst = max(worst, abs(p32 - p16))
     print(f"bf16 storage moves PSNR by at most {worst:.4f} dB on these pairs")
-    assert worst <= 0.05, f"PSNR differs by {worst:.4f} dB"
+    assert worst <= 0.03, f"PSNR differs by {worst:.4f} dB"   # measured: 0.0125 dB on the trained network
