@@ -55,6 +55,9 @@ __device__ __forceinline__ void bbuf_st8(rsrc_t r, uint32_t voff, f8 v) {
     w.y = bf_pack(v.lo.z, v.lo.w);
     w.z = bf_pack(v.hi.x, v.hi.y);
     w.w = bf_pack(v.hi.z, v.hi.w);
+#ifdef DCPT_ABL_NOSTORE   // ablation builds (tools/build_variant.sh): the store is issued but dropped by the range check
+    voff |= ROW_SENT;
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
 }
 __device__ __forceinline__ f8 f8_zero() { return f8{f4_zero(), f4_zero()}; }
@@ -104,6 +107,9 @@ struct GemmNTB {
     int gather2;
 };
 int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
+// 256 x 256-tile kernel for the wide levels (gemm_bf16_256.hip); launch_gemm_nt_bf16 routes eligible launches to it
+bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles = 192);   // min_tiles: fill most of the 256 CUs
+int launch_gemm_nt_bf16_256(const GemmNTB& p, int epi, hipStream_t s);
 int gemm_nt_bf16_tiles_n(const GemmNTB& p, int epi);   // column tiles of the launch (row partials per row written by EB_SGBWD)
 
 // G[n][k] = sum_m X[m][n] * Y[m][k]  (weight gradients): X, Y bf16 row-major, fp32 slabs [splits][N][K] + column sums of X as in

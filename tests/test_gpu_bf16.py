@@ -63,8 +63,10 @@ def test_cast_roundtrip(dev):
 # C < one MFMA tile; (3, 24, 5, 7): odd image, three images; C = 128 / 512 / 1024: two GEMM column tiles, multi-k-tile loops,
 # two LayerNorm chunks per lane
 # (1, 16, 11, 70) / (1, 24, 6, 50) / (1, 8, 70, 9): the depthwise ring kernels' multi-column-tile, 8-piece and two-row-part tilings
+# (24, 512, 32, 32) / (25, 512, 31, 32) / (6, 256, 64, 64): large enough (>= 192 tiles of 256 x 256) for the 256 x 256-tile NT kernel
+# (gemm_bf16_256.hip) to take every conv -- all six epilogues, the per-image batched conv3, and a ragged last row tile (M = 24800)
 @pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8),
-                                   (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9)])
+                                   (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9), (24, 512, 32, 32), (25, 512, 31, 32), (6, 256, 64, 64)])
 def test_nafblock_bf16_oracle(dev, shape):
     from dcpt_amd import functional as DF
 
