@@ -104,7 +104,9 @@ class NAFBlock(nn.Module):
                     raise NotImplementedError("the TLSC (local-mean SCA) block is fp32 only: build NAFNet with act_dtype='fp32'")
                 return DF.nafblock_local(inp, self.fused_params(), k1, k2)
         if self.act_bf16:   # bf16 in / out (an fp32 input -- a block used on its own -- is cast once)
-            return DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params())
+            if getattr(self, "_packed_bf16", None) is None:
+                self._packed_bf16 = DF.PackedWeightsBf16()   # operand copies of the weights, refreshed when the parameters change
+            return DF.nafblock_bf16(DF.to_bf16(inp), self.fused_params(), self._packed_bf16)
         return DF.nafblock(inp, self.fused_params())
 
 

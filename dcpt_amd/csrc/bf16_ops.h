@@ -22,6 +22,7 @@ constexpr int WPACKB_MAX_JOBS = 8;
 struct WpackBJobs {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
                       // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
                       // 4 / 5 / 6 / 7: misc.hip's WP_DOWN / WP_DOWN_T / WP_UP / WP_UP_T (2x2 stride-2 conv, 1x1 conv + PixelShuffle(2))
+                      // 8: depthwise taps [N = 2C][K = 9] -> FP32 [9][2C] (dw_pack layout; `out` points at floats)
     const float* in[WPACKB_MAX_JOBS];
     bf16_t* out[WPACKB_MAX_JOBS];
     const float* rs[WPACKB_MAX_JOBS];

@@ -212,6 +212,11 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobs jobs) 
     const float* __restrict__ ks = jobs.kscale[j];
     const int N = jobs.N[j], K = jobs.K[j], nimg = jobs.nimg[j] > 0 ? jobs.nimg[j] : 1;
     const int64_t total = (int64_t)nimg * N * K;
+    if (jobs.transpose[j] == 8) {   // the depthwise conv's [N = 2C][K = 9] taps -> fp32 [9][2C] (dwconv.hip's dw_pack layout); `out` holds floats
+        float* __restrict__ of = reinterpret_cast<float*>(out);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) of[(i % 9) * N + i / 9] = in[i];
+        return;
+    }
     if (jobs.transpose[j] == 0 && K % 8 == 0) {   // the big one (per-image scaled weights, nimg * N * K elements): 8 per thread, 16-byte stores
         const int64_t nk = (int64_t)N * K;
         for (int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x; i8 * 8 < total; i8 += (int64_t)gridDim.x * 256) {

@@ -146,13 +146,61 @@ int wgrad_b(const bf16_t* X, int N, const bf16_t* Y, int K, int64_t M, float* sl
 
 bool shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 1024; }
 
+// The operand copies of a block's weights that depend on the PARAMETERS only (not on activations): bf16 [N][K] copies for the forward
+// GEMMs, transposed (and beta / gamma-scaled) copies for the data-gradient GEMMs, the depthwise taps as [9][2C] fp32.  A caller that
+// keeps this buffer per block and refreshes it when the parameters change (once per optimizer step) saves the per-call packs:
+// 5 launches per block and step (dcpt_nafblock_wpack_bf16 / *_packed entry points).
+struct PackB {
+    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1;
+    float* w2p;
+};
+size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    PackB k{};
+    k.W1 = a.get<bf16_t>((size_t)2 * C * C);
+    k.W4 = a.get<bf16_t>((size_t)2 * C * C);
+    k.W5 = a.get<bf16_t>((size_t)C * C);
+    k.wT5 = a.get<bf16_t>((size_t)C * C);
+    k.wT4 = a.get<bf16_t>((size_t)2 * C * C);
+    k.wT3 = a.get<bf16_t>((size_t)C * C);
+    k.wT1 = a.get<bf16_t>((size_t)2 * C * C);
+    k.w2p = a.get<float>((size_t)18 * C);
+    if (out) *out = k;
+    return a.off;
+}
+int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
+    const int C2 = 2 * C;
+    WpackBJobs j{};
+    j.n = 8;
+    j.in[0] = p->conv1_w; j.out[0] = k.W1; j.N[0] = C2; j.K[0] = C;
+    j.in[1] = p->conv4_w; j.out[1] = k.W4; j.N[1] = C2; j.K[1] = C;
+    j.in[2] = p->conv5_w; j.out[2] = k.W5; j.N[2] = C; j.K[2] = C;
+    j.in[3] = p->conv5_w; j.out[3] = k.wT5; j.rs[3] = p->gamma; j.N[3] = C;  j.K[3] = C; j.transpose[3] = 1;
+    j.in[4] = p->conv4_w; j.out[4] = k.wT4; j.rs[4] = nullptr;  j.N[4] = C2; j.K[4] = C; j.transpose[4] = 1;
+    j.in[5] = p->conv3_w; j.out[5] = k.wT3; j.rs[5] = p->beta;  j.N[5] = C;  j.K[5] = C; j.transpose[5] = 1;
+    j.in[6] = p->conv1_w; j.out[6] = k.wT1; j.rs[6] = nullptr;  j.N[6] = C2; j.K[6] = C; j.transpose[6] = 1;
+    j.in[7] = p->conv2_w; j.out[7] = reinterpret_cast<bf16_t*>(k.w2p); j.N[7] = C2; j.K[7] = 9; j.transpose[7] = 8;
+    return launch_wpack_bf16(j, s);
+}
+
 }  // namespace
 
 extern "C" size_t dcpt_nafblock_fwd_bf16_ws_bytes(int B, int H, int W, int C) { return fwd_layout(B, H, W, C, nullptr, 0, nullptr); }
 extern "C" size_t dcpt_nafblock_bwd_bf16_ws_bytes(int B, int H, int W, int C) { return bwd_layout(B, H, W, C, nullptr, 0, nullptr); }
 
-extern "C" int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint16_t* inp, uint16_t* out, const dcpt_nafblock_saved_bf16* sv,
-                                      void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+extern "C" size_t dcpt_nafblock_wpack_bf16_bytes(int C) { return pack_layout(C, nullptr, 0, nullptr); }
+
+extern "C" int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(p && packed && C > 0 && C % 8 == 0 && C <= 1024, "nafblock_wpack_bf16: null argument or bad C=%d", C);
+    PackB k;
+    DCPT_CHECK_ARG(pack_layout(C, packed, packed_bytes, &k) <= packed_bytes, "nafblock_wpack_bf16: buffer too small (%zu < %zu)", packed_bytes,
+                   pack_layout(C, nullptr, 0, nullptr));
+    return pack_all(p, k, C, (hipStream_t)stream);
+}
+
+static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t* inp, uint16_t* out, const dcpt_nafblock_saved_bf16* sv,
+                                  void* ws, size_t ws_bytes, int B, int H, int W, int C, const void* packed, size_t packed_bytes,
+                                  dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && inp && out && sv, "nafblock_fwd_bf16: null argument");
     DCPT_CHECK_ARG(shape_ok(B, H, W, C), "nafblock_fwd_bf16: bad shape B=%d H=%d W=%d C=%d (C %% 8 == 0, C <= 1024)", B, H, W, C);
@@ -167,19 +215,25 @@ extern "C" int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint1
     const int64_t M = (int64_t)B * H * W;
     const int P = H * W;
     const float eps = 1e-6f;
-    // operand copies of the weights that do not depend on SCA
+    // operand copies of the weights that do not depend on SCA: the caller's per-block pack, or made here
     WpackBJobs j{};
-    j.n = 3;
-    j.in[0] = p->conv1_w; j.out[0] = w.W1; j.N[0] = 2 * C; j.K[0] = C;
-    j.in[1] = p->conv4_w; j.out[1] = w.W4; j.N[1] = 2 * C; j.K[1] = C;
-    j.in[2] = p->conv5_w; j.out[2] = w.W5; j.N[2] = C; j.K[2] = C;
-    DCPT_TRY(launch_wpack_bf16(j, s));
+    if (packed) {
+        PackB k;
+        DCPT_CHECK_ARG(pack_layout(C, const_cast<void*>(packed), packed_bytes, &k) <= packed_bytes, "nafblock_fwd_bf16: packed weights buffer too small");
+        w.W1 = k.W1; w.W4 = k.W4; w.W5 = k.W5; w.w2p = k.w2p;
+    } else {
+        j.n = 3;
+        j.in[0] = p->conv1_w; j.out[0] = w.W1; j.N[0] = 2 * C; j.K[0] = C;
+        j.in[1] = p->conv4_w; j.out[1] = w.W4; j.N[1] = 2 * C; j.K[1] = C;
+        j.in[2] = p->conv5_w; j.out[2] = w.W5; j.N[2] = C; j.K[2] = C;
+        DCPT_TRY(launch_wpack_bf16(j, s));
+    }
     DCPT_TRY(launch_ln_fwd_bf16(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
     GemmNTB g{};
     g.M = M; g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = w.W1; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
     DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIAS, s));
     DwGeom dg{B, H, W, C};
-    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
+    if (!packed) DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
     if (dw_ring_usable(dg, 2)) DCPT_TRY(launch_dw_ring_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     else DCPT_TRY(launch_dw_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
@@ -203,9 +257,20 @@ extern "C" int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint1
     return launch_gemm_nt_bf16(g, EB_RESID, s);
 }
 
-extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* gr, const uint16_t* inp,
-                                      const dcpt_nafblock_saved_bf16* sv, const uint16_t* dout, uint16_t* dinp, void* ws, size_t ws_bytes, int B,
-                                      int H, int W, int C, dcpt_stream_t stream) {
+extern "C" int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint16_t* inp, uint16_t* out, const dcpt_nafblock_saved_bf16* sv,
+                                      void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+    return nafblock_fwd_bf16_impl(p, inp, out, sv, ws, ws_bytes, B, H, W, C, nullptr, 0, stream);
+}
+extern "C" int dcpt_nafblock_fwd_bf16_packed(const dcpt_nafblock_params* p, const void* packed, size_t packed_bytes, const uint16_t* inp,
+                                             uint16_t* out, const dcpt_nafblock_saved_bf16* sv, void* ws, size_t ws_bytes, int B, int H, int W,
+                                             int C, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(packed, "nafblock_fwd_bf16_packed: null packed weights");
+    return nafblock_fwd_bf16_impl(p, inp, out, sv, ws, ws_bytes, B, H, W, C, packed, packed_bytes, stream);
+}
+
+static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* gr, const uint16_t* inp,
+                                  const dcpt_nafblock_saved_bf16* sv, const uint16_t* dout, uint16_t* dinp, void* ws, size_t ws_bytes, int B,
+                                  int H, int W, int C, const void* packed, size_t packed_bytes, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && gr && inp && sv && dout && dinp, "nafblock_bwd_bf16: null argument");
     DCPT_CHECK_ARG(shape_ok(B, H, W, C), "nafblock_bwd_bf16: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
@@ -220,15 +285,21 @@ extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_
     const int C2 = 2 * C;
     DwGeom dg{B, H, W, C};
 
-    // transposed (and gain-scaled) bf16 weights of the four dgrad GEMMs + the depthwise [9][2C] pack
-    WpackBJobs j{};
-    j.n = 4;
-    j.in[0] = p->conv5_w; j.out[0] = w.wT5; j.rs[0] = p->gamma; j.N[0] = C;  j.K[0] = C; j.transpose[0] = 1;
-    j.in[1] = p->conv4_w; j.out[1] = w.wT4; j.rs[1] = nullptr;  j.N[1] = C2; j.K[1] = C; j.transpose[1] = 1;
-    j.in[2] = p->conv3_w; j.out[2] = w.wT3; j.rs[2] = p->beta;  j.N[2] = C;  j.K[2] = C; j.transpose[2] = 1;
-    j.in[3] = p->conv1_w; j.out[3] = w.wT1; j.rs[3] = nullptr;  j.N[3] = C2; j.K[3] = C; j.transpose[3] = 1;
-    DCPT_TRY(launch_wpack_bf16(j, s));
-    DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, C2, s));
+    // transposed (and gain-scaled) bf16 weights of the four dgrad GEMMs + the depthwise [9][2C] pack: the caller's, or made here
+    if (packed) {
+        PackB k;
+        DCPT_CHECK_ARG(pack_layout(C, const_cast<void*>(packed), packed_bytes, &k) <= packed_bytes, "nafblock_bwd_bf16: packed weights buffer too small");
+        w.wT5 = k.wT5; w.wT4 = k.wT4; w.wT3 = k.wT3; w.wT1 = k.wT1; w.w2p = k.w2p;
+    } else {
+        WpackBJobs j{};
+        j.n = 4;
+        j.in[0] = p->conv5_w; j.out[0] = w.wT5; j.rs[0] = p->gamma; j.N[0] = C;  j.K[0] = C; j.transpose[0] = 1;
+        j.in[1] = p->conv4_w; j.out[1] = w.wT4; j.rs[1] = nullptr;  j.N[1] = C2; j.K[1] = C; j.transpose[1] = 1;
+        j.in[2] = p->conv3_w; j.out[2] = w.wT3; j.rs[2] = p->beta;  j.N[2] = C;  j.K[2] = C; j.transpose[2] = 1;
+        j.in[3] = p->conv1_w; j.out[3] = w.wT1; j.rs[3] = nullptr;  j.N[3] = C2; j.K[3] = C; j.transpose[3] = 1;
+        DCPT_TRY(launch_wpack_bf16(j, s));
+        DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, C2, s));
+    }
 
     const int ln_tiles = (int)cdiv64(M, 128);
     if (w.lrs) {   // u = W w_ln, c = b_conv + W b_ln for conv4 o LN2 and conv1 o LN1 (fp32; gemm.h E_LNBWD2)
@@ -322,6 +393,18 @@ extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_
     DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     DCPT_TRY(side_join(sd, s));
     return DCPT_OK;
+}
+
+extern "C" int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* gr, const uint16_t* inp,
+                                      const dcpt_nafblock_saved_bf16* sv, const uint16_t* dout, uint16_t* dinp, void* ws, size_t ws_bytes, int B,
+                                      int H, int W, int C, dcpt_stream_t stream) {
+    return nafblock_bwd_bf16_impl(p, gr, inp, sv, dout, dinp, ws, ws_bytes, B, H, W, C, nullptr, 0, stream);
+}
+extern "C" int dcpt_nafblock_bwd_bf16_packed(const dcpt_nafblock_params* p, const void* packed, size_t packed_bytes, const dcpt_nafblock_grads* gr,
+                                             const uint16_t* inp, const dcpt_nafblock_saved_bf16* sv, const uint16_t* dout, uint16_t* dinp, void* ws,
+                                             size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(packed, "nafblock_bwd_bf16_packed: null packed weights");
+    return nafblock_bwd_bf16_impl(p, gr, inp, sv, dout, dinp, ws, ws_bytes, B, H, W, C, packed, packed_bytes, stream);
 }
 
 extern "C" int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream) {

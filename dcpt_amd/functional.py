@@ -157,7 +157,7 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
     """NAFBlock.forward (reference nafnet_arch.py:165-186) with bf16 storage -> dcpt_nafblock_fwd_bf16 / bwd_bf16."""
 
     @staticmethod
-    def forward(ctx, inp, *params):
+    def forward(ctx, inp, packed, *params):
         lib = _lib.load()
         _require_gpu_bf16(inp)
         _require_gpu(*params)
@@ -179,8 +179,13 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
                                     stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
                                     acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
         ws = _workspace(dev, lib.dcpt_nafblock_fwd_bf16_ws_bytes(B, H, W, Cc))
-        check(lib.dcpt_nafblock_fwd_bf16(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
-                                         B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd_bf16")
+        if packed is None:
+            check(lib.dcpt_nafblock_fwd_bf16(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
+                                             B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd_bf16")
+        else:
+            check(lib.dcpt_nafblock_fwd_bf16_packed(C.byref(ps), packed.data_ptr(), packed.numel(), inp.data_ptr(), out.data_ptr(), C.byref(sv),
+                                                    ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd_bf16_packed")
+        ctx.packed = packed   # (a plain byte buffer owned by the module; the backward of THIS forward reads the same pack)
         ctx.save_for_backward(inp, t1, v, acts, stats, sca, *params)
         return out
 
@@ -199,14 +204,53 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
                                     stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
                                     acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
         ws = _workspace(dev, lib.dcpt_nafblock_bwd_bf16_ws_bytes(B, H, W, Cc))
-        check(lib.dcpt_nafblock_bwd_bf16(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(), dinp.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_nafblock_bwd_bf16")
-        return (dinp, *grads)
+        packed = ctx.packed
+        if packed is None:
+            check(lib.dcpt_nafblock_bwd_bf16(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(), dinp.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_nafblock_bwd_bf16")
+        else:
+            check(lib.dcpt_nafblock_bwd_bf16_packed(C.byref(ps), packed.data_ptr(), packed.numel(), C.byref(gs), inp.data_ptr(), C.byref(sv),
+                                                    dout.data_ptr(), dinp.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)),
+                  "dcpt_nafblock_bwd_bf16_packed")
+        return (dinp, None, *grads)
 
 
-def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """bf16 activations in / out, fp32 parameters (dict with the keys of _lib.PARAM_FIELDS)."""
-    return _NAFBlockBf16Fn.apply(inp, *[params[k] for k in PARAM_FIELDS])
+# parameters whose values the packed operand copies are made from
+_PACK_DEPS = ("conv1_w", "conv2_w", "conv3_w", "conv4_w", "conv5_w", "beta", "gamma")
+
+
+class PackedWeightsBf16:
+    """Per-block cache of the operand copies of a NAFBlock's weights for the bf16 path (dcpt_nafblock_wpack_bf16): refreshed -- one
+    launch -- when a parameter the copies are made from has changed since the last pack (torch bumps ``_version`` on every in-place
+    update: optimizer steps, load_state_dict, ``.copy_``) or moved (``.to(device)``), reused otherwise: within a training step the
+    forward, the backward and, in the DCPT step, both encoder passes share one pack."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+
+    def get(self, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+        key = tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
+        if key != self.key:
+            lib = _lib.load()
+            ps = tuple(_contig(params[k].detach()) for k in PARAM_FIELDS)
+            _require_gpu(*ps)
+            dev = ps[0].device
+            Cc = params["conv3_w"].shape[0]
+            nbytes = lib.dcpt_nafblock_wpack_bf16_bytes(Cc)
+            if self.buf is None or self.buf.numel() != nbytes or self.buf.device != dev:
+                self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            pp = NafBlockParams(*[p.data_ptr() for p in ps])
+            check(lib.dcpt_nafblock_wpack_bf16(C.byref(pp), self.buf.data_ptr(), self.buf.numel(), Cc, _stream(dev)), "dcpt_nafblock_wpack_bf16")
+            self.key = key
+        return self.buf
+
+
+def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor], packed: PackedWeightsBf16 = None) -> torch.Tensor:
+    """bf16 activations in / out, fp32 parameters (dict with the keys of _lib.PARAM_FIELDS); ``packed``: the block's weight-pack cache
+    (without it every call packs its own operand copies)."""
+    buf = packed.get(params) if packed is not None else None
+    return _NAFBlockBf16Fn.apply(inp, buf, *[params[k] for k in PARAM_FIELDS])
 
 
 class _CastFn(torch.autograd.Function):

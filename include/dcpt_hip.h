@@ -127,6 +127,20 @@ int dcpt_nafblock_fwd_bf16(const dcpt_nafblock_params* p, const uint16_t* inp, u
 int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* g, const uint16_t* inp,
                            const dcpt_nafblock_saved_bf16* saved, const uint16_t* dout, uint16_t* dinp, void* ws, size_t ws_bytes,
                            int B, int H, int W, int C, dcpt_stream_t stream);
+/* Per-block operand copies of the weights (ABI 7).  Everything the block's GEMMs and depthwise kernels read of the PARAMETERS --
+ * bf16 [N][K] copies of conv1 / conv4 / conv5, transposed (beta / gamma-scaled) copies of conv5 / conv4 / conv3 / conv1 for the data
+ * gradients, the depthwise taps as [9][2C] fp32 -- depends on the parameters only: a caller that keeps one buffer of
+ * dcpt_nafblock_wpack_bf16_bytes(C) per block and re-runs dcpt_nafblock_wpack_bf16 (ONE launch) whenever the block's parameters
+ * changed (once per optimizer step) hands it to the *_packed forms below, which then launch no pack kernels except the per-image
+ * SCA-scaled conv3 weights (5 launches fewer per block and step).  Results are bit-identical to dcpt_nafblock_fwd/bwd_bf16. */
+size_t dcpt_nafblock_wpack_bf16_bytes(int C);
+int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream);
+int dcpt_nafblock_fwd_bf16_packed(const dcpt_nafblock_params* p, const void* packed, size_t packed_bytes, const uint16_t* inp, uint16_t* out,
+                                  const dcpt_nafblock_saved_bf16* saved, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                                  dcpt_stream_t stream);
+int dcpt_nafblock_bwd_bf16_packed(const dcpt_nafblock_params* p, const void* packed, size_t packed_bytes, const dcpt_nafblock_grads* g,
+                                  const uint16_t* inp, const dcpt_nafblock_saved_bf16* saved, const uint16_t* dout, uint16_t* dinp, void* ws,
+                                  size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
 /* fp32 <-> bf16 (RNE) on n contiguous elements, n % 8 == 0: the edges of the bf16 path */
 int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream);
 int dcpt_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, dcpt_stream_t stream);
