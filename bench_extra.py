@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k", "naf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--head-dtype", default=None, choices=["fp32", "bf16"], help="dcpt: classifier-head activations (default: --dtype)")
-    ap.add_argument("--restormer-save", default="full", choices=["lean", "full"], help="what the Restormer halves keep for backward")
+    ap.add_argument("--restormer-save", default="balanced", choices=["lean", "balanced", "full"], help="what the Restormer halves keep for backward")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)

@@ -335,6 +335,8 @@ struct DwrBP {
     float* part;        // [B][gridDim.y][10][2C]
     int B, H, W, C;
     int nwc;            // column tiles
+    float* tout;        // GATE 1 only, may be null: [M][C] the gate product gelu(a_1) a_2 itself, recomputed on the way (bit-identical
+                        // to the forward kernel's: same conv recurrences, same GELU) for a caller that did not keep it
 };
 
 // GATE: 0 SimpleGate a_1 a_2 (+ bias, SCA scale / pooled gradient; NAFNet), 1 gelu(a_1) a_2 with the exact erf GELU (Restormer GDFN,
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
     constexpr int ES = sizeof(ST), PBY = 2 * ES;
     constexpr int R = GATE == 2 ? 3 : (ES == 4 ? DWRB_R32 : DWRB_R16);   // (GATE 2: 16-KB slots, three keep two blocks per CU)
     constexpr int DD = GATE == 2 ? 2 : 1;          // gate halves carried by the dts rows
+    constexpr int NSTO = GATE == 1 ? 6 : 4;        // stores per thread and row (vmcnt counts them): dt1 x 4 (+ the gate product x 2)
     constexpr int NDD = (DD * ES + 3) / 4;         // dts DMAs per wave and row (DD x 2 planes x 256 runs x PBY bytes)
     constexpr int NDT = ES / 2;                    // t1 DMAs per wave and row (4 planes x 256 runs x PBY bytes = NDT x 4 KiB)
     constexpr int NCH = 256 / LP;                  // pixel pairs per plane
@@ -470,6 +473,8 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         gmask[o].x = gmask[o].y = oval[o] ? 1.f : 0.f;
     }
     const rsrc_t rs_o = make_rsrc((ST*)p.dt1 + ((int64_t)b * p.H + rb) * p.W * 2 * C);
+    rsrc_t rs_to = rs_o;
+    if constexpr (GATE == 1) rs_to = make_rsrc((p.tout ? p.tout : (float*)p.dt1) + ((int64_t)b * p.H + rb) * p.W * C);
 
     v2 a0[2][2], a1[2][2], B0[2][2], B1[2][2], daP[2][2], T1[2][4], T2[2][4], gr[2][10];
 #pragma unroll
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
         wait_vm<0>();
 #else
         if (it < R - 1) wait_vm<(R - 2) * (NDT + NDD)>();
-        else wait_vm<4 + (R - 2) * (NDT + NDD + 4)>();
+        else wait_vm<NSTO + (R - 2) * (NDT + NDD + NSTO)>();
 #endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -557,6 +562,11 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
                     gd.x = d0; gd.y = d1;
                     da[o][0] = pin ? D[o][0] * f[1] * gd : v2z();
                     da[o][1] = pin ? D[o][0] * gv : v2z();
+                    {   // the gate product of this pixel for a caller that recomputes it here (rows of this block, owned columns)
+                        const bool tok = p.tout != nullptr && rho >= h0 && rho < h1 && oval[o];
+                        const uint32_t toff = tok ? (uint32_t)((((rho - rb) * p.W + xa + o) * C + c1) * 4) : ROW_SENT;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, gv * f[1]), rs_to, toff, 0, 0);
+                    }
                 }
             }
         }
@@ -670,9 +680,10 @@ bool dwr_bwd_enabled() {
 
 template <typename ST, int GATE = 0>
 int launch_bwd(const void* dts, const void* t1, const float* w2p, const float* b2, const float* simg, const float* dpool, void* dt1,
-               float* wpart, const DwGeom& g, hipStream_t s) {
+               float* wpart, const DwGeom& g, hipStream_t s, float* tout = nullptr) {
     const DwrBGeom d = dwr_bwd_geom(g);
     DwrBP p{};
+    p.tout = tout;
     p.t1 = t1; p.dts = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.dt1 = dt1; p.part = wpart;
     p.B = g.B; p.H = g.H; p.W = g.W; p.C = g.C; p.nwc = d.nwc;
     DCPT_CHECK_ARG(((double)cdiv(g.H, d.nrp) + 6.0) * g.W * 2.0 * g.C * sizeof(ST) < 1.0e9, "depthwise ring: a row range exceeds the 32-bit window");
@@ -731,9 +742,10 @@ int launch_dw_ring_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const flo
 
 // Restormer (fp32): GDFN gate backward gelu(a_1) a_2 fused with the transposed conv and the tap gradients (u [M][2 Ch], dt [M][Ch]),
 // and the plain depthwise backward dx = dw^T(dy) + tap gradients over Ctot channels (Ctot % 8 == 0); wpart as above with C = Ch / Ctot / 2
-int launch_dw_ring_bwd_gelu_f32(const float* dt, const float* u, const float* w2p, float* du, float* wpart, int B, int H, int W, int Ch, hipStream_t s) {
+int launch_dw_ring_bwd_gelu_f32(const float* dt, const float* u, const float* w2p, float* du, float* wpart, int B, int H, int W, int Ch, hipStream_t s,
+                                float* tout) {
     const DwGeom g{B, H, W, Ch};
-    return launch_bwd<float, 1>(dt, u, w2p, nullptr, nullptr, nullptr, du, wpart, g, s);
+    return launch_bwd<float, 1>(dt, u, w2p, nullptr, nullptr, nullptr, du, wpart, g, s, tout);
 }
 int launch_dw_ring_bwd_plain_f32(const float* dy, const float* x, const float* w2p, float* dx, float* wpart, int B, int H, int W, int Ctot, hipStream_t s) {
     DCPT_CHECK_ARG(Ctot % 8 == 0, "depthwise ring: Ctot=%d must be a multiple of 8", Ctot);

@@ -70,7 +70,9 @@ int launch_dw_ring_bwd_fused_f32(const float* dts, const float* t1, const float*
 // Restormer forms on the same ring kernel: the GDFN gate gelu(a_1) a_2 backward (launch_dw_gelu_bwd_a + launch_dw_generic_bwd in one
 // pass, da never written) and the plain depthwise backward; block counts from dw_ring_bwd_num_blocks_per_image({B, H, W, Ch | Ctot / 2})
 int launch_dw_ring_gelu_fwd_f32(const float* u, const float* w2p, float* t, int B, int H, int W, int Ch, hipStream_t s);
-int launch_dw_ring_bwd_gelu_f32(const float* dt, const float* u, const float* w2p, float* du, float* wpart, int B, int H, int W, int Ch, hipStream_t s);
+// tout != null: also writes the gate product gelu(a_1) a_2 [M][Ch] (bit-identical to launch_dw_ring_gelu_fwd_f32) for callers that did not keep it
+int launch_dw_ring_bwd_gelu_f32(const float* dt, const float* u, const float* w2p, float* du, float* wpart, int B, int H, int W, int Ch, hipStream_t s,
+                                float* tout = nullptr);
 int launch_dw_ring_bwd_plain_f32(const float* dy, const float* x, const float* w2p, float* dx, float* wpart, int B, int H, int W, int Ctot, hipStream_t s);
 
 // generic depthwise pieces (Restormer): w2p is the [9][Ctot] packed weight (launch_dw_pack_weights)

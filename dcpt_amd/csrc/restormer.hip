@@ -665,22 +665,32 @@ extern "C" int dcpt_gdfn_bwd(const dcpt_gdfn_params* p, const dcpt_gdfn_params_g
         DCPT_TRY(launch_ln_fwd(x, p->norm_w, biasfree ? nullptr : p->norm_b, w.r_xn, w.du, w.du + M, M, C, ln_eps, s));
         xn = w.r_xn;
     }
-    if (!tg) {
+    // the gate product the caller did not keep: the fused backward on the ring recomputes the conv output anyway and writes
+    // gelu(x1) * x2 along the way (no extra pass; the project_out weight gradient then runs after it); otherwise the forward kernel
+    const bool t_from_bwd = !tg && dwb_ring(B, H, W, 2 * hp);
+    if (!tg && !t_from_bwd) {
         if (dwf_ring(B, H, W, 2 * hp)) DCPT_TRY(launch_dw_ring_gelu_fwd_f32(sv->u, w.w2p, w.r_t, B, H, W, hp, s));
         else DCPT_TRY(launch_dw_gelu_fwd(sv->u, w.w2p, w.r_t, B, H, W, hp, s));
-        tg = w.r_t;
     }
+    if (!tg) tg = w.r_t;
     // dt = dy * Wout ; dWout = dy^T t
     g.M = M; g.A = dy; g.lda = C; g.K = C; g.Bw = w.wT_out; g.N = hp; g.C = w.dt; g.ldc = hp;
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
-    DCPT_TRY(tn_reduce(dy, C, C, tg, hp, hp, A_PLAIN, tp, M, w.slab, g_out, sw));
-    gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, sw>>>(g_out, gr->out_w, C, hidden, hp, 2);
-    DCPT_CHECK_LAUNCH("gdfn_unpack_out");
+    if (!t_from_bwd) {
+        DCPT_TRY(tn_reduce(dy, C, C, tg, hp, hp, A_PLAIN, tp, M, w.slab, g_out, sw));
+        gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, sw>>>(g_out, gr->out_w, C, hidden, hp, 2);
+        DCPT_CHECK_LAUNCH("gdfn_unpack_out");
+    }
     // gate backward, depthwise backward
     int nblk_dwb = dw_num_blocks_generic(B, H, W, 2 * hp);
     if (dwb_ring(B, H, W, 2 * hp)) {   // one pass on the row ring: the gate's da never goes to memory
         nblk_dwb = dw_ring_bwd_num_blocks_per_image(DwGeom{B, H, W, hp});
-        DCPT_TRY(launch_dw_ring_bwd_gelu_f32(w.dt, sv->u, w.w2p, w.du, w.wpart, B, H, W, hp, s));
+        DCPT_TRY(launch_dw_ring_bwd_gelu_f32(w.dt, sv->u, w.w2p, w.du, w.wpart, B, H, W, hp, s, t_from_bwd ? w.r_t : nullptr));
+        if (t_from_bwd) {
+            DCPT_TRY(tn_reduce(dy, C, C, tg, hp, hp, A_PLAIN, tp, M, w.slab, g_out, sw));
+            gdfn_unpack_kernel<<<dim3(grid_for((int64_t)C * hidden)), dim3(256), 0, sw>>>(g_out, gr->out_w, C, hidden, hp, 2);
+            DCPT_CHECK_LAUNCH("gdfn_unpack_out");
+        }
     } else {
         DCPT_TRY(launch_dw_gelu_bwd_a(w.dt, sv->u, w.w2p, w.da, B, H, W, hp, s));
         DCPT_TRY(launch_dw_generic_bwd(w.da, sv->u, w.w2p, w.du, w.wpart, B, H, W, 2 * hp, s));

@@ -1173,22 +1173,28 @@ def concat_channels(a, b):
     return _ConcatFn.apply(a, b)
 
 
-# What the Restormer halves keep for backward.  "full" (default): everything the backward pass reads.  "lean": LN(x), the qkv conv
-# output, attn @ v and the GDFN gate product are NOT kept -- the backward entry points recompute them (include/dcpt_hip.h, LEAN
-# MODE): 10.3 instead of 19 [M][C] units per block.  Measured on MI355X, Restormer B = 64, 128 x 128: 117.8 -> 69.0 GB peak,
-# 238.0 -> 271.4 ms per step (bit-identical results).  set_restormer_save() / DCPT_RESTORMER_SAVE=lean when memory is the limit.
+# What the Restormer halves keep for backward (every saved pointer of dcpt_mdta_saved / dcpt_gdfn_saved may be NULL on its own; the
+# backward entry points recompute what is missing with the forward kernels, bit-identical results):
+#   "full"      everything the backward pass reads: 19 [M][C] units per block;
+#   "balanced"  (default) LN(x) of both halves, attn @ v and the GDFN gate product gelu(x1) * x2 are NOT kept -- two bandwidth passes,
+#               one small batched GEMM and one depthwise-gate pass per block in backward: 13.3 units;
+#   "lean"      additionally the qkv conv output (one more C x 3C GEMM in backward): 10.3 units.
+# Measured on MI355X, Restormer B = 64, 128 x 128 (profiles/r3/extra_restormer_*.json).
+# set_restormer_save() / DCPT_RESTORMER_SAVE select the mode.
 import os as _os  # noqa: E402
 
-_RESTORMER_LEAN = _os.environ.get("DCPT_RESTORMER_SAVE", "full") == "lean"
+_RESTORMER_MODES = ("full", "balanced", "lean")
+_RESTORMER_SAVE = _os.environ.get("DCPT_RESTORMER_SAVE", "balanced")
+if _RESTORMER_SAVE not in _RESTORMER_MODES:
+    raise ValueError(f"DCPT_RESTORMER_SAVE={_RESTORMER_SAVE!r}: expected one of {_RESTORMER_MODES}")
 
 
 def set_restormer_save(mode: str) -> str:
-    """'lean' or 'full'; returns the previous mode"""
-    global _RESTORMER_LEAN
-    if mode not in ("lean", "full"):
+    """'full', 'balanced' or 'lean'; returns the previous mode"""
+    global _RESTORMER_SAVE
+    if mode not in _RESTORMER_MODES:
         raise ValueError(mode)
-    prev = "lean" if _RESTORMER_LEAN else "full"
-    _RESTORMER_LEAN = mode == "lean"
+    prev, _RESTORMER_SAVE = _RESTORMER_SAVE, mode
     return prev
 
 
@@ -1206,21 +1212,21 @@ class _MDTAFn(torch.autograd.Function):
         M, ch = B * H * W, Cc // heads
         y = _empty_nhwc(B, Cc, H, W, dev)
         stats = torch.empty((2, M), dtype=torch.float32, device=dev)
-        lean = _RESTORMER_LEAN
-        qkv1 = None if lean else _empty_nhwc(B, 3 * Cc, H, W, dev)
+        mode = _RESTORMER_SAVE
+        qkv1 = None if mode == "lean" else _empty_nhwc(B, 3 * Cc, H, W, dev)
         qkv = _empty_nhwc(B, 3 * Cc, H, W, dev)
         nrm = torch.empty((B, 2 * Cc), dtype=torch.float32, device=dev)
         att = torch.empty((3, B, heads, ch, ch), dtype=torch.float32, device=dev)
-        out_att = None if lean else _empty_nhwc(B, Cc, H, W, dev)
-        xn = None if lean else _empty_nhwc(B, Cc, H, W, dev)
+        out_att = None if mode != "full" else _empty_nhwc(B, Cc, H, W, dev)
+        xn = None if mode != "full" else _empty_nhwc(B, Cc, H, W, dev)
         sv = MdtaSaved(stats[0].data_ptr(), stats[1].data_ptr(), _p(qkv1), qkv.data_ptr(), nrm.data_ptr(),
                        att[0].data_ptr(), att[1].data_ptr(), att[2].data_ptr(), _p(out_att), _p(xn))
         pp = MdtaParams(*[_p(t) for t in ps])
         ws = _workspace(dev, lib.dcpt_mdta_ws_bytes(B, H, W, Cc, heads, 0))
         check(lib.dcpt_mdta_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
                                 heads, int(biasfree), _stream(dev)), "dcpt_mdta_fwd")
-        ctx.lean = lean
-        kept = [] if lean else [qkv1, out_att, xn]
+        kept = [t for t in (qkv1, out_att, xn) if t is not None]
+        ctx.kept = (qkv1 is not None, out_att is not None, xn is not None)
         ctx.save_for_backward(x, stats, qkv, nrm, att, *kept, *[t for t in ps if t is not None])
         ctx.has_bias = ps[1] is not None
         ctx.heads, ctx.biasfree = heads, int(biasfree)
@@ -1230,9 +1236,8 @@ class _MDTAFn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         x, stats, qkv, nrm, att, *ps = ctx.saved_tensors
-        qkv1 = out_att = xn = None
-        if not ctx.lean:
-            qkv1, out_att, xn, *ps = ps
+        ps = list(ps)
+        qkv1, out_att, xn = (ps.pop(0) if k else None for k in ctx.kept)
         if ctx.has_bias:
             norm_w, norm_b, qkv_w, dw_w, proj_w, temp = ps
         else:
@@ -1279,17 +1284,17 @@ class _GDFNFn(torch.autograd.Function):
         hp = (hidden + 3) // 4 * 4
         y = _empty_nhwc(B, Cc, H, W, dev)
         stats = torch.empty((2, M), dtype=torch.float32, device=dev)
-        lean = _RESTORMER_LEAN
+        full = _RESTORMER_SAVE == "full"
         u = _empty_nhwc(B, 2 * hp, H, W, dev)
-        t = None if lean else _empty_nhwc(B, hp, H, W, dev)
-        xn = None if lean else _empty_nhwc(B, Cc, H, W, dev)
+        t = _empty_nhwc(B, hp, H, W, dev) if full else None
+        xn = _empty_nhwc(B, Cc, H, W, dev) if full else None
         sv = GdfnSaved(stats[0].data_ptr(), stats[1].data_ptr(), u.data_ptr(), _p(t), _p(xn))
         pp = GdfnParams(*[_p(q) for q in ps])
         ws = _workspace(dev, lib.dcpt_gdfn_ws_bytes(B, H, W, Cc, hidden, 0))
         check(lib.dcpt_gdfn_fwd(C.byref(pp), x.data_ptr(), y.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(), B, H, W, Cc,
                                 hidden, int(biasfree), _stream(dev)), "dcpt_gdfn_fwd")
-        ctx.lean = lean
-        ctx.save_for_backward(x, stats, u, *([] if lean else [t, xn]), *[q for q in ps if q is not None])
+        ctx.full = full
+        ctx.save_for_backward(x, stats, u, *([t, xn] if full else []), *[q for q in ps if q is not None])
         ctx.has_bias, ctx.biasfree, ctx.hidden = ps[1] is not None, int(biasfree), hidden
         return y
 
@@ -1298,7 +1303,7 @@ class _GDFNFn(torch.autograd.Function):
         lib = _lib.load()
         x, stats, u, *ps = ctx.saved_tensors
         t = xn = None
-        if not ctx.lean:
+        if ctx.full:
             t, xn, *ps = ps
         if ctx.has_bias:
             norm_w, norm_b, in_w, dw_w, out_w = ps

@@ -180,10 +180,11 @@ def test_directional_derivative_full_size(dev):
     assert abs(numeric - analytic) <= 3e-2 * abs(analytic), (numeric, analytic, float(loss))
 
 
-def test_lean_saved_tensors_equal_full(dev):
-    """LEAN mode (DCPT_RESTORMER_SAVE=lean: LN(x), the qkv conv output, attn @ v and the GDFN gate product are recomputed in backward instead of
-    kept) gives bit-identical outputs and gradients to FULL mode -- the recomputation runs the same kernels on the same inputs --
-    and keeps fewer bytes alive between forward and backward."""
+def test_saved_tensor_modes_equal_full(dev):
+    """The save modes of the Restormer halves (functional.set_restormer_save / DCPT_RESTORMER_SAVE) -- "balanced" (default: LN(x), attn @ v and
+    the GDFN gate product recomputed in backward) and "lean" (also the qkv conv output) -- give bit-identical outputs
+    and gradients to "full": the recomputation runs the same kernels on the same inputs; each keeps fewer bytes alive between
+    forward and backward than the one before."""
     from basicsr.archs import build_network
     from dcpt_amd import functional as DF
 
@@ -192,8 +193,9 @@ def test_lean_saved_tensors_equal_full(dev):
     x = keyed_input("lean.x", (2, 3, 32, 32)).to(dev)
     res = {}
     prev = DF.set_restormer_save("full")
+    assert prev == "balanced"   # the default
     try:
-        for mode in ("full", "lean"):
+        for mode in ("full", "balanced", "lean"):
             DF.set_restormer_save(mode)
             net = build_network(dict(type="Restormer", **R_CFG))
             net.load_state_dict(sd, strict=True)
@@ -209,7 +211,9 @@ def test_lean_saved_tensors_equal_full(dev):
             del net, y
     finally:
         DF.set_restormer_save(prev)
-    assert torch.equal(res["full"][0], res["lean"][0])
-    for k in res["full"][1]:
-        assert torch.equal(res["full"][1][k], res["lean"][1][k]), k
+    for mode in ("balanced", "lean"):
+        assert torch.equal(res["full"][0], res[mode][0])
+        for k in res["full"][1]:
+            assert torch.equal(res["full"][1][k], res[mode][1][k]), (mode, k)
+    assert res["balanced"][2] < 0.85 * res["full"][2], (res["balanced"][2], res["full"][2])
     assert res["lean"][2] < 0.7 * res["full"][2], (res["lean"][2], res["full"][2])
