@@ -37,6 +37,20 @@ void dcpt_set_error(const char* fmt, ...);
         if (rc__ != DCPT_OK) return rc__; \
     } while (0)
 
+// Tuning switches (A/B experiments on the GPU box) exist only in diagnostic builds: tools/build_variant.sh compiles with -DDCPT_TUNING and
+// then DCPT_* environment variables override the defaults below; the product library reads NO environment variables -- every switch is
+// its measured default (DESIGN.md lists what each one was for).
+#include <stdlib.h>
+static inline int dcpt_tuning(const char* name, int dflt) {
+#ifdef DCPT_TUNING
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

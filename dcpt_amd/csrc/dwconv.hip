@@ -576,16 +576,14 @@ __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __res
 int dw_vw() {
     static int v = 0;
     if (v == 0) {
-        const char* e = getenv("DCPT_DW_VW");
-        v = (e && e[0] == '2') ? 2 : 4;
+        v = dcpt_tuning("DCPT_DW_VW", 4) == 2 ? 2 : 4;
     }
     return v;
 }
 int dw_target_blocks() {
     static int v = 0;
     if (v == 0) {
-        const char* e = getenv("DCPT_DW_BLOCKS");
-        v = e ? atoi(e) : 0;
+        v = dcpt_tuning("DCPT_DW_BLOCKS", 1024);
         if (v <= 0) v = 1024;
     }
     return v;
@@ -605,8 +603,7 @@ int nblk_for(const DwGeom& g, int quads) {
 int dw_fused_vw() {   // channels per thread of the fused backward kernel (DCPT_DW_FUSED_VW overrides for experiments)
     static int v = 0;
     if (v == 0) {
-        const char* e = getenv("DCPT_DW_FUSED_VW");
-        v = (e && e[0] == '2') ? 2 : 4;
+        v = dcpt_tuning("DCPT_DW_FUSED_VW", 4) == 2 ? 2 : 4;
     }
     return v;
 }

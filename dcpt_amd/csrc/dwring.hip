@@ -261,7 +261,7 @@ DwrGeom dwr_geom(const DwGeom& g, int es) {
 }
 
 bool dwr_enabled() {
-    static const int on = getenv("DCPT_DW_RING") ? atoi(getenv("DCPT_DW_RING")) : 1;
+    static const int on = dcpt_tuning("DCPT_DW_RING", 1);
     return on != 0;
 }
 
@@ -648,8 +648,8 @@ DwrBGeom dwr_bwd_geom(const DwGeom& g) {
     const int PH = g.C / 2;
     int cap = 8;
     while (cap < PH && cap < 32) cap <<= 1;
-    static const int force_lp = getenv("DCPT_DWR_BWD_LP") ? atoi(getenv("DCPT_DWR_BWD_LP")) : 0;   // experiments
-    static const int force_multi = getenv("DCPT_DWR_BWD_MULTI") ? atoi(getenv("DCPT_DWR_BWD_MULTI")) : -1;
+    static const int force_lp = dcpt_tuning("DCPT_DWR_BWD_LP", 0);   // experiments
+    static const int force_multi = dcpt_tuning("DCPT_DWR_BWD_MULTI", -1);
     int lp = g.W <= 16 ? 32 : g.W <= 32 ? 16 : g.W <= 64 ? 8 : 0;
     d.multi = lp == 0;
     if (lp == 0) lp = 16;
@@ -667,14 +667,14 @@ DwrBGeom dwr_bwd_geom(const DwGeom& g) {
     const int64_t maxp = g.H / 32 > 0 ? g.H / 32 : 1;
     if (nrp > maxp) nrp = maxp;
     if (nrp < 1) nrp = 1;
-    static const int force_nrp = getenv("DCPT_DWR_BWD_NRP") ? atoi(getenv("DCPT_DWR_BWD_NRP")) : 0;
+    static const int force_nrp = dcpt_tuning("DCPT_DWR_BWD_NRP", 0);
     if (force_nrp > 0) nrp = force_nrp < g.H ? force_nrp : g.H;
     d.nrp = (int)nrp;
     return d;
 }
 
 bool dwr_bwd_enabled() {
-    static const int on = getenv("DCPT_DW_RING_BWD") ? atoi(getenv("DCPT_DW_RING_BWD")) : 1;
+    static const int on = dcpt_tuning("DCPT_DW_RING_BWD", 1);
     return on != 0;
 }
 
@@ -700,7 +700,7 @@ int launch_bwd(const void* dts, const void* t1, const float* w2p, const float* b
     }
 #undef DWRB
     DCPT_CHECK_LAUNCH("dwr_bwd_fused");
-    static const bool dbg = getenv("DCPT_DWR_DEBUG") != nullptr;
+    static const bool dbg = dcpt_tuning("DCPT_DWR_DEBUG", 0) != 0;
     if (dbg) {
         int n16 = -1, n8 = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, dwr_bwd_fused_kernel<ST, 16, 1, GATE>, 256, 0);

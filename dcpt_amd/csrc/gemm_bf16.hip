@@ -463,7 +463,7 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     if (epi == EB_RESID || epi == EB_DOTCOL || epi == EB_SCATTER_ADD) bytes += mn;
     if (epi == EB_LNBWD2) bytes += 2 * mn;
     ProfScope prof(s, PROF_NT + 256 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * p.nb, bytes * 2.0 * p.nb);
-    static const int use256 = getenv("DCPT_NT256") ? atoi(getenv("DCPT_NT256")) : 1;   // (A/B switch while the kernel is being tuned)
+    static const int use256 = dcpt_tuning("DCPT_NT256", 1);   // (A/B switch while the kernel is being tuned)
     if (use256 && gemm_nt_bf16_256_ok(p, epi, use256 == 2 ? 1 : 192)) return launch_gemm_nt_bf16_256(p, epi, s);
     switch (epi) {
         case EB_PLAIN: return launch_nt<EB_PLAIN>(p, s);

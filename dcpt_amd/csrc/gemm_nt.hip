@@ -498,9 +498,9 @@ int nt_pick_bn(const GemmNT& p, int epi) {
     const bool gate = (epi == E_BIASGATE);
     const unsigned nbatch = (unsigned)((p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1));
     if (epi == E_LNBWD || epi == E_RESIDLN) return p.N <= 64 ? 64 : 128;
-    static const int smallk = getenv("DCPT_NT_SMALLK") ? atoi(getenv("DCPT_NT_SMALLK")) : 0;
-    static const int use96 = getenv("DCPT_NT_96") ? atoi(getenv("DCPT_NT_96")) : 1;
-    static const int use64_below = getenv("DCPT_NT_64_BELOW") ? atoi(getenv("DCPT_NT_64_BELOW")) : 2100;
+    static const int smallk = dcpt_tuning("DCPT_NT_SMALLK", 0);
+    static const int use96 = dcpt_tuning("DCPT_NT_96", 1);
+    static const int use64_below = dcpt_tuning("DCPT_NT_64_BELOW", 2100);
     if (!gate && use96 && p.N > 64 && cdiv(p.N, 96) * 96 < cdiv(p.N, 128) * 128 && cdiv64(p.M, 128) * cdiv(p.N, 96) * nbatch > 256) return 96;
     const int64_t tiles128 = cdiv64(p.M, 128) * (gate ? cdiv(p.N / 2, 64) : cdiv(p.N, 128));
     if (p.N <= 64 || tiles128 * nbatch < use64_below || p.K <= smallk) return 64;

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
 // Output-tile shape for an N x K gradient: 64 for narrow sides, otherwise whichever of 128 x 128, 128 x 96, 96 x 128 pads the
 // least (Restormer's 96 / 192 / 288 / 576-wide layers); the 96-wide tiles take plain operands and no column sums.
 static int tn_narrow() {   // experiment knob: 128 x 64 output tiles everywhere (three resident blocks per CU); measured +-0 on the training step
-    static const int v = getenv("DCPT_TN_NARROW") ? atoi(getenv("DCPT_TN_NARROW")) : 0;
+    static const int v = dcpt_tuning("DCPT_TN_NARROW", 0);
     return v;
 }
 
@@ -251,7 +251,7 @@ static void tn_tile_shape(int N, int K, bool plain, int* bn, int* bk) {
     *bn = (N <= 64) ? 64 : 128;
     *bk = (K <= 64 || tn_narrow()) ? 64 : 128;
     if (tn_narrow()) return;
-    static const int use96 = getenv("DCPT_TN_96") ? atoi(getenv("DCPT_TN_96")) : 1;
+    static const int use96 = dcpt_tuning("DCPT_TN_96", 1);
     if (N <= 64 || K <= 64 || !plain || !use96) return;
     const int64_t a128 = (int64_t)cdiv(N, 128) * 128 * cdiv(K, 128) * 128;
     const int64_t a_k96 = (int64_t)cdiv(N, 128) * 128 * cdiv(K, 96) * 96;
@@ -323,7 +323,7 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
     if (smax > max_by_rows) smax = max_by_rows;
     if (smax > 65535) smax = 65535;
     if (smax < 1) smax = 1;
-    static const int plan_model = getenv("DCPT_TN_PLAN") ? atoi(getenv("DCPT_TN_PLAN")) : 1;
+    static const int plan_model = dcpt_tuning("DCPT_TN_PLAN", 1);
     int64_t want = 1;
     if (plan_model) {
         double best = 1e300;

@@ -133,7 +133,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
 // from 120.7 to 124.4 ms, a level-3 block's backward from 1.95 to 2.09 ms: the wide levels' GEMMs are MFMA-bound, their
 // epilogues are exposed time, and the separate LayerNorm kernel was overlapping the side stream's weight-gradient GEMMs.
 bool ln_rowsums(int C, int rp_sg, int rp_dw) {
-    static const int on = getenv("DCPT_LN_ROWSUMS") ? atoi(getenv("DCPT_LN_ROWSUMS")) : 0;
+    static const int on = dcpt_tuning("DCPT_LN_ROWSUMS", 0);
     return on && C > 128 && rp_sg <= 16 && rp_dw <= 16;
 }
 
@@ -141,7 +141,7 @@ bool ln_rowsums(int C, int rp_sg, int rp_dw) {
 // that produces its incoming gradient, so that gradient is never written and re-read (2 tensor passes and one launch per
 // LayerNorm).  DCPT_LN_EPILOGUE=0 switches back to the separate kernel.
 bool ln_in_epilogue(int C) {
-    static const int on = getenv("DCPT_LN_EPILOGUE") ? atoi(getenv("DCPT_LN_EPILOGUE")) : 1;
+    static const int on = dcpt_tuning("DCPT_LN_EPILOGUE", 1);
     return on && C <= 128;
 }
 

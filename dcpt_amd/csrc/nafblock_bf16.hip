@@ -119,7 +119,7 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
     // backward 2.68 vs 2.47 ms, level 3 0.64 vs 0.60 ms, the NAFNet-64 step 53.2 vs 51.3 ms).  A GEMM whose epilogue moves more bytes
     // than its k-loop runs at ~3 TB/s -- its loads are not overlapped across tiles -- while the separate LayerNorm kernel streams
     // at 5.3 TB/s; the two passes it saves do not pay for that.
-    static const int on = getenv("DCPT_LN_ROWSUMS_BF16") ? atoi(getenv("DCPT_LN_ROWSUMS_BF16")) : 0;
+    static const int on = dcpt_tuning("DCPT_LN_ROWSUMS_BF16", 0);
     w.lrs = on && w.rp_sg <= 8 && w.rp_dw <= 8;
     w.rowpart = a.get<float>((size_t)M * (w.rp_sg > w.rp_dw ? w.rp_sg : w.rp_dw) * 2);
     {   // the GEMM-epilogue form of the LayerNorm column partials: [M / 128 tiles][2][C]

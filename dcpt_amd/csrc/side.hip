@@ -26,8 +26,7 @@ int g_side_enabled = -1;
 
 void side_init_locked() {
     if (g_side_enabled < 0) {
-        const char* e = getenv("DCPT_SIDE_STREAM");
-        g_side_enabled = (e && e[0] == '0') ? 0 : 1;
+        g_side_enabled = dcpt_tuning("DCPT_SIDE_STREAM", 1) ? 1 : 0;   // (the product switch is dcpt_set_side_stream())
     }
 }
 }  // namespace
