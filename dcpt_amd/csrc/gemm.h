@@ -68,6 +68,10 @@ struct GemmNT {
 };
 
 int launch_gemm_nt(const GemmNT& p, int aload, int epi, hipStream_t stream);
+// opt-in split-operand mode (gemm_x3.hip, dcpt_set_gemm_x3): fp32-class results on the bf16 matrix pipe; launch_gemm_nt routes eligible
+// launches there while the mode is on
+bool gemm_nt_x3_ok(const GemmNT& p, int aload, int epi);
+int launch_gemm_nt_x3(const GemmNT& p, int aload, int epi, hipStream_t stream);
 // number of column tiles the launch of this problem uses (= row partials per row written by E_SGBWD with rowpart)
 int gemm_nt_tiles_n(const GemmNT& p, int aload, int epi);
 

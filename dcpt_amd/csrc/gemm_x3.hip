@@ -1,0 +1,420 @@
+// fp32-class NT GEMM on the bf16 matrix pipe by SPLIT OPERANDS ("bf16x3"):  C[m][n] = sum_k A[m][k] * Bw[n][k]  with fp32 A, Bw, C.
+//
+// An fp32 value is the exact sum of three bfloat16 pieces obtained by truncation, x = x0 + x1 + x2 (x0 = the top 8 significand bits,
+// x1 = the top 8 of the exact remainder x - x0, x2 = the exact rest: 24 bits in all).  A product a*b is then nine piece products, each of
+// them EXACT in fp32 (8 x 8 significand bits); the kernel keeps the six with i + j <= 2,
+//     a*b ~= a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0,
+// the dropped ones (a1 b2, a2 b1, a2 b2) are <= 2^-24 |a b| each, i.e. below the rounding error an fp32 FMA makes on the full product.
+// Sums are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The matrix pipe runs bf16 at 16x the fp32-MFMA rate, so six bf16 MFMAs
+// replace eight fp32 MFMAs of a k = 16 block at 3/8 of their issue time -- an fp32-CLASS GEMM (not bit-identical to the fp32-MFMA path:
+// the summation order and the dropped 2^-24 terms differ; tests/test_gpu_x3.py measures both paths against fp64).  This is a SEPARATELY
+// REPORTED mode (dcpt_set_gemm_x3): the fp32-MFMA kernels stay the product default and the headline.
+//
+// Data path.  WEIGHTS are rewritten ("split") once per launch into a tiled image of 12-KB pieces -- piece (row block of 128, k-tile of 16) =
+// 3 planes x [128 rows][16 k] bf16, the two 16-byte halves of a row swapped on rows with bit 3 set -- which is byte for byte what the GEMM
+// keeps in LDS, so a B half-tile is ONE contiguous 24-KB LDS-DMA read.  ACTIVATIONS are NOT rewritten (a separate split pass over every A
+// operand cost 12 ms per training step: 4 B read + 6 B written per element): the A half-tiles go HBM -> LDS as fp32 by LDS-DMA in the fp32
+// kernel's own swizzled [128 rows][32 floats] image, a wave reads its fragment (8 consecutive k of a row: two ds_read_b128) and splits it
+// IN REGISTERS (~44 VALU operations per fragment, issued while the partner wave of the SIMD runs its MFMAs).  The GEMM is the 256 x 256
+// kernel of gemm_bf16_256.hip (two alternating wave groups, half-tile ring of two k-tiles = the CU's whole 160 KB, counted vmcnt,
+// interleaved wave outputs) with a k-tile of 32 walked as two 16-k sub-steps: eight phases of 12 MFMAs; the epilogue is the fp32 kernel's
+// own (gemm_nt_epi.h).
+#include "gemm_nt_epi.h"
+#include "bf16.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int PIECE = 12288;       // bytes of a piece: 3 planes x 128 rows x 32 B
+constexpr int PLANE = 4096;
+constexpr int STG3 = 4 * PIECE;    // one k-tile in LDS: A-lo | A-hi | B-lo | B-hi
+constexpr int NSTG = 3;
+
+// ---- split: fp32 [R][K] (row stride ld) -> tiled 3-plane image [ceil(R / 128)][K / 16][3][128][16] bf16 ------------------------------
+// A block converts a [128 rows][64 k] tile: coalesced 256-B row reads, split in registers, pieces assembled in LDS, linear 16-B writes.
+// grid.z = batch: problem z reads the SAME X (weights) with scale row z of kscale and writes image z (the per-image SCA-scaled conv3 weights).
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X, int64_t R, int K, int ld, unsigned char* __restrict__ out,
+                                                     const float* __restrict__ kscale, int64_t img_bytes) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[4 * PIECE];
+    const int tid = threadIdx.x;
+    const int64_t rb = blockIdx.y;
+    const int kq = blockIdx.x;                 // group of four k-tiles
+    const int KT = K / 16;
+    const int nkt = (KT - 4 * kq) < 4 ? (KT - 4 * kq) : 4;
+    // thread -> (row, 16-B column chunk): 16 chunks of 4 floats per row of 64 k; 16 rows per pass, 8 passes
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int r = ps * 16 + (tid >> 4), c4 = tid & 15;
+        const int64_t row = rb * 128 + r;
+        const int k = 64 * kq + 4 * c4;
+        float4 v = f4_zero();
+        if (row < R && k < K) {
+            v = ldg4(X + row * (int64_t)ld + k);
+            if (kscale) v = f4_mul(v, ldg4(kscale + (int64_t)blockIdx.z * K + k));
+        }
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+        uint32_t pc[3][2];   // plane -> two packed bf16 pairs
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t b0 = __builtin_bit_cast(uint32_t, xs[e]) & 0xffff0000u;
+            const float r1 = xs[e] - __builtin_bit_cast(float, b0);
+            const uint32_t b1 = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, b1);
+            const uint32_t b2 = __builtin_bit_cast(uint32_t, r2) & 0xffff0000u;   // (r2 has <= 8 significant bits: exact)
+            const uint32_t bs[3] = {b0, b1, b2};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (e & 1) pc[p][e >> 1] |= bs[p];
+                else pc[p][e >> 1] = bs[p] >> 16;
+            }
+        }
+        // element k -> k-tile kt = c4 / 4, position 4 (c4 % 4) .. +3 inside the tile: half kh = (c4 % 4) / 2, 8-byte piece (c4 % 2)
+        const int kt = c4 >> 2, kh = (c4 >> 1) & 1, q = c4 & 1;
+        unsigned char* dst = sm + kt * PIECE + r * 32 + ((kh ^ ((r >> 3) & 1)) * 16) + q * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            u32x2 w;
+            w.x = pc[p][0];
+            w.y = pc[p][1];
+            *reinterpret_cast<u32x2*>(dst + p * PLANE) = w;
+        }
+    }
+    __syncthreads();
+    unsigned char* o = out + (int64_t)blockIdx.z * img_bytes + ((rb * KT + 4 * kq) * (int64_t)PIECE);
+    for (int i = tid; i < nkt * (PIECE / 16); i += 256) *reinterpret_cast<u32x4*>(o + (int64_t)i * 16) = *reinterpret_cast<const u32x4*>(sm + i * 16);
+}
+
+typedef __attribute__((address_space(3))) const volatile bf16x8* lds_frag_p;
+typedef __attribute__((address_space(3))) const volatile floatx4* lds_f4_p;
+
+struct GemmX3 {
+    GemmNT g;                   // the fp32 problem: A is read as it is (fp32, LDS-DMA), Bw through its split image
+    const unsigned char* B3;    // tiled split image of Bw [N / 128][K / 16] pieces (per batch problem: + b * sB3 bytes)
+    int64_t sB3;
+};
+
+// 8 fp32 values -> their three bf16 pieces (truncating splits, exact: x = hi + mid + lo), packed as MFMA operands
+__device__ __forceinline__ void split8(const floatx4 lo4, const floatx4 hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    u32x4 w0, w1, w2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = x[2 * i + e];
+            h[e] = __builtin_bit_cast(uint32_t, v) & 0xffff0000u;
+            const float r1 = v - __builtin_bit_cast(float, h[e]);
+            m[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+            l[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m[e]));   // <= 8 significant bits: its low half is zero
+        }
+        w0[i] = (h[0] >> 16) | h[1];
+        w1[i] = (m[0] >> 16) | m[1];
+        w2[i] = (l[0] >> 16) | (l[1] & 0xffff0000u);
+    }
+    p0 = __builtin_bit_cast(bf16x8, w0);
+    p1 = __builtin_bit_cast(bf16x8, w1);
+    p2 = __builtin_bit_cast(bf16x8, w2);
+}
+
+// LDS of one k-tile of 32: A-lo | A-hi as fp32 [128 rows][32 floats] (the fp32 kernel's swizzled image, 16 KB each), B-lo | B-hi as two
+// consecutive pieces each (24 KB each)
+constexpr int AHT = 16384, BHT = 2 * PIECE, STGF = 2 * AHT + 2 * BHT;   // 80 KB: two stages are the whole 160 KB of a CU
+
+template <int EK>
+__global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
+    constexpr bool GATE = (EK == E_BIASGATE);
+    GemmNT p = pin.g;
+    const unsigned char* B3 = pin.B3;
+    if (gridDim.y > 1) {
+        const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
+        p.A += b1 * p.sA1 + b2 * p.sA2;
+        p.C += b1 * p.sC1 + b2 * p.sC2;
+        if (p.res) p.res += b1 * p.sR1 + b2 * p.sR2;
+        if (p.cscale) p.cscale += b1 * p.sS1 + b2 * p.sS2;
+        B3 += (int64_t)blockIdx.y * pin.sB3;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STGF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    // wave -> 64 x 128 of the tile as 4 (rows) x 2 (columns): an A fragment is split by two waves only (the in-register split is what this
+    // kernel's load phases are made of), interleaved over the halves: rows 32 wm.. of A-lo and of A-hi, columns 64 wn.. of B-lo and of B-hi
+    const int wm = wave & 3, wn = wave >> 2;
+    const int Ch = p.N / 2;
+    const int tilesN = p.N / 256;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(lin / tilesN) * 256;
+    const int n0 = (lin % tilesN) * (GATE ? 128 : 256);
+    const int KT = p.K / 16;
+    const int rbB[2] = {n0 / 128, (GATE ? Ch + n0 : n0 + 128) / 128};
+    const i32x4 rsA = make_rsrc_dma(p.A + (m0 < p.M ? m0 : 0) * (int64_t)p.lda);
+    const i32x4 rsB0 = make_rsrc_dma(B3 + (int64_t)rbB[0] * KT * PIECE);
+    const i32x4 rsB1 = make_rsrc_dma(B3 + (int64_t)rbB[1] * KT * PIECE);
+    // A half-tile = 16 DMAs of 8 rows (wave w: rows 8 w.. and 64 + 8 w..), lane -> row (lane >> 3), LDS slot lane & 7 = k-quad ^ ((row >> 1) & 7);
+    // B half-tile = 24 linear KiB (wave w: KiB w, 8 + w, 16 + w)
+    uint32_t voffA[2][2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int row = 8 * wave + (lane >> 3) + 64 * ps;
+        const uint32_t ch = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = h * 128 + row;
+            voffA[h][ps] = (m0 + r < p.M) ? (uint32_t)r * (uint32_t)p.lda * 4u + ch : ROW_SENT;
+        }
+    }
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint32_t lds_base = lds_addr(reinterpret_cast<const float*>(smem));
+    // X: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi; s: stage; t: k-tile of 32
+    auto stage = [&](int X, int s, int t, uint32_t dead) {
+        if (X < 2) {
+            const uint32_t dst = lds_base + (uint32_t)(s * STGF + X * AHT) + (uint32_t)wave * 1024u;
+            dma16(rsA, dst, voffA[X][0] | dead, (uint32_t)t * 128u);
+            dma16(rsA, dst + 8192u, voffA[X][1] | dead, (uint32_t)t * 128u);
+        } else {
+            const uint32_t dst = lds_base + (uint32_t)(s * STGF + 2 * AHT + (X - 2) * BHT) + (uint32_t)wave * 1024u;
+            const uint32_t src = ((uint32_t)t * BHT + (uint32_t)wave * 1024u + lane_off) | dead;
+            const i32x4 rs = X == 2 ? rsB0 : rsB1;
+            dma16(rs, dst, src, 0);
+            dma16(rs, dst + 8192u, src + 8192u, 0);
+            dma16(rs, dst + 16384u, src + 16384u, 0);
+        }
+    };
+
+    // A fragments (fp32): row (lane & 31); sub-step u (16 k), half fh = lane >> 5: the 8 consecutive k are k-quads 4 u + 2 fh and + 1
+    const int fr = lane & 31, fh = lane >> 5, fi = (fr >> 1) & 7;
+    const unsigned char* abase = smem + (wm * 32 + fr) * 128;
+    int aslot[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) aslot[u][q] = ((4 * u + 2 * fh + q) ^ fi) * 16;
+    // B fragments (split image): 16-byte half fh of the 32-byte row, swapped on rows with bit 3
+    const unsigned char* bbase = smem + 2 * AHT + (wn * 64 + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) * 16);
+
+    floatx16 acc[2][2][2];   // [A half][B half][n-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
+    bf16x8 fa[3], fb[2][2][3];   // A sub-tile in use [piece]; B sub-tiles [half][n-tile][piece] of the current 16-k sub-step
+
+    const int nkt = p.K / 32;   // (K % 64 == 0: k-tiles of 32 in pairs)
+    stage(0, 0, 0, 0);
+    stage(2, 0, 0, 0);
+    stage(3, 0, 0, 0);
+    stage(1, 0, 0, 0);
+    stage(0, 1, 1, 0);
+    stage(2, 1, 1, 0);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+// read the fp32 A sub-tile (half H, sub-step U) and split it into pieces
+#define DCPT_LD_A(S, H, U)                                                                                                         \
+    {                                                                                                                             \
+        const floatx4 r0_ = *(lds_f4_p)(abase + (S)*STGF + (H)*AHT + aslot[U][0]);                                                \
+        const floatx4 r1_ = *(lds_f4_p)(abase + (S)*STGF + (H)*AHT + aslot[U][1]);                                                \
+        split8(r0_, r1_, fa[0], fa[1], fa[2]);                                                                                    \
+    }
+#define DCPT_LD_B(S, H, U)                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                 \
+        fb[H][j][pl] = *(lds_frag_p)(bbase + (S)*STGF + (H)*BHT + (U)*PIECE + pl * PLANE + j * 1024);
+#define DCPT_MM(ACC, I, BH, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[BH][I][PB], ACC, 0, 0, 0)
+#define DCPT_MFMA(AH, BH)                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                                \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 2, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 2, 0);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 2); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 2);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 1, 1); DCPT_MM(acc[AH][BH][1], 1, BH, 1, 1);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 1, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 1, 0);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 1); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 1);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 0);                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    __builtin_amdgcn_s_barrier();
+#define DCPT_PUBLISH()                                    \
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();
+
+    // eight phases per k-tile of 32 (stage s = t & 1): sub-step 0 then 1, quadrants (lo,lo) (lo,hi) (hi,hi) (hi,lo).  Staging, two k-tiles
+    // ahead and at least two phases after a half-tile's last read: ph0 B-hi(t+1), ph1 A-hi(t+1), ph6 A-lo(t+2), ph7 B-lo(t+2); every
+    // phase's wait leaves ten DMAs (= the four youngest half-tiles) in flight.
+    for (int t = 0; t < nkt; t += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kt = t + s;
+            const uint32_t dead1 = (kt + 1 < nkt) ? 0u : ROW_SENT, dead2 = (kt + 2 < nkt) ? 0u : ROW_SENT;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // (A-lo, B-lo)
+                DCPT_LD_B(s, 0, u)
+                DCPT_LD_A(s, 0, u)
+                if (u == 0) stage(3, s ^ 1, kt + 1, dead1);
+                DCPT_PUBLISH()
+                DCPT_MFMA(0, 0)
+                // (A-lo, B-hi)
+                DCPT_LD_B(s, 1, u)
+                if (u == 0) stage(1, s ^ 1, kt + 1, dead1);
+                DCPT_PUBLISH()
+                DCPT_MFMA(0, 1)
+                // (A-hi, B-hi)
+                DCPT_LD_A(s, 1, u)
+                if (u == 1) stage(0, s, kt + 2, dead2);
+                DCPT_PUBLISH()
+                DCPT_MFMA(1, 1)
+                // (A-hi, B-lo)
+                if (u == 1) stage(2, s, kt + 2, dead2);
+                DCPT_PUBLISH()
+                DCPT_MFMA(1, 0)
+            }
+        }
+    }
+#undef DCPT_LD_A
+#undef DCPT_LD_B
+#undef DCPT_MM
+#undef DCPT_MFMA
+#undef DCPT_PUBLISH
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+    dma_wait_all();
+    __syncthreads();
+
+    // epilogue: quadrant (a, b) of every wave = the 128 x 128 sub-block (a, b) of the tile -> the fp32 kernel's row epilogues
+    float* const Cs0 = reinterpret_cast<float*>(smem);
+    if constexpr (GATE) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float* const Cs = Cs0;   // [128][256]: columns 0..127 first gate half, 128..255 second
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int nl = b * 128 + wn * 64 + i * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Cs[ml * 256 + nl] = acc[a][b][i][r];
+                    }
+                }
+            __syncthreads();
+            epilogue_gate<128, 256, 512>(p, Cs, m0 + a * 128, n0, tid);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = q >> 1, b = q & 1;
+            float* const Cs = Cs0 + (q & 1) * (128 * 128);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nl = wn * 64 + i * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Cs[ml * 128 + nl] = acc[a][b][i][r];
+                }
+            }
+            __syncthreads();
+            epilogue_rows<EK, 128, 128, 512>(p, Cs, m0 + a * 128, n0 + b * 128, tid);
+            if constexpr (EK == E_DOTCOL) __syncthreads();
+        }
+    }
+}
+
+// process-wide state of the opt-in mode: a caller-provided scratch for the split images (dcpt_set_gemm_x3)
+unsigned char* g_x3_scratch = nullptr;
+size_t g_x3_bytes = 0;
+int g_x3_min_tiles = 192;
+
+size_t split_bytes(int64_t R, int K) { return (size_t)cdiv64(R, 128) * (size_t)(K / 16) * PIECE; }
+
+}  // namespace
+
+// nimg > 1: the same matrix with scale row z of kscale ([nimg][K]) into image z (images img_bytes apart)
+int launch_split3(const float* X, int64_t R, int K, int ld, void* out, const float* kscale, int nimg, hipStream_t s) {
+    DCPT_CHECK_ARG(X && out && R > 0 && K > 0 && K % 16 == 0 && ld % 4 == 0, "split3: bad argument (K=%d must be a multiple of 16)", K);
+    DCPT_CHECK_ARG(cdiv64(R, 128) < 65536 && nimg >= 1 && nimg < 65536, "split3: too many row blocks / images");
+    split3_kernel<<<dim3((unsigned)cdiv(K / 16, 4), (unsigned)cdiv64(R, 128), (unsigned)nimg), dim3(256), 0, s>>>(X, R, K, ld, (unsigned char*)out,
+                                                                                                                  kscale, (int64_t)split_bytes(R, K));
+    DCPT_CHECK_LAUNCH("split3");
+    return DCPT_OK;
+}
+
+bool gemm_x3_enabled() { return g_x3_scratch != nullptr; }
+
+// eligibility: plain (or per-image scaled) fp32 A operand, row-wise epilogue, full 256-column tiles, k-tiles of 32 in pairs, enough tiles
+bool gemm_nt_x3_ok(const GemmNT& p, int aload, int epi) {
+    if (!g_x3_scratch || !(aload == A_PLAIN || aload == A_SCALE)) return false;
+    if (!(epi == E_PLAIN || epi == E_BIAS || epi == E_RESID || epi == E_SGBWD || epi == E_BIASGATE || epi == E_DOTCOL || epi == E_ADDSCALED ||
+          epi == E_MUL))
+        return false;
+    if (epi == E_SGBWD && p.rowpart) return false;
+    if (p.K % 64 != 0 || p.N % 256 != 0 || p.lda % 4 != 0) return false;
+    int64_t nb = (int64_t)(p.nb1 > 0 ? p.nb1 : 1) * (p.nb2 > 0 ? p.nb2 : 1);
+    int64_t M = p.M;
+    if (aload == A_SCALE) {   // the per-image scale moves into per-image weights: one GEMM problem per image
+        if (nb != 1 || p.P <= 0 || p.M % p.P != 0 || p.M / p.P >= 65536) return false;
+        nb = p.M / p.P;
+        M = p.P;
+    }
+    const int64_t tiles = cdiv64(M, 256) * (p.N / 256) * nb;
+    if (tiles < g_x3_min_tiles) return false;
+    return split_bytes(p.N, p.K) * (size_t)nb <= g_x3_bytes;
+}
+
+int launch_gemm_nt_x3(const GemmNT& pin, int aload, int epi, hipStream_t s) {
+    GemmX3 x{};
+    x.g = pin;
+    GemmNT& p = x.g;
+    if (p.nb1 < 1) p.nb1 = 1;
+    if (p.nb2 < 1) p.nb2 = 1;
+    const size_t bbytes = split_bytes(p.N, p.K);
+    x.B3 = g_x3_scratch;
+    x.sB3 = (int64_t)bbytes;
+    if (aload == A_SCALE) {
+        const int nimg = (int)(p.M / p.P);
+        const int ldres = p.ldres ? p.ldres : p.ldc;
+        DCPT_TRY(launch_split3(p.Bw, p.N, p.K, p.K, g_x3_scratch, p.simg, nimg, s));
+        p.M = p.P;
+        p.nb1 = nimg;
+        p.nb2 = 1;
+        p.sA1 = (int64_t)p.P * p.lda;
+        p.sC1 = (int64_t)p.P * p.ldc;
+        p.sR1 = (int64_t)p.P * ldres;
+        p.sS1 = 0;
+        p.sA2 = p.sC2 = p.sR2 = p.sS2 = 0;
+    } else {
+        const int nb = p.nb1 * p.nb2;
+        for (int b = 0; b < nb; ++b) {   // (already batched problems bring their own weights: one split each)
+            const float* Bb = p.Bw + (b / p.nb2) * p.sB1 + (b % p.nb2) * p.sB2;
+            DCPT_TRY(launch_split3(Bb, p.N, p.K, p.K, g_x3_scratch + bbytes * b, nullptr, 1, s));
+        }
+    }
+    const dim3 grid((unsigned)(cdiv64(p.M, 256) * (p.N / 256)), (unsigned)(p.nb1 * p.nb2));
+    switch (epi) {
+        case E_PLAIN: gemm_nt_x3_kernel<E_PLAIN><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_BIAS: gemm_nt_x3_kernel<E_BIAS><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_RESID: gemm_nt_x3_kernel<E_RESID><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_SGBWD: gemm_nt_x3_kernel<E_SGBWD><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_BIASGATE: gemm_nt_x3_kernel<E_BIASGATE><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_DOTCOL: gemm_nt_x3_kernel<E_DOTCOL><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_ADDSCALED: gemm_nt_x3_kernel<E_ADDSCALED><<<grid, dim3(512), 0, s>>>(x); break;
+        case E_MUL: gemm_nt_x3_kernel<E_MUL><<<grid, dim3(512), 0, s>>>(x); break;
+        default: dcpt_set_error("gemm_nt_x3: epilogue %d not supported", epi); return DCPT_ERR_ARG;
+    }
+    DCPT_CHECK_LAUNCH("gemm_nt_x3");
+    return DCPT_OK;
+}
+
+extern "C" int dcpt_set_gemm_x3(void* scratch, size_t bytes, int min_tiles) {
+    g_x3_scratch = (unsigned char*)scratch;
+    g_x3_bytes = scratch ? bytes : 0;
+    g_x3_min_tiles = min_tiles > 0 ? min_tiles : 192;
+    return DCPT_OK;
+}

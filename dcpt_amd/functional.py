@@ -308,6 +308,37 @@ def nafblock_local(inp: torch.Tensor, params: Dict[str, torch.Tensor], k1: int, 
 
 
 # ------------------------------------------------------------------------------------------------
+# Opt-in GEMM precision mode (include/dcpt_hip.h dcpt_set_gemm_x3): "fp32" = the exact fp32 MFMA kernels (default, the reference's
+# arithmetic); "bf16x3" = the wide fp32 GEMMs on the bf16 matrix pipe with operands split into three bf16 pieces (fp32-class results).
+_X3_SCRATCH = None
+_GEMM_PRECISION = "fp32"
+
+
+def set_gemm_precision(mode: str, device=None, scratch_mb: int = 256, min_tiles: int = 0) -> str:
+    """'fp32' (default) or 'bf16x3'; returns the previous mode.  In 'bf16x3' the split-operand kernels take the whole CU (160 KB of LDS, 8
+    waves), so a weight-gradient block of the side stream cannot share a CU with them: the side stream is switched off for the mode
+    (measured: 107.0 ms serialized vs 109.2 ms with it) and back on with 'fp32'.  ``scratch_mb``: the split images of one launch's
+    weights (6 bytes per element; the per-image conv3 weights of a batch are the largest: B x C x C x 6).  ``min_tiles`` > 0 lowers the
+    size threshold (tests force the mode onto small launches with 1)."""
+    global _X3_SCRATCH, _GEMM_PRECISION
+    lib = _lib.load()
+    prev = _GEMM_PRECISION
+    if mode == "fp32":
+        check(lib.dcpt_set_gemm_x3(None, 0, 0), "dcpt_set_gemm_x3")
+        _X3_SCRATCH = None
+        lib.dcpt_set_side_stream(1)
+    elif mode == "bf16x3":
+        dev = torch.device(device if device is not None else "cuda:0")
+        _X3_SCRATCH = torch.empty(int(scratch_mb) << 20, dtype=torch.uint8, device=dev)
+        check(lib.dcpt_set_gemm_x3(_X3_SCRATCH.data_ptr(), _X3_SCRATCH.numel(), int(min_tiles)), "dcpt_set_gemm_x3")
+        lib.dcpt_set_side_stream(0)
+    else:
+        raise ValueError(f"gemm precision {mode!r}: expected 'fp32' or 'bf16x3'")
+    _GEMM_PRECISION = mode
+    return prev
+
+
+# ------------------------------------------------------------------------------------------------
 class _TakeBatchFn(torch.autograd.Function):
     """x[lo:hi] along the batch axis as a view; the backward builds the zero-padded gradient WITH THE INPUT'S STRIDES (torch's own
     slice backward allocates it NCHW-contiguous, which costs two layout conversions of the whole feature map per use for NHWC

@@ -101,6 +101,15 @@ int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* 
                       const dcpt_nafblock_saved* saved, const float* dout, float* dinp, void* ws, size_t ws_bytes,
                       int B, int H, int W, int C, dcpt_stream_t stream);
 
+/* ---- Opt-in GEMM precision mode "bf16x3" (gemm_x3.hip): while a scratch buffer is registered, the wide fp32 NT GEMMs of every entry point
+ * (plain or per-image-scaled A operand, N % 256 == 0, K % 16 == 0, >= 192 tiles of 256 x 256) run on the bf16 matrix pipe with both operands
+ * split into three bfloat16 pieces (x = x0 + x1 + x2 exactly), six piece products per element pair, fp32 accumulation: fp32-CLASS results
+ * (dropped terms <= 2^-24 relative; not bit-identical to the default fp32-MFMA kernels).  PROCESS-WIDE state: the scratch (>= 6 bytes per
+ * element of the largest A operand + weights) is shared by all launches, which must therefore all be on ONE stream while the mode is on.
+ * scratch == NULL switches the mode off (the default).  The reference computes in fp32; this mode is reported separately. */
+/* min_tiles: launches with fewer 256 x 256 tiles keep the fp32-MFMA kernels (<= 0: the default, 192 -- most of the 256 CUs busy). */
+int dcpt_set_gemm_x3(void* scratch, size_t bytes, int min_tiles);
+
 /* ---- NAFBlock, bf16 storage (BASELINE.json configs[2]) --------------------------------------------------------------
  * Same block (nafnet_arch.py:83-186), activations and saved tensors as bfloat16 (raw uint16_t, upper half of an fp32, stored
  * round-to-nearest-even), fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 parameters / parameter gradients / LayerNorm
