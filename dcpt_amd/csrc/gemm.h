@@ -106,3 +106,7 @@ void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split)
 bool gemm_tn_plan_images(int64_t M, int N, int K, int P, int* splits, int64_t* rows_per_split);
 // number of k-tile columns of the TN grid for this shape (= partial colsum rows per split)
 int gemm_tn_tiles_k(int N, int K);
+// opt-in split-operand mode for the weight-gradient GEMM (gemm_x3.hip)
+bool gemm_tn_x3_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split);   // false: not a shape / size for the mode
+bool gemm_tn_x3_ok(const GemmTN& p, int xload, int yload);
+int launch_gemm_tn_x3(const GemmTN& p, int fp32_tiles_k, hipStream_t stream);

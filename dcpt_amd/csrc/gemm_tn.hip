@@ -308,6 +308,7 @@ int gemm_tn_tiles_k(int N, int K) {   // launches with column sums never use the
 }
 
 void gemm_tn_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split) {
+    if (gemm_tn_x3_plan(M, N, K, splits, rows_per_split)) return;   // (opt-in bf16x3 mode: one 256 x 256-tile block per CU)
     int bn, bk;
     tn_tile_shape(N, K, true, &bn, &bk);   // (a transformed-operand launch of the same shape uses at most as many tiles)
     const int64_t tiles = (int64_t)cdiv(N, bn) * cdiv(K, bk);
@@ -378,6 +379,7 @@ int launch_gemm_tn(const GemmTN& pin, int xload, int yload, hipStream_t s) {
     const double bytes = (double)p.M * p.N + (double)p.M * p.K * (yload == A_SG ? 2 : 1) + (double)p.splits * p.N * p.K;
     ProfScope prof(s, PROF_TN + xload * 8 + yload, p.M, p.N, p.K, 2.0 * (double)p.M * p.N * p.K * p.nb1 * p.nb2,
                    bytes * 4.0 * p.nb1 * p.nb2);
+    if (gemm_tn_x3_ok(p, xload, yload)) return launch_gemm_tn_x3(p, gemm_tn_tiles_k(p.N, p.K), s);   // (opt-in mode; off by default)
 #define CASE(XK, YK) \
     if (xload == XK && yload == YK) return launch_cfg<XK, YK>(p, s);
     CASE(A_PLAIN, A_PLAIN)

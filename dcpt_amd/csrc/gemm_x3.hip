@@ -99,18 +99,16 @@ __device__ __forceinline__ void split8(const floatx4 lo4, const floatx4 hi4, bf1
     u32x4 w0, w1, w2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        uint32_t h[2], m[2], l[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float v = x[2 * i + e];
-            h[e] = __builtin_bit_cast(uint32_t, v) & 0xffff0000u;
-            const float r1 = v - __builtin_bit_cast(float, h[e]);
-            m[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-            l[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m[e]));   // <= 8 significant bits: its low half is zero
-        }
-        w0[i] = (h[0] >> 16) | h[1];
-        w1[i] = (m[0] >> 16) | m[1];
-        w2[i] = (l[0] >> 16) | (l[1] & 0xffff0000u);
+        // the upper halves of a pair of words, packed {even element: low half, odd element: high half}, are one v_perm_b32
+        const uint32_t a0 = __builtin_bit_cast(uint32_t, x[2 * i]), a1 = __builtin_bit_cast(uint32_t, x[2 * i + 1]);
+        w0[i] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        const float r0 = x[2 * i] - __builtin_bit_cast(float, a0 & 0xffff0000u);
+        const float r1 = x[2 * i + 1] - __builtin_bit_cast(float, a1 & 0xffff0000u);
+        const uint32_t b0 = __builtin_bit_cast(uint32_t, r0), b1 = __builtin_bit_cast(uint32_t, r1);
+        w1[i] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xffff0000u);   // <= 8 significant bits left: its low half is zero
+        const float s1 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+        w2[i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, s0), 0x07060302u);
     }
     p0 = __builtin_bit_cast(bf16x8, w0);
     p1 = __builtin_bit_cast(bf16x8, w1);
@@ -327,6 +325,194 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
     }
 }
 
+// ---- weight-gradient (TN) GEMM in the same arithmetic:  G[n][k] = sum_m X[m][n] * Y[m][k]  over a chunk of pixels -> fp32 slab ------------
+// Both operands are fp32 activations: their [16 m][128 columns] half-tiles go HBM -> LDS by LDS-DMA as they are (row-major, 512-B runs);
+// a wave gathers the 8 consecutive m of its column with eight ds_read_b32 (stride-1 across the lanes: conflict-free without a swizzle)
+// and splits them in registers.  256 x 256 output tile, waves as 4 (n) x 2 (k) interleaved over the halves {X-lo, X-hi, Y-lo, Y-hi},
+// four phases of 12 MFMAs per 16 pixels, FOUR-stage ring (128 KB), one DMA per wave and half-tile, ten in flight.  Partial column sums of X
+// (bias gradients) in the fp32 kernel's [split * tiles_k + tile_k][N] layout (this kernel's tile_k covers two of that kernel's: the odd row
+// is written as zeros).
+constexpr int THT = 8192;            // TN half-tile: 16 rows x 128 floats
+constexpr int TSTG = 4 * THT;        // X-lo | X-hi | Y-lo | Y-hi
+
+typedef __attribute__((address_space(3))) const volatile float* lds_f1_p;
+
+__device__ __forceinline__ void split8s(const float x[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    floatx4 a, b;
+    a.x = x[0]; a.y = x[1]; a.z = x[2]; a.w = x[3];
+    b.x = x[4]; b.y = x[5]; b.z = x[6]; b.w = x[7];
+    split8(a, b, p0, p1, p2);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp32_tiles_k) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TSTG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave & 3, wn = wave >> 2;      // rows 32 wm.. of each X half (n), columns 64 wn.. of each Y half (k)
+    const int tilesK = p.K / 256, tilesN = p.N / 256;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / (tilesN * tilesK);
+    const int tile = lin % (tilesN * tilesK);
+    const int tile_n = tile / tilesK, tile_k = tile % tilesK;
+    const int n0 = tile_n * 256, k0 = tile_k * 256;
+    const int64_t mbeg = (int64_t)split * p.rows_per_split;
+    int64_t mend = mbeg + p.rows_per_split;
+    if (mend > p.M) mend = p.M;
+    const int64_t mw = mbeg < p.M ? mbeg : 0;
+    const i32x4 rsX = make_rsrc_dma(p.X + mw * (int64_t)p.ldx + n0);
+    const i32x4 rsY = make_rsrc_dma(p.Y + mw * (int64_t)p.ldy + k0);
+    // a half-tile = 8 DMAs of two 512-byte row runs: wave w stages rows 2 w and 2 w + 1
+    const int drow = 2 * wave + (lane >> 5);
+    const uint32_t dcol = (uint32_t)(lane & 31) * 16u;
+    const uint32_t voffX[2] = {(uint32_t)drow * (uint32_t)p.ldx * 4u + dcol, (uint32_t)drow * (uint32_t)p.ldx * 4u + 512u + dcol};
+    const uint32_t voffY[2] = {(uint32_t)drow * (uint32_t)p.ldy * 4u + dcol, (uint32_t)drow * (uint32_t)p.ldy * 4u + 512u + dcol};
+    const uint32_t lds_base = lds_addr(reinterpret_cast<const float*>(smem)) + (uint32_t)wave * 1024u;
+    const int64_t nmt = (mend - mbeg + 15) / 16;
+    // Hx: 0 X-lo, 1 X-hi, 2 Y-lo, 3 Y-hi; stage offset so; pixel step t
+    auto stage = [&](int Hx, uint32_t so, int64_t t) {
+        const int64_t row = mbeg + t * 16 + drow;
+        const bool ok = t < nmt && row < mend;
+        const uint32_t dst = lds_base + so + (uint32_t)(Hx * THT);
+        if (Hx < 2) dma16(rsX, dst, ok ? voffX[Hx] : ROW_SENT, (uint32_t)(t * 16) * (uint32_t)p.ldx * 4u);
+        else dma16(rsY, dst, ok ? voffY[Hx - 2] : ROW_SENT, (uint32_t)(t * 16) * (uint32_t)p.ldy * 4u);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned char* xbase = smem + (8 * fh) * 512 + (wm * 32 + fr) * 4;
+    const unsigned char* ybase = smem + 2 * THT + (8 * fh) * 512 + (wn * 64 + fr) * 4;
+
+    floatx16 acc[2][2][2];   // [X half][Y half][k-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
+    bf16x8 fa[3], fb[2][2][3];
+    float cs_lo = 0.f, cs_hi = 0.f;
+    const bool do_cs = p.colsum != nullptr;
+
+    // prologue: pixel steps 0, 1, 2 (12 half-tiles, order X-lo Y-lo Y-hi X-hi)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        stage(0, q * TSTG, q);
+        stage(2, q * TSTG, q);
+        stage(3, q * TSTG, q);
+        stage(1, q * TSTG, q);
+    }
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+#define DCPT_LD_X(SO, H)                                                                                                           \
+    {                                                                                                                             \
+        float r_[8];                                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = *(lds_f1_p)(xbase + (SO) + (H)*THT + e * 512);                      \
+        split8s(r_, fa[0], fa[1], fa[2]);                                                                                         \
+    }
+#define DCPT_LD_Y(SO, H)                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                               \
+        float r_[8];                                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = *(lds_f1_p)(ybase + (SO) + (H)*THT + e * 512 + j * 128);            \
+        split8s(r_, fb[H][j][0], fb[H][j][1], fb[H][j][2]);                                                                       \
+    }
+#define DCPT_MM(ACC, I, BH, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[BH][I][PB], ACC, 0, 0, 0)
+#define DCPT_MFMA(AH, BH)                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                                \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 2, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 2, 0);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 2); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 2);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 1, 1); DCPT_MM(acc[AH][BH][1], 1, BH, 1, 1);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 1, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 1, 0);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 1); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 1);                                                     \
+    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 0);                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    __builtin_amdgcn_s_barrier();
+#define DCPT_PUBLISH()                                    \
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();
+
+    uint32_t so0 = 0, so1 = TSTG, so2 = 2 * TSTG, so3 = 3 * TSTG;   // stages of pixel steps t, t + 1, t + 2, t + 3
+    for (int64_t t = 0; t < nmt; ++t) {
+        const bool cs_step = do_cs && (int)(t % tilesK) == tile_k && tid < 128;
+        // (X-lo, Y-lo)
+        DCPT_LD_X(so0, 0)
+        DCPT_LD_Y(so0, 0)
+        stage(0, so3, t + 3);
+        DCPT_PUBLISH()
+        DCPT_MFMA(0, 0)
+        // (X-lo, Y-hi)
+        DCPT_LD_Y(so0, 1)
+        stage(2, so3, t + 3);
+        DCPT_PUBLISH()
+        DCPT_MFMA(0, 1)
+        // (X-hi, Y-hi)
+        DCPT_LD_X(so0, 1)
+        if (cs_step) {   // column sums of X-lo (its slot is re-staged two phases from here at the earliest)
+            float sm_ = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm_ += *(lds_f1_p)(smem + so0 + r * 512 + tid * 4);
+            cs_lo += sm_;
+        }
+        stage(3, so3, t + 3);
+        DCPT_PUBLISH()
+        DCPT_MFMA(1, 1)
+        // (X-hi, Y-lo)
+        if (cs_step) {
+            float sm_ = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm_ += *(lds_f1_p)(smem + so0 + THT + r * 512 + tid * 4);
+            cs_hi += sm_;
+        }
+        stage(1, so3, t + 3);
+        DCPT_PUBLISH()
+        DCPT_MFMA(1, 0)
+        const uint32_t tmp = so0;
+        so0 = so1;
+        so1 = so2;
+        so2 = so3;
+        so3 = tmp;
+    }
+#undef DCPT_LD_X
+#undef DCPT_LD_Y
+#undef DCPT_MM
+#undef DCPT_MFMA
+#undef DCPT_PUBLISH
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    dma_wait_all();
+    __syncthreads();
+
+    // slab tile [256 n][256 k] of this split
+    const rsrc_t rsS = make_rsrc(p.slab + (int64_t)split * p.N * p.K + (int64_t)n0 * p.K + k0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kl = b * 128 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nl = a * 128 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    buf_st1(rsS, ((uint32_t)nl * (uint32_t)p.K + (uint32_t)kl) * 4u, acc[a][b][j][r]);
+                }
+            }
+    if (do_cs && tid < 128) {
+        // the fp32 kernel's layout has fp32_tiles_k (= K / 128) partial rows per split: this tile_k owns rows 2 tile_k (the sums) and + 1 (zeros)
+        float* c0 = p.colsum + ((int64_t)split * fp32_tiles_k + 2 * tile_k) * p.N + n0;
+        c0[tid] = cs_lo;
+        c0[128 + tid] = cs_hi;
+        if (2 * tile_k + 1 < fp32_tiles_k) {
+            c0[p.N + tid] = 0.f;
+            c0[p.N + 128 + tid] = 0.f;
+        }
+    }
+}
+
 // process-wide state of the opt-in mode: a caller-provided scratch for the split images (dcpt_set_gemm_x3)
 unsigned char* g_x3_scratch = nullptr;
 size_t g_x3_bytes = 0;
@@ -409,6 +595,38 @@ int launch_gemm_nt_x3(const GemmNT& pin, int aload, int epi, hipStream_t s) {
         default: dcpt_set_error("gemm_nt_x3: epilogue %d not supported", epi); return DCPT_ERR_ARG;
     }
     DCPT_CHECK_LAUNCH("gemm_nt_x3");
+    return DCPT_OK;
+}
+
+// shapes the TN kernel takes: full 256 x 256 output tiles, plain operands, dense enough rows
+bool gemm_tn_x3_shape_ok(int N, int K) { return g_x3_scratch != nullptr && N % 256 == 0 && K % 256 == 0; }
+
+// split plan for such a shape: one block per CU (tiles x splits ~ 256), chunks of >= 256 pixels, multiples of 32
+bool gemm_tn_x3_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split) {
+    if (!gemm_tn_x3_shape_ok(N, K)) return false;
+    const int64_t tiles = (int64_t)(N / 256) * (K / 256);
+    int64_t want = 256 / tiles;
+    const int64_t max_by_rows = cdiv64(M, 256);
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    if (tiles * want < g_x3_min_tiles && g_x3_min_tiles > 1) return false;   // too little work for one-block-per-CU tiles
+    const int64_t rps = cdiv64(cdiv64(M, want), 32) * 32;
+    *rows_per_split = rps;
+    *splits = (int)cdiv64(M, rps);
+    return true;
+}
+
+bool gemm_tn_x3_ok(const GemmTN& p, int xload, int yload) {
+    if (!gemm_tn_x3_shape_ok(p.N, p.K) || xload != A_PLAIN || yload != A_PLAIN) return false;
+    if ((p.nb1 > 1) || (p.nb2 > 1) || p.ldx % 4 != 0 || p.ldy % 4 != 0 || p.rows_per_split % 16 != 0) return false;
+    const int64_t blocks = (int64_t)(p.N / 256) * (p.K / 256) * p.splits;
+    return blocks >= (g_x3_min_tiles > 1 ? 128 : 1);
+}
+
+int launch_gemm_tn_x3(const GemmTN& p, int fp32_tiles_k, hipStream_t s) {
+    const unsigned blocks = (unsigned)((p.N / 256) * (p.K / 256) * p.splits);
+    gemm_tn_x3_kernel<<<dim3(blocks), dim3(512), 0, s>>>(p, fp32_tiles_k);
+    DCPT_CHECK_LAUNCH("gemm_tn_x3");
     return DCPT_OK;
 }
 
