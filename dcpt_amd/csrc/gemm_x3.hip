@@ -326,16 +326,22 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
 }
 
 // ---- weight-gradient (TN) GEMM in the same arithmetic:  G[n][k] = sum_m X[m][n] * Y[m][k]  over a chunk of pixels -> fp32 slab ------------
-// Both operands are fp32 activations: their [16 m][128 columns] half-tiles go HBM -> LDS by LDS-DMA as they are (row-major, 512-B runs);
-// a wave gathers the 8 consecutive m of its column with eight ds_read_b32 (stride-1 across the lanes: conflict-free without a swizzle)
-// and splits them in registers.  256 x 256 output tile, waves as 4 (n) x 2 (k) interleaved over the halves {X-lo, X-hi, Y-lo, Y-hi},
-// four phases of 12 MFMAs per 16 pixels, FOUR-stage ring (128 KB), one DMA per wave and half-tile, ten in flight.  Partial column sums of X
-// (bias gradients) in the fp32 kernel's [split * tiles_k + tile_k][N] layout (this kernel's tile_k covers two of that kernel's: the odd row
-// is written as zeros).
+// Both operands are fp32 activations.  Their [16 m][128 columns] half-tiles go HBM -> LDS by LDS-DMA as they are (row-major, 512-B runs, a
+// ring of two pixel steps).  An MFMA operand is 8 consecutive PIXELS of one column: a CONVERT pass gathers them (eight ds_read_b32, stride-1
+// across the lanes: conflict-free without a swizzle), splits them in registers and writes the three pieces as lane-linear 16-byte records
+// into a fragment-major plane buffer -- each of the 16 fragments of a pixel step ONCE per block (wave w converts X fragment w and Y fragment
+// w, one step ahead), where the first version split every fragment in each of the 2-4 waves that use it (264 VALU operations per wave and
+// pixel step next to 48 MFMAs; now 88).  The MFMA phases then read their fragments as plain ds_read_b128 from the planes.  256 x 256 output
+// tile, waves as 4 (n) x 2 (k) interleaved over the halves, four phases of 12 MFMAs per 16 pixels, two alternating wave groups as in the NT
+// kernel.  LDS: 64 KB fp32 ring + 2 x 48 KB planes = the CU's 160 KB.  Partial column sums of X (bias gradients) in the fp32 kernel's
+// [split * tiles_k + tile_k][N] layout (this kernel's tile_k covers two of that kernel's: the odd row is written as zeros).
 constexpr int THT = 8192;            // TN half-tile: 16 rows x 128 floats
 constexpr int TSTG = 4 * THT;        // X-lo | X-hi | Y-lo | Y-hi
+constexpr int TPL = 48 * 1024;       // plane buffer of one pixel step: 16 fragments x 3 pieces x 1 KiB
+constexpr int TPL0 = 2 * TSTG;       // planes start behind the fp32 ring
 
 typedef __attribute__((address_space(3))) const volatile float* lds_f1_p;
+typedef __attribute__((address_space(3))) bf16x8* lds_wr_p;
 
 __device__ __forceinline__ void split8s(const float x[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     floatx4 a, b;
@@ -345,7 +351,7 @@ __device__ __forceinline__ void split8s(const float x[8], bf16x8& p0, bf16x8& p1
 }
 
 __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp32_tiles_k) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TSTG];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TSTG + 2 * TPL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
@@ -369,18 +375,23 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
     const uint32_t voffY[2] = {(uint32_t)drow * (uint32_t)p.ldy * 4u + dcol, (uint32_t)drow * (uint32_t)p.ldy * 4u + 512u + dcol};
     const uint32_t lds_base = lds_addr(reinterpret_cast<const float*>(smem)) + (uint32_t)wave * 1024u;
     const int64_t nmt = (mend - mbeg + 15) / 16;
-    // Hx: 0 X-lo, 1 X-hi, 2 Y-lo, 3 Y-hi; stage offset so; pixel step t
-    auto stage = [&](int Hx, uint32_t so, int64_t t) {
+    // Hx: 0 X-lo, 1 X-hi, 2 Y-lo, 3 Y-hi; fp32 stage st (0 / 1); pixel step t (past the chunk: zeros)
+    auto stage = [&](int Hx, int st, int64_t t) {
         const int64_t row = mbeg + t * 16 + drow;
         const bool ok = t < nmt && row < mend;
-        const uint32_t dst = lds_base + so + (uint32_t)(Hx * THT);
+        const uint32_t dst = lds_base + (uint32_t)(st * TSTG + Hx * THT);
         if (Hx < 2) dma16(rsX, dst, ok ? voffX[Hx] : ROW_SENT, (uint32_t)(t * 16) * (uint32_t)p.ldx * 4u);
         else dma16(rsY, dst, ok ? voffY[Hx - 2] : ROW_SENT, (uint32_t)(t * 16) * (uint32_t)p.ldy * 4u);
     };
 
     const int fr = lane & 31, fh = lane >> 5;
-    const unsigned char* xbase = smem + (8 * fh) * 512 + (wm * 32 + fr) * 4;
-    const unsigned char* ybase = smem + 2 * THT + (8 * fh) * 512 + (wn * 64 + fr) * 4;
+    // convert source: this wave's X fragment = columns 32 wave.. of the 256-column X tile, its Y fragment likewise
+    const unsigned char* cvx = smem + (wave >> 2) * THT + (8 * fh) * 512 + ((wave & 3) * 32 + fr) * 4;
+    const unsigned char* cvy = cvx + 2 * THT;
+    // plane records: fragment f (X: n-tile 0..7, Y: 8 + k-tile), piece pl at ((f * 3 + pl) * 1024) + lane * 16
+    unsigned char* const pl_wr = smem + TPL0 + lane * 16;
+    const unsigned char* const pl_rd = smem + TPL0 + lane * 16;
+    const int fx_lo = wm, fx_hi = 4 + wm, fy_lo = 8 + 2 * wn, fy_hi = 12 + 2 * wn;
 
     floatx16 acc[2][2][2];   // [X half][Y half][k-tile]
 #pragma unroll
@@ -393,33 +404,46 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
                 for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
     bf16x8 fa[3], fb[2][2][3];
     float cs_lo = 0.f, cs_hi = 0.f;
-    const bool do_cs = p.colsum != nullptr;
+    const bool do_cs = p.colsum != nullptr && tid < 128;
 
-    // prologue: pixel steps 0, 1, 2 (12 half-tiles, order X-lo Y-lo Y-hi X-hi)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        stage(0, q * TSTG, q);
-        stage(2, q * TSTG, q);
-        stage(3, q * TSTG, q);
-        stage(1, q * TSTG, q);
-    }
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-
-#define DCPT_LD_X(SO, H)                                                                                                           \
+// gather + split fragment (X or Y of this wave) of fp32 stage ST into plane buffer PB
+#define DCPT_CONVERT(SRC, ST, PB, F)                                                                                               \
     {                                                                                                                             \
         float r_[8];                                                                                                              \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = *(lds_f1_p)(xbase + (SO) + (H)*THT + e * 512);                      \
-        split8s(r_, fa[0], fa[1], fa[2]);                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = *(lds_f1_p)((SRC) + (ST)*TSTG + e * 512);                           \
+        bf16x8 q0_, q1_, q2_;                                                                                                     \
+        split8s(r_, q0_, q1_, q2_);                                                                                               \
+        *(lds_wr_p)(pl_wr + (PB)*TPL + ((F)*3 + 0) * 1024) = q0_;                                                                 \
+        *(lds_wr_p)(pl_wr + (PB)*TPL + ((F)*3 + 1) * 1024) = q1_;                                                                 \
+        *(lds_wr_p)(pl_wr + (PB)*TPL + ((F)*3 + 2) * 1024) = q2_;                                                                 \
     }
-#define DCPT_LD_Y(SO, H)                                                                                                           \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                               \
-        float r_[8];                                                                                                              \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = *(lds_f1_p)(ybase + (SO) + (H)*THT + e * 512 + j * 128);            \
-        split8s(r_, fb[H][j][0], fb[H][j][1], fb[H][j][2]);                                                                       \
+#define DCPT_COLSUM(ST)                                                                                                            \
+    {                                                                                                                             \
+        float s0_ = 0.f, s1_ = 0.f;                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                          \
+            s0_ += *(lds_f1_p)(smem + (ST)*TSTG + r * 512 + tid * 4);                                                             \
+            s1_ += *(lds_f1_p)(smem + (ST)*TSTG + THT + r * 512 + tid * 4);                                                       \
+        }                                                                                                                         \
+        cs_lo += s0_;                                                                                                             \
+        cs_hi += s1_;                                                                                                             \
     }
-#define DCPT_MM(ACC, I, BH, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[BH][I][PB], ACC, 0, 0, 0)
+
+    // prologue: raw steps 0 and 1 in flight, step 0 converted by everybody
+    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+    stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); stage(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+    DCPT_CONVERT(cvx, 0, 0, wave)
+    DCPT_CONVERT(cvy, 0, 0, 8 + wave)
+    if (do_cs && tile_k == 0) DCPT_COLSUM(0)
+    __syncthreads();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind from here on
+
+#define DCPT_RD_X(PB, F) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) fa[pl] = *(lds_frag_p)(pl_rd + (PB)*TPL + ((F)*3 + pl) * 1024);
+#define DCPT_RD_Y(PB, H, F)                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                 \
+        fb[H][j][pl] = *(lds_frag_p)(pl_rd + (PB)*TPL + (((F) + j) * 3 + pl) * 1024);
+#define DCPT_MM(ACC, I, BH, PA, PB_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[BH][I][PB_], ACC, 0, 0, 0)
 #define DCPT_MFMA(AH, BH)                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                                \
@@ -432,56 +456,52 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
     __builtin_amdgcn_s_setprio(0);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_barrier();
-#define DCPT_PUBLISH()                                    \
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      \
-    __builtin_amdgcn_s_barrier();
 
-    uint32_t so0 = 0, so1 = TSTG, so2 = 2 * TSTG, so3 = 3 * TSTG;   // stages of pixel steps t, t + 1, t + 2, t + 3
-    for (int64_t t = 0; t < nmt; ++t) {
-        const bool cs_step = do_cs && (int)(t % tilesK) == tile_k && tid < 128;
-        // (X-lo, Y-lo)
-        DCPT_LD_X(so0, 0)
-        DCPT_LD_Y(so0, 0)
-        stage(0, so3, t + 3);
-        DCPT_PUBLISH()
-        DCPT_MFMA(0, 0)
-        // (X-lo, Y-hi)
-        DCPT_LD_Y(so0, 1)
-        stage(2, so3, t + 3);
-        DCPT_PUBLISH()
-        DCPT_MFMA(0, 1)
-        // (X-hi, Y-hi)
-        DCPT_LD_X(so0, 1)
-        if (cs_step) {   // column sums of X-lo (its slot is re-staged two phases from here at the earliest)
-            float sm_ = 0.f;
+    // Step t (plane buffer t & 1 holds its fragments; fp32 stage (t + 1) & 1 holds raw step t + 1, stage t & 1 receives raw step t + 2):
+    //   ph0  read X-lo, Y-lo                                              MFMA (lo,lo)
+    //   ph1  read Y-hi; DMA raw(t+2) X-lo, Y-lo; vmcnt(2): raw(t+1) landed      MFMA (lo,hi)
+    //   ph2  read X-hi; DMA raw(t+2) Y-hi, X-hi; convert X fragment of raw(t+1)  MFMA (hi,hi)
+    //   ph3  convert Y fragment of raw(t+1); column sums of raw(t+1)             MFMA (hi,lo)
+    // (LDS-DMA rules: a raw stage is re-staged two phases after its last read -- ph3 -> ph1 --, read one phase after the wait that
+    // retired it; a plane buffer is rewritten four phases after its last read and read a phase after the writers' lgkmcnt(0) + barrier.)
+    for (int64_t t = 0; t < nmt; t += 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sm_ += *(lds_f1_p)(smem + so0 + r * 512 + tid * 4);
-            cs_lo += sm_;
+        for (int u = 0; u < 2; ++u) {   // u = parity of the step: plane buffer u, raw stage u receives step t + u + 2
+            const int64_t tt = t + u;
+            // ph0
+            DCPT_RD_X(u, fx_lo)
+            DCPT_RD_Y(u, 0, fy_lo)
+            __builtin_amdgcn_s_barrier();
+            DCPT_MFMA(0, 0)
+            // ph1
+            DCPT_RD_Y(u, 1, fy_hi)
+            stage(0, u, tt + 2);
+            stage(2, u, tt + 2);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            DCPT_MFMA(0, 1)
+            // ph2
+            DCPT_RD_X(u, fx_hi)
+            stage(3, u, tt + 2);
+            stage(1, u, tt + 2);
+            DCPT_CONVERT(cvx, u ^ 1, u ^ 1, wave)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            DCPT_MFMA(1, 1)
+            // ph3
+            DCPT_CONVERT(cvy, u ^ 1, u ^ 1, 8 + wave)
+            if (do_cs && tt + 1 < nmt && (int)((tt + 1) % tilesK) == tile_k) DCPT_COLSUM(u ^ 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            DCPT_MFMA(1, 0)
         }
-        stage(3, so3, t + 3);
-        DCPT_PUBLISH()
-        DCPT_MFMA(1, 1)
-        // (X-hi, Y-lo)
-        if (cs_step) {
-            float sm_ = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sm_ += *(lds_f1_p)(smem + so0 + THT + r * 512 + tid * 4);
-            cs_hi += sm_;
-        }
-        stage(1, so3, t + 3);
-        DCPT_PUBLISH()
-        DCPT_MFMA(1, 0)
-        const uint32_t tmp = so0;
-        so0 = so1;
-        so1 = so2;
-        so2 = so3;
-        so3 = tmp;
     }
-#undef DCPT_LD_X
-#undef DCPT_LD_Y
+#undef DCPT_CONVERT
+#undef DCPT_COLSUM
+#undef DCPT_RD_X
+#undef DCPT_RD_Y
 #undef DCPT_MM
 #undef DCPT_MFMA
-#undef DCPT_PUBLISH
     if (grp == 0) __builtin_amdgcn_s_barrier();
     dma_wait_all();
     __syncthreads();
@@ -501,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
                     buf_st1(rsS, ((uint32_t)nl * (uint32_t)p.K + (uint32_t)kl) * 4u, acc[a][b][j][r]);
                 }
             }
-    if (do_cs && tid < 128) {
+    if (p.colsum != nullptr && tid < 128) {
         // the fp32 kernel's layout has fp32_tiles_k (= K / 128) partial rows per split: this tile_k owns rows 2 tile_k (the sums) and + 1 (zeros)
         float* c0 = p.colsum + ((int64_t)split * fp32_tiles_k + 2 * tile_k) * p.N + n0;
         c0[tid] = cs_lo;
