@@ -506,21 +506,30 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
     dma_wait_all();
     __syncthreads();
 
-    // slab tile [256 n][256 k] of this split
-    const rsrc_t rsS = make_rsrc(p.slab + (int64_t)split * p.N * p.K + (int64_t)n0 * p.K + k0);
+    // slab tile [256 n][256 k] of this split: the four 128 x 128 quadrants through LDS (two alternating 64 KB buffers) into the fp32
+    // kernel's plain row epilogue -- 16-byte stores, 512-byte runs (4-byte stores straight from the accumulators cost ~6x per byte)
+    GemmNT sp{};
+    sp.C = p.slab + (int64_t)split * p.N * p.K;
+    sp.M = p.N;
+    sp.N = p.K;
+    sp.ldc = p.K;
+    float* const Cs0 = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int q = 0; q < 4; ++q) {
+        const int a = q >> 1, b = q & 1;
+        float* const Cs = Cs0 + (q & 1) * (128 * 128);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int j = 0; j < 2; ++j) {
+            const int kl = wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kl = b * 128 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int nl = a * 128 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    buf_st1(rsS, ((uint32_t)nl * (uint32_t)p.K + (uint32_t)kl) * 4u, acc[a][b][j][r]);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int nl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cs[nl * 128 + kl] = acc[a][b][j][r];
             }
+        }
+        __syncthreads();
+        epilogue_rows<E_PLAIN, 128, 128, 512>(sp, Cs, (int64_t)n0 + a * 128, k0 + b * 128, tid);
+    }
     if (p.colsum != nullptr && tid < 128) {
         // the fp32 kernel's layout has fp32_tiles_k (= K / 128) partial rows per split: this tile_k owns rows 2 tile_k (the sums) and + 1 (zeros)
         float* c0 = p.colsum + ((int64_t)split * fp32_tiles_k + 2 * tile_k) * p.N + n0;
