@@ -137,9 +137,10 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
-    // wave -> 64 x 128 of the tile as 4 (rows) x 2 (columns): an A fragment is split by two waves only (the in-register split is what this
-    // kernel's load phases are made of), interleaved over the halves: rows 32 wm.. of A-lo and of A-hi, columns 64 wn.. of B-lo and of B-hi
-    const int wm = wave & 3, wn = wave >> 2;
+    // wave -> 32 rows x 256 columns of the tile (waves 0..3 in A-lo, 4..7 in A-hi; eight 32 x 32 tiles each): the in-register split of an A
+    // fragment -- what this kernel's load phases are made of -- is done by exactly ONE wave per tile (two with 64 x 128 wave tiles: 193 vs
+    // 215 us with four, 128 x 64); the B fragments are plain 16-byte records, reading each in eight waves costs LDS cycles that are free
+    const int ah = wave >> 2, ar = (wave & 3) * 32;
     const int Ch = p.N / 2;
     const int tilesN = p.N / 256;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -181,69 +182,65 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
         }
     };
 
-    // A fragments (fp32): row (lane & 31); sub-step u (16 k), half fh = lane >> 5: the 8 consecutive k are k-quads 4 u + 2 fh and + 1
+    // A fragment (fp32): row (lane & 31) of this wave's 32 rows; sub-step u (16 k), half fh = lane >> 5: the 8 consecutive k are k-quads
+    // 4 u + 2 fh and + 1
     const int fr = lane & 31, fh = lane >> 5, fi = (fr >> 1) & 7;
-    const unsigned char* abase = smem + (wm * 32 + fr) * 128;
+    const unsigned char* abase = smem + ah * AHT + (ar + fr) * 128;
     int aslot[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int q = 0; q < 2; ++q) aslot[u][q] = ((4 * u + 2 * fh + q) ^ fi) * 16;
-    // B fragments (split image): 16-byte half fh of the 32-byte row, swapped on rows with bit 3
-    const unsigned char* bbase = smem + 2 * AHT + (wn * 64 + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) * 16);
+    // B fragments (split image): row fr of a 32-row tile, 16-byte half fh of the 32-byte row, swapped on rows with bit 3
+    const unsigned char* bbase = smem + 2 * AHT + fr * 32 + ((fh ^ ((fr >> 3) & 1)) * 16);
 
-    floatx16 acc[2][2][2];   // [A half][B half][n-tile]
+    floatx16 acc[8];   // n-tile j: columns 32 j.. of the tile (j < 4: B-lo, else B-hi)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
-    bf16x8 fa[3], fb[2][2][3];   // A sub-tile in use [piece]; B sub-tiles [half][n-tile][piece] of the current 16-k sub-step
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf16x8 fa[3], fb[2][3];   // the wave's A fragment of the current 16-k sub-step [piece]; the two B tiles of the current phase [tile][piece]
 
     const int nkt = p.K / 32;   // (K % 64 == 0: k-tiles of 32 in pairs)
+    // prologue: k-tile 0 completely, the A halves of k-tile 1
     stage(0, 0, 0, 0);
+    stage(1, 0, 0, 0);
     stage(2, 0, 0, 0);
     stage(3, 0, 0, 0);
-    stage(1, 0, 0, 0);
     stage(0, 1, 1, 0);
-    stage(2, 1, 1, 0);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    stage(1, 1, 1, 0);
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // A(0), B-lo(0) landed (this wave's part; the barrier publishes all)
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
 
-// read the fp32 A sub-tile (half H, sub-step U) and split it into pieces
-#define DCPT_LD_A(S, H, U)                                                                                                         \
+#define DCPT_LD_A(S, U)                                                                                                            \
     {                                                                                                                             \
-        const floatx4 r0_ = *(lds_f4_p)(abase + (S)*STGF + (H)*AHT + aslot[U][0]);                                                \
-        const floatx4 r1_ = *(lds_f4_p)(abase + (S)*STGF + (H)*AHT + aslot[U][1]);                                                \
+        const floatx4 r0_ = *(lds_f4_p)(abase + (S)*STGF + aslot[U][0]);                                                          \
+        const floatx4 r1_ = *(lds_f4_p)(abase + (S)*STGF + aslot[U][1]);                                                          \
         split8(r0_, r1_, fa[0], fa[1], fa[2]);                                                                                    \
     }
-#define DCPT_LD_B(S, H, U)                                                                                                         \
+// the two B tiles of phase Q (columns 64 Q..): half Q / 2, rows 64 (Q % 2).. of that half-tile's piece of sub-step U
+#define DCPT_LD_B(S, U, Q)                                                                                                         \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                 \
-        fb[H][j][pl] = *(lds_frag_p)(bbase + (S)*STGF + (H)*BHT + (U)*PIECE + pl * PLANE + j * 1024);
-#define DCPT_MM(ACC, I, BH, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[BH][I][PB], ACC, 0, 0, 0)
-#define DCPT_MFMA(AH, BH)                                                                                                          \
+        fb[j][pl] = *(lds_frag_p)(bbase + (S)*STGF + ((Q) >> 1) * BHT + (U)*PIECE + pl * PLANE + (((Q)&1) * 2 + j) * 1024);
+#define DCPT_MM(J, PA, PB) acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[(J)&1][PB], acc[J], 0, 0, 0)
+#define DCPT_MFMA(Q)                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                                \
-    DCPT_MM(acc[AH][BH][0], 0, BH, 2, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 2, 0);                                                     \
-    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 2); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 2);                                                     \
-    DCPT_MM(acc[AH][BH][0], 0, BH, 1, 1); DCPT_MM(acc[AH][BH][1], 1, BH, 1, 1);                                                     \
-    DCPT_MM(acc[AH][BH][0], 0, BH, 1, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 1, 0);                                                     \
-    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 1); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 1);                                                     \
-    DCPT_MM(acc[AH][BH][0], 0, BH, 0, 0); DCPT_MM(acc[AH][BH][1], 1, BH, 0, 0);                                                     \
+    DCPT_MM(2 * (Q), 2, 0); DCPT_MM(2 * (Q) + 1, 2, 0);                                                                             \
+    DCPT_MM(2 * (Q), 0, 2); DCPT_MM(2 * (Q) + 1, 0, 2);                                                                             \
+    DCPT_MM(2 * (Q), 1, 1); DCPT_MM(2 * (Q) + 1, 1, 1);                                                                             \
+    DCPT_MM(2 * (Q), 1, 0); DCPT_MM(2 * (Q) + 1, 1, 0);                                                                             \
+    DCPT_MM(2 * (Q), 0, 1); DCPT_MM(2 * (Q) + 1, 0, 1);                                                                             \
+    DCPT_MM(2 * (Q), 0, 0); DCPT_MM(2 * (Q) + 1, 0, 0);                                                                             \
     __builtin_amdgcn_s_setprio(0);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_barrier();
-#define DCPT_PUBLISH()                                    \
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      \
-    __builtin_amdgcn_s_barrier();
 
-    // eight phases per k-tile of 32 (stage s = t & 1): sub-step 0 then 1, quadrants (lo,lo) (lo,hi) (hi,hi) (hi,lo).  Staging, two k-tiles
-    // ahead and at least two phases after a half-tile's last read: ph0 B-hi(t+1), ph1 A-hi(t+1), ph6 A-lo(t+2), ph7 B-lo(t+2); every
-    // phase's wait leaves ten DMAs (= the four youngest half-tiles) in flight.
+    // eight phases per k-tile of 32 (stage s = t & 1): sub-step u = 0, 1 x column quarters Q = 0..3 (12 MFMAs each).  Last reads of a stage:
+    // A ph4, B-lo ph5, B-hi ph7.  Staging (>= two phases after the last read of the slot, LDS-DMA rule): ph0 B-lo(t+1), ph1 B-hi(t+1) into the
+    // other stage, ph6 A-lo(t+2), ph7 A-hi(t+2) into this one.  Waits (read >= one phase after the wait): ph1 vmcnt(10) retires B-hi(t)
+    // (read at ph2), ph7 vmcnt(7) retires A(t+1) and B-lo(t+1) (read at ph0 of t+1).
     for (int t = 0; t < nkt; t += 2) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -251,26 +248,33 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
             const uint32_t dead1 = (kt + 1 < nkt) ? 0u : ROW_SENT, dead2 = (kt + 2 < nkt) ? 0u : ROW_SENT;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                // (A-lo, B-lo)
-                DCPT_LD_B(s, 0, u)
-                DCPT_LD_A(s, 0, u)
-                if (u == 0) stage(3, s ^ 1, kt + 1, dead1);
-                DCPT_PUBLISH()
-                DCPT_MFMA(0, 0)
-                // (A-lo, B-hi)
-                DCPT_LD_B(s, 1, u)
-                if (u == 0) stage(1, s ^ 1, kt + 1, dead1);
-                DCPT_PUBLISH()
-                DCPT_MFMA(0, 1)
-                // (A-hi, B-hi)
-                DCPT_LD_A(s, 1, u)
+                // column quarter 0
+                DCPT_LD_B(s, u, 0)
+                DCPT_LD_A(s, u)
+                if (u == 0) stage(2, s ^ 1, kt + 1, dead1);
+                __builtin_amdgcn_s_barrier();
+                DCPT_MFMA(0)
+                // quarter 1
+                DCPT_LD_B(s, u, 1)
+                if (u == 0) {
+                    stage(3, s ^ 1, kt + 1, dead1);
+                    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                DCPT_MFMA(1)
+                // quarter 2
+                DCPT_LD_B(s, u, 2)
                 if (u == 1) stage(0, s, kt + 2, dead2);
-                DCPT_PUBLISH()
-                DCPT_MFMA(1, 1)
-                // (A-hi, B-lo)
-                if (u == 1) stage(2, s, kt + 2, dead2);
-                DCPT_PUBLISH()
-                DCPT_MFMA(1, 0)
+                __builtin_amdgcn_s_barrier();
+                DCPT_MFMA(2)
+                // quarter 3
+                DCPT_LD_B(s, u, 3)
+                if (u == 1) {
+                    stage(1, s, kt + 2, dead2);
+                    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                DCPT_MFMA(3)
             }
         }
     }
@@ -278,28 +282,28 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
 #undef DCPT_LD_B
 #undef DCPT_MM
 #undef DCPT_MFMA
-#undef DCPT_PUBLISH
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
     dma_wait_all();
     __syncthreads();
 
-    // epilogue: quadrant (a, b) of every wave = the 128 x 128 sub-block (a, b) of the tile -> the fp32 kernel's row epilogues
+    // epilogue: the 128 x 128 sub-blocks (a, b) of the tile through LDS -> the fp32 kernel's row epilogues.  Rows of half a belong to waves
+    // 4 a .. 4 a + 3 (32 rows each); every wave parks its own accumulators of the current half and both groups meet at the barriers.
     float* const Cs0 = reinterpret_cast<float*>(smem);
     if constexpr (GATE) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float* const Cs = Cs0;   // [128][256]: columns 0..127 first gate half, 128..255 second
+            if (ah == a) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int nl = b * 128 + wn * 64 + i * 32 + (lane & 31);
+                for (int j = 0; j < 8; ++j) {
+                    const int nl = j * 32 + (lane & 31);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        Cs[ml * 256 + nl] = acc[a][b][i][r];
+                        const int ml = ar + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Cs[ml * 256 + nl] = acc[j][r];
                     }
                 }
+            }
             __syncthreads();
             epilogue_gate<128, 256, 512>(p, Cs, m0 + a * 128, n0, tid);
             __syncthreads();
@@ -309,13 +313,15 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
         for (int q = 0; q < 4; ++q) {
             const int a = q >> 1, b = q & 1;
             float* const Cs = Cs0 + (q & 1) * (128 * 128);
+            if (ah == a) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int nl = wn * 64 + i * 32 + (lane & 31);
+                for (int j = 0; j < 4; ++j) {
+                    const int nl = j * 32 + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    Cs[ml * 128 + nl] = acc[a][b][i][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = ar + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Cs[ml * 128 + nl] = acc[4 * b + j][r];
+                    }
                 }
             }
             __syncthreads();
