@@ -115,6 +115,19 @@ __device__ __forceinline__ void split8(const floatx4 lo4, const floatx4 hi4, bf1
     p2 = __builtin_bit_cast(bf16x8, w2);
 }
 
+// one pair of fp32 values -> one dword of each piece operand (the same arithmetic as split8)
+__device__ __forceinline__ void split_pair(const float x0, const float x1, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    const uint32_t a0 = __builtin_bit_cast(uint32_t, x0), a1 = __builtin_bit_cast(uint32_t, x1);
+    w0 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float r0 = x0 - __builtin_bit_cast(float, a0 & 0xffff0000u);
+    const float r1 = x1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
+    const uint32_t b0 = __builtin_bit_cast(uint32_t, r0), b1 = __builtin_bit_cast(uint32_t, r1);
+    w1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xffff0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+    w2 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, s0), 0x07060302u);
+}
+
 // LDS of one k-tile of 32: A-lo | A-hi as fp32 [128 rows][32 floats] (the fp32 kernel's swizzled image, 16 KB each), B-lo | B-hi as two
 // consecutive pieces each (24 KB each)
 constexpr int AHT = 16384, BHT = 2 * PIECE, STGF = 2 * AHT + 2 * BHT;   // 80 KB: two stages are the whole 160 KB of a CU
@@ -137,6 +150,9 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
+#ifdef X3_ABL_CLOCK
+    const uint64_t clk0_ = __builtin_readcyclecounter(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     // wave -> 32 rows x 256 columns of the tile (waves 0..3 in A-lo, 4..7 in A-hi; eight 32 x 32 tiles each): the in-register split of an A
     // fragment -- what this kernel's load phases are made of -- is done by exactly ONE wave per tile (two with 64 x 128 wave tiles: 193 vs
     // 215 us with four, 128 x 64); the B fragments are plain 16-byte records, reading each in eight waves costs LDS cycles that are free
@@ -193,13 +209,23 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
         for (int q = 0; q < 2; ++q) aslot[u][q] = ((4 * u + 2 * fh + q) ^ fi) * 16;
     // B fragments (split image): row fr of a 32-row tile, 16-byte half fh of the 32-byte row, swapped on rows with bit 3
     const unsigned char* bbase = smem + 2 * AHT + fr * 32 + ((fh ^ ((fr >> 3) & 1)) * 16);
+    // one opaque base register per stage: every fragment read is then base + a 16-bit immediate (left to itself the compiler materialises
+    // ~50 address registers for the offsets beyond 64 KB, which this kernel's register budget does not have)
+    const uint32_t b0_ = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)bbase);
+    const uint32_t a0_ = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)abase);
+    uint32_t bst[2] = {b0_, b0_ + (uint32_t)STGF}, ast[2] = {a0_, a0_ + (uint32_t)STGF};
+    asm volatile("" : "+v"(bst[0]), "+v"(bst[1]), "+v"(ast[0]), "+v"(ast[1]));
 
     floatx16 acc[8];   // n-tile j: columns 32 j.. of the tile (j < 4: B-lo, else B-hi)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    bf16x8 fa[3], fb[2][3];   // the wave's A fragment of the current 16-k sub-step [piece]; the two B tiles of the current phase [tile][piece]
+    // the wave's A fragment [sub-step parity][piece] -- the fragment of sub-step u + 1 is built (read one phase, split in quarters over the
+    // next phases) while the MFMAs of sub-step u run --; the two B tiles of the current phase [tile][piece]
+    bf16x8 fa[2][3], fb[2][3];
+    uint32_t fw[3][4];  // the fragment under construction [piece][pair of k]
+    floatx4 ra0, ra1;   // its eight fp32 values
 
     const int nkt = p.K / 32;   // (K % 64 == 0: k-tiles of 32 in pairs)
     // prologue: k-tile 0 completely, the A halves of k-tile 1
@@ -211,36 +237,74 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
     stage(1, 1, 1, 0);
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // A(0), B-lo(0) landed (this wave's part; the barrier publishes all)
     __builtin_amdgcn_s_barrier();
+    ra0 = *(lds_f4_p)(uintptr_t)(ast[0] + aslot[0][0]);
+    ra1 = *(lds_f4_p)(uintptr_t)(ast[0] + aslot[0][1]);
+    split8(ra0, ra1, fa[0][0], fa[0][1], fa[0][2]);
     if (grp == 1) __builtin_amdgcn_s_barrier();
 
-#define DCPT_LD_A(S, U)                                                                                                            \
-    {                                                                                                                             \
-        const floatx4 r0_ = *(lds_f4_p)(abase + (S)*STGF + aslot[U][0]);                                                          \
-        const floatx4 r1_ = *(lds_f4_p)(abase + (S)*STGF + aslot[U][1]);                                                          \
-        split8(r0_, r1_, fa[0], fa[1], fa[2]);                                                                                    \
+// raw fragment of sub-step U of stage S (two ds_read_b128: the 8 consecutive k of this lane's row)
+#define DCPT_RD_A(S, U)                                                                                                            \
+    ra0 = *(lds_f4_p)(uintptr_t)(ast[S] + aslot[U][0]);                                                                           \
+    ra1 = *(lds_f4_p)(uintptr_t)(ast[S] + aslot[U][1]);
+// split pair I (k = 2 I, 2 I + 1) of the raw fragment
+#ifdef X3_ABL_NOSPLIT
+#define DCPT_SPLIT_Q(I) fw[0][I] = fw[1][I] = fw[2][I] = __builtin_bit_cast(uint32_t, (I) < 2 ? ra0[2 * ((I)&1)] : ra1[2 * ((I)&1)]);
+#else
+#define DCPT_SPLIT_Q(I) split_pair((I) < 2 ? ra0[2 * ((I)&1)] : ra1[2 * ((I)&1)], (I) < 2 ? ra0[2 * ((I)&1) + 1] : ra1[2 * ((I)&1) + 1], fw[0][I], fw[1][I], fw[2][I]);
+#endif
+#define DCPT_PUT_A(PAR)                                                                                                            \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                                            \
+        u32x4 w_;                                                                                                                 \
+        w_.x = fw[pl][0]; w_.y = fw[pl][1]; w_.z = fw[pl][2]; w_.w = fw[pl][3];                                                     \
+        fa[PAR][pl] = __builtin_bit_cast(bf16x8, w_);                                                                             \
     }
 // the two B tiles of phase Q (columns 64 Q..): half Q / 2, rows 64 (Q % 2).. of that half-tile's piece of sub-step U
 #define DCPT_LD_B(S, U, Q)                                                                                                         \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                 \
-        fb[j][pl] = *(lds_frag_p)(bbase + (S)*STGF + ((Q) >> 1) * BHT + (U)*PIECE + pl * PLANE + (((Q)&1) * 2 + j) * 1024);
-#define DCPT_MM(J, PA, PB) acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[(J)&1][PB], acc[J], 0, 0, 0)
-#define DCPT_MFMA(Q)                                                                                                               \
+        fb[j][pl] = *(lds_frag_p)(uintptr_t)(bst[S] + ((Q) >> 1) * BHT + (U)*PIECE + pl * PLANE + (((Q)&1) * 2 + j) * 1024);
+#ifdef X3_ABL_NOMFMA
+#define DCPT_MM(U, J, PA, PB) asm volatile("" ::"v"(fa[U][PA]), "v"(fb[(J)&1][PB]))
+#else
+#define DCPT_MM(U, J, PA, PB) acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[U][PA], fb[(J)&1][PB], acc[J], 0, 0, 0)
+#endif
+#define DCPT_MFMA(U, Q)                                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                                \
-    DCPT_MM(2 * (Q), 2, 0); DCPT_MM(2 * (Q) + 1, 2, 0);                                                                             \
-    DCPT_MM(2 * (Q), 0, 2); DCPT_MM(2 * (Q) + 1, 0, 2);                                                                             \
-    DCPT_MM(2 * (Q), 1, 1); DCPT_MM(2 * (Q) + 1, 1, 1);                                                                             \
-    DCPT_MM(2 * (Q), 1, 0); DCPT_MM(2 * (Q) + 1, 1, 0);                                                                             \
-    DCPT_MM(2 * (Q), 0, 1); DCPT_MM(2 * (Q) + 1, 0, 1);                                                                             \
-    DCPT_MM(2 * (Q), 0, 0); DCPT_MM(2 * (Q) + 1, 0, 0);                                                                             \
+    DCPT_MM(U, 2 * (Q), 2, 0); DCPT_MM(U, 2 * (Q) + 1, 2, 0);                                                                       \
+    DCPT_MM(U, 2 * (Q), 0, 2); DCPT_MM(U, 2 * (Q) + 1, 0, 2);                                                                       \
+    DCPT_MM(U, 2 * (Q), 1, 1); DCPT_MM(U, 2 * (Q) + 1, 1, 1);                                                                       \
+    DCPT_MM(U, 2 * (Q), 1, 0); DCPT_MM(U, 2 * (Q) + 1, 1, 0);                                                                       \
+    DCPT_MM(U, 2 * (Q), 0, 1); DCPT_MM(U, 2 * (Q) + 1, 0, 1);                                                                       \
+    DCPT_MM(U, 2 * (Q), 0, 0); DCPT_MM(U, 2 * (Q) + 1, 0, 0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_barrier();
 
-    // eight phases per k-tile of 32 (stage s = t & 1): sub-step u = 0, 1 x column quarters Q = 0..3 (12 MFMAs each).  Last reads of a stage:
-    // A ph4, B-lo ph5, B-hi ph7.  Staging (>= two phases after the last read of the slot, LDS-DMA rule): ph0 B-lo(t+1), ph1 B-hi(t+1) into the
-    // other stage, ph6 A-lo(t+2), ph7 A-hi(t+2) into this one.  Waits (read >= one phase after the wait): ph1 vmcnt(10) retires B-hi(t)
-    // (read at ph2), ph7 vmcnt(7) retires A(t+1) and B-lo(t+1) (read at ph0 of t+1).
+// compile-time ablations (tools/build_variant.sh ... -DX3_ABL_*): never defined in the product build
+#ifdef X3_ABL_NODMA
+#define X3_STAGE(...)
+#else
+#define X3_STAGE(...) __VA_ARGS__
+#endif
+#ifdef X3_ABL_NOLDB
+#define X3_LDB(...)
+    DCPT_LD_B(0, 0, 0)
+#else
+#define X3_LDB(...) __VA_ARGS__
+#endif
+#ifdef X3_ABL_NOLDA
+#define X3_LDA(...)
+#else
+#define X3_LDA(...) __VA_ARGS__
+#endif
+    // Eight phases g = 4 u + Q per k-tile of 32 (stage s = t & 1): sub-step u = 0, 1 x column quarters Q = 0..3, 12 MFMAs each.  The load
+    // half of a phase is kept EVEN (the other wave of the SIMD runs 12 MFMAs = 384 cycles meanwhile; a phase with the whole 44-operation
+    // split of a fragment in it took ~2x that and cost a quarter of the loop): six B fragment reads, one quarter of the NEXT sub-step's A
+    // split (raw fragment read at Q = 0, pairs 0 / 1 / 2+3 split at Q = 1 / 2 / 3), at most three DMAs.
+    //   reads     A(t) sub-step 1 raw: g0;  A(t+1) sub-step 0 raw: g4 (other stage);  B-lo(t): g0 1 4 5;  B-hi(t): g2 3 6 7
+    //   staging   (>= two phases after the last read of the slot, LDS-DMA rule)  g0 B-lo(t+1), g1 B-hi(t+1) -> other stage;
+    //             g2 A-lo(t+2), g3 A-hi(t+2) -> this stage
+    //   waits     (read >= one phase after the wait)  g1 vmcnt(10): B-hi(t);  g3 vmcnt(10): A(t+1);  g7 vmcnt(7): B-lo(t+1)
     for (int t = 0; t < nkt; t += 2) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -249,43 +313,70 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 // column quarter 0
-                DCPT_LD_B(s, u, 0)
-                DCPT_LD_A(s, u)
-                if (u == 0) stage(2, s ^ 1, kt + 1, dead1);
-                __builtin_amdgcn_s_barrier();
-                DCPT_MFMA(0)
-                // quarter 1
-                DCPT_LD_B(s, u, 1)
+                X3_LDB(DCPT_LD_B(s, u, 0))
                 if (u == 0) {
-                    stage(3, s ^ 1, kt + 1, dead1);
-                    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    X3_LDA(DCPT_RD_A(s, 1))
+                    X3_STAGE(stage(2, s ^ 1, kt + 1, dead1));
+                } else {
+                    X3_LDA(DCPT_RD_A(s ^ 1, 0))
                 }
                 __builtin_amdgcn_s_barrier();
-                DCPT_MFMA(1)
+                DCPT_MFMA(u, 0)
+                // quarter 1
+                X3_LDB(DCPT_LD_B(s, u, 1))
+                DCPT_SPLIT_Q(0)
+                if (u == 0) {
+                    X3_STAGE(stage(3, s ^ 1, kt + 1, dead1));
+                    X3_STAGE(asm volatile("s_waitcnt vmcnt(10)" ::: "memory"));
+                }
+                __builtin_amdgcn_s_barrier();
+                DCPT_MFMA(u, 1)
                 // quarter 2
-                DCPT_LD_B(s, u, 2)
-                if (u == 1) stage(0, s, kt + 2, dead2);
+                X3_LDB(DCPT_LD_B(s, u, 2))
+                DCPT_SPLIT_Q(1)
+                if (u == 0) X3_STAGE(stage(0, s, kt + 2, dead2));
                 __builtin_amdgcn_s_barrier();
-                DCPT_MFMA(2)
+                DCPT_MFMA(u, 2)
                 // quarter 3
-                DCPT_LD_B(s, u, 3)
-                if (u == 1) {
-                    stage(1, s, kt + 2, dead2);
-                    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                X3_LDB(DCPT_LD_B(s, u, 3))
+                DCPT_SPLIT_Q(2)
+                DCPT_SPLIT_Q(3)
+                DCPT_PUT_A(u ^ 1)
+                if (u == 0) {
+                    X3_STAGE(stage(1, s, kt + 2, dead2));
+                    X3_STAGE(asm volatile("s_waitcnt vmcnt(10)" ::: "memory"));
+                } else {
+                    X3_STAGE(asm volatile("s_waitcnt vmcnt(7)" ::: "memory"));
                 }
                 __builtin_amdgcn_s_barrier();
-                DCPT_MFMA(3)
+                DCPT_MFMA(u, 3)
             }
         }
     }
-#undef DCPT_LD_A
+#undef DCPT_RD_A
+#undef DCPT_SPLIT_Q
+#undef DCPT_PUT_A
 #undef DCPT_LD_B
 #undef DCPT_MM
 #undef DCPT_MFMA
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
     dma_wait_all();
     __syncthreads();
+#ifdef X3_ABL_CLOCK
+    const uint64_t clk1_ = __builtin_readcyclecounter(), rt1_ = __builtin_amdgcn_s_memrealtime();
+#endif
 
+#ifdef X3_ABL_NOEPI
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[j][r];
+        if (keep == 12345.678f) p.C[0] = keep;
+        return;
+    }
+#endif
     // epilogue: the 128 x 128 sub-blocks (a, b) of the tile through LDS -> the fp32 kernel's row epilogues.  Rows of half a belong to waves
     // 4 a .. 4 a + 3 (32 rows each); every wave parks its own accumulators of the current half and both groups meet at the barriers.
     float* const Cs0 = reinterpret_cast<float*>(smem);
@@ -313,6 +404,7 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
         for (int q = 0; q < 4; ++q) {
             const int a = q >> 1, b = q & 1;
             float* const Cs = Cs0 + (q & 1) * (128 * 128);
+#ifndef X3_ABL_NOPARK
             if (ah == a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -324,11 +416,25 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
                     }
                 }
             }
+#else
+            if (acc[4 * b][0] == 12345.678f) Cs[tid] = acc[4 * b + 1][1];
+#endif
             __syncthreads();
+#ifndef X3_ABL_NOROWS
             epilogue_rows<EK, 128, 128, 512>(p, Cs, m0 + a * 128, n0 + b * 128, tid);
+#else
+            if (Cs[tid] == 12345.678f) p.C[tid] = Cs[tid + 1];
+#endif
             if constexpr (EK == E_DOTCOL) __syncthreads();
         }
     }
+#ifdef X3_ABL_CLOCK
+    __syncthreads();
+    if (tid == 0 && lin == 0) {   // main-loop shader cycles and 100-MHz ticks of block 0 into C[0][0..1]
+        p.C[0] = (float)(clk1_ - clk0_);
+        p.C[1] = (float)(rt1_ - rt0_);
+    }
+#endif
 }
 
 // ---- weight-gradient (TN) GEMM in the same arithmetic:  G[n][k] = sum_m X[m][n] * Y[m][k]  over a chunk of pixels -> fp32 slab ------------
@@ -412,13 +518,13 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
     float cs_lo = 0.f, cs_hi = 0.f;
     const bool do_cs = p.colsum != nullptr && tid < 128;
 
-// gather + split fragment (X or Y of this wave) of fp32 stage ST into plane buffer PB
-#define DCPT_CONVERT(SRC, ST, PB, F)                                                                                               \
+// gather the fragment (X or Y of this wave) of fp32 stage ST: 8 consecutive pixels of this lane's column
+#define DCPT_GATHER(SRC, ST) _Pragma("unroll") for (int e = 0; e < 8; ++e) gr[e] = *(lds_f1_p)((SRC) + (ST)*TSTG + e * 512);
+// split the gathered fragment and write its three pieces into plane buffer PB as fragment F
+#define DCPT_SPLITW(PB, F)                                                                                                         \
     {                                                                                                                             \
-        float r_[8];                                                                                                              \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = *(lds_f1_p)((SRC) + (ST)*TSTG + e * 512);                           \
         bf16x8 q0_, q1_, q2_;                                                                                                     \
-        split8s(r_, q0_, q1_, q2_);                                                                                               \
+        split8s(gr, q0_, q1_, q2_);                                                                                               \
         *(lds_wr_p)(pl_wr + (PB)*TPL + ((F)*3 + 0) * 1024) = q0_;                                                                 \
         *(lds_wr_p)(pl_wr + (PB)*TPL + ((F)*3 + 1) * 1024) = q1_;                                                                 \
         *(lds_wr_p)(pl_wr + (PB)*TPL + ((F)*3 + 2) * 1024) = q2_;                                                                 \
@@ -433,15 +539,23 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
         cs_lo += s0_;                                                                                                             \
         cs_hi += s1_;                                                                                                             \
     }
+    float gr[8];   // the gathered fragment between its read phase and its split phase
 
-    // prologue: raw steps 0 and 1 in flight, step 0 converted by everybody
-    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-    stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); stage(1, 1, 1);
+    // prologue: raw step 0 -> stage 0, raw step 1 -> stage 1; step 0 converted by everybody; then X(2) -> stage 0 (the loop's order of
+    // outstanding DMAs before its first phase is ..., Y(t+1), X(t+2))
+    stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
+    stage(0, 1, 1); stage(1, 1, 1); stage(2, 1, 1); stage(3, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
-    DCPT_CONVERT(cvx, 0, 0, wave)
-    DCPT_CONVERT(cvy, 0, 0, 8 + wave)
+    DCPT_GATHER(cvx, 0)
+    DCPT_SPLITW(0, wave)
+    DCPT_GATHER(cvy, 0)
+    DCPT_SPLITW(0, 8 + wave)
     if (do_cs && tile_k == 0) DCPT_COLSUM(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(0, 0, 2); stage(1, 0, 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // X(1) landed (Y(1), X(2) may be in flight)
     __syncthreads();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind from here on
 
@@ -449,7 +563,11 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
 #define DCPT_RD_Y(PB, H, F)                                                                                                        \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                 \
         fb[H][j][pl] = *(lds_frag_p)(pl_rd + (PB)*TPL + (((F) + j) * 3 + pl) * 1024);
+#ifdef X3_ABL_NOMFMA
+#define DCPT_MM(ACC, I, BH, PA, PB_) asm volatile("" ::"v"(fa[PA]), "v"(fb[BH][I][PB_]))
+#else
 #define DCPT_MM(ACC, I, BH, PA, PB_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[BH][I][PB_], ACC, 0, 0, 0)
+#endif
 #define DCPT_MFMA(AH, BH)                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                                                \
@@ -463,46 +581,67 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
     __builtin_amdgcn_sched_barrier(0);                                                                                            \
     __builtin_amdgcn_s_barrier();
 
-    // Step t (plane buffer t & 1 holds its fragments; fp32 stage (t + 1) & 1 holds raw step t + 1, stage t & 1 receives raw step t + 2):
-    //   ph0  read X-lo, Y-lo                                              MFMA (lo,lo)
-    //   ph1  read Y-hi; DMA raw(t+2) X-lo, Y-lo; vmcnt(2): raw(t+1) landed      MFMA (lo,hi)
-    //   ph2  read X-hi; DMA raw(t+2) Y-hi, X-hi; convert X fragment of raw(t+1)  MFMA (hi,hi)
-    //   ph3  convert Y fragment of raw(t+1); column sums of raw(t+1)             MFMA (hi,lo)
-    // (LDS-DMA rules: a raw stage is re-staged two phases after its last read -- ph3 -> ph1 --, read one phase after the wait that
-    // retired it; a plane buffer is rewritten four phases after its last read and read a phase after the writers' lgkmcnt(0) + barrier.)
+#ifdef X3_ABL_NORD
+#define X3_RD(...)
+    DCPT_RD_X(0, fx_lo)
+    DCPT_RD_Y(0, 0, fy_lo)
+    DCPT_RD_Y(0, 1, fy_hi)
+#else
+#define X3_RD(...) __VA_ARGS__
+#endif
+#ifdef X3_ABL_NOCONV
+#define X3_CONV(...)
+#else
+#define X3_CONV(...) __VA_ARGS__
+#endif
+    // Step t: plane buffer u = t & 1 holds its fragments; raw stage u ^ 1 holds raw step t + 1, converted during this step into plane
+    // buffer u ^ 1.  The load half of every phase is kept short of the 384 cycles of the other group's 12 MFMAs: no phase both reads and
+    // uses the same data (the gather of a fragment is issued a phase before its 44-operation split), and nothing waits for LDS writes
+    // before ph3.
+    //   ph0  read X-lo, Y-lo;  gather X of raw(t+1);  column sums of raw(t+1);  DMA Y(t+2) -> stage u     MFMA (lo,lo)
+    //   ph1  read Y-hi;  split + write X;  vmcnt(4): Y(t+1) landed                                       MFMA (lo,hi)
+    //   ph2  read X-hi;  gather Y of raw(t+1);  DMA X(t+3) -> stage u ^ 1                                MFMA (hi,hi)
+    //   ph3  split + write Y;  vmcnt(4): X(t+2) landed;  lgkmcnt(0): plane t + 1 complete                MFMA (hi,lo)
+    // LDS-DMA rules: the X halves of a raw stage are last read at ph0 (gather, column sums) and re-staged at ph2, the Y halves read at
+    // ph2 and re-staged at ph0 of the next step (>= two phases); every half is read >= one phase after the wait that retired it (X: ph3 ->
+    // ph0, Y: ph1 -> ph2); five phases of flight for every DMA.  A plane buffer is rewritten from ph1 on, three phases after its last
+    // read (X-hi, ph2 of the step before).
     for (int64_t t = 0; t < nmt; t += 2) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {   // u = parity of the step: plane buffer u, raw stage u receives step t + u + 2
+        for (int u = 0; u < 2; ++u) {   // u = parity of the step
             const int64_t tt = t + u;
             // ph0
-            DCPT_RD_X(u, fx_lo)
-            DCPT_RD_Y(u, 0, fy_lo)
+            X3_RD(DCPT_RD_X(u, fx_lo))
+            X3_RD(DCPT_RD_Y(u, 0, fy_lo))
+            X3_CONV(DCPT_GATHER(cvx, u ^ 1))
+            if (do_cs && tt + 1 < nmt && (int)((tt + 1) % tilesK) == tile_k) DCPT_COLSUM(u ^ 1)
+            X3_STAGE(stage(2, u, tt + 2);)
+            X3_STAGE(stage(3, u, tt + 2);)
             __builtin_amdgcn_s_barrier();
             DCPT_MFMA(0, 0)
             // ph1
-            DCPT_RD_Y(u, 1, fy_hi)
-            stage(0, u, tt + 2);
-            stage(2, u, tt + 2);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            X3_RD(DCPT_RD_Y(u, 1, fy_hi))
+            X3_CONV(DCPT_SPLITW(u ^ 1, wave))
+            X3_STAGE(asm volatile("s_waitcnt vmcnt(4)" ::: "memory");)
             __builtin_amdgcn_s_barrier();
             DCPT_MFMA(0, 1)
             // ph2
-            DCPT_RD_X(u, fx_hi)
-            stage(3, u, tt + 2);
-            stage(1, u, tt + 2);
-            DCPT_CONVERT(cvx, u ^ 1, u ^ 1, wave)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            X3_RD(DCPT_RD_X(u, fx_hi))
+            X3_CONV(DCPT_GATHER(cvy, u ^ 1))
+            X3_STAGE(stage(0, u ^ 1, tt + 3);)
+            X3_STAGE(stage(1, u ^ 1, tt + 3);)
             __builtin_amdgcn_s_barrier();
             DCPT_MFMA(1, 1)
             // ph3
-            DCPT_CONVERT(cvy, u ^ 1, u ^ 1, 8 + wave)
-            if (do_cs && tt + 1 < nmt && (int)((tt + 1) % tilesK) == tile_k) DCPT_COLSUM(u ^ 1)
+            X3_CONV(DCPT_SPLITW(u ^ 1, 8 + wave))
+            X3_STAGE(asm volatile("s_waitcnt vmcnt(4)" ::: "memory");)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             DCPT_MFMA(1, 0)
         }
     }
-#undef DCPT_CONVERT
+#undef DCPT_GATHER
+#undef DCPT_SPLITW
 #undef DCPT_COLSUM
 #undef DCPT_RD_X
 #undef DCPT_RD_Y
@@ -512,6 +651,21 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
     dma_wait_all();
     __syncthreads();
 
+#ifdef X3_ABL_NOEPI
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[a][b][i][r];
+        if (keep == 12345.678f) p.slab[0] = keep;
+        return;
+    }
+#endif
     // slab tile [256 n][256 k] of this split: the four 128 x 128 quadrants through LDS (two alternating 64 KB buffers) into the fp32
     // kernel's plain row epilogue -- 16-byte stores, 512-byte runs (4-byte stores straight from the accumulators cost ~6x per byte)
     GemmNT sp{};

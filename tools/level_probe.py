@@ -1,5 +1,5 @@
 """Time one NAFBlock forward / backward at every level of the bench configuration (B=32, 256^2, width 64).
-    python tools/level_probe.py [bf16]"""
+    python tools/level_probe.py [bf16|x3]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
@@ -8,6 +8,8 @@ from dcpt_amd.keyed_init import fill_module_
 from dcpt_amd import functional as DF
 BF = len(sys.argv) > 1 and sys.argv[1] == 'bf16'
 ES = 2 if BF else 4
+if len(sys.argv) > 1 and sys.argv[1] == 'x3':
+    DF.set_gemm_precision('bf16x3')
 dev = torch.device('cuda:0')
 def ev(): return torch.cuda.Event(enable_timing=True)
 tot = 0.0

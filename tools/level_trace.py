@@ -1,5 +1,5 @@
 """One NAFBlock forward + backward at one level of the bench configuration, 5 times (run under rocprofv3 --kernel-trace).
-    python tools/level_trace.py <level 0..4> [bf16]      (SIDE=1 in the environment: weight gradients on the side stream)"""
+    python tools/level_trace.py <level 0..4> [bf16|x3]   (x3: fp32 storage, GEMMs in the bf16x3 split-operand mode; SIDE=1 in the environment: weight gradients on the side stream)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant  # noqa: E401,F401  (DCPT_TOOL_LIB)
@@ -15,6 +15,8 @@ x = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channe
 go = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
 if bf:
     x, go = x.bfloat16(), go.bfloat16()
+if len(sys.argv) > 2 and sys.argv[2] == "x3":
+    DF.set_gemm_precision("bf16x3")
 x.requires_grad_(True)
 for _ in range(5):
     y = DF.nafblock_bf16(x, blk.fused_params()) if bf else blk(x)
