@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 _lock = threading.Lock()
 
@@ -91,6 +91,7 @@ SIGNATURES = {
                                       f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_set_gemm_x3": (cint, [C.c_void_p, sz, cint]),
     "dcpt_nafblock_wpack_bf16_bytes": (sz, [cint]),
+    "dcpt_nafblock_bf16_fused_ffn": (cint, [cint]),
     "dcpt_nafblock_wpack_bf16": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, cint, stream_t]),
     "dcpt_nafblock_fwd_bf16_packed": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, f32p, f32p, C.POINTER(NafBlockSavedBf16), C.c_void_p, sz,
                                              cint, cint, cint, cint, stream_t]),

@@ -1,0 +1,30 @@
+// Fused LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual of a NAFBlock in bf16 storage for the narrow levels (ffn_bf16.hip).
+#pragma once
+#include "bf16.h"
+
+struct FfnFwdB {
+    const bf16_t* y;      // [M][C] the block's mid-point (input of LayerNorm2 and of the residual)
+    const float *lnw, *lnb;      // [C]
+    const bf16_t *W4, *W5;       // bf16 operand copies [2C][C], [C][C] (k contiguous)
+    const float *b4, *b5, *gamma;
+    bf16_t* out;          // [M][C]  y + (conv5(SG(conv4(LN2(y)))) + b5) * gamma
+    bf16_t* v;            // [M][2C] conv4 output (saved for backward) or null (inference)
+    bf16_t *xn2, *g;      // [M][C] LN2(y), SimpleGate(v): both or neither (null: the fused backward recomputes them)
+    float *mu, *rstd;     // [M] LayerNorm statistics or null
+    int64_t M;
+    float eps;
+};
+bool ffn_fwd_bf16_ok(int C);
+int launch_ffn_fwd_bf16(const FfnFwdB& p, int C, hipStream_t s);
+
+struct FfnBwdB {
+    const bf16_t *dout, *v, *y;   // [M][C], [M][2C], [M][C]
+    const bf16_t *wT5, *wT4;      // dgrad operand copies: wT5[k][n] = W5[n][k] gamma[n]  ([C][C]),  wT4[c][j] = W4[j][c]  ([C][2C])
+    const float* lnw;             // [C]
+    bf16_t *dv, *dy;              // [M][2C] (operand of conv4's weight-gradient GEMM), [M][C] = dout + LayerNorm2 backward
+    float* lnpart;                // [ffn_bwd_bf16_waves(M)][2][C]: sum_rows dxn2 * xhat, sum_rows dxn2
+    int64_t M;
+    float eps;
+};
+int ffn_bwd_bf16_waves(int64_t M);   // rows of lnpart the launch writes (one per wave)
+int launch_ffn_bwd_bf16(const FfnBwdB& p, int C, hipStream_t s);

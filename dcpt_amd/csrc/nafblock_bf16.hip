@@ -17,10 +17,17 @@
 // Weight gradients go through the transposing-LDS-read TN GEMM into fp32 slabs and the fp32 path's deterministic reducers, on
 // the same side stream as the fp32 block.
 #include "bf16_ops.h"
+#include "ffn_bf16.h"
 #include "side.h"
 #include "../../include/dcpt_hip.h"
 
 namespace {
+
+// fused second half of the block at the narrow levels (ffn_bf16.hip)
+bool ffn_fused(int C) {
+    static const int on = dcpt_tuning("DCPT_FFN_FUSED", 1);
+    return on && ffn_fwd_bf16_ok(C);
+}
 
 struct FwdWsB {
     float* w2p;
@@ -58,6 +65,7 @@ struct BwdWsB {
     float *u4, *c4, *u1, *c1, *rowpart;
     int rp_sg, rp_dw;
     bool lrs;
+    float* ffn_part;   // LayerNorm2 column partials of the fused narrow-level backward: [waves][2][C]
 };
 
 size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* out) {
@@ -129,6 +137,7 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
             w.lnpart2 = a.get<float>(need);
         }
     }
+    w.ffn_part = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
     if (out) *out = w;
     return a.off;
 }
@@ -189,6 +198,7 @@ extern "C" size_t dcpt_nafblock_fwd_bf16_ws_bytes(int B, int H, int W, int C) { 
 extern "C" size_t dcpt_nafblock_bwd_bf16_ws_bytes(int B, int H, int W, int C) { return bwd_layout(B, H, W, C, nullptr, 0, nullptr); }
 
 extern "C" size_t dcpt_nafblock_wpack_bf16_bytes(int C) { return pack_layout(C, nullptr, 0, nullptr); }
+extern "C" int dcpt_nafblock_bf16_fused_ffn(int C) { return ffn_fused(C) ? 1 : 0; }
 
 extern "C" int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream) {
     DCPT_CHECK_ARG(p && packed && C > 0 && C % 8 == 0 && C <= 1024, "nafblock_wpack_bf16: null argument or bad C=%d", C);
@@ -204,8 +214,10 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && inp && out && sv, "nafblock_fwd_bf16: null argument");
     DCPT_CHECK_ARG(shape_ok(B, H, W, C), "nafblock_fwd_bf16: bad shape B=%d H=%d W=%d C=%d (C %% 8 == 0, C <= 1024)", B, H, W, C);
-    DCPT_CHECK_ARG(sv->t1 && sv->t2 && sv->y && sv->v && sv->xn1 && sv->xn2 && sv->g && sv->mu1 && sv->rstd1 && sv->mu2 && sv->rstd2 &&
-                       sv->pooled && sv->s, "nafblock_fwd_bf16: saved buffers missing");
+    DCPT_CHECK_ARG(sv->t1 && sv->t2 && sv->y && sv->xn1 && sv->mu1 && sv->rstd1 && sv->pooled && sv->s, "nafblock_fwd_bf16: saved buffers missing");
+    const bool infer = !sv->v && !sv->xn2 && !sv->g && !sv->mu2 && !sv->rstd2;   // inference with the fused second half: nothing of it is kept
+    DCPT_CHECK_ARG((sv->v && sv->xn2 && sv->g && sv->mu2 && sv->rstd2) || (infer && ffn_fused(C)),
+                   "nafblock_fwd_bf16: saved v / xn2 / g / mu2 / rstd2 missing (all five may be null only where dcpt_nafblock_bf16_fused_ffn(C) is 1)");
     FwdWsB w;
     const size_t need = fwd_layout(B, H, W, C, ws, ws_bytes, &w);
     if (need > ws_bytes || ws == nullptr) {
@@ -247,6 +259,12 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     g.res = inp; g.ldres = C; g.cscale = p->beta;
     g.nb = B; g.sA = (int64_t)P * C; g.sB = (int64_t)C * C; g.sC = (int64_t)P * C; g.sR = (int64_t)P * C;
     DCPT_TRY(launch_gemm_nt_bf16(g, EB_RESID, s));
+    if (ffn_fused(C)) {   // narrow levels: LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual in one pass over y (ffn_bf16.hip)
+        FfnFwdB f{};
+        f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.W4 = w.W4; f.W5 = w.W5; f.b4 = p->conv4_b; f.b5 = p->conv5_b; f.gamma = p->gamma;
+        f.out = out; f.v = sv->v; f.xn2 = sv->xn2; f.g = sv->g; f.mu = sv->mu2; f.rstd = sv->rstd2; f.M = M; f.eps = eps;
+        return launch_ffn_fwd_bf16(f, C, s);
+    }
     DCPT_TRY(launch_ln_fwd_bf16(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
     g = GemmNTB{};
     g.M = M; g.A = sv->xn2; g.lda = C; g.K = C; g.Bw = w.W4; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b; g.gate = sv->g;
@@ -313,31 +331,45 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
     hipStream_t sw = side_stream(sd, s);
     DCPT_TRY(side_fork(sd, 0, s));
     GemmNTB g{};
-    // B1: dv = SimpleGate'(dout * gamma * W5; v)   (+ the row sums of LN2's backward, linear in dv)
-    g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = w.dv; g.ldc = C2; g.aux = sv->v;
-    if (w.lrs) {
-        g.rowpart = w.rowpart; g.uvec = w.u4; g.cvec = w.c4;
-    }
-    DCPT_TRY(launch_gemm_nt_bf16(g, EB_SGBWD, s));
-    // B2: conv5 / gamma gradients
-    DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
-    DCPT_TRY(side_fork(sd, 1, s));
-    // B3: gradient of LN2's output
-    g = GemmNTB{};
-    g.M = M; g.A = w.dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = w.gln; g.ldc = C;
-    if (w.lrs) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv W4^T), the LayerNorm's incoming gradient is never written
-        g.C = w.dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
-        g.rowpart = w.rowpart; g.rowparts = w.rp_sg;
-        DCPT_TRY(launch_gemm_nt_bf16(g, EB_LNBWD2, s));
+    const bool ffn = ffn_fused(C);
+    if (ffn) {
+        // B1 + B3 + B5 in one pass (ffn_bf16.hip): dv for conv4's weight gradient and dy = dout + LayerNorm2 backward
+        FfnBwdB f{};
+        f.dout = dout; f.v = sv->v; f.y = sv->y; f.wT5 = w.wT5; f.wT4 = w.wT4; f.lnw = p->norm2_w; f.dv = w.dv; f.dy = w.dy;
+        f.lnpart = w.ffn_part; f.M = M; f.eps = 1e-6f;
+        DCPT_TRY(launch_ffn_bwd_bf16(f, C, s));
+        DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
+        DCPT_TRY(side_fork(sd, 1, s));
+        DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
+        DCPT_TRY(side_fork(sd, 2, s));
+        DCPT_TRY(launch_colpart_reduce(w.ffn_part, ffn_bwd_bf16_waves(M), 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     } else {
-        DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        // B1: dv = SimpleGate'(dout * gamma * W5; v)   (+ the row sums of LN2's backward, linear in dv)
+        g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = w.dv; g.ldc = C2; g.aux = sv->v;
+        if (w.lrs) {
+            g.rowpart = w.rowpart; g.uvec = w.u4; g.cvec = w.c4;
+        }
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_SGBWD, s));
+        // B2: conv5 / gamma gradients
+        DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
+        DCPT_TRY(side_fork(sd, 1, s));
+        // B3: gradient of LN2's output
+        g = GemmNTB{};
+        g.M = M; g.A = w.dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = w.gln; g.ldc = C;
+        if (w.lrs) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv W4^T), the LayerNorm's incoming gradient is never written
+            g.C = w.dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
+            g.rowpart = w.rowpart; g.rowparts = w.rp_sg;
+            DCPT_TRY(launch_gemm_nt_bf16(g, EB_LNBWD2, s));
+        } else {
+            DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        }
+        // B4: conv4 gradients
+        DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
+        // B5: dy = dout + LN2-backward
+        if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
+        DCPT_TRY(side_fork(sd, 2, s));
+        DCPT_TRY(launch_colpart_reduce(w.lnpart, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     }
-    // B4: conv4 gradients
-    DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
-    // B5: dy = dout + LN2-backward
-    if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
-    DCPT_TRY(side_fork(sd, 2, s));
-    DCPT_TRY(launch_colpart_reduce(w.lnpart, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2 * s) (+ SCA's per-image channel sums out of the epilogue when an image is a whole number of 128-pixel tiles)
     g = GemmNTB{};
     g.M = M; g.A = w.dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = w.dts; g.ldc = C;

@@ -170,14 +170,21 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         M = B * H * W
         out = _empty_nhwc_bf16(B, Cc, H, W, dev)
         t1 = _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
-        v = _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
-        acts = torch.empty((5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp), LN2(y), SimpleGate(v)
-        stats = torch.empty((4, M), dtype=torch.float32, device=dev)
+        # no backward coming (torch.no_grad / nothing requires grad) and the block's second half is one kernel at this width: the five
+        # tensors only that backward reads (v, LN2(y), SimpleGate(v), LN2's statistics) are neither allocated nor written
+        infer = not any(ctx.needs_input_grad) and bool(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
+        v = None if infer else _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
+        acts = torch.empty((3 if infer else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
+        stats = torch.empty((2 if infer else 4, M), dtype=torch.float32, device=dev)
         sca = torch.empty((2, B, Cc), dtype=torch.float32, device=dev)           # pooled, s
         ps = NafBlockParams(*[p.data_ptr() for p in params])
-        sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                                    stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
-                                    acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
+        if infer:
+            sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), 0, stats[0].data_ptr(), stats[1].data_ptr(), 0, 0,
+                                        sca[0].data_ptr(), sca[1].data_ptr(), acts[2].data_ptr(), 0, 0)
+        else:
+            sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(),
+                                        stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
+                                        acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
         ws = _workspace(dev, lib.dcpt_nafblock_fwd_bf16_ws_bytes(B, H, W, Cc))
         if packed is None:
             check(lib.dcpt_nafblock_fwd_bf16(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
@@ -186,7 +193,8 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
             check(lib.dcpt_nafblock_fwd_bf16_packed(C.byref(ps), packed.data_ptr(), packed.numel(), inp.data_ptr(), out.data_ptr(), C.byref(sv),
                                                     ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd_bf16_packed")
         ctx.packed = packed   # (a plain byte buffer owned by the module; the backward of THIS forward reads the same pack)
-        ctx.save_for_backward(inp, t1, v, acts, stats, sca, *params)
+        if not infer:
+            ctx.save_for_backward(inp, t1, v, acts, stats, sca, *params)
         return out
 
     @staticmethod

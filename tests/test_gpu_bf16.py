@@ -65,7 +65,9 @@ def test_cast_roundtrip(dev):
 # (1, 16, 11, 70) / (1, 24, 6, 50) / (1, 8, 70, 9): the depthwise ring kernels' multi-column-tile, 8-piece and two-row-part tilings
 # (24, 512, 32, 32) / (25, 512, 31, 32) / (6, 256, 64, 64): large enough (>= 192 tiles of 256 x 256) for the 256 x 256-tile NT kernel
 # (gemm_bf16_256.hip) to take every conv -- all six epilogues, the per-image batched conv3, and a ragged last row tile (M = 24800)
-@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8),
+# (3, 64, 5, 7) / (1, 64, 9, 13) / (5, 64, 48, 40): the fused second half of the narrow levels (ffn_bf16.hip) with a ragged last group of
+# 32 pixels (M = 105, 117) and with more groups than one launch has waves (M = 9600: every wave walks its ring more than three times)
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (3, 64, 5, 7), (1, 64, 9, 13), (5, 64, 48, 40), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8),
                                    (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9), (24, 512, 32, 32), (25, 512, 31, 32), (6, 256, 64, 64)])
 def test_nafblock_bf16_oracle(dev, shape):
     from dcpt_amd import functional as DF
@@ -654,3 +656,25 @@ def test_packed_weights_cache_is_exact_and_follows_the_parameters(dev):
     assert not torch.equal(ref2[0], ref[0])
     assert torch.equal(ref2[0], got2[0]) and torch.equal(ref2[1], got2[1]) and all(torch.equal(a, b) for a, b in zip(ref2[2], got2[2]))
     assert not any("packed" in k for k in blk.state_dict())
+
+
+@pytest.mark.gpu
+def test_fused_second_half_inference_drops_saved_tensors(dev):
+    """Where the second half of the block is one kernel (dcpt_nafblock_bf16_fused_ffn(C) = 1: C = 64, ffn_bf16.hip) a forward that no
+    backward will follow passes no v / LN2(y) / gate / LN2-statistics buffers; the output is bit-identical to the training forward's,
+    ragged last group of 32 pixels included."""
+    from dcpt_amd import _lib, functional as DF
+
+    lib = _lib.load()
+    assert lib.dcpt_nafblock_bf16_fused_ffn(64) == 1 and lib.dcpt_nafblock_bf16_fused_ffn(512) == 0
+    for shape in [(3, 64, 5, 7), (2, 64, 32, 32)]:
+        c = shape[1]
+        tag = f"bf.inf.{c}.{shape[2]}."
+        P = _params(c, tag)
+        Pd = {k: P[v].to(dev).requires_grad_(True) for k, v in FUSED.items()}
+        x = keyed_input(tag + "x", shape, lo=-1.5, hi=1.5).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        y_train = DF.nafblock_bf16(x.clone().requires_grad_(True), Pd)
+        with torch.no_grad():
+            y_inf = DF.nafblock_bf16(x, Pd)
+        torch.cuda.synchronize()
+        assert torch.equal(y_train.detach(), y_inf)
