@@ -31,6 +31,9 @@ __device__ __forceinline__ void buf_st4(rsrc_t r, uint32_t voff, float4 f) {
     v.y = f.y;
     v.z = f.z;
     v.w = f.w;
+#ifdef DCPT_ABL_NOSTORE   // ablation builds (tools/build_variant.sh): the store is issued but dropped by the range check
+    voff |= ROW_SENT;
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, DCPT_ST_AUX);
 }
 __device__ __forceinline__ float buf_ld1(rsrc_t r, uint32_t voff) {

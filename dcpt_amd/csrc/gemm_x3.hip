@@ -128,6 +128,134 @@ __device__ __forceinline__ void split_pair(const float x0, const float x1, uint3
     w2 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, s0), 0x07060302u);
 }
 
+// ---- epilogue straight from the accumulators (no LDS parking) ------------------------------------------------------------------------
+// A 32 x 32 accumulator tile holds, on lane l, column l & 31 and the rows (r & 3) + 8 (r >> 2) + 4 (l >> 5): four registers r = 4 g .. 4 g + 3
+// are four consecutive ROWS of one column.  A 4 x 4 transpose over the four lanes of a quad (two DPP butterfly steps, 16 VALU operations
+// per four registers) turns them into four consecutive COLUMNS of one row -- a float4 at (row 8 g + 4 h + q, columns 4 cq .., q = l & 3,
+// cq = (l & 31) >> 2, h = l >> 5) -- which is what the row epilogues of the fp32 kernel compute on: 16-byte loads and stores, every
+// instruction covering eight rows x 128 contiguous bytes (whole cache lines).  The tile never visits LDS and no barrier separates the
+// loop from the first store.  NOT the default (-DX3_EPI_REGS selects it; parity-green, tools/x3_check.sh): measured equal to the LDS-parked
+// row epilogue on every level-3 launch (plain 169.9 vs 167.1 us, the step 97.8 vs 96.8 ms) -- the ~40 us a launch spends after its
+// k-loop are not the parking (9 us when ablated alone) but the drain of 67-134 MB of output through an L2 whose clock the loop has just
+// pulled down to 1.35 GHz (profiles/r3/power_and_clock.txt: the same epilogue costs 9 us when the loop is compiled out).
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float4 quad_transpose(float r0, float r1, float r2, float r3, bool b0, bool b1) {
+    // butterfly over lane bit 0 (quad_perm [1,0,3,2]) then bit 1 ([2,3,0,1]): new[i][q] = (q_b == i_b) ? old[i][q] : old[i ^ b][q ^ b]
+    const float s0 = dpp_quad<0xB1>(r1), s1 = dpp_quad<0xB1>(r0), s2 = dpp_quad<0xB1>(r3), s3 = dpp_quad<0xB1>(r2);
+    const float n0 = b0 ? s0 : r0, n1 = b0 ? r1 : s1, n2 = b0 ? s2 : r2, n3 = b0 ? r3 : s3;
+    const float t0 = dpp_quad<0x4E>(n2), t2 = dpp_quad<0x4E>(n0), t1 = dpp_quad<0x4E>(n3), t3 = dpp_quad<0x4E>(n1);
+    return make_float4(b1 ? t0 : n0, b1 ? t1 : n1, b1 ? n2 : t2, b1 ? n3 : t3);
+}
+
+// one wave's 32 rows x 256 columns (acc[j]: columns 32 j ..): rows mw .. mw + 31 of the problem, columns n0 + 32 j (plain) resp. the two
+// gate halves n0h + 32 j and Ch + n0h + 32 (j - 4) (E_BIASGATE).  red: 1 KiB of LDS per wave for the column sums of E_DOTCOL.
+template <int EK>
+__device__ __forceinline__ void epilogue_regs(const GemmNT& p, floatx16 (&acc)[8], int64_t mw, int n0, int lane, float* __restrict__ red) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const int q = lane & 3, cq = (lane & 31) >> 2, h = lane >> 5;
+    const int ldres = p.ldres ? p.ldres : p.ldc;
+    const int64_t mb = mw < p.M ? mw : 0;
+    const rsrc_t rsC = make_rsrc(p.C + mb * (int64_t)p.ldc);
+    uint32_t rowC[4], rowR[4], rowX[4];   // byte offsets of this lane's four rows (g = 0..3) in C / res / aux, ROW_SENT past M
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int rl = 8 * g + 4 * h + q;
+        const bool ok = mw + rl < p.M;
+        rowC[g] = ok ? (uint32_t)rl * (uint32_t)p.ldc * 4u : ROW_SENT;
+        rowR[g] = ok ? (uint32_t)rl * (uint32_t)ldres * 4u : ROW_SENT;
+        rowX[g] = ok ? (uint32_t)rl * (uint32_t)p.N * 8u : ROW_SENT;
+    }
+    if constexpr (EK == E_BIASGATE) {
+        const int Ch = p.N / 2;
+        const rsrc_t rsG = make_rsrc(p.gate + mb * (int64_t)Ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 32 * j + 4 * cq;
+            float4 bA = f4_zero(), bB = f4_zero();
+            if (p.bias) {
+                bA = ldg4(p.bias + n);
+                bB = ldg4(p.bias + Ch + n);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v1 = f4_add(quad_transpose(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3], b0, b1), bA);
+                const float4 v2 = f4_add(quad_transpose(acc[j + 4][4 * g], acc[j + 4][4 * g + 1], acc[j + 4][4 * g + 2], acc[j + 4][4 * g + 3], b0, b1), bB);
+                buf_st4(rsC, rowC[g] + 4u * (uint32_t)n, v1);
+                buf_st4(rsC, rowC[g] + 4u * (uint32_t)(Ch + n), v2);
+                const bool ok = rowC[g] != ROW_SENT;
+                buf_st4(rsG, ok ? ((uint32_t)(8 * g + 4 * h + q) * (uint32_t)Ch + (uint32_t)n) * 4u : ROW_SENT, f4_mul(v1, v2));
+            }
+        }
+    } else {
+        rsrc_t rsR = rsC, rsX = rsC;
+        if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL) rsR = make_rsrc(p.res + mb * (int64_t)ldres);
+        if constexpr (EK == E_SGBWD) rsX = make_rsrc(p.aux + mb * (2 * (int64_t)p.N));
+        float4 dot[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + 32 * j + 4 * cq;
+            const uint32_t nb = 4u * (uint32_t)n;
+            float4 bias = f4_zero(), cs = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (EK == E_BIAS || EK == E_RESID || EK == E_MUL) {
+                if (p.bias) bias = ldg4(p.bias + n);
+            }
+            if constexpr (EK == E_RESID || EK == E_ADDSCALED) {
+                if (p.cscale) cs = ldg4(p.cscale + n);
+            }
+            float4 pre1[4], pre2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (EK == E_RESID || EK == E_ADDSCALED || EK == E_MUL || EK == E_DOTCOL) pre1[g] = buf_ld4(rsR, rowR[g] == ROW_SENT ? ROW_SENT : rowR[g] + nb);
+                if constexpr (EK == E_SGBWD) {
+                    const uint32_t xo = rowX[g] == ROW_SENT ? ROW_SENT : rowX[g] + nb;
+                    pre1[g] = buf_ld4(rsX, xo);
+                    pre2[g] = buf_ld4(rsX, xo == ROW_SENT ? ROW_SENT : xo + 4u * (uint32_t)p.N);
+                }
+            }
+            dot[j] = f4_zero();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = quad_transpose(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3], b0, b1);
+                const uint32_t o = rowC[g] == ROW_SENT ? ROW_SENT : rowC[g] + nb;
+                if constexpr (EK == E_PLAIN) {
+                    buf_st4(rsC, o, v);
+                } else if constexpr (EK == E_BIAS) {
+                    buf_st4(rsC, o, f4_add(v, bias));
+                } else if constexpr (EK == E_RESID) {
+                    buf_st4(rsC, o, f4_fma(f4_add(v, bias), cs, pre1[g]));
+                } else if constexpr (EK == E_ADDSCALED) {
+                    buf_st4(rsC, o, f4_fma(cs, pre1[g], v));
+                } else if constexpr (EK == E_MUL) {
+                    buf_st4(rsC, o, f4_mul(f4_add(v, bias), pre1[g]));
+                } else if constexpr (EK == E_SGBWD) {
+                    buf_st4(rsC, o, f4_mul(v, pre2[g]));
+                    buf_st4(rsC, o == ROW_SENT ? ROW_SENT : o + 4u * (uint32_t)p.N, f4_mul(v, pre1[g]));
+                } else {   // E_DOTCOL
+                    buf_st4(rsC, o, v);
+                    dot[j] = f4_fma(v, pre1[g], dot[j]);   // rows past M loaded 0
+                }
+            }
+        }
+        if constexpr (EK == E_DOTCOL) {
+            // column sums over the wave's 32 rows: the lanes q = 0..3 of a quad and the two halves h hold different rows of the same
+            // columns (fixed butterfly order); lane (q = 0, h = 0) of column group cq leaves the wave's partial in LDS
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float4 d = dot[j];
+#pragma unroll
+                for (int m = 1; m <= 2; m <<= 1) {
+                    d.x += __shfl_xor(d.x, m); d.y += __shfl_xor(d.y, m); d.z += __shfl_xor(d.z, m); d.w += __shfl_xor(d.w, m);
+                }
+                d.x += __shfl_xor(d.x, 32); d.y += __shfl_xor(d.y, 32); d.z += __shfl_xor(d.z, 32); d.w += __shfl_xor(d.w, 32);
+                if (q == 0 && h == 0) *reinterpret_cast<float4*>(red + 32 * j + 4 * cq) = d;
+            }
+        }
+    }
+}
+
 // LDS of one k-tile of 32: A-lo | A-hi as fp32 [128 rows][32 floats] (the fp32 kernel's swizzled image, 16 KB each), B-lo | B-hi as two
 // consecutive pieces each (24 KB each)
 constexpr int AHT = 16384, BHT = 2 * PIECE, STGF = 2 * AHT + 2 * BHT;   // 80 KB: two stages are the whole 160 KB of a CU
@@ -305,7 +433,11 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
     //   staging   (>= two phases after the last read of the slot, LDS-DMA rule)  g0 B-lo(t+1), g1 B-hi(t+1) -> other stage;
     //             g2 A-lo(t+2), g3 A-hi(t+2) -> this stage
     //   waits     (read >= one phase after the wait)  g1 vmcnt(10): B-hi(t);  g3 vmcnt(10): A(t+1);  g7 vmcnt(7): B-lo(t+1)
+#ifdef X3_ABL_NOLOOP
+    for (int t = 0; t < 0; t += 2) {
+#else
     for (int t = 0; t < nkt; t += 2) {
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int kt = t + s;
@@ -377,6 +509,7 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
         return;
     }
 #endif
+#ifndef X3_EPI_REGS
     // epilogue: the 128 x 128 sub-blocks (a, b) of the tile through LDS -> the fp32 kernel's row epilogues.  Rows of half a belong to waves
     // 4 a .. 4 a + 3 (32 rows each); every wave parks its own accumulators of the current half and both groups meet at the barriers.
     float* const Cs0 = reinterpret_cast<float*>(smem);
@@ -428,6 +561,21 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmX3 pin) {
             if constexpr (EK == E_DOTCOL) __syncthreads();
         }
     }
+#else
+    // epilogue straight from the accumulators (epilogue_regs): every wave stores its own 32 rows, both wave groups at once
+    {
+        float* const red = reinterpret_cast<float*>(smem) + wave * 256;
+        epilogue_regs<EK>(p, acc, m0 + ah * 128 + ar, n0, lane, red);
+        if constexpr (EK == E_DOTCOL) {
+            // colpart[row tile of 128][n]: the four waves of a half (32 rows each) in fixed order
+            __syncthreads();
+            const int a = tid >> 8, c = tid & 255;
+            const float* r4 = reinterpret_cast<const float*>(smem) + (4 * a) * 256 + c;
+            const float t = ((r4[0] + r4[256]) + r4[512]) + r4[768];
+            if (m0 + a * 128 < p.M && n0 + c < p.N) p.colpart[((m0 + a * 128) / 128) * (int64_t)p.N + n0 + c] = t;
+        }
+    }
+#endif
 #ifdef X3_ABL_CLOCK
     __syncthreads();
     if (tid == 0 && lin == 0) {   // main-loop shader cycles and 100-MHz ticks of block 0 into C[0][0..1]
