@@ -16,6 +16,8 @@ struct FfnFwdB {
 };
 bool ffn_fwd_bf16_ok(int C);
 int launch_ffn_fwd_bf16(const FfnFwdB& p, int C, hipStream_t s);
+// the first two links only, t1 = conv1(LN1(inp)) + b1:  y = inp, W4 / b4 = conv1, v = t1, xn2 = LN1(inp) (mu / rstd optional)
+int launch_ln_conv_bf16(const FfnFwdB& p, int C, hipStream_t s);
 
 struct FfnBwdB {
     const bf16_t *dout, *v, *y;   // [M][C], [M][2C], [M][C]
@@ -28,3 +30,5 @@ struct FfnBwdB {
 };
 int ffn_bwd_bf16_waves(int64_t M);   // rows of lnpart the launch writes (one per wave)
 int launch_ffn_bwd_bf16(const FfnBwdB& p, int C, hipStream_t s);
+// the last two links only, dx = dres + LN'(dz W; x):  v = dz [M][2C], wT4 = W^T, y = x, dout = dres, dy = dx
+int launch_conv_ln_bwd_tail_bf16(const FfnBwdB& p, int C, hipStream_t s);

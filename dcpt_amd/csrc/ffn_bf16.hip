@@ -36,7 +36,9 @@ typedef __attribute__((address_space(3))) unsigned char* lds_p;
 
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int C>
+// HEAD = 1: only the first two links, t1 = conv1(LayerNorm1(inp)) + b1 (the block's FIRST half up to the depthwise conv: `y` is the block
+// input, `v` receives t1, `xn2` LN1(inp) for conv1's weight gradient; W5 / b5 / gamma / out / g are not touched)
+template <int C, int HEAD>
 __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
     static_assert(C == 64, "ffn_fwd_bf16: C = 64");
     __shared__ __attribute__((aligned(16))) unsigned char smem[F_TAB + T_N * 4];
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const tab = reinterpret_cast<float*>(smem + F_TAB);
     for (int i = tid; i < T_N; i += 256)
-        tab[i] = i < T_B5 ? p.b4[i] : i < T_GM ? p.b5[i - T_B5] : i < T_LW ? p.gamma[i - T_GM] : i < T_LB ? p.lnw[i - T_LW] : p.lnb[i - T_LB];
+        tab[i] = i < T_B5 ? p.b4[i] : i < T_LW ? (HEAD ? 0.f : (i < T_GM ? p.b5[i - T_B5] : p.gamma[i - T_GM])) : i < T_LB ? p.lnw[i - T_LW] : p.lnb[i - T_LB];
     // weight fragments (A operands of the transposed products): rows n = 32 j + (lane & 31), k = 16 ks + 8 (lane >> 5) .. + 7
     const int fr = lane & 31, kh = lane >> 5;
     bf16x8 W4f[4][4], W5f[2][4];
@@ -52,10 +54,12 @@ __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) W4f[j][ks] = *reinterpret_cast<const bf16x8*>(p.W4 + (32 * j + fr) * C + 16 * ks + 8 * kh);
+    if constexpr (!HEAD) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) W5f[j][ks] = *reinterpret_cast<const bf16x8*>(p.W5 + (32 * j + fr) * C + 16 * ks + 8 * kh);
+            for (int ks = 0; ks < 4; ++ks) W5f[j][ks] = *reinterpret_cast<const bf16x8*>(p.W5 + (32 * j + fr) * C + 16 * ks + 8 * kh);
+    }
     __syncthreads();
 
     unsigned char* const wb = smem + wave * F_WAVE;
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
                 w.y = bf_pack(acc1[j][4 * g + 2], acc1[j][4 * g + 3]);
                 *reinterpret_cast<u32x2*>(wb + F_VST + fr * 256 + (((4 * j + g) ^ (fr & 15)) * 16) + kh * 8) = w;
             }
+        if constexpr (!HEAD) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -181,13 +186,14 @@ __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
                 o.w = yv.w + acc2[j][4 * g + 3] * gm.w;
                 *reinterpret_cast<u32x2*>(wb + F_OST + off) = bf4_pack(o);
             }
+        }
         lds_fence();
         // ---- ring: the slot of this group is free; wait for the next group BEFORE this group's stores are issued ----
         issue(gi + 3 * TW, s);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         // ---- stores: full 16-byte chunks, row-contiguous ----
         const int64_t r0 = gi * 32;
-        {
+        if constexpr (!HEAD) {
             const rsrc_t rsO = make_rsrc(p.out + r0 * C);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -206,14 +212,14 @@ __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
             }
         }
         if (p.xn2) {   // (kept for a caller whose backward still reads LN2(y) and the gate: two more passes)
-            const rsrc_t rsX = make_rsrc(p.xn2 + r0 * C), rsG = make_rsrc(p.g + r0 * C);
+            const rsrc_t rsX = make_rsrc(p.xn2 + r0 * C), rsG = make_rsrc((HEAD ? p.xn2 : p.g) + r0 * C);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + (lane >> 3), ch = lane & 7;
                 const uint32_t lo = (uint32_t)(row * 128 + ((ch ^ (row & 7)) * 16));
                 const uint32_t go = r0 + row < p.M ? (uint32_t)(row * 128 + ch * 16) : ROW_SENT;
                 __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(wb + F_XN + lo), rsX, go, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(wb + F_GT + lo), rsG, go, 0, 0);
+                if constexpr (!HEAD) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(wb + F_GT + lo), rsG, go, 0, 0);
             }
         }
         if (p.mu && hf == 0 && r0 + lr < p.M) {
@@ -238,7 +244,9 @@ __global__ __launch_bounds__(256) void ffn_fwd_bf16_kernel(const FfnFwdB p) {
 constexpr int B_DO = 0, B_V = 4096, B_Y = 12288, B_SLOT = 16384, B_WAVE = 2 * B_SLOT;
 constexpr int B_TAB = FW * B_WAVE;   // fp32 table: lnw[64]
 
-template <int C>
+// TAIL = 1: only the last two links, dx = dres + LayerNorm'(dz W; x) -- the end of the block's FIRST half (dz = dt1 [M][2C] arrives where v
+// does, W = conv1^T where wT4 does, x = the block input, dres = dy; nothing is gated and no dv is written)
+template <int C, int TAIL>
 __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
     static_assert(C == 64, "ffn_bwd_bf16: C = 64");
     __shared__ __attribute__((aligned(16))) unsigned char smem[B_TAB + 64 * 4];
@@ -249,10 +257,12 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
     const int fr = lane & 31, kh = lane >> 5;
     // A operands: wT5[k][n] = W5[n][k] gamma[n] (rows k of dg, contraction over n), wT4[c][j] = W4[j][c] (rows c of dxn2, contraction over j)
     bf16x8 W5f[2][4], W4f[2][8];
+    if constexpr (!TAIL) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) W5f[j][ks] = *reinterpret_cast<const bf16x8*>(p.wT5 + (32 * j + fr) * C + 16 * ks + 8 * kh);
+            for (int ks = 0; ks < 4; ++ks) W5f[j][ks] = *reinterpret_cast<const bf16x8*>(p.wT5 + (32 * j + fr) * C + 16 * ks + 8 * kh);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
     int s = 0;
     for (int64_t gi = wg; gi < ng; gi += TW) {
         unsigned char* const sl = wb + s * B_SLOT;
+        if constexpr (!TAIL) {
         // ---- dg^T = wT5 dout^T ----
         bf16x8 df[4];
 #pragma unroll
@@ -322,6 +333,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
                 *reinterpret_cast<u32x2*>(a2) = bf4_pack(f4_mul(d, v1));
             }
         lds_fence();
+        }
         // ---- dxn2^T = wT4 dv^T ----
         floatx16 dx[2];
 #pragma unroll
@@ -405,25 +417,29 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
             ody[it] = *reinterpret_cast<const u32x4*>(sl + B_DO + row * 128 + ((ch ^ (row & 7)) * 16));
         }
+        if constexpr (!TAIL) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 4 + (lane >> 4), ch = lane & 15;
-            odv[it] = *reinterpret_cast<const u32x4*>(sl + B_V + row * 256 + ((ch ^ (row & 15)) * 16));
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4), ch = lane & 15;
+                odv[it] = *reinterpret_cast<const u32x4*>(sl + B_V + row * 256 + ((ch ^ (row & 15)) * 16));
+            }
         }
         lds_fence();
         issue(gi + 2 * TW, s);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         const int64_t r0 = gi * 32;
-        const rsrc_t rsO = make_rsrc(p.dy + r0 * C), rsV = make_rsrc(p.dv + r0 * (2 * C));
+        const rsrc_t rsO = make_rsrc(p.dy + r0 * C), rsV = make_rsrc((TAIL ? p.dy : p.dv) + r0 * (TAIL ? C : 2 * C));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
             __builtin_amdgcn_raw_buffer_store_b128(ody[it], rsO, r0 + row < p.M ? (uint32_t)(row * 128 + ch * 16) : ROW_SENT, 0, 0);
         }
+        if constexpr (!TAIL) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 4 + (lane >> 4), ch = lane & 15;
-            __builtin_amdgcn_raw_buffer_store_b128(odv[it], rsV, r0 + row < p.M ? (uint32_t)(row * 256 + ch * 16) : ROW_SENT, 0, 0);
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4), ch = lane & 15;
+                __builtin_amdgcn_raw_buffer_store_b128(odv[it], rsV, r0 + row < p.M ? (uint32_t)(row * 256 + ch * 16) : ROW_SENT, 0, 0);
+            }
         }
         s ^= 1;
     }
@@ -458,8 +474,20 @@ int launch_ffn_fwd_bf16(const FfnFwdB& p, int C, hipStream_t s) {
     const int64_t ng = cdiv64(p.M, 32);
     int64_t blocks = cdiv64(ng, FW);
     if (blocks > 256) blocks = 256;   // one block per CU, persistent over its groups
-    ffn_fwd_bf16_kernel<64><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+    ffn_fwd_bf16_kernel<64, 0><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("ffn_fwd_bf16");
+    return DCPT_OK;
+}
+
+// t1 = conv1(LayerNorm1(inp)) + b1 in one pass: p.y = inp, p.W4 / p.b4 = conv1, p.v = t1 [M][2C], p.xn2 = LN1(inp) (kept for conv1's weight
+// gradient), p.mu / p.rstd optional
+int launch_ln_conv_bf16(const FfnFwdB& p, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ln_conv_bf16: C=%d not supported (64)", C);
+    DCPT_CHECK_ARG(p.y && p.v && p.xn2 && p.W4 && p.b4 && p.lnw && p.lnb && p.M > 0, "ln_conv_bf16: null argument");
+    int64_t blocks = cdiv64(cdiv64(p.M, 32), FW);
+    if (blocks > 256) blocks = 256;
+    ffn_fwd_bf16_kernel<64, 1><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("ln_conv_bf16");
     return DCPT_OK;
 }
 
@@ -472,7 +500,16 @@ int ffn_bwd_bf16_waves(int64_t M) {
 int launch_ffn_bwd_bf16(const FfnBwdB& p, int C, hipStream_t s) {
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ffn_bwd_bf16: C=%d not supported (64)", C);
     DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT5 && p.wT4 && p.lnw && p.dv && p.dy && p.lnpart && p.M > 0, "ffn_bwd_bf16: null argument");
-    ffn_bwd_bf16_kernel<64><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
+    ffn_bwd_bf16_kernel<64, 0><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("ffn_bwd_bf16");
+    return DCPT_OK;
+}
+
+// dx = dres + LayerNorm'(dz W; x) in one pass: p.v = dz [M][2C], p.wT4 = W^T [C][2C], p.y = x, p.dout = dres, p.dy = dx, p.lnpart as above
+int launch_conv_ln_bwd_tail_bf16(const FfnBwdB& p, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "conv_ln_bwd_tail_bf16: C=%d not supported (64)", C);
+    DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT4 && p.lnw && p.dy && p.lnpart && p.M > 0, "conv_ln_bwd_tail_bf16: null argument");
+    ffn_bwd_bf16_kernel<64, 1><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("conv_ln_bwd_tail_bf16");
     return DCPT_OK;
 }

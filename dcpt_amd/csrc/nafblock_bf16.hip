@@ -65,7 +65,7 @@ struct BwdWsB {
     float *u4, *c4, *u1, *c1, *rowpart;
     int rp_sg, rp_dw;
     bool lrs;
-    float* ffn_part;   // LayerNorm2 column partials of the fused narrow-level backward: [waves][2][C]
+    float *ffn_part, *ffn_part1;   // LayerNorm2 / LayerNorm1 column partials of the fused narrow-level backward kernels: [waves][2][C] each
 };
 
 size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* out) {
@@ -138,6 +138,7 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
         }
     }
     w.ffn_part = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
+    w.ffn_part1 = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
     if (out) *out = w;
     return a.off;
 }
@@ -240,10 +241,17 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         j.in[2] = p->conv5_w; j.out[2] = w.W5; j.N[2] = C; j.K[2] = C;
         DCPT_TRY(launch_wpack_bf16(j, s));
     }
-    DCPT_TRY(launch_ln_fwd_bf16(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
     GemmNTB g{};
-    g.M = M; g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = w.W1; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
-    DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIAS, s));
+    if (ffn_fused(C)) {   // narrow levels: LayerNorm1 -> conv1 in one pass over the input (ffn_bf16.hip)
+        FfnFwdB f{};
+        f.y = inp; f.lnw = p->norm1_w; f.lnb = p->norm1_b; f.W4 = w.W1; f.b4 = p->conv1_b; f.v = sv->t1; f.xn2 = sv->xn1; f.mu = sv->mu1;
+        f.rstd = sv->rstd1; f.M = M; f.eps = eps;
+        DCPT_TRY(launch_ln_conv_bf16(f, C, s));
+    } else {
+        DCPT_TRY(launch_ln_fwd_bf16(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
+        g.M = M; g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = w.W1; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
+        DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIAS, s));
+    }
     DwGeom dg{B, H, W, C};
     if (!packed) DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
     if (dw_ring_usable(dg, 2)) DCPT_TRY(launch_dw_ring_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
@@ -407,22 +415,32 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
     DCPT_TRY(side_fork(sd, 3, s));
     DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
     DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
-    // B11: gradient of LN1's output
-    g = GemmNTB{};
-    g.M = M; g.A = w.dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = w.gln; g.ldc = C;
-    if (w.lrs) {   // B11 + B13: dinp = dy + LN1-backward(dt1 W1^T)
-        g.C = dinp; g.res = inp; g.ldres = C; g.aux = w.dy; g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.colpart = w.lnpart2;
-        g.rowpart = w.rowpart; g.rowparts = w.rp_dw;
-        DCPT_TRY(launch_gemm_nt_bf16(g, EB_LNBWD2, s));
+    if (ffn) {
+        // B11 + B13 in one pass (ffn_bf16.hip): dinp = dy + LayerNorm1 backward of dt1 W1^T
+        FfnBwdB f{};
+        f.dout = w.dy; f.v = w.dt1; f.y = inp; f.wT4 = w.wT1; f.lnw = p->norm1_w; f.dy = dinp; f.lnpart = w.ffn_part1; f.M = M; f.eps = 1e-6f;
+        DCPT_TRY(launch_conv_ln_bwd_tail_bf16(f, C, s));
+        DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
+        DCPT_TRY(side_fork(sd, 5, s));
+        DCPT_TRY(launch_colpart_reduce(w.ffn_part1, ffn_bwd_bf16_waves(M), 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     } else {
-        DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        // B11: gradient of LN1's output
+        g = GemmNTB{};
+        g.M = M; g.A = w.dt1; g.lda = C2; g.K = C2; g.Bw = w.wT1; g.N = C; g.C = w.gln; g.ldc = C;
+        if (w.lrs) {   // B11 + B13: dinp = dy + LN1-backward(dt1 W1^T)
+            g.C = dinp; g.res = inp; g.ldres = C; g.aux = w.dy; g.mu = sv->mu1; g.rstd = sv->rstd1; g.lnw = p->norm1_w; g.colpart = w.lnpart2;
+            g.rowpart = w.rowpart; g.rowparts = w.rp_dw;
+            DCPT_TRY(launch_gemm_nt_bf16(g, EB_LNBWD2, s));
+        } else {
+            DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        }
+        // B12: conv1 gradients
+        DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
+        // B13: dinp = dy + LN1-backward
+        if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, inp, sv->mu1, sv->rstd1, p->norm1_w, w.dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
+        DCPT_TRY(side_fork(sd, 5, s));
+        DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     }
-    // B12: conv1 gradients
-    DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
-    // B13: dinp = dy + LN1-backward
-    if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, inp, sv->mu1, sv->rstd1, p->norm1_w, w.dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
-    DCPT_TRY(side_fork(sd, 5, s));
-    DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
     DCPT_TRY(side_join(sd, s));
     return DCPT_OK;
 }
