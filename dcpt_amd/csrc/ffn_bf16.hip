@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
             ody[it] = *reinterpret_cast<const u32x4*>(sl + B_DO + row * 128 + ((ch ^ (row & 7)) * 16));
         }
-        if constexpr (!TAIL) {
+        if (!TAIL && p.dv) {   // (no dv for a caller whose conv4 weight gradient comes from ffn_wgrad_bf16)
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 4 + (lane >> 4), ch = lane & 15;
@@ -428,13 +428,13 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
         issue(gi + 2 * TW, s);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         const int64_t r0 = gi * 32;
-        const rsrc_t rsO = make_rsrc(p.dy + r0 * C), rsV = make_rsrc((TAIL ? p.dy : p.dv) + r0 * (TAIL ? C : 2 * C));
+        const rsrc_t rsO = make_rsrc(p.dy + r0 * C), rsV = make_rsrc(((TAIL || !p.dv) ? p.dy : p.dv) + r0 * (TAIL ? C : 2 * C));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
             __builtin_amdgcn_raw_buffer_store_b128(ody[it], rsO, r0 + row < p.M ? (uint32_t)(row * 128 + ch * 16) : ROW_SENT, 0, 0);
         }
-        if constexpr (!TAIL) {
+        if (!TAIL && p.dv) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 4 + (lane >> 4), ch = lane & 15;
@@ -461,6 +461,227 @@ __global__ __launch_bounds__(256) void ffn_bwd_bf16_kernel(const FfnBwdB p) {
                 p.lnpart[(wg * 2 + 1) * C + c] = b;
             }
         }
+}
+
+
+// ---- weight gradients of the same half, accumulated where the operands are recomputed ---------------------------------------------------
+// conv5:  G5[n][k] = sum_m dout[m][n] g[m][k]   (g = SimpleGate(v));   conv4:  G4[j][k] = sum_m dv[m][j] LN2(y)[m][k]
+// Both contract over PIXELS.  With the TN GEMM kernel they cost 5 tensor passes of reads plus the 5 that wrote g, LN2(y) and dv first; here
+// a wave recomputes the three operands for its 32 pixels from (dout, v, y) -- the SimpleGate backward and the LayerNorm exactly as the
+// data-path kernel does them, bf16-rounded as its MFMA operands are -- leaves them in LDS in place of their inputs, and feeds them to the
+// matrix pipe through the transposing LDS read (ds_read_b64_tr_b16: 8 consecutive pixels of one column per lane).  The 64 x 64 and
+// 128 x 64 products stay in the wave's accumulators (192 registers) over ALL its groups; the column sums (bias gradients) fall out of
+// the A fragments (8 pixels of a column per lane).  One fp32 slab per wave for the fixed-order reducer.  No stores in the loop: the ring's
+// vmcnt counts are exact.
+constexpr int W_G = 2 * B_SLOT, W_WAVE = 2 * B_SLOT + 4096;   // per wave: two (dout | v | y) slots + the gate buffer
+constexpr int W_TAB = FW * W_WAVE;                             // fp32 tables: lnw[64] | lnb[64]
+
+typedef __attribute__((address_space(3))) bf16x4* lds_tr_p;
+// 8 consecutive pixels mrow .. mrow + 7 of column `col` of a row-major bf16 tile (row pitch PITCH bytes, 16-byte chunk c of row r at chunk
+// position c ^ (r & SW)): lane t of a 16-lane group supplies the address of row mrow + (t >> 2), columns col16 + 4 (t & 3) .. + 3 and
+// receives column col16 + t
+template <int PITCH, int SW>
+__device__ __forceinline__ bf16x8 tr_cols(const unsigned char* tile, int mrow, int col16, int t) {
+    const int r0 = mrow + (t >> 2), r1 = r0 + 4;
+    const int c = col16 + 4 * (t & 3);
+    const int chunk = c >> 3, within = (c & 7) * 2;
+    const unsigned char* a0 = tile + r0 * PITCH + ((chunk ^ (r0 & SW)) << 4) + within;
+    const unsigned char* a1 = tile + r1 * PITCH + ((chunk ^ (r1 & SW)) << 4) + within;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_p)(const_cast<unsigned char*>(a0)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_p)(const_cast<unsigned char*>(a1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float sum8(bf16x8 v) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    return ((bf_lo(w.x) + bf_hi(w.x)) + (bf_lo(w.y) + bf_hi(w.y))) + ((bf_lo(w.z) + bf_hi(w.z)) + (bf_lo(w.w) + bf_hi(w.w)));
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void ffn_wgrad_bf16_kernel(const FfnWgB p) {
+    static_assert(C == 64, "ffn_wgrad_bf16: C = 64");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W_TAB + 128 * 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const tab = reinterpret_cast<float*>(smem + W_TAB);
+    if (tid < 128) tab[tid] = tid < 64 ? p.lnw[tid] : p.lnb[tid - 64];
+    const int fr = lane & 31, kh = lane >> 5;
+    bf16x8 W5f[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) W5f[j][ks] = *reinterpret_cast<const bf16x8*>(p.wT5 + (32 * j + fr) * C + 16 * ks + 8 * kh);
+    __syncthreads();
+
+    unsigned char* const wb = smem + wave * W_WAVE;
+    const uint32_t wb_lds = lds_addr(reinterpret_cast<const float*>(wb));
+    const int64_t ng = (p.M + 31) / 32;
+    const int64_t wg = (int64_t)blockIdx.x * FW + wave, TW = (int64_t)gridDim.x * FW;
+    const uint32_t voff128 = (uint32_t)(lane >> 3) * 128u + (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
+    auto issue = [&](int64_t gi, int s) {
+        const int64_t gg = gi < ng ? gi : 0;
+        const i32x4 rsD = make_rsrc_dma(p.dout + gg * (32 * C)), rsY = make_rsrc_dma(p.y + gg * (32 * C)), rsV = make_rsrc_dma(p.v + gg * (64 * C));
+        const uint32_t base = wb_lds + (uint32_t)(s * B_SLOT);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const bool ok = gi < ng && gi * 32 + 8 * pc + (lane >> 3) < p.M;
+            const uint32_t vo = ok ? voff128 + (uint32_t)pc * 1024u : ROW_SENT;
+            dma16(rsD, base + (uint32_t)(B_DO + pc * 1024), vo, 0);
+            dma16(rsY, base + (uint32_t)(B_Y + pc * 1024), vo, 0);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            const int row = 4 * pc + (lane >> 4);
+            const bool ok = gi < ng && gi * 32 + row < p.M;
+            dma16(rsV, base + (uint32_t)(B_V + pc * 1024), ok ? (uint32_t)(row * 256 + (((lane & 15) ^ (row & 15)) * 16)) : ROW_SENT, 0);
+        }
+    };
+    issue(wg, 0);
+    issue(wg + TW, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+
+    floatx16 G5[2][2], G4[4][2];   // [n / j tile][k tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G5[a][b][r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G4[a][b][r] = 0.f;
+    float cs5[2] = {0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of dout / dv at column 32 a + (lane & 31), this lane's pixel half
+
+    const int t16 = lane & 15, c16 = 16 * ((lane >> 4) & 1);
+    int s = 0;
+    for (int64_t gi = wg; gi < ng; gi += TW) {
+        unsigned char* const sl = wb + s * B_SLOT;
+        unsigned char* const gb = wb + W_G;
+        const bool rowok = gi * 32 + fr < p.M;
+        // ---- LN2(y) in place (rows past M: zeros, so that they add nothing to G4) ----
+        {
+            float xh[2][16];
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 yv = bf4_unpack(*reinterpret_cast<const u32x2*>(sl + B_Y + fr * 128 + (((4 * t + g) ^ (fr & 7)) * 16) + kh * 8));
+                    xh[t][4 * g + 0] = yv.x; xh[t][4 * g + 1] = yv.y; xh[t][4 * g + 2] = yv.z; xh[t][4 * g + 3] = yv.w;
+                    sum += (yv.x + yv.y) + (yv.z + yv.w);
+                }
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    xh[t][r] -= mean;
+                    sq += xh[t][r] * xh[t][r];
+                }
+            sq += __shfl_xor(sq, 32);
+            const float rs = rowok ? 1.0f / sqrtf(sq * (1.0f / C) + p.eps) : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 lw = *reinterpret_cast<const float4*>(tab + 32 * t + 8 * g + 4 * kh);
+                    const float4 lb = *reinterpret_cast<const float4*>(tab + 64 + 32 * t + 8 * g + 4 * kh);
+                    float4 o;
+                    o.x = rowok ? xh[t][4 * g + 0] * rs * lw.x + lb.x : 0.f;
+                    o.y = rowok ? xh[t][4 * g + 1] * rs * lw.y + lb.y : 0.f;
+                    o.z = rowok ? xh[t][4 * g + 2] * rs * lw.z + lb.z : 0.f;
+                    o.w = rowok ? xh[t][4 * g + 3] * rs * lw.w + lb.w : 0.f;
+                    *reinterpret_cast<u32x2*>(sl + B_Y + fr * 128 + (((4 * t + g) ^ (fr & 7)) * 16) + kh * 8) = bf4_pack(o);
+                }
+        }
+        // ---- dg^T = wT5 dout^T, SimpleGate backward in place, the gate ----
+        {
+            bf16x8 df[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) df[ks] = *reinterpret_cast<const bf16x8*>(sl + B_DO + fr * 128 + (((2 * ks + kh) ^ (fr & 7)) * 16));
+            floatx16 dg[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dg[j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dg[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W5f[j][ks], df[ks], dg[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned char* const a1 = sl + B_V + fr * 256 + (((4 * j + g) ^ (fr & 15)) * 16) + kh * 8;
+                    unsigned char* const a2 = sl + B_V + fr * 256 + (((8 + 4 * j + g) ^ (fr & 15)) * 16) + kh * 8;
+                    const float4 v1 = bf4_unpack(*reinterpret_cast<const u32x2*>(a1)), v2 = bf4_unpack(*reinterpret_cast<const u32x2*>(a2));
+                    const float4 d = make_float4(dg[j][4 * g + 0], dg[j][4 * g + 1], dg[j][4 * g + 2], dg[j][4 * g + 3]);
+                    *reinterpret_cast<u32x2*>(a1) = bf4_pack(f4_mul(d, v2));
+                    *reinterpret_cast<u32x2*>(a2) = bf4_pack(f4_mul(d, v1));
+                    *reinterpret_cast<u32x2*>(gb + fr * 128 + (((4 * j + g) ^ (fr & 7)) * 16) + kh * 8) = bf4_pack(f4_mul(v1, v2));
+                }
+        }
+        lds_fence();
+        // ---- the two pixel contractions: A = 8 consecutive pixels of a dout / dv column, B = of a gate / LN2(y) column ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int mrow = 16 * ks + 8 * kh;
+            bf16x8 Yg[2], Yx[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                Yg[b] = tr_cols<128, 7>(gb, mrow, 32 * b + c16, t16);
+                Yx[b] = tr_cols<128, 7>(sl + B_Y, mrow, 32 * b + c16, t16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16x8 X = tr_cols<128, 7>(sl + B_DO, mrow, 32 * a + c16, t16);
+                cs5[a] += sum8(X);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) G5[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Yg[b], G5[a][b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bf16x8 X = tr_cols<256, 15>(sl + B_V, mrow, 32 * a + c16, t16);
+                cs4[a] += sum8(X);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) G4[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Yx[b], G4[a][b], 0, 0, 0);
+            }
+        }
+        lds_fence();
+        issue(gi + 2 * TW, s);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        s ^= 1;
+    }
+    dma_wait_all();
+    // ---- this wave's slabs: G[tile row i = (r & 3) + 8 (r >> 2) + 4 kh][tile column lane & 31] ----
+    float* const o5 = p.g5 + wg * (int64_t)(C * C);
+    float* const o4 = p.g4 + wg * (int64_t)(2 * C * C);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o5[(32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh) * C + 32 * b + fr] = G5[a][b][r];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o4[(32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh) * C + 32 * b + fr] = G4[a][b][r];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float t = cs5[a] + __shfl_xor(cs5[a], 32);
+        if (kh == 0) p.cs5[wg * C + 32 * a + fr] = t;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float t = cs4[a] + __shfl_xor(cs4[a], 32);
+        if (kh == 0) p.cs4[wg * (2 * C) + 32 * a + fr] = t;
+    }
 }
 
 }  // namespace
@@ -499,7 +720,7 @@ int ffn_bwd_bf16_waves(int64_t M) {
 
 int launch_ffn_bwd_bf16(const FfnBwdB& p, int C, hipStream_t s) {
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ffn_bwd_bf16: C=%d not supported (64)", C);
-    DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT5 && p.wT4 && p.lnw && p.dv && p.dy && p.lnpart && p.M > 0, "ffn_bwd_bf16: null argument");
+    DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT5 && p.wT4 && p.lnw && p.dy && p.lnpart && p.M > 0, "ffn_bwd_bf16: null argument");
     ffn_bwd_bf16_kernel<64, 0><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("ffn_bwd_bf16");
     return DCPT_OK;
@@ -511,5 +732,13 @@ int launch_conv_ln_bwd_tail_bf16(const FfnBwdB& p, int C, hipStream_t s) {
     DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT4 && p.lnw && p.dy && p.lnpart && p.M > 0, "conv_ln_bwd_tail_bf16: null argument");
     ffn_bwd_bf16_kernel<64, 1><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("conv_ln_bwd_tail_bf16");
+    return DCPT_OK;
+}
+
+int launch_ffn_wgrad_bf16(const FfnWgB& p, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ffn_wgrad_bf16: C=%d not supported (64)", C);
+    DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT5 && p.lnw && p.lnb && p.g5 && p.g4 && p.cs5 && p.cs4 && p.M > 0, "ffn_wgrad_bf16: null argument");
+    ffn_wgrad_bf16_kernel<64><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("ffn_wgrad_bf16");
     return DCPT_OK;
 }

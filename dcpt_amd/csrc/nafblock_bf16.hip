@@ -65,6 +65,7 @@ struct BwdWsB {
     float *u4, *c4, *u1, *c1, *rowpart;
     int rp_sg, rp_dw;
     bool lrs;
+    float *ffn_g5, *ffn_g4, *ffn_cs5, *ffn_cs4;   // per-wave slabs / column sums of ffn_wgrad_bf16
     float *ffn_part, *ffn_part1;   // LayerNorm2 / LayerNorm1 column partials of the fused narrow-level backward kernels: [waves][2][C] each
 };
 
@@ -139,6 +140,14 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
     }
     w.ffn_part = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
     w.ffn_part1 = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
+    w.ffn_g5 = w.ffn_g4 = w.ffn_cs5 = w.ffn_cs4 = nullptr;
+    if (ffn_fused(C)) {
+        const size_t nw = (size_t)ffn_bwd_bf16_waves(M);
+        w.ffn_g5 = a.get<float>(nw * C * C);
+        w.ffn_g4 = a.get<float>(nw * 2 * C * C);
+        w.ffn_cs5 = a.get<float>(nw * C);
+        w.ffn_cs4 = a.get<float>(nw * 2 * C);
+    }
     if (out) *out = w;
     return a.off;
 }
@@ -270,7 +279,8 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     if (ffn_fused(C)) {   // narrow levels: LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual in one pass over y (ffn_bf16.hip)
         FfnFwdB f{};
         f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.W4 = w.W4; f.W5 = w.W5; f.b4 = p->conv4_b; f.b5 = p->conv5_b; f.gamma = p->gamma;
-        f.out = out; f.v = sv->v; f.xn2 = sv->xn2; f.g = sv->g; f.mu = sv->mu2; f.rstd = sv->rstd2; f.M = M; f.eps = eps;
+        // (LN2(y), the gate and the statistics are recomputed by the backward kernels: sv->xn2 / g / mu2 / rstd2 stay unwritten)
+        f.out = out; f.v = sv->v; f.M = M; f.eps = eps;
         return launch_ffn_fwd_bf16(f, C, s);
     }
     DCPT_TRY(launch_ln_fwd_bf16(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
@@ -343,12 +353,18 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
     if (ffn) {
         // B1 + B3 + B5 in one pass (ffn_bf16.hip): dv for conv4's weight gradient and dy = dout + LayerNorm2 backward
         FfnBwdB f{};
-        f.dout = dout; f.v = sv->v; f.y = sv->y; f.wT5 = w.wT5; f.wT4 = w.wT4; f.lnw = p->norm2_w; f.dv = w.dv; f.dy = w.dy;
+        f.dout = dout; f.v = sv->v; f.y = sv->y; f.wT5 = w.wT5; f.wT4 = w.wT4; f.lnw = p->norm2_w; f.dv = nullptr; f.dy = w.dy;
         f.lnpart = w.ffn_part; f.M = M; f.eps = 1e-6f;
         DCPT_TRY(launch_ffn_bwd_bf16(f, C, s));
-        DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
-        DCPT_TRY(side_fork(sd, 1, s));
-        DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
+        {   // B2 + B4: both weight gradients from (dout, v, y) on the side stream, operands recomputed per 32 pixels (ffn_wgrad_bf16)
+            FfnWgB q{};
+            q.dout = dout; q.v = sv->v; q.y = sv->y; q.wT5 = w.wT5; q.lnw = p->norm2_w; q.lnb = p->norm2_b; q.g5 = w.ffn_g5; q.g4 = w.ffn_g4;
+            q.cs5 = w.ffn_cs5; q.cs4 = w.ffn_cs4; q.M = M; q.eps = 1e-6f;
+            DCPT_TRY(launch_ffn_wgrad_bf16(q, C, sw));
+            const int nw = ffn_bwd_bf16_waves(M);
+            DCPT_TRY(launch_wgrad_reduce(w.ffn_g5, w.ffn_cs5, nw, nw, C, C, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, WR_PLAIN, sw));
+            DCPT_TRY(launch_wgrad_reduce(w.ffn_g4, w.ffn_cs4, nw, nw, C2, C, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, WR_PLAIN, sw));
+        }
         DCPT_TRY(side_fork(sd, 2, s));
         DCPT_TRY(launch_colpart_reduce(w.ffn_part, ffn_bwd_bf16_waves(M), 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     } else {
