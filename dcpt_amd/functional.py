@@ -153,6 +153,19 @@ def _require_gpu_bf16(*ts):
             raise _lib.DcptHipError(f"the bf16-storage path takes torch.bfloat16 activations (got {t.dtype})")
 
 
+def _saved_bf16(t1, v, acts, stats, sca, infer):
+    """dcpt_nafblock_saved_bf16 over the forward's buffers.  acts / stats have 5 / 4 rows, or 3 / 2 where the fused second half keeps
+    nothing but v (dcpt_nafblock_bf16_fused_ffn): the missing pointers are NULL when no backward follows (``infer``: the library then
+    skips v as well) and stand-ins that the fused kernels never touch otherwise (the struct's contract asks for non-null in training)."""
+    full = acts.shape[0] == 5
+    if infer:
+        return _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), 0, stats[0].data_ptr(), stats[1].data_ptr(), 0, 0,
+                                      sca[0].data_ptr(), sca[1].data_ptr(), acts[2].data_ptr(), 0, 0)
+    return _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                  stats[2 if full else 0].data_ptr(), stats[3 if full else 1].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
+                                  acts[2].data_ptr(), acts[3 if full else 2].data_ptr(), acts[4 if full else 2].data_ptr())
+
+
 class _NAFBlockBf16Fn(torch.autograd.Function):
     """NAFBlock.forward (reference nafnet_arch.py:165-186) with bf16 storage -> dcpt_nafblock_fwd_bf16 / bwd_bf16."""
 
@@ -172,19 +185,15 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         t1 = _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
         # no backward coming (torch.no_grad / nothing requires grad) and the block's second half is one kernel at this width: the five
         # tensors only that backward reads (v, LN2(y), SimpleGate(v), LN2's statistics) are neither allocated nor written
-        infer = not any(ctx.needs_input_grad) and bool(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
+        # where the block's second half is one kernel, its backward recomputes LN2(y), the gate and LN2's statistics: never allocated
+        fused = bool(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
+        infer = fused and not any(ctx.needs_input_grad)
         v = None if infer else _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
-        acts = torch.empty((3 if infer else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
-        stats = torch.empty((2 if infer else 4, M), dtype=torch.float32, device=dev)
+        acts = torch.empty((3 if fused else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
+        stats = torch.empty((2 if fused else 4, M), dtype=torch.float32, device=dev)
         sca = torch.empty((2, B, Cc), dtype=torch.float32, device=dev)           # pooled, s
         ps = NafBlockParams(*[p.data_ptr() for p in params])
-        if infer:
-            sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), 0, stats[0].data_ptr(), stats[1].data_ptr(), 0, 0,
-                                        sca[0].data_ptr(), sca[1].data_ptr(), acts[2].data_ptr(), 0, 0)
-        else:
-            sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                                        stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
-                                        acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
+        sv = _saved_bf16(t1, v, acts, stats, sca, infer)
         ws = _workspace(dev, lib.dcpt_nafblock_fwd_bf16_ws_bytes(B, H, W, Cc))
         if packed is None:
             check(lib.dcpt_nafblock_fwd_bf16(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
@@ -208,9 +217,7 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         dinp = _empty_nhwc_bf16(B, Cc, H, W, dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         gs = NafBlockGrads(*[g.data_ptr() for g in grads])
-        sv = _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                                    stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
-                                    acts[2].data_ptr(), acts[3].data_ptr(), acts[4].data_ptr())
+        sv = _saved_bf16(t1, v, acts, stats, sca, False)
         ws = _workspace(dev, lib.dcpt_nafblock_bwd_bf16_ws_bytes(B, H, W, Cc))
         packed = ctx.packed
         if packed is None:

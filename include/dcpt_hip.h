@@ -145,8 +145,9 @@ int dcpt_nafblock_bwd_bf16(const dcpt_nafblock_params* p, const dcpt_nafblock_gr
 size_t dcpt_nafblock_wpack_bf16_bytes(int C);
 /* 1 when dcpt_nafblock_fwd_bf16 at width C runs the second half of the block (LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual,
  * nafnet_arch.py:180-186) as ONE kernel (ffn_bf16.hip, the narrow levels): a caller that will not run the backward pass (inference)
- * may then pass saved->v = xn2 = g = mu2 = rstd2 = NULL -- all five or none -- and the forward skips those writes (6 -> 2 tensor passes
- * for that half).  0: every saved buffer is required. */
+ * may then pass saved->v = xn2 = g = mu2 = rstd2 = NULL -- all five or none -- and the forward skips v as well (4 -> 2 tensor passes for
+ * that half).  With 1 the library never reads or writes saved->xn2 / g / mu2 / rstd2 in either pass (its backward kernels recompute
+ * LayerNorm2, the gate and the statistics from y and v): in training they only have to be non-null.  0: every saved buffer is used. */
 int dcpt_nafblock_bf16_fused_ffn(int C);
 int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream);
 int dcpt_nafblock_fwd_bf16_packed(const dcpt_nafblock_params* p, const void* packed, size_t packed_bytes, const uint16_t* inp, uint16_t* out,
