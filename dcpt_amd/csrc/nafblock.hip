@@ -17,6 +17,7 @@
 // for the reference's zero-initialised beta/gamma.
 #include "gemm.h"
 #include "kernels.h"
+#include "ffn_f32.h"
 #include "side.h"
 #include "../../include/dcpt_hip.h"
 
@@ -140,6 +141,14 @@ bool ln_rowsums(int C, int rp_sg, int rp_dw) {
 // Narrow levels (C <= 128: one GEMM tile spans all channels): LayerNorm backward runs inside the epilogue of the dgrad GEMM
 // that produces its incoming gradient, so that gradient is never written and re-read (2 tensor passes and one launch per
 // LayerNorm).  DCPT_LN_EPILOGUE=0 switches back to the separate kernel.
+// Narrowest level (C = 64): LayerNorm1 -> conv1 and LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual as one pass each (ffn_f32.hip).
+// The normalised tensors and the gate are then never written: the two weight-gradient GEMMs that read them take them from their
+// operand loaders (A_LN on the LayerNorm's input, A_SG on v).
+bool ffn_fused_f32(int C) {
+    static const int on = dcpt_tuning("DCPT_FFN_FUSED_F32", 1);
+    return on && ffn_fwd_f32_ok(C);
+}
+
 bool ln_in_epilogue(int C) {
     static const int on = dcpt_tuning("DCPT_LN_EPILOGUE", 1);
     return on && C <= 128;
@@ -181,12 +190,20 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     DCPT_CHECK_ARG(sv->xn1 && sv->xn2 && sv->g, "nafblock_fwd: saved.xn1 / saved.xn2 / saved.g missing");
     // the normalised activations are materialised once: conv1's forward GEMM and (in backward) its weight-gradient GEMM
     // then take them as plain operands, i.e. straight global -> LDS by DMA
-    DCPT_TRY(launch_ln_fwd(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
+    const bool ffn = ffn_fused_f32(C);
     GemmNT g{};
-    g.M = M;
-    // t1 = conv1(LN1(inp))
-    g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
+    if (ffn) {
+        FfnFwdF f{};
+        f.y = inp; f.lnw = p->norm1_w; f.lnb = p->norm1_b; f.W4 = p->conv1_w; f.b4 = p->conv1_b; f.v = sv->t1; f.mu = sv->mu1; f.rstd = sv->rstd1;
+        f.M = M; f.eps = eps;
+        DCPT_TRY(launch_ln_conv_f32(f, C, s));
+    } else {
+        DCPT_TRY(launch_ln_fwd(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
+        g.M = M;
+        // t1 = conv1(LN1(inp))
+        g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = p->conv1_w; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_BIAS, s));
+    }
     // t2 = SG(dw(t1)+b2) and pooling partials
     DwGeom dg{B, H, W, C};
     DCPT_TRY(launch_dw_pack_weights(p->conv2_w, w.w2p, 2 * C, s));
@@ -197,6 +214,13 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     g = GemmNT{};
     g.M = M; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = p->conv3_w; g.N = C; g.C = sv->y; g.ldc = C;
     g.simg = sv->s; g.P = P; g.bias = p->conv3_b; g.res = inp; g.cscale = p->beta;
+    if (ffn) {   // narrowest level: everything behind y is one kernel
+        DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESID, s));
+        FfnFwdF f{};
+        f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.W4 = p->conv4_w; f.b4 = p->conv4_b; f.W5 = p->conv5_w; f.b5 = p->conv5_b;
+        f.gamma = p->gamma; f.out = out; f.v = sv->v; f.mu = sv->mu2; f.rstd = sv->rstd2; f.M = M; f.eps = eps;
+        return launch_ffn_fwd_f32(f, C, s);
+    }
     if (ln_in_epilogue(C)) {   // narrow levels: LN2(y) (statistics and normalised tensor) comes out of the same epilogue
         g.lnw = p->norm2_w; g.lnb = p->norm2_b; g.ln_out = sv->xn2; g.ln_mu = sv->mu2; g.ln_rstd = sv->rstd2; g.ln_eps = eps;
         DCPT_TRY(launch_gemm_nt(g, A_SCALE, E_RESIDLN, s));
@@ -277,6 +301,9 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SGBWD, s));
     // B2: conv5 / gamma gradients
     tp = GemmTN{};
+    const bool ffn = ffn_fused_f32(C);   // (the forward kept neither LN1(inp), LN2(y) nor the gate: operand loaders make them)
+    if (ffn) DCPT_TRY(wgrad(dout, C, C, sv->v, C2, C, A_SG, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
+    else
     DCPT_TRY(wgrad(dout, C, C, sv->g, C, C, A_PLAIN, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w,
                    gr->gamma, gr->conv5_b, sw));
     DCPT_TRY(side_fork(sd, 1, s));      // dv
@@ -296,6 +323,10 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     }
     // B4: conv4 gradients (Y = LN2(y), kept by the forward pass)
     tp = GemmTN{};
+    if (ffn) {
+        tp.mu = sv->mu2; tp.rstd = sv->rstd2; tp.lnw = p->norm2_w; tp.lnb = p->norm2_b;
+        DCPT_TRY(wgrad(dv, C2, C2, sv->y, C, C, A_LN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
+    } else
     DCPT_TRY(wgrad(dv, C2, C2, sv->xn2, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
                    gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
@@ -363,6 +394,10 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     }
     // B12: conv1 gradients (Y = LN1(inp), kept by the forward pass)
     tp = GemmTN{};
+    if (ffn) {
+        tp.mu = sv->mu1; tp.rstd = sv->rstd1; tp.lnw = p->norm1_w; tp.lnb = p->norm1_b;
+        DCPT_TRY(wgrad(dt1, C2, C2, inp, C, C, A_LN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
+    } else
     DCPT_TRY(wgrad(dt1, C2, C2, sv->xn1, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr,
                    gr->conv1_b, sw));
     // B13: dinp = dy + LN1-backward
