@@ -24,6 +24,12 @@
 
 namespace {
 
+#ifdef F32_ABL_NOMFMA   // ablation builds only (tools/build_variant.sh)
+#define FFN_MFMA(a, b, c) (c)
+#else
+#define FFN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+#endif
+
 constexpr int FW = 4;   // waves per block
 // per-wave LDS: a ring of four y slots of 32 rows x 256 B (three groups = 24 KB in flight per wave: with one wave per SIMD the HBM latency
 // is covered by bytes in flight, not by occupancy)
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void ffn_fwd_f32_kernel(const FfnFwdF p) {
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(W4f[j][ks], xf[ks], acc1[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc1[j] = FFN_MFMA(W4f[j][ks], xf[ks], acc1[j]);
         if (p.v) {
             const rsrc_t rsV = make_rsrc(p.v + r0 * (2 * C));
 #pragma unroll
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void ffn_fwd_f32_kernel(const FfnFwdF p) {
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(W5f[j][ks], xf[ks], acc2[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc2[j] = FFN_MFMA(W5f[j][ks], xf[ks], acc2[j]);
             const rsrc_t rsO = make_rsrc(p.out + r0 * C);
 #pragma unroll
             for (int j = 0; j < 2; ++j)

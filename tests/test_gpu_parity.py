@@ -117,8 +117,10 @@ def test_nafblock_golden(dev, golden_dir, c):
 
 # the last three shapes walk the depthwise ring kernels' other tilings (dwring.hip): several column tiles with recomputed edge
 # columns (W > 64), the 8-piece single tile (32 < W <= 64), and two row parts (H >= 64 with few blocks)
+# (3, 64, 5, 7) / (5, 64, 48, 40): the fused forward chains of the narrowest level (ffn_f32.hip) with a ragged last group of 32 pixels
+# (M = 105) and with more groups than the launch has waves' ring slots (M = 9600)
 @pytest.mark.parametrize("B,c,H,W", [(1, 8, 5, 7), (3, 24, 9, 4), (2, 128, 12, 20), (1, 512, 8, 8), (2, 32, 33, 17),
-                                     (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9)])
+                                     (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9), (3, 64, 5, 7), (5, 64, 48, 40)])
 def test_nafblock_oracle(dev, B, c, H, W):
     P = block_params(c, f"ob{c}.")
     x = keyed_input(f"ob{c}.x", (B, c, H, W), lo=-1.0, hi=1.0)
