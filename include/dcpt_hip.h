@@ -93,7 +93,9 @@ typedef struct {   /* activations kept for backward (M = B*H*W pixels) */
 
 size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C);
 size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C);
-/* inp,out: [B][H][W][C].  `saved` buffers are always written (inference callers may recycle them). */
+/* inp,out: [B][H][W][C].  `saved` is the forward's scratch for ITS OWN backward (inference callers may recycle the buffers): every
+ * pointer must be valid, but which of the tensors hold data afterwards is the library's business -- at C = 64 the fused forward chains
+ * (ffn_f32.hip) write neither xn1, xn2 nor g: dcpt_nafblock_bwd takes them from its GEMMs' operand loaders. */
 int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp, float* out, const dcpt_nafblock_saved* saved,
                       void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
 /* dout,dinp: [B][H][W][C]; dinp may alias dout. */
