@@ -92,6 +92,7 @@ SIGNATURES = {
     "dcpt_set_gemm_x3": (cint, [C.c_void_p, sz, cint]),
     "dcpt_nafblock_wpack_bf16_bytes": (sz, [cint]),
     "dcpt_nafblock_bf16_fused_ffn": (cint, [cint]),
+    "dcpt_nafblock_fused_ffn": (cint, [cint]),
     "dcpt_nafblock_wpack_bf16": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, cint, stream_t]),
     "dcpt_nafblock_fwd_bf16_packed": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, f32p, f32p, C.POINTER(NafBlockSavedBf16), C.c_void_p, sz,
                                              cint, cint, cint, cint, stream_t]),

@@ -169,6 +169,7 @@ int wgrad(const float* X, int ldx, int N, const float* Y, int ldy, int K, int yl
 
 }  // namespace
 
+extern "C" int dcpt_nafblock_fused_ffn(int C) { return ffn_fused_f32(C) ? 1 : 0; }
 extern "C" size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C) { return fwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
 extern "C" size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C) { return bwd_ws_layout(B, H, W, C, nullptr, 0, nullptr); }
 
@@ -187,7 +188,9 @@ extern "C" int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp
     const int P = H * W;
     const float eps = 1e-6f;  // nafnet_arch.py:57
 
-    DCPT_CHECK_ARG(sv->xn1 && sv->xn2 && sv->g, "nafblock_fwd: saved.xn1 / saved.xn2 / saved.g missing");
+    DCPT_CHECK_ARG(ffn_fused_f32(C) || (sv->xn1 && sv->xn2 && sv->g && sv->v && sv->mu1 && sv->rstd1 && sv->mu2 && sv->rstd2),
+                   "nafblock_fwd: saved.xn1 / xn2 / g / v / statistics missing (optional only where dcpt_nafblock_fused_ffn(C) is 1)");
+    DCPT_CHECK_ARG((sv->mu1 == nullptr) == (sv->rstd1 == nullptr) && (sv->mu2 == nullptr) == (sv->rstd2 == nullptr), "nafblock_fwd: mu / rstd come in pairs");
     // the normalised activations are materialised once: conv1's forward GEMM and (in backward) its weight-gradient GEMM
     // then take them as plain operands, i.e. straight global -> LDS by DMA
     const bool ffn = ffn_fused_f32(C);
@@ -246,7 +249,8 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
                                  int B, int H, int W, int C, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(p && gr && inp && sv && dout && dinp, "nafblock_bwd: null argument");
-    DCPT_CHECK_ARG(sv->xn1 && sv->xn2 && sv->g, "nafblock_bwd: saved.xn1 / saved.xn2 / saved.g missing");
+    DCPT_CHECK_ARG(sv->v && sv->mu1 && sv->rstd1 && sv->mu2 && sv->rstd2 && (ffn_fused_f32(C) || (sv->xn1 && sv->xn2 && sv->g)),
+                   "nafblock_bwd: saved tensors missing");
     DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nafblock_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     BwdWs w;
     const size_t need = bwd_ws_layout(B, H, W, C, ws, ws_bytes, &w);

@@ -80,6 +80,14 @@ def _contig(t):
 
 
 # ------------------------------------------------------------------------------------------------
+def _saved_f32(t1, t2, y, v, stats, pooled, s, xn):
+    """dcpt_nafblock_saved over the forward's buffers; v / stats / xn are None where the library does not use them (NULL pointers)."""
+    st = [0, 0, 0, 0] if stats is None else [stats[i].data_ptr() for i in range(4)]
+    xs = [0, 0, 0] if xn is None else [xn[i].data_ptr() for i in range(3)]
+    return NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), 0 if v is None else v.data_ptr(), st[0], st[1], st[2], st[3],
+                         pooled.data_ptr(), s.data_ptr(), xs[0], xs[1], xs[2])
+
+
 class _NAFBlockFn(torch.autograd.Function):
     """reference basicsr/archs/nafnet_arch.py:165-186 (NAFBlock.forward) -> dcpt_nafblock_fwd/bwd."""
 
@@ -96,26 +104,33 @@ class _NAFBlockFn(torch.autograd.Function):
         t1 = _empty_nhwc(B, 2 * Cc, H, W, dev)
         t2 = _empty_nhwc(B, Cc, H, W, dev)
         y = _empty_nhwc(B, Cc, H, W, dev)
-        v = _empty_nhwc(B, 2 * Cc, H, W, dev)
-        xn = torch.empty((3, B, H, W, Cc), dtype=torch.float32, device=dev)   # LN1(inp), LN2(y), SimpleGate(v)
-        stats = torch.empty((4, M), dtype=torch.float32, device=dev)
+        # where the forward 1 x 1 chains are fused (dcpt_nafblock_fused_ffn) LN1(inp), LN2(y) and the gate do not exist; with no
+        # backward coming, v and the statistics are not written either
+        fused = bool(lib.dcpt_nafblock_fused_ffn(Cc))
+        infer = fused and not any(ctx.needs_input_grad)
+        v = None if infer else _empty_nhwc(B, 2 * Cc, H, W, dev)
+        xn = None if fused else torch.empty((3, B, H, W, Cc), dtype=torch.float32, device=dev)   # LN1(inp), LN2(y), SimpleGate(v)
+        stats = None if infer else torch.empty((4, M), dtype=torch.float32, device=dev)
         pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         s = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
-        sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr(),
-                           xn[0].data_ptr(), xn[1].data_ptr(), xn[2].data_ptr())
+        sv = _saved_f32(t1, t2, y, v, stats, pooled, s, xn)
         nws = lib.dcpt_nafblock_fwd_ws_bytes(B, H, W, Cc)
         ws = _workspace(dev, nws)
         check(lib.dcpt_nafblock_fwd(C.byref(ps), inp.data_ptr(), out.data_ptr(), C.byref(sv), ws.data_ptr(), ws.numel(),
                                     B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd")
-        ctx.save_for_backward(inp, t1, t2, y, v, stats, pooled, s, xn, *params)
+        if not infer:
+            ctx.has_xn = xn is not None
+            ctx.save_for_backward(inp, t1, t2, y, v, stats, pooled, s, *(() if xn is None else (xn,)), *params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        inp, t1, t2, y, v, stats, pooled, s, xn, *params = ctx.saved_tensors
+        if ctx.has_xn:
+            inp, t1, t2, y, v, stats, pooled, s, xn, *params = ctx.saved_tensors
+        else:
+            (inp, t1, t2, y, v, stats, pooled, s, *params), xn = ctx.saved_tensors, None
         dout = _nhwc(dout)
         B, Cc, H, W = inp.shape
         dev = inp.device
@@ -123,9 +138,7 @@ class _NAFBlockFn(torch.autograd.Function):
         dinp = _empty_nhwc(B, Cc, H, W, dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         gs = NafBlockGrads(*[g.data_ptr() for g in grads])
-        sv = NafBlockSaved(t1.data_ptr(), t2.data_ptr(), y.data_ptr(), v.data_ptr(), stats[0].data_ptr(),
-                           stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), pooled.data_ptr(), s.data_ptr(),
-                           xn[0].data_ptr(), xn[1].data_ptr(), xn[2].data_ptr())
+        sv = _saved_f32(t1, t2, y, v, stats, pooled, s, xn)
         nws = lib.dcpt_nafblock_bwd_ws_bytes(B, H, W, Cc)
         ws = _workspace(dev, nws)
         check(lib.dcpt_nafblock_bwd(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(),

@@ -93,9 +93,12 @@ typedef struct {   /* activations kept for backward (M = B*H*W pixels) */
 
 size_t dcpt_nafblock_fwd_ws_bytes(int B, int H, int W, int C);
 size_t dcpt_nafblock_bwd_ws_bytes(int B, int H, int W, int C);
-/* inp,out: [B][H][W][C].  `saved` is the forward's scratch for ITS OWN backward (inference callers may recycle the buffers): every
- * pointer must be valid, but which of the tensors hold data afterwards is the library's business -- at C = 64 the fused forward chains
- * (ffn_f32.hip) write neither xn1, xn2 nor g: dcpt_nafblock_bwd takes them from its GEMMs' operand loaders. */
+/* inp,out: [B][H][W][C].  `saved` is the forward's scratch for ITS OWN backward (inference callers may recycle the buffers); which of
+ * the tensors hold data afterwards is the library's business.  Where dcpt_nafblock_fused_ffn(C) is 1 (C = 64: the forward 1 x 1 chains
+ * run as one pass each, ffn_f32.hip) saved->xn1 / xn2 / g are never read or written in either pass and may be NULL (dcpt_nafblock_bwd takes
+ * them from its GEMMs' operand loaders), and a caller that will not run the backward pass may also pass v = mu1 = rstd1 = mu2 = rstd2 =
+ * NULL: the forward then skips those writes (the second half moves 2 tensor passes instead of 4).  Elsewhere every pointer is required. */
+int dcpt_nafblock_fused_ffn(int C);
 int dcpt_nafblock_fwd(const dcpt_nafblock_params* p, const float* inp, float* out, const dcpt_nafblock_saved* saved,
                       void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
 /* dout,dinp: [B][H][W][C]; dinp may alias dout. */

@@ -428,3 +428,23 @@ def test_training_trajectory_matches_oracle(dev):
         assert abs(a - b) <= (2e-6 if i < 3 else 1e-4) * abs(b), (i, lg, lr_)
     for k in sd:
         check("param " + k, net.state_dict()[k], P[k].detach(), 5e-3)   # lr = 2e-3: an update whose sign flips shows up as ~4e-3
+
+
+@pytest.mark.gpu
+def test_fused_narrow_level_inference_drops_saved_tensors(dev):
+    """Where the forward 1 x 1 chains are fused (dcpt_nafblock_fused_ffn(C) = 1: C = 64, ffn_f32.hip) LN1(inp) / LN2(y) / the gate are
+    never allocated, and a forward that no backward follows passes no v / statistics buffers either; its output is bit-identical to
+    the training forward's (ragged last group of 32 pixels included)."""
+    from dcpt_amd import _lib, functional as DF
+
+    lib = _lib.load()
+    assert lib.dcpt_nafblock_fused_ffn(64) == 1 and lib.dcpt_nafblock_fused_ffn(128) == 0
+    for shape in [(3, 64, 5, 7), (2, 64, 32, 32)]:
+        P = block_params(64, "inf64.")
+        Pd = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
+        x = keyed_input("inf64.x", shape, lo=-1.0, hi=1.0).to(dev).contiguous(memory_format=torch.channels_last)
+        y_train = DF.nafblock(x.clone().requires_grad_(True), {fk: Pd[rk] for fk, rk in FUSED.items()})
+        with torch.no_grad():
+            y_inf = DF.nafblock(x, {fk: Pd[rk] for fk, rk in FUSED.items()})
+        torch.cuda.synchronize()
+        assert torch.equal(y_train.detach(), y_inf)
