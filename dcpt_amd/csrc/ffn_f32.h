@@ -16,3 +16,16 @@ struct FfnFwdF {
 bool ffn_fwd_f32_ok(int C);
 int launch_ffn_fwd_f32(const FfnFwdF& p, int C, hipStream_t s);   // FFN
 int launch_ln_conv_f32(const FfnFwdF& p, int C, hipStream_t s);   // HEAD: v = conv(LN(y)) + b4
+
+// backward data path of the second half in one pass: dv (operand of conv4's weight-gradient GEMM) and dy = dout + LayerNorm2 backward
+struct FfnBwdF {
+    const float *dout, *v, *y;   // [M][C], [M][2C], [M][C]
+    const float *wT5, *wT4;      // wT5[k][n] = W5[n][k] gamma[n]  ([C][C]),  wT4[c][j] = W4[j][c]  ([C][2C])
+    const float* lnw;            // [C]
+    float *dv, *dy;              // [M][2C], [M][C]
+    float* lnpart;               // [ffn_bwd_f32_waves(M)][2][C]: sum_rows dxn2 * xhat, sum_rows dxn2
+    int64_t M;
+    float eps;
+};
+int ffn_bwd_f32_waves(int64_t M);
+int launch_ffn_bwd_f32(const FfnBwdF& p, int C, hipStream_t s);

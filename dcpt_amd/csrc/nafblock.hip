@@ -57,9 +57,11 @@ struct BwdWs {
     // LayerNorm backward with supplied row sums (C > 128, gemm.h E_LNBWD2): u / cvec of conv4 o LN2 and conv1 o LN1, row partials
     float *u4, *c4, *u1, *c1, *rowpart;
     int rp_sg, rp_dw;   // partials per row written by the SimpleGate-backward GEMM / the fused depthwise backward
+    float* ffn_part;    // LayerNorm2 column partials of the fused narrowest-level backward (ffn_f32.hip): [waves][2][C]
 };
 
 bool ln_in_epilogue(int C);
+bool ffn_fused_f32(int C);
 size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs* out) {
     WsAlloc a(base, base ? bytes : (size_t)-1);
     const int64_t M = (int64_t)B * H * W;
@@ -122,6 +124,7 @@ size_t bwd_ws_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWs
     w.rp_sg = cdiv(C, 64);   // upper bound over the tile widths the SimpleGate-backward launch may pick (64 / 96 / 128)
     w.rp_dw = dw_fused_row_chunks(g);
     w.rowpart = a.get<float>((size_t)M * (w.rp_sg > w.rp_dw ? w.rp_sg : w.rp_dw) * 2);
+    w.ffn_part = ffn_fused_f32(C) ? a.get<float>((size_t)ffn_bwd_f32_waves(M) * 2 * C) : nullptr;
     if (out) *out = w;
     return a.off;
 }
@@ -295,17 +298,24 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     }
     GemmNT g{};
     GemmTN tp{};
-    // B1: dv = SG'(dout*gamma * W5; v)  (+ the row sums of LN2's backward, which are linear in dv)
-    g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = dv; g.ldc = C2; g.aux = sv->v;
+    const bool ffn = ffn_fused_f32(C);   // narrowest level: B1 + B3 + B5 as one pass (ffn_f32.hip); the forward kept neither LN outputs nor the gate
     int rp_b1 = 0;
-    if (lrs) {
-        g.rowpart = w.rowpart; g.uvec = w.u4; g.cvec = w.c4;
-        rp_b1 = gemm_nt_tiles_n(g, A_PLAIN, E_SGBWD);
+    if (ffn) {
+        FfnBwdF f{};
+        f.dout = dout; f.v = sv->v; f.y = sv->y; f.wT5 = w.wT5; f.wT4 = w.wT4; f.lnw = p->norm2_w; f.dv = dv; f.dy = dy; f.lnpart = w.ffn_part;
+        f.M = M; f.eps = 1e-6f;
+        DCPT_TRY(launch_ffn_bwd_f32(f, C, s));
+    } else {
+        // B1: dv = SG'(dout*gamma * W5; v)  (+ the row sums of LN2's backward, which are linear in dv)
+        g.M = M; g.A = dout; g.lda = C; g.K = C; g.Bw = w.wT5; g.N = C; g.C = dv; g.ldc = C2; g.aux = sv->v;
+        if (lrs) {
+            g.rowpart = w.rowpart; g.uvec = w.u4; g.cvec = w.c4;
+            rp_b1 = gemm_nt_tiles_n(g, A_PLAIN, E_SGBWD);
+        }
+        DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SGBWD, s));
     }
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SGBWD, s));
     // B2: conv5 / gamma gradients
     tp = GemmTN{};
-    const bool ffn = ffn_fused_f32(C);   // (the forward kept neither LN1(inp), LN2(y) nor the gate: operand loaders make them)
     if (ffn) DCPT_TRY(wgrad(dout, C, C, sv->v, C2, C, A_SG, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
     else
     DCPT_TRY(wgrad(dout, C, C, sv->g, C, C, A_PLAIN, tp, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w,
@@ -315,7 +325,9 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     g = GemmNT{};
     const int ln_tiles = (int)cdiv64(M, 128);
     g.M = M; g.A = dv; g.lda = C2; g.K = C2; g.Bw = w.wT4; g.N = C; g.C = gln; g.ldc = C;
-    if (lne) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv * W4^T)
+    if (ffn) {
+        // (done above)
+    } else if (lne) {   // B3 + B5 in one launch: dy = dout + LN2-backward(dv * W4^T)
         g.C = dy; g.res = sv->y; g.ldres = C; g.aux = dout; g.mu = sv->mu2; g.rstd = sv->rstd2; g.lnw = p->norm2_w; g.colpart = w.lnpart;
         DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_LNBWD, s));
     } else if (lrs) {   // the same in one launch at any width: the row sums were left by B1
@@ -334,9 +346,10 @@ extern "C" int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafbl
     DCPT_TRY(wgrad(dv, C2, C2, sv->xn2, C, C, A_PLAIN, tp, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr,
                    gr->conv4_b, sw));
     // B5: dy = dout + LN2-backward
-    if (!lne && !lrs) DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
+    if (!ffn && !lne && !lrs) DCPT_TRY(launch_ln_bwd(gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, dy, w.lnpart, w.ln_nblk, M, C, s));
     DCPT_TRY(side_fork(sd, 2, s));      // dy, LN2 partial sums
-    if (lne || lrs) DCPT_TRY(launch_colpart_reduce(w.lnpart, ln_tiles, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    if (ffn) DCPT_TRY(launch_colpart_reduce(w.ffn_part, ffn_bwd_f32_waves(M), 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+    else if (lne || lrs) DCPT_TRY(launch_colpart_reduce(w.lnpart, ln_tiles, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     else DCPT_TRY(launch_colpart_reduce(w.lnpart, w.ln_nblk, 3, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     // B6: dts = d(t2*s)
     // when an image is a whole number of 128-pixel GEMM tiles, SCA's ds[b][k] = sum_p dts * t2 comes out of this GEMM's epilogue
