@@ -12,6 +12,7 @@ import torch
 from torch.nn.parallel import DataParallel, DistributedDataParallel
 
 from basicsr.utils import get_root_logger
+from dcpt_amd import functional as DF
 from basicsr.utils.dist_util import master_only
 
 
@@ -132,8 +133,11 @@ class BaseModel:
         dst = dict(self.net_g_ema.named_parameters())
         keys = list(dst.keys())
         with torch.no_grad():  # one multi-tensor launch pair instead of the reference's 664 mul_/add_ pairs
-            torch._foreach_mul_([dst[k].data for k in keys], decay)
-            torch._foreach_add_([dst[k].data for k in keys], [src[k].data for k in keys], alpha=1 - decay)
+            torch._foreach_mul_([dst[k] for k in keys], decay)
+            torch._foreach_add_([dst[k] for k in keys], [src[k].detach() for k in keys], alpha=1 - decay)
+        # foreach / fused updates do not reliably bump the parameters' version counters: tell the kernels' weight caches
+        # (dcpt_amd.functional.PackedWeightsBf16) explicitly that net_g_ema's parameters have new values
+        DF.invalidate_packed_weights()
 
     # -- checkpoints ------------------------------------------------------------------------------
     @master_only
@@ -192,6 +196,7 @@ class BaseModel:
                 load_net.pop(k)
         self._print_different_keys_loading(net, load_net, strict)
         net.load_state_dict(load_net, strict=strict)
+        DF.invalidate_packed_weights()
 
     # -- logging ----------------------------------------------------------------------------------
     def reduce_loss_dict(self, loss_dict):

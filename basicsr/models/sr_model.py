@@ -128,7 +128,7 @@ class SRModel(BaseModel):
         :398): the input under the 8 elements of the dihedral group (built as the reference builds its list: width flip "v", height
         flip "h", transpose "t", each applied to everything before it), the network on each, every output mapped back and the 8
         results averaged.  The flips / transposes stay on the device (the reference goes through numpy), and augmentations of
-        equal shape run as one batch (the network is per-sample): 1 launch sequence for a square image, 2 otherwise."""
+        equal shape run as one batch (the network is per-sample) up to a pixel budget: 1 pass for a small square image, 2 otherwise."""
         tf = {"v": lambda t: t.flip(-1), "h": lambda t: t.flip(-2), "t": lambda t: t.transpose(-1, -2)}
         lq_list = [self.lq]
         for op in ("v", "h", "t"):
@@ -141,11 +141,17 @@ class SRModel(BaseModel):
         by_shape = {}
         for i, a in enumerate(lq_list):
             by_shape.setdefault(tuple(a.shape), []).append(i)
+        # at most ``val.ensemble_max_pixels`` input pixels per pass (default 2^24 = what a 2K tiled pass already holds; the reference
+        # runs one augmentation at a time, so a large validation image must not need 4-8x its activation memory here)
+        budget = int((self.opt.get("val") or {}).get("ensemble_max_pixels", 1 << 24))
         with torch.no_grad():
             for idx in by_shape.values():
-                out = net(torch.cat([lq_list[i] for i in idx], 0))
-                for j, i in enumerate(idx):
-                    out_list[i] = out[j * b:(j + 1) * b]
+                per = max(1, budget // max(1, lq_list[idx[0]][:, 0].numel()))
+                for c0 in range(0, len(idx), per):
+                    part = idx[c0:c0 + per]
+                    out = net(torch.cat([lq_list[i] for i in part], 0)) if len(part) > 1 else net(lq_list[part[0]])
+                    for j, i in enumerate(part):
+                        out_list[i] = out[j * b:(j + 1) * b]
         for i in range(8):   # undo in the reverse order of application (reference :218-226)
             if i > 3:
                 out_list[i] = tf["t"](out_list[i])
@@ -266,8 +272,11 @@ class SRModel(BaseModel):
                     del self.gt
                 continue
             vis = self.get_current_visuals()
-            result = vis["result"].clamp(0, 1) if clamp else torch.nan_to_num(vis["result"], nan=0.0)   # reference sr_model.py:408-413, :432-436
+            # reference sr_model.py:408-413: clamp if asked; without clamp the metrics see the raw output (:421-430) and NaNs are zeroed
+            # only afterwards (:431-436), i.e. for the saved image
+            result = vis["result"].clamp(0, 1) if clamp else vis["result"]
             if save_img:
+                result_img = result if clamp else torch.nan_to_num(result, nan=0.0)
                 import os
 
                 from PIL import Image
@@ -275,7 +284,7 @@ class SRModel(BaseModel):
                 stem = osp.splitext(osp.basename(val_data["lq_path"][0]))[0]
                 folder = osp.join(self.opt["path"]["visualization"], name)
                 os.makedirs(folder, exist_ok=True)
-                Image.fromarray(tensor2img_rgb(result)).save(osp.join(folder, f"{stem}_{self.opt['name']}.png"))
+                Image.fromarray(tensor2img_rgb(result_img)).save(osp.join(folder, f"{stem}_{self.opt['name']}.png"))
             if "gt" in vis and metrics_opt:
                 # the reference hands the float BCHW arrays in [0,1] to the metric, which quantises them to uint8 (:421-430)
                 gt = (vis["gt"].clamp(0, 1) if clamp else vis["gt"]).numpy()

@@ -13,6 +13,7 @@ import ctypes as C
 from typing import Dict, Tuple
 
 import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import _lib
 from ._lib import NafBlockGrads, NafBlockParams, NafBlockSaved, PARAM_FIELDS, check
@@ -92,7 +93,7 @@ class _NAFBlockFn(torch.autograd.Function):
     """reference basicsr/archs/nafnet_arch.py:165-186 (NAFBlock.forward) -> dcpt_nafblock_fwd/bwd."""
 
     @staticmethod
-    def forward(ctx, inp, *params):
+    def forward(ctx, inp, grad_mode, *params):
         lib = _lib.load()
         _require_gpu(inp, *params)
         inp = _nhwc(inp)
@@ -107,7 +108,9 @@ class _NAFBlockFn(torch.autograd.Function):
         # where the forward 1 x 1 chains are fused (dcpt_nafblock_fused_ffn) LN1(inp), LN2(y) and the gate do not exist; with no
         # backward coming, v and the statistics are not written either
         fused = bool(lib.dcpt_nafblock_fused_ffn(Cc))
-        infer = fused and not any(ctx.needs_input_grad)
+        # (needs_input_grad follows requires_grad alone -- it stays True under torch.no_grad() --, hence the caller's grad mode)
+        infer = fused and not (grad_mode and any(ctx.needs_input_grad))
+        _NAFBlockFn.last_infer = infer   # (read by the tests: which form the last forward took)
         v = None if infer else _empty_nhwc(B, 2 * Cc, H, W, dev)
         xn = None if fused else torch.empty((3, B, H, W, Cc), dtype=torch.float32, device=dev)   # LN1(inp), LN2(y), SimpleGate(v)
         stats = None if infer else torch.empty((4, M), dtype=torch.float32, device=dev)
@@ -144,12 +147,12 @@ class _NAFBlockFn(torch.autograd.Function):
         check(lib.dcpt_nafblock_bwd(C.byref(ps), C.byref(gs), inp.data_ptr(), C.byref(sv), dout.data_ptr(),
                                     dinp.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)),
               "dcpt_nafblock_bwd")
-        return (dinp, *grads)
+        return (dinp, None, *grads)
 
 
 def nafblock(inp: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
     """params: dict with the keys of _lib.PARAM_FIELDS (reference state-dict tensors)."""
-    return _NAFBlockFn.apply(inp, *[params[k] for k in PARAM_FIELDS])
+    return _NAFBlockFn.apply(inp, torch.is_grad_enabled(), *[params[k] for k in PARAM_FIELDS])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -183,7 +186,7 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
     """NAFBlock.forward (reference nafnet_arch.py:165-186) with bf16 storage -> dcpt_nafblock_fwd_bf16 / bwd_bf16."""
 
     @staticmethod
-    def forward(ctx, inp, packed, *params):
+    def forward(ctx, inp, packed, grad_mode, *params):
         lib = _lib.load()
         _require_gpu_bf16(inp)
         _require_gpu(*params)
@@ -200,7 +203,8 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         # tensors only that backward reads (v, LN2(y), SimpleGate(v), LN2's statistics) are neither allocated nor written
         # where the block's second half is one kernel, its backward recomputes LN2(y), the gate and LN2's statistics: never allocated
         fused = bool(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
-        infer = fused and not any(ctx.needs_input_grad)
+        infer = fused and not (grad_mode and any(ctx.needs_input_grad))
+        _NAFBlockBf16Fn.last_infer = infer
         v = None if infer else _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
         acts = torch.empty((3 if fused else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
         stats = torch.empty((2 if fused else 4, M), dtype=torch.float32, device=dev)
@@ -240,25 +244,47 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
             check(lib.dcpt_nafblock_bwd_bf16_packed(C.byref(ps), packed.data_ptr(), packed.numel(), C.byref(gs), inp.data_ptr(), C.byref(sv),
                                                     dout.data_ptr(), dinp.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)),
                   "dcpt_nafblock_bwd_bf16_packed")
-        return (dinp, None, *grads)
+        return (dinp, None, None, *grads)
 
 
 # parameters whose values the packed operand copies are made from
 _PACK_DEPS = ("conv1_w", "conv2_w", "conv3_w", "conv4_w", "conv5_w", "beta", "gamma")
 
 
+# Generation counter of "the parameters may have changed".  torch's ``_version`` is NOT enough to detect that: fused / foreach
+# optimizers (``AdamW(fused=True)``: aten::_fused_adamw_) and updates through ``p.data`` change a parameter's values without bumping
+# the parameter's version counter.  Every optimizer step of the process bumps the generation (a global post-step hook), as do
+# ``BaseModel.model_ema`` / ``load_network``; code that writes parameters any other way calls ``invalidate_packed_weights()``.
+_PACK_GENERATION = 0
+
+
+def invalidate_packed_weights() -> int:
+    """Mark every cached operand copy of the weights (PackedWeightsBf16) stale; returns the new generation."""
+    global _PACK_GENERATION
+    _PACK_GENERATION += 1
+    return _PACK_GENERATION
+
+
+def _optimizer_step_post_hook(optimizer, args, kwargs):
+    invalidate_packed_weights()
+
+
+register_optimizer_step_post_hook(_optimizer_step_post_hook)
+
+
 class PackedWeightsBf16:
     """Per-block cache of the operand copies of a NAFBlock's weights for the bf16 path (dcpt_nafblock_wpack_bf16): refreshed -- one
-    launch -- when a parameter the copies are made from has changed since the last pack (torch bumps ``_version`` on every in-place
-    update: optimizer steps, load_state_dict, ``.copy_``) or moved (``.to(device)``), reused otherwise: within a training step the
-    forward, the backward and, in the DCPT step, both encoder passes share one pack."""
+    launch -- when the parameters may have changed since the last pack, reused otherwise: within a training step the forward, the
+    backward and, in the DCPT step, both encoder passes share one pack.  "May have changed" = a new generation (any optimizer step,
+    EMA update or checkpoint load of the process, ``invalidate_packed_weights()``), a bumped ``_version`` (ordinary in-place updates:
+    ``load_state_dict``, ``.copy_``) or a new address (``.to(device)``)."""
 
     def __init__(self):
         self.key = None
         self.buf = None
 
     def get(self, params: Dict[str, torch.Tensor]) -> torch.Tensor:
-        key = tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
+        key = (_PACK_GENERATION,) + tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
         if key != self.key:
             lib = _lib.load()
             ps = tuple(_contig(params[k].detach()) for k in PARAM_FIELDS)
@@ -278,7 +304,7 @@ def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor], packed: Pa
     """bf16 activations in / out, fp32 parameters (dict with the keys of _lib.PARAM_FIELDS); ``packed``: the block's weight-pack cache
     (without it every call packs its own operand copies)."""
     buf = packed.get(params) if packed is not None else None
-    return _NAFBlockBf16Fn.apply(inp, buf, *[params[k] for k in PARAM_FIELDS])
+    return _NAFBlockBf16Fn.apply(inp, buf, torch.is_grad_enabled(), *[params[k] for k in PARAM_FIELDS])
 
 
 class _CastFn(torch.autograd.Function):

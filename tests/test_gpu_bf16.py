@@ -659,6 +659,44 @@ def test_packed_weights_cache_is_exact_and_follows_the_parameters(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused,foreach", [(True, False), (False, True), (False, False)])
+def test_packed_weights_follow_an_optimizer_step(dev, fused, foreach):
+    """Fused / foreach optimizers change the parameters WITHOUT bumping ``_version`` (aten::_fused_adamw_): the pack cache must not
+    key on the version alone.  After one AdamW step the cached block equals the uncached call bit for bit, forward and backward; the
+    same for an EMA-style ``torch._foreach_*`` update followed by ``invalidate_packed_weights()`` (BaseModel.model_ema)."""
+    from basicsr.archs.nafnet_arch import NAFBlock
+    from dcpt_amd import functional as DF
+    from dcpt_amd.keyed_init import fill_module_
+
+    blk = fill_module_(NAFBlock(64)).to(dev)
+    blk.act_bf16 = True
+    x = keyed_input("pko.x", (2, 64, 16, 24), lo=-1.5, hi=1.5).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gw = keyed_input("pko.g", (2, 64, 16, 24), lo=-1, hi=1).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    opt = torch.optim.AdamW(blk.parameters(), lr=1e-2, fused=fused, foreach=foreach)
+
+    def run(use_cache):
+        for p in blk.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi) if use_cache else DF.nafblock_bf16(xi, blk.fused_params())
+        y.backward(gw)
+        return y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+
+    y0 = run(True)[0]
+    opt.step()
+    ref, got = run(False), run(True)
+    assert not torch.equal(ref[0], y0)                                 # the step moved the weights ...
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and all(torch.equal(a, b) for a, b in zip(ref[2], got[2]))
+    with torch.no_grad():                                              # ... and so does an EMA-style foreach update
+        ps = list(blk.parameters())
+        torch._foreach_mul_(ps, 0.9)
+    DF.invalidate_packed_weights()
+    ref2, got2 = run(False), run(True)
+    assert not torch.equal(ref2[0], ref[0])
+    assert torch.equal(ref2[0], got2[0]) and torch.equal(ref2[1], got2[1]) and all(torch.equal(a, b) for a, b in zip(ref2[2], got2[2]))
+
+
+@pytest.mark.gpu
 def test_fused_second_half_inference_drops_saved_tensors(dev):
     """Where the second half of the block is one kernel (dcpt_nafblock_bf16_fused_ffn(C) = 1: C = 64, ffn_bf16.hip) a forward that no
     backward will follow passes no v / LN2(y) / gate / LN2-statistics buffers; the output is bit-identical to the training forward's,
@@ -674,7 +712,12 @@ def test_fused_second_half_inference_drops_saved_tensors(dev):
         Pd = {k: P[v].to(dev).requires_grad_(True) for k, v in FUSED.items()}
         x = keyed_input(tag + "x", shape, lo=-1.5, hi=1.5).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
         y_train = DF.nafblock_bf16(x.clone().requires_grad_(True), Pd)
-        with torch.no_grad():
+        assert DF._NAFBlockBf16Fn.last_infer is False
+        with torch.no_grad():   # parameters that require grad, as net_g / net_g_ema have in validation: the grad MODE decides
             y_inf = DF.nafblock_bf16(x, Pd)
+        assert DF._NAFBlockBf16Fn.last_infer is True    # the NULL-pointer form of dcpt_nafblock_fwd_bf16 ran
         torch.cuda.synchronize()
         assert torch.equal(y_train.detach(), y_inf)
+        Pf = {k: v.detach() for k, v in Pd.items()}
+        y_inf2 = DF.nafblock_bf16(x, Pf)                  # grad mode on, nothing requires grad
+        assert DF._NAFBlockBf16Fn.last_infer is True and torch.equal(y_inf2, y_inf)

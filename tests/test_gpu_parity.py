@@ -444,7 +444,9 @@ def test_fused_narrow_level_inference_drops_saved_tensors(dev):
         Pd = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
         x = keyed_input("inf64.x", shape, lo=-1.0, hi=1.0).to(dev).contiguous(memory_format=torch.channels_last)
         y_train = DF.nafblock(x.clone().requires_grad_(True), {fk: Pd[rk] for fk, rk in FUSED.items()})
-        with torch.no_grad():
+        assert DF._NAFBlockFn.last_infer is False
+        with torch.no_grad():   # parameters that require grad (net_g in validation): the grad MODE selects the inference form
             y_inf = DF.nafblock(x, {fk: Pd[rk] for fk, rk in FUSED.items()})
+        assert DF._NAFBlockFn.last_infer is True   # the NULL v / statistics form of dcpt_nafblock_fwd ran
         torch.cuda.synchronize()
         assert torch.equal(y_train.detach(), y_inf)
