@@ -45,8 +45,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--size", type=int, default=0)
+    ap.add_argument("--side-stream", type=int, default=1, choices=[0, 1], help="0: weight-gradient work on the caller's stream (serialized kernel times)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if not args.side_stream:
+        from dcpt_amd import _lib
+
+        _lib.load().dcpt_set_side_stream(0)
     from basicsr.archs import build_network
     from dcpt_amd.keyed_init import fill_module_
 

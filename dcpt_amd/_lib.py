@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 _lock = threading.Lock()
 
@@ -98,6 +98,8 @@ SIGNATURES = {
                                              cint, cint, cint, cint, stream_t]),
     "dcpt_nafblock_bwd_bf16_packed": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, C.POINTER(NafBlockGrads), f32p,
                                              C.POINTER(NafBlockSavedBf16), f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv1x1_wgrad_bf16_ws_bytes": (sz, [i64, cint, cint]),
+    "dcpt_conv1x1_wgrad_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, i64, cint, cint, stream_t]),
     "dcpt_cast_f32_bf16": (cint, [f32p, f32p, i64, stream_t]),
     "dcpt_cast_bf16_f32": (cint, [f32p, f32p, i64, stream_t]),
     "dcpt_conv_ln_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint, cint]),

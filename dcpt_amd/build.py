@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libdcpt_hip.so")
 ARCH = "gfx950"
-SOURCES = ["gemm_nt.hip", "gemm_x3.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip", "prof.hip", "side.hip", "dchead.hip", "restormer.hip", "promptir.hip", "comm.hip", "gemm_bf16.hip", "gemm_bf16_256.hip", "bf16_ops.hip", "nafblock_bf16.hip", "dwring.hip", "dchead_bf16.hip", "edge_bf16.hip", "ffn_bf16.hip", "ffn_f32.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_x3.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip", "prof.hip", "side.hip", "dchead.hip", "restormer.hip", "promptir.hip", "comm.hip", "gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_tn_bf16_256.hip", "bf16_ops.hip", "nafblock_bf16.hip", "dwring.hip", "dchead_bf16.hip", "edge_bf16.hip", "ffn_bf16.hip", "ffn_f32.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 

@@ -132,3 +132,62 @@ int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s);
 int gemm_tn_bf16_tiles_k(int N, int K);
 void gemm_tn_bf16_plan(int64_t M, int N, int K, int* splits, int64_t* rows_per_split);
 bool gemm_tn_bf16_plan_images(int64_t M, int N, int K, int P, int* splits, int64_t* rows_per_split);
+
+// ---- grouped weight-gradient GEMM with 256 x 256 tiles + the finisher (gemm_tn_bf16_256.hip) ------------------------------
+// G_p[n][k] = sum_m X_p[m][n] * Y_p[m][k] for up to TNG_MAX problems in one launch; N, K multiples of 256; every (problem, tile,
+// pixel range) is one block, partial sums go to fp32 slabs in the accumulator layout ([splits][tiles][65536], read back only by
+// launch_wgrad_finish), column sums of X to colsum[splits][N] (optional).
+constexpr int TNG_MAX = 4;
+struct TnProb {
+    const bf16_t* X;
+    const bf16_t* Y;
+    float* slab;
+    float* colsum;
+    int64_t M;
+    int N, K, ldx, ldy;
+    // filled by gemm_tn_bf16_256_plan: `splits` blocks per tile of rows_per_split pixels each; seg_rows > 0: a block's pixels are cut into
+    // pieces of seg_rows (one image each; rows_per_split is a multiple) with ONE PARTIAL-SUM SLOT PER PIECE, so that the finisher can
+    // weight every image's sum on its own; `slots` = partial sums per tile (= splits, or the number of pieces)
+    int splits, tiles_k, blk0, seg_rows, slots;
+    int64_t rows_per_split;
+};
+struct GemmTNG {
+    TnProb p[TNG_MAX];
+    int n;
+};
+bool gemm_tn_bf16_256_ok(int N, int K);
+// img_P[i] > 0: problem i needs partial sums per image of img_P[i] pixels (false if that is not possible: no plan is made)
+bool gemm_tn_bf16_256_plan(GemmTNG& g, const int* img_P = nullptr, int target_blocks = 256);
+size_t gemm_tn_bf16_256_slab_floats(const TnProb& p);
+size_t gemm_tn_bf16_256_colsum_floats(const TnProb& p);
+int launch_gemm_tn_bf16_256(const GemmTNG& g, hipStream_t s);
+
+// Finisher: one launch for every parameter-gradient reduction of a block.
+//   slab jobs: dW[n][k] = rowscale[n] * sum_s (kscale ? kscale[s / ks_div][k] : 1) * slab_s[n][k];
+//              dgain[n] = sum_k W[n][k] G[n][k] + wbias[n] cs[n];  dbias[n] = rowscale[n] cs[n]   (cs = sum_s colsum[s][n])
+//   cols jobs: out_j[c] = sum_r part[r][j][c]  (mode 0: j < nj <= 2 -> out0 / out1;  mode 1: nj = 10 depthwise taps -> out0[c][9], out1[c])
+//   sca job  : dW[n][k] = sum_b ds[b][n] pooled[b][k],  db[n] = sum_b ds[b][n]   (ds == null: none)
+constexpr int FIN_MAX_COLS = 4;
+struct FinSlab {
+    const float *slab, *colsum, *rowscale, *W, *wbias, *kscale;
+    float *dW, *dgain, *dbias;
+    int N, K, splits, tiles_k, ks_div, cs_rows;   // splits = partial sums per tile; cs_rows = rows of colsum (blocks per tile)
+};
+struct FinCols {
+    const float* part;
+    float *out0, *out1;
+    int R, nj, C, mode;
+};
+struct FinSca {
+    const float *ds, *pooled;
+    float *dW, *db;
+    int B, C;
+};
+struct FinJobs {
+    FinSlab slab[TNG_MAX];
+    FinCols cols[FIN_MAX_COLS];
+    FinSca sca;
+    int nslab, ncols;
+    int slab_blk0[TNG_MAX], cols_blk0[FIN_MAX_COLS], slab_end, cols_end;   // filled by launch_wgrad_finish
+};
+int launch_wgrad_finish(FinJobs& j, hipStream_t s);

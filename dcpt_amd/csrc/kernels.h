@@ -98,7 +98,8 @@ int sca_ds_fused_slices(int P);   // P / 128 when the E_DOTCOL form applies, els
 int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B, int C, int P, hipStream_t s);
 // (the slices may also come out of the dts GEMM's E_DOTCOL epilogue: 128-pixel slices, nslices = P / 128)
 // critical path: dpool[b][k] = (1/P) sum_n Wsca[n][k] * sum_j part[b][j][n]
-int launch_sca_dpool(const float* ds_part, int nslices, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s);
+// (ds_out != null: also stores ds[b][n] = sum_j part[b][j][n], which the parameter-gradient side needs)
+int launch_sca_dpool(const float* ds_part, int nslices, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s, float* ds_out = nullptr);
 // parameter gradients (off the critical path): ds = sum_j part, dWsca = ds^T pooled, dbsca = sum_b ds
 int launch_sca_wgrad(const float* ds_part, int nslices, float* ds, const float* pooled, float* dWsca, float* dbsca, int B, int C,
                      hipStream_t s);

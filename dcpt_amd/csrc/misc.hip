@@ -89,7 +89,7 @@ __global__ void sca_ds_final_kernel(const float* __restrict__ part, float* __res
 // grid (C/32, B): 32 k-columns x 8 n-groups; the block first sums the pixel slices of its image into LDS (so there is no
 // separate ds pass on this path), then every thread runs an 8-way unrolled dot over its n values.
 __global__ __launch_bounds__(256) void sca_dpool_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ Wsca,
-                                                        float* __restrict__ dpool, int C, float invP) {
+                                                        float* __restrict__ dpool, int C, float invP, float* __restrict__ ds_out) {
     extern __shared__ __attribute__((aligned(16))) float dsl[];   // ds[C]
     __shared__ float red[8][32];
     __shared__ float psum[256];
@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void sca_dpool_kernel(const float* __restrict_
         }
     }
     __syncthreads();
+    if (ds_out != nullptr && blockIdx.x == 0)   // (the parameter-gradient side reads ds instead of summing the slices again)
+        for (int n = tid; n < C; n += 256) ds_out[(int64_t)b * C + n] = dsl[n];
     const int kl = tid & 31, ng = tid >> 5;
     const int k = blockIdx.x * 32 + kl;
     float s = 0.f;
@@ -389,9 +391,9 @@ int launch_sca_ds_part(const float* dts, const float* t2, float* ds_part, int B,
     return DCPT_OK;
 }
 
-int launch_sca_dpool(const float* ds_part, int nslices, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s) {
+int launch_sca_dpool(const float* ds_part, int nslices, const float* Wsca, float* dpool, int B, int C, int P, hipStream_t s, float* ds_out) {
     DCPT_CHECK_ARG(B <= 65535 && C * 4 <= 65536 && nslices >= 1, "sca_dpool: B=%d C=%d", B, C);
-    sca_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), C * sizeof(float), s>>>(ds_part, nslices, Wsca, dpool, C, 1.0f / (float)P);
+    sca_dpool_kernel<<<dim3(cdiv(C, 32), B), dim3(256), C * sizeof(float), s>>>(ds_part, nslices, Wsca, dpool, C, 1.0f / (float)P, ds_out);
     DCPT_CHECK_LAUNCH("sca_dpool");
     return DCPT_OK;
 }

@@ -67,7 +67,30 @@ struct BwdWsB {
     bool lrs;
     float *ffn_g5, *ffn_g4, *ffn_cs5, *ffn_cs4;   // per-wave slabs / column sums of ffn_wgrad_bf16
     float *ffn_part, *ffn_part1;   // LayerNorm2 / LayerNorm1 column partials of the fused narrow-level backward kernels: [waves][2][C] each
+    // wide levels (C % 256 == 0): the four weight gradients as two grouped 256 x 256-tile launches + one finisher (gemm_tn_bf16_256.hip)
+    bool tn256, conv3_images;
+    GemmTNG wg;   // conv5, conv4, conv3, conv1: shapes, pixel ranges, partial-sum / column-sum buffers
 };
+
+// The four weight gradients of a wide block as ONE grouped launch (after dt1 exists): the more tiles a launch has, the fewer partial sums
+// per output element its 256 blocks make -- 24 tiles at C = 512 are 10 per element and 86 MB of slabs per block backward where two
+// launches of 12 tiles made 21 and 132 MB, four single launches 32 and 256 MB -- and the two streams time-slice rather than overlap
+// (profiles/r4/), so what counts is the bytes, not how early a weight gradient can start.
+bool plan_wg256(int64_t M, int C, int P, GemmTNG* g, bool* conv3_images) {
+    if (!gemm_tn_bf16_256_ok(C, C)) return false;
+    *g = GemmTNG{};
+    g->n = 4;
+    const int Ns[4] = {C, 2 * C, C, 2 * C};   // conv5, conv4, conv3, conv1
+    for (int i = 0; i < 4; ++i) {
+        g->p[i].M = M;
+        g->p[i].N = g->p[i].ldx = Ns[i];
+        g->p[i].K = g->p[i].ldy = C;
+    }
+    const int imgP[4] = {0, 0, P, 0};
+    *conv3_images = gemm_tn_bf16_256_plan(*g, imgP);   // conv3's partial sums per image: the SCA scale goes into the finisher
+    if (!*conv3_images) gemm_tn_bf16_256_plan(*g);     // otherwise its Y operand is the scaled copy t2 * s
+    return true;
+}
 
 size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* out) {
     WsAlloc a(base, base ? bytes : (size_t)-1);
@@ -99,8 +122,18 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
     }
     w.slab_elems = slab1 > slab2 ? slab1 : slab2;
     w.colsum_elems = cs1 > cs2 ? cs1 : cs2;
-    w.slab = a.get<float>(w.slab_elems);
-    w.colsum = a.get<float>(w.colsum_elems);
+    w.tn256 = !ffn_fused(C) && plan_wg256(M, C, P, &w.wg, &w.conv3_images);
+    if (w.tn256) {
+        w.slab_elems = w.colsum_elems = 0;
+        w.slab = w.colsum = nullptr;
+        for (int i = 0; i < w.wg.n; ++i) {
+            w.wg.p[i].slab = a.get<float>(gemm_tn_bf16_256_slab_floats(w.wg.p[i]));
+            w.wg.p[i].colsum = a.get<float>(gemm_tn_bf16_256_colsum_floats(w.wg.p[i]));
+        }
+    } else {
+        w.slab = a.get<float>(w.slab_elems);
+        w.colsum = a.get<float>(w.colsum_elems);
+    }
     w.ln_nblk = ln_bwd_bf16_num_blocks(M, C);
     w.lnpart = a.get<float>((size_t)w.ln_nblk * 2 * C);
     w.lnpart2 = a.get<float>((size_t)w.ln_nblk * 2 * C);
@@ -345,7 +378,10 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
         lj.W[1] = p->conv1_w; lj.bz[1] = p->conv1_b; lj.lnw[1] = p->norm1_w; lj.lnb[1] = p->norm1_b; lj.u[1] = w.u1; lj.cvec[1] = w.c1;
         DCPT_TRY(launch_lnvec(lj, s));
     }
-    Side* sd = side_for(s);
+    // weight-gradient side stream: 0 never, 1 always, 2 only at the levels without the grouped 256-tile weight-gradient launch (whose
+    // 128-KB blocks cannot share a CU with a main-stream GEMM block: with it the two streams only time-slice)
+    static const int side_mode = dcpt_tuning("DCPT_BF16_SIDE", 2);
+    Side* sd = (side_mode == 1 || (side_mode == 2 && !w.tn256)) ? side_for(s) : nullptr;
     hipStream_t sw = side_stream(sd, s);
     DCPT_TRY(side_fork(sd, 0, s));
     GemmNTB g{};
@@ -375,7 +411,7 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
         }
         DCPT_TRY(launch_gemm_nt_bf16(g, EB_SGBWD, s));
         // B2: conv5 / gamma gradients
-        DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
+        if (!w.tn256) DCPT_TRY(wgrad_b(dout, C, sv->g, C, M, w.slab, w.colsum, p->gamma, p->conv5_w, p->conv5_b, gr->conv5_w, gr->gamma, gr->conv5_b, sw));
         DCPT_TRY(side_fork(sd, 1, s));
         // B3: gradient of LN2's output
         g = GemmNTB{};
@@ -388,11 +424,11 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
             DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
         }
         // B4: conv4 gradients
-        DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
+        if (!w.tn256) DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
         // B5: dy = dout + LN2-backward
         if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
         DCPT_TRY(side_fork(sd, 2, s));
-        DCPT_TRY(launch_colpart_reduce(w.lnpart, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+        if (!w.tn256) DCPT_TRY(launch_colpart_reduce(w.lnpart, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     }
     // B6: dts = d(t2 * s) (+ SCA's per-image channel sums out of the epilogue when an image is a whole number of 128-pixel tiles)
     g = GemmNTB{};
@@ -405,7 +441,9 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
         DCPT_TRY(launch_sca_ds_part_bf16(w.dts, sv->t2, w.ds_part, B, C, P, w.ds_slices, s));
     }
     // B7: conv3 / beta gradients: G = sum_m dy[m][n] t2[m][k] s[img(m)][k]
-    {
+    if (w.tn256) {   // (joins conv1's weight gradient in the second grouped launch; only a scaled operand copy, if needed, is made here)
+        if (!w.conv3_images) DCPT_TRY(launch_scale_rows_bf16(sv->t2, sv->s, w.t2s, M, C, P, sw));
+    } else {
         GemmTNB t{};
         t.X = w.dy; t.ldx = C; t.N = C; t.Y = sv->t2; t.ldy = C; t.K = C; t.M = M; t.slab = w.slab; t.colsum = w.colsum;
         if (gemm_tn_bf16_plan_images(M, C, C, P, &t.splits, &t.rows_per_split) && (size_t)t.splits * C * C <= w.slab_elems &&
@@ -420,7 +458,7 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
         }
     }
     // B8: SCA backward
-    DCPT_TRY(launch_sca_dpool(w.ds_part, w.ds_slices, p->sca_w, w.dpool, B, C, P, s));
+    DCPT_TRY(launch_sca_dpool(w.ds_part, w.ds_slices, p->sca_w, w.dpool, B, C, P, s, w.tn256 ? w.ds : nullptr));
     // B9 / B10: SimpleGate + depthwise backward, da on chip
     const bool ring_b = !w.lrs && dw_ring_bwd_usable(dg, 2);
     const int nblk_b = ring_b ? dw_ring_bwd_num_blocks_per_image(dg) : dw_num_blocks_per_image_fused_bf16(dg);
@@ -429,8 +467,16 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
         DCPT_TRY(launch_dw_bwd_fused_bf16(w.dts, sv->t1, w.w2p, p->conv2_b, sv->s, w.dpool, w.dt1, w.wpart, dg, s, w.lrs ? w.rowpart : nullptr, w.u1,
                                           w.c1));
     DCPT_TRY(side_fork(sd, 3, s));
-    DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
-    DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
+    if (w.tn256) {   // B2 + B4 + B7 + B12 as ONE grouped launch: G5 = dout^T g, G4 = dv^T LN2(y), G3 = dy^T t2 (per image, or t2 * s), G1 = dt1^T LN1(inp)
+        w.wg.p[0].X = dout; w.wg.p[0].Y = sv->g;
+        w.wg.p[1].X = w.dv; w.wg.p[1].Y = sv->xn2;
+        w.wg.p[2].X = w.dy; w.wg.p[2].Y = w.conv3_images ? sv->t2 : w.t2s;
+        w.wg.p[3].X = w.dt1; w.wg.p[3].Y = sv->xn1;
+        DCPT_TRY(launch_gemm_tn_bf16_256(w.wg, sw));
+    } else {
+        DCPT_TRY(launch_sca_wgrad(w.ds_part, w.ds_slices, w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C, sw));
+        DCPT_TRY(launch_dw_wgrad_reduce(w.wpart, B * nblk_b, C2, gr->conv2_w, gr->conv2_b, sw));
+    }
     if (ffn) {
         // B11 + B13 in one pass (ffn_bf16.hip): dinp = dy + LayerNorm1 backward of dt1 W1^T
         FfnBwdB f{};
@@ -451,11 +497,40 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
             DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
         }
         // B12: conv1 gradients
-        DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
+        if (!w.tn256) DCPT_TRY(wgrad_b(w.dt1, C2, sv->xn1, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv1_w, nullptr, gr->conv1_b, sw));
         // B13: dinp = dy + LN1-backward
         if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, inp, sv->mu1, sv->rstd1, p->norm1_w, w.dy, dinp, w.lnpart2, w.ln_nblk, M, C, s));
         DCPT_TRY(side_fork(sd, 5, s));
-        DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+        if (w.tn256) {
+            // the finisher: the four weight gradients out of their partial sums (gain algebra of nafblock.hip: dW = gain G,
+            // dgain = W . G + b sum dO, db = gain sum dO) and every other parameter-gradient reduction of the block, one launch
+            FinJobs f{};
+            f.nslab = 4;
+            const TnProb* q[4] = {&w.wg.p[0], &w.wg.p[1], &w.wg.p[2], &w.wg.p[3]};
+            for (int i = 0; i < 4; ++i) {
+                f.slab[i].slab = q[i]->slab; f.slab[i].colsum = q[i]->colsum; f.slab[i].N = q[i]->N; f.slab[i].K = q[i]->K;
+                f.slab[i].splits = q[i]->slots; f.slab[i].cs_rows = q[i]->splits; f.slab[i].tiles_k = q[i]->tiles_k; f.slab[i].ks_div = 1;
+            }
+            f.slab[0].rowscale = p->gamma; f.slab[0].W = p->conv5_w; f.slab[0].wbias = p->conv5_b;
+            f.slab[0].dW = gr->conv5_w; f.slab[0].dgain = gr->gamma; f.slab[0].dbias = gr->conv5_b;
+            f.slab[1].dW = gr->conv4_w; f.slab[1].dbias = gr->conv4_b;
+            f.slab[2].rowscale = p->beta; f.slab[2].W = p->conv3_w; f.slab[2].wbias = p->conv3_b;
+            f.slab[2].dW = gr->conv3_w; f.slab[2].dgain = gr->beta; f.slab[2].dbias = gr->conv3_b;
+            if (w.conv3_images) {   // slots per image: 1 (whole images per block) or the number of ranges an image is cut into
+                f.slab[2].kscale = sv->s;
+                f.slab[2].ks_div = q[2]->seg_rows > 0 ? 1 : (int)(P / q[2]->rows_per_split);
+            }
+            f.slab[3].dW = gr->conv1_w; f.slab[3].dbias = gr->conv1_b;
+            const int lnR = w.lrs ? ln_tiles : w.ln_nblk;
+            f.ncols = 3;
+            f.cols[0] = FinCols{w.lnpart, gr->norm2_w, gr->norm2_b, lnR, 2, C, 0};
+            f.cols[1] = FinCols{w.lnpart2, gr->norm1_w, gr->norm1_b, lnR, 2, C, 0};
+            f.cols[2] = FinCols{w.wpart, gr->conv2_w, gr->conv2_b, B * nblk_b, 10, C2, 1};
+            f.sca = FinSca{w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C};
+            DCPT_TRY(launch_wgrad_finish(f, sw));
+        } else {
+            DCPT_TRY(launch_colpart_reduce(w.lnpart2, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm1_w, gr->norm1_b, nullptr, sw));
+        }
     }
     DCPT_TRY(side_join(sd, s));
     return DCPT_OK;
@@ -471,6 +546,67 @@ extern "C" int dcpt_nafblock_bwd_bf16_packed(const dcpt_nafblock_params* p, cons
                                              size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
     DCPT_CHECK_ARG(packed, "nafblock_bwd_bf16_packed: null packed weights");
     return nafblock_bwd_bf16_impl(p, gr, inp, sv, dout, dinp, ws, ws_bytes, B, H, W, C, packed, packed_bytes, stream);
+}
+
+// ---- the weight gradient of a 1 x 1 convolution as an operator of its own ------------------------------------------------------------
+namespace {
+struct WgWs {
+    bool tn256;
+    GemmTNG g;
+    GemmTNB t;
+    float *slab, *colsum;
+};
+size_t wg_layout(int64_t M, int N, int K, void* base, size_t bytes, WgWs* out) {
+    WsAlloc a(base, base ? bytes : (size_t)-1);
+    WgWs w{};
+    w.tn256 = gemm_tn_bf16_256_ok(N, K);
+    if (w.tn256) {
+        w.g.n = 1;
+        w.g.p[0].M = M; w.g.p[0].N = w.g.p[0].ldx = N; w.g.p[0].K = w.g.p[0].ldy = K;
+        gemm_tn_bf16_256_plan(w.g);
+        w.g.p[0].slab = a.get<float>(gemm_tn_bf16_256_slab_floats(w.g.p[0]));
+        w.g.p[0].colsum = a.get<float>(gemm_tn_bf16_256_colsum_floats(w.g.p[0]));
+    } else {
+        w.t.ldx = w.t.N = N; w.t.ldy = w.t.K = K; w.t.M = M;
+        gemm_tn_bf16_plan(M, N, K, &w.t.splits, &w.t.rows_per_split);
+        w.slab = a.get<float>((size_t)w.t.splits * N * K);
+        w.colsum = a.get<float>((size_t)w.t.splits * gemm_tn_bf16_tiles_k(N, K) * N);
+    }
+    if (out) *out = w;
+    return a.off;
+}
+}  // namespace
+
+extern "C" size_t dcpt_conv1x1_wgrad_bf16_ws_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 8 || K % 8) return 0;
+    return wg_layout(M, N, K, nullptr, 0, nullptr);
+}
+extern "C" int dcpt_conv1x1_wgrad_bf16(const uint16_t* dY, const uint16_t* X, float* dW, float* db, void* ws, size_t ws_bytes, int64_t M, int N,
+                                       int K, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, "conv1x1_wgrad_bf16: null argument or N=%d / K=%d not multiples of 8",
+                   N, K);
+    WgWs w;
+    const size_t need = wg_layout(M, N, K, ws, ws_bytes, &w);
+    if (need > ws_bytes || ws == nullptr) {
+        dcpt_set_error("conv1x1_wgrad_bf16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return DCPT_ERR_WS;
+    }
+    if (w.tn256) {
+        w.g.p[0].X = dY; w.g.p[0].Y = X;
+        if (!db) w.g.p[0].colsum = nullptr;
+        DCPT_TRY(launch_gemm_tn_bf16_256(w.g, s));
+        FinJobs f{};
+        f.nslab = 1;
+        f.slab[0].slab = w.g.p[0].slab; f.slab[0].colsum = w.g.p[0].colsum; f.slab[0].N = N; f.slab[0].K = K; f.slab[0].splits = w.g.p[0].slots;
+        f.slab[0].cs_rows = w.g.p[0].splits;
+        f.slab[0].tiles_k = w.g.p[0].tiles_k; f.slab[0].ks_div = 1; f.slab[0].dW = dW; f.slab[0].dbias = db;
+        return launch_wgrad_finish(f, s);
+    }
+    w.t.X = dY; w.t.Y = X; w.t.slab = w.slab; w.t.colsum = db ? w.colsum : nullptr;
+    DCPT_TRY(launch_gemm_tn_bf16(w.t, s));
+    return launch_wgrad_reduce(w.slab, w.t.colsum, w.t.splits, w.t.splits * gemm_tn_bf16_tiles_k(N, K), N, K, nullptr, nullptr, nullptr, dW, nullptr, db,
+                               WR_PLAIN, s);
 }
 
 extern "C" int dcpt_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, dcpt_stream_t stream) {

@@ -307,6 +307,31 @@ def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor], packed: Pa
     return _NAFBlockBf16Fn.apply(inp, buf, torch.is_grad_enabled(), *[params[k] for k in PARAM_FIELDS])
 
 
+def conv1x1_wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True):
+    """Weight (and bias) gradient of a 1 x 1 convolution in bf16 storage (dcpt_conv1x1_wgrad_bf16; the four such products of
+    NAFBlock's backward, reference nafnet_arch.py:170-186): dy [M][N], x [M][K] bf16 row-major (or NHWC feature maps) ->
+    dW [N][K] fp32 (= dy^T x) and db [N] fp32 (column sums of dy)."""
+    lib = _lib.load()
+    _require_gpu_bf16(dy, x)
+    dy2 = (_nhwc(dy).permute(0, 2, 3, 1) if dy.dim() == 4 else dy).reshape(-1, dy.shape[1] if dy.dim() == 4 else dy.shape[-1])
+    x2 = (_nhwc(x).permute(0, 2, 3, 1) if x.dim() == 4 else x).reshape(-1, x.shape[1] if x.dim() == 4 else x.shape[-1])
+    dy2, x2 = _contig(dy2), _contig(x2)
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if x2.shape[0] != M:
+        raise ValueError(f"conv1x1_wgrad_bf16: {tuple(dy2.shape)} vs {tuple(x2.shape)}")
+    dev = dy2.device
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev) if with_bias else None
+    nws = lib.dcpt_conv1x1_wgrad_bf16_ws_bytes(M, N, K)
+    if nws == 0:
+        raise _lib.DcptHipError(f"conv1x1_wgrad_bf16: N={N}, K={K} must be positive multiples of 8")
+    ws = _workspace(dev, nws)
+    check(lib.dcpt_conv1x1_wgrad_bf16(dy2.data_ptr(), x2.data_ptr(), dW.data_ptr(), _p(db), ws.data_ptr(), ws.numel(), M, N, K, _stream(dev)),
+          "dcpt_conv1x1_wgrad_bf16")
+    return (dW, db) if with_bias else dW
+
+
 class _CastFn(torch.autograd.Function):
     """edge of the bf16 path: fp32 -> bf16 (RNE) in forward, the bf16 gradient back to fp32 in backward (or the reverse)"""
 

@@ -155,6 +155,15 @@ size_t dcpt_nafblock_wpack_bf16_bytes(int C);
  * LayerNorm2, the gate and the statistics from y and v): in training they only have to be non-null.  0: every saved buffer is used. */
 int dcpt_nafblock_bf16_fused_ffn(int C);
 int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream);
+/* Weight (and bias) gradient of a 1 x 1 convolution in bf16 storage (ABI 9; the conv1 / conv3 / conv4 / conv5 weight gradients of
+ * nafnet_arch.py:170-186 as an operator of its own): dW[n][k] = sum_m dY[m][n] * X[m][k], db[n] = sum_m dY[m][n] (db may be NULL).
+ * dY: [M][N] bf16, X: [M][K] bf16, dW: [N][K] fp32.  N, K multiples of 8; where both are multiples of 256 the 256 x 256-tile grouped
+ * kernel + finisher of gemm_tn_bf16_256.hip run (what dcpt_nafblock_bwd_bf16 uses at the wide levels), else the 128-wide kernel.
+ * Deterministic (fixed summation order). */
+size_t dcpt_conv1x1_wgrad_bf16_ws_bytes(int64_t M, int N, int K);
+int dcpt_conv1x1_wgrad_bf16(const uint16_t* dY, const uint16_t* X, float* dW, float* db, void* ws, size_t ws_bytes, int64_t M, int N, int K,
+                            dcpt_stream_t stream);
+
 int dcpt_nafblock_fwd_bf16_packed(const dcpt_nafblock_params* p, const void* packed, size_t packed_bytes, const uint16_t* inp, uint16_t* out,
                                   const dcpt_nafblock_saved_bf16* saved, void* ws, size_t ws_bytes, int B, int H, int W, int C,
                                   dcpt_stream_t stream);

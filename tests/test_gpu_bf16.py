@@ -721,3 +721,27 @@ def test_fused_second_half_inference_drops_saved_tensors(dev):
         Pf = {k: v.detach() for k, v in Pd.items()}
         y_inf2 = DF.nafblock_bf16(x, Pf)                  # grad mode on, nothing requires grad
         assert DF._NAFBlockBf16Fn.last_infer is True and torch.equal(y_inf2, y_inf)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 256), (1000, 256, 256), (8192 + 77, 1024, 512), (64 * 33, 512, 512), (300, 256, 512),
+                                   (2048, 128, 64), (513, 64, 128)])
+def test_conv1x1_wgrad_bf16(dev, M, N, K):
+    """dcpt_conv1x1_wgrad_bf16 = the weight-gradient product of the 1 x 1 convs (nafnet_arch.py:170-186): 256 x 256-tile grouped kernel
+    + finisher where N, K are multiples of 256 (ragged pixel counts, pixel ranges that end inside a 64-pixel tile), the 128-wide kernel
+    elsewhere; against the exact product of the same bf16 values in float64, and bit-reproducible."""
+    from dcpt_amd import functional as DF
+
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn((M, N), generator=g).bfloat16()
+    x = (torch.randn((M, K), generator=g) + 0.25).bfloat16()
+    ref = dy.double().t() @ x.double()
+    refb = dy.double().sum(0)
+    dW, db = DF.conv1x1_wgrad_bf16(dy.to(dev), x.to(dev))
+    dW2, db2 = DF.conv1x1_wgrad_bf16(dy.to(dev), x.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    scale = float(ref.abs().max())
+    assert float((dW.double().cpu() - ref).abs().max()) <= 2e-5 * scale + 1e-3, float((dW.double().cpu() - ref).abs().max())
+    assert float((db.double().cpu() - refb).abs().max()) <= 2e-5 * float(refb.abs().max()) + 1e-3
+    dW3 = DF.conv1x1_wgrad_bf16(dy.to(dev), x.to(dev), with_bias=False)
+    assert torch.equal(dW3, dW)

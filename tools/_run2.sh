@@ -1,0 +1,12 @@
+R=$PWD; O=$R/gpurun_out/r4_tn2; mkdir -p $O
+tools/build_variant.sh tn "nafblock_bf16.hip gemm_tn_bf16_256.hip" > $O/build.log 2>&1
+L=$R/experiments/lib/libdcpt_hip_tn.so
+for v in 1 0; do
+  DCPT_TOOL_LIB=$L DCPT_TN256=$v tools/level_kernels.sh 3 bf16 $O/l3_tn256_$v.txt; echo "== level 3 serialized, DCPT_TN256=$v"; head -30 $O/l3_tn256_$v.txt | cut -c1-140
+done
+for v in 1 0 1 0; do
+  echo "== naf bf16 step, DCPT_TN256=$v"; DCPT_TOOL_LIB=$L DCPT_TN256=$v python tools/bench_extra_variant.py --workload naf --dtype bf16 2>&1 | tail -1 | cut -c1-200
+done
+for v in 1 0; do
+  echo "== naf bf16 step serialized, DCPT_TN256=$v"; DCPT_TOOL_LIB=$L DCPT_TN256=$v python tools/bench_extra_variant.py --workload naf --dtype bf16 --side-stream 0 2>&1 | tail -1 | cut -c1-200
+done
