@@ -128,10 +128,17 @@ class _UpConv(nn.Conv2d):
 
 @ARCH_REGISTRY.register()
 class NAFNetBaseline(nn.Module):
-    def __init__(self, img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=[], dec_blk_nums=[], window_size=8, act_dtype="fp32"):
+    def __init__(self, img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=[], dec_blk_nums=[], window_size=8, act_dtype="fp32",
+                 gemm_precision=None):
         super().__init__()
         if act_dtype not in ("fp32", "bf16"):
             raise ValueError(f"act_dtype must be 'fp32' or 'bf16', got {act_dtype!r}")
+        if gemm_precision not in (None, "fp32", "bf16x3"):
+            raise ValueError(f"gemm_precision must be 'fp32' or 'bf16x3', got {gemm_precision!r}")
+        # ``network_g.gemm_precision`` (this repo's extension, fp32 storage only): "fp32" = exact fp32 MFMA, the reference's arithmetic;
+        # "bf16x3" = the wide 1 x 1 convs as split-operand products on the bf16 matrix pipe (fp32-class).  Absent: the
+        # process default (dcpt_amd.functional.set_gemm_precision), which is "fp32" unless a caller changed it.
+        self.gemm_precision = gemm_precision
         self.intro = nn.Conv2d(img_channel, width, 3, padding=1, bias=True)
         self.ending = nn.Conv2d(width, img_channel, 3, padding=1, bias=True)
         self.encoders = nn.ModuleList()
@@ -166,6 +173,10 @@ class NAFNetBaseline(nn.Module):
                 m.act_bf16 = act_dtype == "bf16"
 
     def forward(self, inp, hook=False):
+        with DF.gemm_precision(self.gemm_precision):   # (the backward of every node built here runs under the same mode)
+            return self._forward(inp, hook)
+
+    def _forward(self, inp, hook=False):
         # bf16 storage: the intro conv emits bf16 features and every layer up to the ending conv's input stays bf16 (forward hooks on
         # the block groups then see bf16 feature maps; the classifier head takes either dtype)
         x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias, out_bf16=self.act_dtype == "bf16")

@@ -35,6 +35,65 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def run_restormer(dev, save="balanced", steps=5, warmup=2, B=64, S=128):
+    """BASELINE.json configs[3]: Restormer defaults (reference restormer_arch.py:234-422), fwd + L1 + bwd + AdamW, fp32."""
+    from basicsr.archs import build_network
+    from dcpt_amd import functional as DF
+    from dcpt_amd.keyed_init import fill_module_
+
+    g = torch.Generator(device=dev).manual_seed(1234)
+    torch.cuda.reset_peak_memory_stats()
+    DF.set_restormer_save(save)
+    net = fill_module_(build_network(dict(type="Restormer"))).to(dev)
+    optm = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
+    lq = torch.rand((B, 3, S, S), generator=g, device=dev)
+    gt = torch.rand((B, 3, S, S), generator=g, device=dev)
+
+    def step():
+        optm.zero_grad(set_to_none=True)
+        (net(lq) - gt).abs().mean().backward()
+        optm.step()
+
+    dt = timed(step, steps, warmup)
+    flops = B * (S / 128.0) ** 2 * 232e9      # SURVEY 8d: 77.45 GF fwd -> 232 GF fwd+bwd per 128^2 image
+    return dict(workload=f"Restormer (dim 48, [4,6,6,8], BiasFree LN) fwd+L1+bwd+AdamW, B={B}, {S}x{S}, fp32, saved tensors: {save} "
+                         "(BASELINE.json configs[3])",
+                ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3), steps=steps, warmup=warmup,
+                alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4),
+                peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+
+
+def run_infer2k(dev, dtype="fp32", steps=5, warmup=2, S=2048):
+    """BASELINE.json configs[4]: one S x S image through SRModel.test_tile (reference sr_model.py:273-361), 512-pixel tiles with 16 pixels
+    of context, NAFNet-64 inference."""
+    from basicsr.models import build_model
+    from dcpt_amd.keyed_init import fill_module_
+
+    g = torch.Generator(device=dev).manual_seed(1234)
+    torch.cuda.reset_peak_memory_stats()
+    peak = 2.5e15 if dtype == "bf16" else 157.3e12
+    opt = dict(name="b", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
+               network_g=dict(type="NAFNetBaseline", window_size=16, **dict(NAF, act_dtype=dtype)), path=dict(),
+               tile=dict(infer_size=512, tile_pad=16), val=dict(save_img=False))
+    m = build_model(opt)
+    fill_module_(m.net_g)
+    img = torch.rand((1, 3, S, S), generator=g, device=dev)
+
+    def run():
+        m.feed_data({"lq": img})
+        m.pre_test()
+        m.test_tile()
+        m.post_test()
+
+    dt = timed(run, steps, warmup)
+    flops = (S / 256.0) ** 2 * 126.11e9 * (544 / 512.0) ** 2
+    return dict(workload=f"NAFNet-64 tiled inference, {S}x{S}, test_tile infer_size 512 / tile_pad 16, feature maps {dtype} "
+                         "(BASELINE.json configs[4])",
+                ms_per_image=round(dt * 1e3, 2), megapixels_per_s=round(S * S / 1e6 / dt, 3), steps=steps, warmup=warmup,
+                alg_tflops=round(flops / dt / 1e12, 2), mfma_peak_tflops=peak / 1e12, mfma_frac=round(flops / dt / peak, 4),
+                peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k", "naf"])
@@ -121,49 +180,9 @@ def main():
         else:
             res.update(alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4))
     elif args.workload == "restormer":
-        # configs[3]: Restormer defaults, 128x128, fwd + L1 + bwd + AdamW
-        B, S = args.batch or 64, args.size or 128
-        from dcpt_amd import functional as DF
-
-        DF.set_restormer_save(args.restormer_save)
-        net = fill_module_(build_network(dict(type="Restormer"))).to(dev)
-        optm = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
-        lq = torch.rand((B, 3, S, S), generator=g, device=dev)
-        gt = torch.rand((B, 3, S, S), generator=g, device=dev)
-
-        def step():
-            optm.zero_grad(set_to_none=True)
-            (net(lq) - gt).abs().mean().backward()
-            optm.step()
-
-        dt = timed(step, args.steps, args.warmup)
-        flops = B * (S / 128.0) ** 2 * 232e9      # 77.45 GF fwd -> 232 GF fwd+bwd per 128^2 image
-        res = dict(workload=f"Restormer (dim 48, [4,6,6,8], BiasFree LN) fwd+L1+bwd+AdamW, B={B}, {S}x{S}, fp32, saved tensors: {args.restormer_save}",
-                   ms_per_step=round(dt * 1e3, 2), megapixels_per_s=round(B * S * S / 1e6 / dt, 3),
-                   alg_tflops=round(flops / dt / 1e12, 2), mfma_frac=round(flops / dt / 157.3e12, 4))
+        res = run_restormer(dev, args.restormer_save, args.steps, args.warmup, args.batch or 64, args.size or 128)
     else:
-        # configs[4]: 2K image, SRModel.test_tile with 512 tiles / 16 px context, NAFNet-64 inference
-        S = args.size or 2048
-        from basicsr.models import build_model
-
-        opt = dict(name="b", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
-                   network_g=dict(type="NAFNetBaseline", window_size=16, **naf), path=dict(), tile=dict(infer_size=512, tile_pad=16),
-                   val=dict(save_img=False))
-        m = build_model(opt)
-        fill_module_(m.net_g)
-        img = torch.rand((1, 3, S, S), generator=g, device=dev)
-
-        def run():
-            m.feed_data({"lq": img})
-            m.pre_test()
-            m.test_tile()
-            m.post_test()
-
-        dt = timed(run, args.steps, args.warmup)
-        flops = (S / 256.0) ** 2 * 126.11e9 * (544 / 512.0) ** 2
-        res = dict(workload=f"NAFNet-64 tiled inference, {S}x{S}, test_tile infer_size 512 / tile_pad 16, feature maps {args.dtype}",
-                   ms_per_image=round(dt * 1e3, 2), megapixels_per_s=round(S * S / 1e6 / dt, 3),
-                   alg_tflops=round(flops / dt / 1e12, 2), mfma_peak_tflops=peak / 1e12, mfma_frac=round(flops / dt / peak, 4))
+        res = run_infer2k(dev, args.dtype, args.steps, args.warmup, args.size or 2048)
     res["peak_mem_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
     print(json.dumps(res), flush=True)
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "dcpt_nafblock_bwd_bf16": (cint, [C.POINTER(NafBlockParams), C.POINTER(NafBlockGrads), f32p, C.POINTER(NafBlockSavedBf16),
                                       f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_set_gemm_x3": (cint, [C.c_void_p, sz, cint]),
+    "dcpt_gemm_x3_scratch_misses": (C.c_longlong, []),
     "dcpt_nafblock_wpack_bf16_bytes": (sz, [cint]),
     "dcpt_nafblock_bf16_fused_ffn": (cint, [cint]),
     "dcpt_nafblock_fused_ffn": (cint, [cint]),

@@ -854,6 +854,7 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const GemmTN p, int fp3
 unsigned char* g_x3_scratch = nullptr;
 size_t g_x3_bytes = 0;
 int g_x3_min_tiles = 192;
+long long g_x3_scratch_misses = 0;   // eligible launches that fell back to the fp32 kernels because the scratch was too small
 
 size_t split_bytes(int64_t R, int K) { return (size_t)cdiv64(R, 128) * (size_t)(K / 16) * PIECE; }
 
@@ -888,7 +889,11 @@ bool gemm_nt_x3_ok(const GemmNT& p, int aload, int epi) {
     }
     const int64_t tiles = cdiv64(M, 256) * (p.N / 256) * nb;
     if (tiles < g_x3_min_tiles) return false;
-    return split_bytes(p.N, p.K) * (size_t)nb <= g_x3_bytes;
+    if (split_bytes(p.N, p.K) * (size_t)nb > g_x3_bytes) {
+        ++g_x3_scratch_misses;
+        return false;
+    }
+    return true;
 }
 
 int launch_gemm_nt_x3(const GemmNT& pin, int aload, int epi, hipStream_t s) {
@@ -966,6 +971,8 @@ int launch_gemm_tn_x3(const GemmTN& p, int fp32_tiles_k, hipStream_t s) {
     DCPT_CHECK_LAUNCH("gemm_tn_x3");
     return DCPT_OK;
 }
+
+extern "C" long long dcpt_gemm_x3_scratch_misses(void) { return g_x3_scratch_misses; }
 
 extern "C" int dcpt_set_gemm_x3(void* scratch, size_t bytes, int min_tiles) {
     g_x3_scratch = (unsigned char*)scratch;

@@ -81,6 +81,112 @@ def _contig(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# Opt-in GEMM precision mode (include/dcpt_hip.h dcpt_set_gemm_x3): "fp32" = the exact fp32 MFMA kernels (default, the reference's
+# arithmetic); "bf16x3" = the wide fp32 GEMMs on the bf16 matrix pipe with operands split into three bf16 pieces (fp32-class results).
+# The library's switch is process-wide; here it is driven per NETWORK (``network_g.gemm_precision`` in the options): a network's forward
+# runs inside ``gemm_precision(mode)``, every autograd node built there remembers the mode and its backward runs under it again.
+_X3_SCRATCH: Dict[int, torch.Tensor] = {}       # device index -> scratch for the split weight images
+_GEMM_DEFAULT = ("fp32", 0)                     # the process default: (mode, min_tiles)
+_GEMM_ACTIVE = ("fp32", 0)                      # what the library is switched to right now
+_GEMM_SCRATCH_MB = 256
+_SIDE_BEFORE_X3 = None                          # the side-stream setting the mode found when it was switched on
+
+
+def _activate_gemm_mode(mode: str, min_tiles: int = 0, device=None):
+    global _GEMM_ACTIVE, _SIDE_BEFORE_X3
+    if (mode, min_tiles) == _GEMM_ACTIVE:
+        return
+    lib = _lib.load()
+    if mode == "fp32":
+        check(lib.dcpt_set_gemm_x3(None, 0, 0), "dcpt_set_gemm_x3")
+        if _SIDE_BEFORE_X3 is not None:
+            lib.dcpt_set_side_stream(_SIDE_BEFORE_X3)   # what the caller had, not a hard-wired "on"
+            _SIDE_BEFORE_X3 = None
+    elif mode == "bf16x3":
+        idx = torch.device(device).index if device is not None else torch.cuda.current_device()   # (one process per GPU: its own device)
+        if idx is None:
+            idx = torch.cuda.current_device()
+        buf = _X3_SCRATCH.get(idx)
+        if buf is None or buf.numel() < (_GEMM_SCRATCH_MB << 20):
+            buf = _X3_SCRATCH[idx] = torch.empty(_GEMM_SCRATCH_MB << 20, dtype=torch.uint8, device=torch.device("cuda", idx))
+        check(lib.dcpt_set_gemm_x3(buf.data_ptr(), buf.numel(), int(min_tiles)), "dcpt_set_gemm_x3")
+        # the split-operand kernels take the whole CU (160 KB of LDS, 8 waves): a weight-gradient block of the side stream cannot share a
+        # CU with them (measured: 107.0 ms serialized vs 109.2 ms with it), so the side stream is off while the mode is on
+        prev = lib.dcpt_set_side_stream(0)
+        if _SIDE_BEFORE_X3 is None:
+            _SIDE_BEFORE_X3 = prev
+    else:
+        raise ValueError(f"gemm precision {mode!r}: expected 'fp32' or 'bf16x3'")
+    _GEMM_ACTIVE = (mode, min_tiles)
+
+
+def set_gemm_precision(mode: str, device=None, scratch_mb: int = 256, min_tiles: int = 0) -> str:
+    """Process default: 'fp32' (exact fp32 MFMA, the reference's arithmetic) or 'bf16x3'; returns the previous default.  ``scratch_mb``:
+    room for the split images of one launch's weights (6 bytes per element; the per-image conv3 weights of a batch are the largest:
+    B x C x C x 6) -- ``gemm_x3_scratch_misses()`` counts eligible launches that did not fit.  ``min_tiles`` > 0 lowers the size
+    threshold (tests force the mode onto small launches with 1)."""
+    global _GEMM_DEFAULT, _GEMM_SCRATCH_MB
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError(f"gemm precision {mode!r}: expected 'fp32' or 'bf16x3'")
+    prev = _GEMM_DEFAULT[0]
+    _GEMM_SCRATCH_MB = max(_GEMM_SCRATCH_MB, int(scratch_mb))
+    _GEMM_DEFAULT = (mode, int(min_tiles))
+    _activate_gemm_mode(mode, int(min_tiles), device)
+    return prev
+
+
+def get_gemm_precision() -> str:
+    return _GEMM_ACTIVE[0]
+
+
+def gemm_x3_scratch_misses() -> int:
+    return int(_lib.load().dcpt_gemm_x3_scratch_misses())
+
+
+class gemm_precision:
+    """``with gemm_precision(mode):`` -- the GEMM precision for the kernels launched inside (None: leave it as it is); the autograd nodes
+    created inside run their backward under the same mode."""
+
+    def __init__(self, mode, min_tiles=None):
+        self.want = None if mode is None else (mode, _GEMM_DEFAULT[1] if min_tiles is None else int(min_tiles))
+
+    def __enter__(self):
+        self.prev = _GEMM_ACTIVE
+        if self.want is not None:
+            _activate_gemm_mode(*self.want)
+        return self
+
+    def __exit__(self, *exc):
+        if self.want is not None:
+            _activate_gemm_mode(*self.prev)
+        return False
+
+
+def _remember_gemm_mode(cls):
+    """forward notes the active mode on the node, backward re-activates it (a no-op comparison when nothing changed)"""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._gemm_mode = _GEMM_ACTIVE
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        mode = getattr(ctx, "_gemm_mode", _GEMM_ACTIVE)
+        if mode == _GEMM_ACTIVE:
+            return bwd(ctx, *grads)
+        prev = _GEMM_ACTIVE
+        _activate_gemm_mode(*mode)
+        try:
+            return bwd(ctx, *grads)
+        finally:
+            _activate_gemm_mode(*prev)
+
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
+
+
+# ------------------------------------------------------------------------------------------------
 def _saved_f32(t1, t2, y, v, stats, pooled, s, xn):
     """dcpt_nafblock_saved over the forward's buffers; v / stats / xn are None where the library does not use them (NULL pointers)."""
     st = [0, 0, 0, 0] if stats is None else [stats[i].data_ptr() for i in range(4)]
@@ -89,6 +195,7 @@ def _saved_f32(t1, t2, y, v, stats, pooled, s, xn):
                          pooled.data_ptr(), s.data_ptr(), xs[0], xs[1], xs[2])
 
 
+@_remember_gemm_mode
 class _NAFBlockFn(torch.autograd.Function):
     """reference basicsr/archs/nafnet_arch.py:165-186 (NAFBlock.forward) -> dcpt_nafblock_fwd/bwd."""
 
@@ -387,37 +494,6 @@ def nafblock_local(inp: torch.Tensor, params: Dict[str, torch.Tensor], k1: int, 
 
 
 # ------------------------------------------------------------------------------------------------
-# Opt-in GEMM precision mode (include/dcpt_hip.h dcpt_set_gemm_x3): "fp32" = the exact fp32 MFMA kernels (default, the reference's
-# arithmetic); "bf16x3" = the wide fp32 GEMMs on the bf16 matrix pipe with operands split into three bf16 pieces (fp32-class results).
-_X3_SCRATCH = None
-_GEMM_PRECISION = "fp32"
-
-
-def set_gemm_precision(mode: str, device=None, scratch_mb: int = 256, min_tiles: int = 0) -> str:
-    """'fp32' (default) or 'bf16x3'; returns the previous mode.  In 'bf16x3' the split-operand kernels take the whole CU (160 KB of LDS, 8
-    waves), so a weight-gradient block of the side stream cannot share a CU with them: the side stream is switched off for the mode
-    (measured: 107.0 ms serialized vs 109.2 ms with it) and back on with 'fp32'.  ``scratch_mb``: the split images of one launch's
-    weights (6 bytes per element; the per-image conv3 weights of a batch are the largest: B x C x C x 6).  ``min_tiles`` > 0 lowers the
-    size threshold (tests force the mode onto small launches with 1)."""
-    global _X3_SCRATCH, _GEMM_PRECISION
-    lib = _lib.load()
-    prev = _GEMM_PRECISION
-    if mode == "fp32":
-        check(lib.dcpt_set_gemm_x3(None, 0, 0), "dcpt_set_gemm_x3")
-        _X3_SCRATCH = None
-        lib.dcpt_set_side_stream(1)
-    elif mode == "bf16x3":
-        dev = torch.device(device if device is not None else "cuda:0")
-        _X3_SCRATCH = torch.empty(int(scratch_mb) << 20, dtype=torch.uint8, device=dev)
-        check(lib.dcpt_set_gemm_x3(_X3_SCRATCH.data_ptr(), _X3_SCRATCH.numel(), int(min_tiles)), "dcpt_set_gemm_x3")
-        lib.dcpt_set_side_stream(0)
-    else:
-        raise ValueError(f"gemm precision {mode!r}: expected 'fp32' or 'bf16x3'")
-    _GEMM_PRECISION = mode
-    return prev
-
-
-# ------------------------------------------------------------------------------------------------
 class _TakeBatchFn(torch.autograd.Function):
     """x[lo:hi] along the batch axis as a view; the backward builds the zero-padded gradient WITH THE INPUT'S STRIDES (torch's own
     slice backward allocates it NCHW-contiguous, which costs two layout conversions of the whole feature map per use for NHWC
@@ -654,6 +730,7 @@ def conv3x3_out(x, weight, bias, res=None):
 
 
 # ------------------------------------------------------------------------------------------------
+@_remember_gemm_mode
 class _DownFn(torch.autograd.Function):
     """Conv2d(C, 2C, 2, 2) (reference nafnet_arch.py:230)."""
 
@@ -692,6 +769,7 @@ class _DownFn(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None)
 
 
+@_remember_gemm_mode
 class _UpFn(torch.autograd.Function):
     """Conv2d(C, 2C, 1, bias=False) + PixelShuffle(2) + skip add (reference nafnet_arch.py:238-242, :264-265)."""
 
@@ -856,6 +934,7 @@ def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
 
 # ------------------------------------------------------------------------------------------------
 # degradation-classifier head (reference basicsr/archs/degrad_classify_arch.py)
+@_remember_gemm_mode
 class _ConvLNFn(torch.autograd.Function):
     """conv(1x1 | 3x3, no bias) -> channels-first LayerNorm -> [+res] -> [ReLU]
     (Conv2d wrapper :69-103 with norm=LN; BottleneckBlock tail :227-243)."""
@@ -1038,6 +1117,7 @@ def conv_embed_ln(x, weight, bias, lnw, lnb, stride=2, pad=3):
     return conv_ln(A, wext, lnw, lnb, None, relu=False)
 
 
+@_remember_gemm_mode
 class _ConvPoolReluFn(torch.autograd.Function):
     """Conv2d(1x1, bias=False) -> MaxPool2d(2,2) -> ReLU (degrad_classify_arch.py:596-602)."""
 
@@ -1114,6 +1194,7 @@ def mix(prev, feat, mixing_weights, idx):
     return _MixFn.apply(prev, feat, mixing_weights, idx)
 
 
+@_remember_gemm_mode
 class _MeanPoolFCFn(torch.autograd.Function):
     """x.mean(dim=[-1,-2]) -> Linear (degrad_classify_arch.py:639-640)."""
 
@@ -1162,6 +1243,7 @@ def meanpool_fc(x, fw, fb):
 from ._lib import GdfnParams, GdfnSaved, MdtaParams, MdtaSaved  # noqa: E402
 
 
+@_remember_gemm_mode
 class _ConvFn(torch.autograd.Function):
     """bias-free conv (1x1 or dense 3x3 / pad 1), NHWC -> NHWC."""
 
@@ -1308,6 +1390,7 @@ def set_restormer_save(mode: str) -> str:
     return prev
 
 
+@_remember_gemm_mode
 class _MDTAFn(torch.autograd.Function):
     """x + project_out(attn(LN(x)))  (restormer_arch.py:103-145, :156-157)."""
 
@@ -1378,6 +1461,7 @@ def mdta(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, biasfree, e
     return _MDTAFn.apply(x, norm_w, norm_b, qkv_w, dw_w, proj_w, temperature, heads, flags)
 
 
+@_remember_gemm_mode
 class _GDFNFn(torch.autograd.Function):
     """x + project_out(gelu(x1) * x2)  (restormer_arch.py:75-100, :158)."""
 

@@ -114,6 +114,9 @@ int dcpt_nafblock_bwd(const dcpt_nafblock_params* p, const dcpt_nafblock_grads* 
  * scratch == NULL switches the mode off (the default).  The reference computes in fp32; this mode is reported separately. */
 /* min_tiles: launches with fewer 256 x 256 tiles keep the fp32-MFMA kernels (<= 0: the default, 192 -- most of the 256 CUs busy). */
 int dcpt_set_gemm_x3(void* scratch, size_t bytes, int min_tiles);
+/* launches since process start that were eligible for the mode but ran on the fp32 kernels because `bytes` was too small for their weight
+ * images (a mode that is silently only partly on would be a wrong label on a measurement: callers check this stays 0) */
+long long dcpt_gemm_x3_scratch_misses(void);
 
 /* ---- NAFBlock, bf16 storage (BASELINE.json configs[2]) --------------------------------------------------------------
  * Same block (nafnet_arch.py:83-186), activations and saved tensors as bfloat16 (raw uint16_t, upper half of an fp32, stored
