@@ -60,6 +60,10 @@ class BaseModel:
                 kwargs["bucket_cap_mb"] = self.opt.get("ddp_bucket_cap_mb", 64)
                 kwargs["gradient_as_bucket_view"] = True
             net = DistributedDataParallel(net, **kwargs)
+            if self.device.type == "cuda":
+                from dcpt_amd import ddp as dcpt_ddp
+
+                dcpt_ddp.prepare(net)   # one divide per bucket, parameter gradients written straight into the bucket views
         elif self.opt["num_gpu"] > 1 and dist:
             net = DataParallel(net)
         return net

@@ -140,6 +140,28 @@ def secondary_dcpt_bf16(dev, steps=5, warmup=3):
     return out
 
 
+def ddp_wrap_overhead(unwrapped_ms: float) -> dict:
+    """What the DDP wrap itself costs (reference base_model.py:108-115), on a ONE-rank RCCL group: `python bench.py --force-ddp` as its own
+    process right after the headline run on the same GPU -- the process group exists before the first kernel, as under torchrun (wrapping
+    a network that has already trained in this process measured 13 % slower for reasons that have nothing to do with the wrap:
+    tools/ddp_probe.py vs profiles/r4/ddp_probe.txt) -- against the unwrapped ms_per_step of this run."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--force-ddp", "--no-secondary", "--no-cpu-baseline", "--steps", "6", "--warmup", "4"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT).stdout.strip().splitlines()
+        line = json.loads([ln for ln in out if ln.startswith("{")][-1])
+        ms = float(line["ms_per_step"])
+        return {"workload": "the headline step with the network wrapped in DistributedDataParallel (64 MB buckets as gradient views, built-in "
+                            "all-reduce hook, the blocks' gradients written straight into the bucket views: dcpt_amd/ddp.py) on a 1-rank RCCL group",
+                "command": "python bench.py --force-ddp --no-secondary --no-cpu-baseline --steps 6 --warmup 4",
+                "ms_per_step": round(ms, 3), "unwrapped_ms_per_step": round(unwrapped_ms, 3),
+                "ddp_wrap_overhead_ms": round(ms - unwrapped_ms, 3), "ddp_wrap_overhead_frac": round(ms / unwrapped_ms - 1.0, 4),
+                "rccl_ranks": line["config"].get("rccl_ranks")}
+    except Exception as e:  # noqa: BLE001  (a secondary line must never take the headline down)
+        return {"error": repr(e)[:300]}
+
+
 def spawn_ranks(n: int) -> None:
     """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run, one process per GPU."""
     import socket
@@ -225,6 +247,9 @@ def main():
 
         # reference base_model.py:108-115; buckets all-reduce on RCCL's stream while backward continues
         model = DDP(net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        from dcpt_amd import ddp as dcpt_ddp
+
+        dcpt_ddp.prepare(model)   # per-bucket divide + the blocks' gradients written straight into the bucket views (no per-parameter copies)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0, fused=True)
 
     g = torch.Generator(device=dev)
@@ -479,6 +504,8 @@ def main():
             del net, model, opt, lq, gt, loss
             torch.cuda.empty_cache()
             sec.update(secondary_dcpt_bf16(dev))
+            if args.gemm_precision == "fp32":
+                sec["ddp_wrap_one_rank"] = ddp_wrap_overhead(ms_per_step)
             # BASELINE.json configs[3] and configs[4] on the same record (bench_extra.py holds the workloads)
             import bench_extra as BX
 
@@ -490,6 +517,11 @@ def main():
             res["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        try:   # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: push it out BEFORE the line, so that
+            ctypes.CDLL(None).fflush(None)   # the JSON line is the last line of the output
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
         print(json.dumps(res), flush=True)
     if use_ddp:
         dist.destroy_process_group()

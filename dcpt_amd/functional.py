@@ -204,6 +204,7 @@ class _NAFBlockFn(torch.autograd.Function):
         lib = _lib.load()
         _require_gpu(inp, *params)
         inp = _nhwc(inp)
+        ctx.owners = params   # (the Parameter objects: their DDP bucket views, if any, receive the gradients)
         params = tuple(_contig(p.detach()) for p in params)
         B, Cc, H, W = inp.shape
         dev = inp.device
@@ -244,7 +245,7 @@ class _NAFBlockFn(torch.autograd.Function):
         dout = _nhwc(dout)
         B, Cc, H, W = inp.shape
         dev = inp.device
-        grads = [torch.empty_like(p) for p in params]
+        grads = _grad_buffers(params, ctx.owners)
         dinp = _empty_nhwc(B, Cc, H, W, dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         gs = NafBlockGrads(*[g.data_ptr() for g in grads])
@@ -298,6 +299,7 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         _require_gpu_bf16(inp)
         _require_gpu(*params)
         inp = _nhwc(inp)
+        ctx.owners = params
         params = tuple(_contig(p.detach()) for p in params)
         B, Cc, H, W = inp.shape
         if Cc % 8:
@@ -337,7 +339,7 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         dout = _nhwc(dout if dout.dtype == torch.bfloat16 else dout.to(torch.bfloat16))
         B, Cc, H, W = inp.shape
         dev = inp.device
-        grads = [torch.empty_like(p) for p in params]
+        grads = _grad_buffers(params, ctx.owners)
         dinp = _empty_nhwc_bf16(B, Cc, H, W, dev)
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         gs = NafBlockGrads(*[g.data_ptr() for g in grads])
@@ -374,6 +376,32 @@ def invalidate_packed_weights() -> int:
 
 def _optimizer_step_post_hook(optimizer, args, kwargs):
     invalidate_packed_weights()
+    # DistributedDataParallel with gradient_as_bucket_view: remember the bucket views now sitting in .grad (dcpt_amd/ddp.py)
+    first = next((p for grp in optimizer.param_groups for p in grp["params"]), None)
+    if first is not None and getattr(first, "_dcpt_ddp", False):
+        from .ddp import refresh_views
+
+        refresh_views(p for grp in optimizer.param_groups for p in grp["params"])
+
+
+def _grad_buffers(saved, owners):
+    """Output tensors for a fused block's parameter gradients: a fresh tensor per parameter, or -- where DDP's bucket view of that parameter
+    is known and not yet used since the last optimizer step (dcpt_amd/ddp.py) -- an alias of the view, so that the kernels write the
+    gradient where the all-reduce will read it."""
+    outs = []
+    for t, p in zip(saved, owners or (None,) * len(saved)):
+        v = getattr(p, "_dcpt_grad_view", None) if p is not None else None
+        if (v is not None and p.grad is None and not getattr(p, "_dcpt_view_busy", True) and v.shape == t.shape and v.device == t.device
+                and v.dtype == t.dtype):
+            p._dcpt_view_busy = True
+            _grad_buffers.hits += 1
+            outs.append(v.view(v.shape))   # a new tensor object on the bucket's storage: AccumulateGrad adopts it as param.grad
+        else:
+            outs.append(torch.empty_like(t))
+    return outs
+
+
+_grad_buffers.hits = 0   # (gradients written straight into a DDP bucket view so far: read by the tests and bench.py)
 
 
 register_optimizer_step_post_hook(_optimizer_step_post_hook)

@@ -214,6 +214,78 @@ def test_ddp_wrapped_hip_net_one_rank_rccl(dev):
         assert torch.equal(g0[k], g1[k]), k
 
 
+def test_ddp_bucket_order_and_zero_copy_gradients(dev):
+    """Multi-GPU readiness that one GPU can show (reference base_model.py:108-115).  On a 1-rank RCCL group, the HIP network
+    wrapped as BaseModel.model_to_device wraps it: (i) from DDP's re-bucketing on, the buckets are all-reduced in exactly the order in
+    which the backward pass finishes the gradients -- ``ending`` first, ``intro`` last -- so the all-reduce of a bucket overlaps the
+    backward kernels of the blocks before it by construction, not by luck; (ii) the fused blocks write their parameter gradients
+    straight into the bucket views (dcpt_amd/ddp.py): after the optimizer steps that teach the views, every NAFBlock gradient of a
+    step is produced in place and the wrap adds no per-parameter copy kernels; gradients stay bit-identical to the unwrapped run."""
+    import torch.distributed as dist
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from torch.nn.parallel import DistributedDataParallel
+
+    from basicsr.archs import build_network
+    from basicsr.archs.nafnet_arch import NAFBlock
+    from dcpt_amd import ddp as dcpt_ddp, functional as DF
+
+    sd = keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0)
+    x = keyed_input("ddp2.x", (4, 3, 32, 32)).to(dev)
+    gw = keyed_input("ddp2.gw", (4, 3, 32, 32), lo=-1, hi=1).to(dev)
+
+    def grads_of(net):
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    net0 = build_network(dict(type="NAFNetBaseline", **TINY))
+    net0.load_state_dict(sd, strict=True)
+    net0 = net0.to(dev)
+    (net0(x) * gw).sum().backward()
+    g0 = grads_of(net0)
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        net = build_network(dict(type="NAFNetBaseline", **TINY))
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev)
+        names = {id(p): k for k, p in net.named_parameters()}
+        model = DistributedDataParallel(net, device_ids=[torch.cuda.current_device()], bucket_cap_mb=0.02, gradient_as_bucket_view=True)
+        buckets, ready = [], []
+
+        def hook(state, bucket):
+            buckets.append([names[id(p)] for p in bucket.parameters()])
+            return default_hooks.allreduce_hook(state, bucket)
+
+        dcpt_ddp.prepare(model, hook)
+        for p in net.parameters():
+            p.register_post_accumulate_grad_hook(lambda q: ready.append(names[id(q)]))
+        opt = torch.optim.AdamW(net.parameters(), lr=0.0, fused=True)   # (lr = 0: the weights stay, its post-step hook teaches the views)
+        nblock = sum(len(list(m.parameters())) for m in net.modules() if isinstance(m, NAFBlock))
+        for it in range(4):
+            buckets.clear()
+            ready.clear()
+            hits = DF._grad_buffers.hits
+            opt.zero_grad(set_to_none=True)
+            (model(x) * gw).sum().backward()
+            torch.cuda.synchronize()
+            if it >= 2:   # DDP re-bucketed after its first iteration; the views of the new buckets were learned after the second
+                flat = [k for b in buckets for k in b]
+                assert len(buckets) >= 4 and flat == ready, (len(buckets), flat[:6], ready[:6])
+                assert ready[0].startswith("ending.") and ready[-1].startswith("intro."), (ready[0], ready[-1])
+                assert DF._grad_buffers.hits - hits == nblock, (DF._grad_buffers.hits - hits, nblock)
+                for m in net.modules():
+                    if isinstance(m, NAFBlock):
+                        for p in m.parameters():
+                            assert p.grad.data_ptr() == p._dcpt_grad_view.data_ptr()
+            g1 = grads_of(net)
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), (it, k)
+            opt.step()
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def trained_denoiser(dev):

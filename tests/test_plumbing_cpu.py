@@ -639,3 +639,86 @@ def test_selfensemble_matches_reference_construction():
     from basicsr.metrics import calculate_psnr
     direct = calculate_psnr(m.output.clamp(0, 1).numpy(), (one * 0.9).numpy(), crop_border=0, test_y_channel=False)
     assert abs(res_e["psnr"] - direct) < 1e-9 and abs(res_e["psnr"] - res_p["psnr"]) > 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+def _bucket_order_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from torch.nn.parallel import DistributedDataParallel
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from basicsr.archs import build_network
+    from oracle import nafnet_oracle as O
+
+    torch.manual_seed(0)
+    net = build_network(dict(type="NAFNetBaseline", img_channel=3, width=64, middle_blk_num=1, enc_blk_nums=[1, 1, 1, 28], dec_blk_nums=[1, 1, 1, 1]))
+    with torch.no_grad():
+        for k, p in net.named_parameters():   # (beta / gamma = 0 would cut the graph behind every block)
+            if k.endswith("beta") or k.endswith("gamma"):
+                p.fill_(0.1)
+
+    class OnCpu(torch.nn.Module):   # the product network's module tree and parameters, the oracle's arithmetic (the HIP kernels need a GPU)
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return O.nafnet_forward(x, dict(self.net.named_parameters()))[0]
+
+    names = {id(p): k for k, p in net.named_parameters()}
+    model = DistributedDataParallel(OnCpu(net), bucket_cap_mb=64, gradient_as_bucket_view=True)
+    buckets, ready = [], []
+
+    def hook(state, bucket):
+        buckets.append([names[id(p)] for p in bucket.parameters()])
+        return default_hooks.allreduce_hook(state, bucket)
+
+    model.register_comm_hook(None, hook)
+    for p in net.parameters():
+        p.register_post_accumulate_grad_hook(lambda q: ready.append(names[id(q)]))
+    g = torch.Generator().manual_seed(7 + rank)
+    x = torch.rand(1, 3, 16, 16, generator=g)
+    for it in range(3):
+        buckets.clear()
+        ready.clear()
+        model.zero_grad(set_to_none=True)
+        model(x).abs().mean().backward()
+    torch.save({"buckets": list(buckets), "ready": list(ready)}, os.path.join(out, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ddp_bucket_order_is_backward_completion_order_gloo(tmp_path):
+    """SURVEY 8e / reference base_model.py:108-115: NAFNet-64 under DDP with the 64 MB buckets of bench.py and BaseModel.model_to_device,
+    two ranks on gloo.  After DDP's one re-bucketing the buckets hold the parameters in the order the backward pass finishes them and are
+    all-reduced in that order -- ending first, then decoder3 ... decoder0, middle, the 28 blocks of encoders.3 from last to first, ...,
+    intro last -- so every bucket's all-reduce has the rest of the backward pass to hide behind."""
+    import torch.multiprocessing as mp
+
+    port = 23500 + (os.getpid() % 2000)
+    mp.spawn(_bucket_order_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"b{i}.pt")) for i in range(2)]
+    assert r[0]["buckets"] == r[1]["buckets"]
+    buckets, ready = r[0]["buckets"], r[0]["ready"]
+    flat = [k for b in buckets for k in b]
+    assert sorted(flat) == sorted(ready) and len(flat) == 664
+    assert len(buckets) >= 4                      # 271.6 MB of gradients in 64 MB buckets
+    # bucket k holds exactly the k-th run of the completion order
+    pos = {k: i for i, k in enumerate(ready)}
+    lo = 0
+    for b in buckets:
+        idx = sorted(pos[k] for k in b)
+        assert idx == list(range(lo, lo + len(b))), (lo, idx[:4])
+        lo += len(b)
+    group = lambda k: k.split(".")[0] if not k.startswith("encoders") else ".".join(k.split(".")[:2])   # noqa: E731
+    seen = []
+    for k in ready:
+        if not seen or seen[-1] != group(k):
+            seen.append(group(k))
+    blocks_only = [s for s in seen if not s.startswith(("ups", "downs"))]
+    assert blocks_only == ["ending", "decoder3", "decoder2", "decoder1", "decoder0", "middle_blks", "encoders.3", "encoders.2", "encoders.1",
+                           "encoders.0", "intro"], blocks_only
+    enc3 = [int(k.split(".")[2]) for k in ready if k.startswith("encoders.3.") and k.endswith("conv1.weight")]
+    assert enc3 == list(range(27, -1, -1))
