@@ -150,6 +150,9 @@ struct TnProb {
     // weight every image's sum on its own; `slots` = partial sums per tile (= splits, or the number of pieces)
     int splits, tiles_k, blk0, seg_rows, slots;
     int64_t rows_per_split;
+    // yconv != 0 (every problem of the launch, or none): Y is the NHWC image [.][gH][gW][gC] gathered like GemmNTB's conv3 operand -- the
+    // weight gradient of a dense 3 x 3, K = 9 * gC, column tap * gC + ch <-> pixel (h + ky - 1, w + kx - 1); gC % 128 == 0, no seg_rows
+    int yconv, gH, gW, gC;
 };
 struct GemmTNG {
     TnProb p[TNG_MAX];
@@ -172,6 +175,7 @@ struct FinSlab {
     const float *slab, *colsum, *rowscale, *W, *wbias, *kscale;
     float *dW, *dgain, *dbias;
     int N, K, splits, tiles_k, ks_div, cs_rows;   // splits = partial sums per tile; cs_rows = rows of colsum (blocks per tile)
+    int conv3;                                    // != 0: K = 9 * Ci packed as tap * Ci + ic, written as dW[n][ic][tap] (a dense 3 x 3's weight layout)
 };
 struct FinCols {
     const float* part;

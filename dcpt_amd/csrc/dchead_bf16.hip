@@ -90,7 +90,12 @@ struct ConvWsB {
     int splits;
     int64_t rps;
     int ln_nblk;
+    bool tn256;     // weight gradient on the 256 x 256-tile kernel + finisher (gemm_tn_bf16_256.hip)
+    GemmTNG wg;
 };
+
+// the wide layers' weight gradient: N = Cout, K = ks * ks * Cin multiples of 256 (a dense 3 x 3 also needs 128-channel taps)
+bool conv_tn256(int Cin, int Cout, int ks) { return gemm_tn_bf16_256_ok(Cout, ks * ks * Cin) && (ks == 1 || Cin % 128 == 0); }
 
 size_t conv_layout(int B, int H, int W, int Cin, int Cout, int ks, int backward, bool with_ln, void* base, size_t bytes, ConvWsB* out) {
     WsAlloc a(base, base ? bytes : (size_t)-1);
@@ -100,8 +105,20 @@ size_t conv_layout(int B, int H, int W, int Cin, int Cout, int ks, int backward,
     w.wp = a.get<bf16_t>((size_t)Cout * K);
     if (backward) {
         w.dz = a.get<bf16_t>((size_t)M * Cout);
-        gemm_tn_bf16_plan(M, Cout, K, &w.splits, &w.rps);
-        w.slab = a.get<float>((size_t)w.splits * Cout * K);
+        w.tn256 = conv_tn256(Cin, Cout, ks);
+        if (w.tn256) {
+            w.wg.n = 1;
+            TnProb& q = w.wg.p[0];
+            q.M = M; q.N = q.ldx = Cout; q.K = K; q.ldy = ks == 1 ? Cin : 0;
+            if (ks == 3) {
+                q.yconv = 1; q.gH = H; q.gW = W; q.gC = Cin;
+            }
+            gemm_tn_bf16_256_plan(w.wg);
+            q.slab = a.get<float>(gemm_tn_bf16_256_slab_floats(q));
+        } else {
+            gemm_tn_bf16_plan(M, Cout, K, &w.splits, &w.rps);
+            w.slab = a.get<float>((size_t)w.splits * Cout * K);
+        }
         if (with_ln) {
             w.ln_nblk = ln_bwd_bf16_num_blocks(M, Cout);
             w.lnpart = a.get<float>((size_t)w.ln_nblk * 2 * Cout);
@@ -131,12 +148,34 @@ int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int 
     return launch_gemm_nt_bf16(g, EB_PLAIN, s);
 }
 
-// dx = conv^T(dz), dw = wgrad(dz, x)
+// dx = conv^T(dz), dw = wgrad(dz, x); `ln` (optional): the LayerNorm's column partials, reduced here as well
 int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, float* dw, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout,
-             int ks, hipStream_t s) {
+             int ks, hipStream_t s, const FinCols* ln = nullptr) {
     const int64_t M = (int64_t)B * H * W;
     GemmNTB g{};
     g.M = M; g.A = dz; g.N = Cin; g.C = dx; g.ldc = Cin; g.Bw = cw.wp;
+    if (cw.tn256) {   // data gradient as before; the weight gradient as one 256-tile launch + one finisher launch (which also takes the LN sums)
+        DCPT_TRY(pack(w, cw.wp, Cout, ks * ks * Cin, ks == 1 ? 1 : 3, s));
+        if (ks == 1) {
+            g.lda = Cout; g.K = Cout;
+        } else {
+            g.K = 9 * Cout; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cout;
+        }
+        if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        GemmTNG wg = cw.wg;
+        wg.p[0].X = dz; wg.p[0].Y = x;
+        DCPT_TRY(launch_gemm_tn_bf16_256(wg, s));
+        FinJobs f{};
+        f.nslab = 1;
+        f.slab[0].slab = wg.p[0].slab; f.slab[0].N = Cout; f.slab[0].K = wg.p[0].K; f.slab[0].splits = wg.p[0].slots; f.slab[0].cs_rows = wg.p[0].splits;
+        f.slab[0].tiles_k = wg.p[0].tiles_k; f.slab[0].ks_div = 1; f.slab[0].dW = dw; f.slab[0].conv3 = ks == 3;
+        if (ln) {
+            f.ncols = 1;
+            f.cols[0] = *ln;
+        }
+        return launch_wgrad_finish(f, s);
+    }
+    if (ln) DCPT_TRY(launch_colpart_reduce(ln->part, ln->R, 2, ln->C, ln->out0, ln->out1, nullptr, s));
     GemmTNB t{};
     t.M = M; t.X = dz; t.ldx = Cout; t.N = Cout; t.Y = x; t.slab = cw.slab; t.colsum = nullptr; t.splits = cw.splits; t.rows_per_split = cw.rps;
     if (ks == 1) {
@@ -194,8 +233,8 @@ extern "C" int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, cons
     }
     const int64_t M = (int64_t)B * H * W;
     DCPT_TRY(launch_ln_act_bwd_bf16(dy, z, mu, rstd, lnw, relu ? y : nullptr, dres, cw.dz, cw.lnpart, cw.ln_nblk, M, Cout, s));
-    DCPT_TRY(launch_colpart_reduce(cw.lnpart, cw.ln_nblk, 2, Cout, dlnw, dlnb, nullptr, s));
-    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s);
+    const FinCols ln{cw.lnpart, dlnw, dlnb, cw.ln_nblk, 2, Cout, 0};
+    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s, &ln);
 }
 
 extern "C" size_t dcpt_conv1x1_pool_relu_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward) {

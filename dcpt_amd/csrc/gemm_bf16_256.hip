@@ -34,9 +34,10 @@ constexpr int STG = 4 * HT;     // one k-tile: A-lo | A-hi | B-lo | B-hi
 
 typedef __attribute__((address_space(3))) const volatile bf16x8* lds_frag_p;
 
-template <int EK>
+template <int EK, int AM = 0>   // AM 1: implicit 3 x 3 (conv3): A rows are pixels, a k-tile of 64 channels lies inside one tap (gC % 64 == 0)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin) {
     constexpr bool GATE = (EK == EB_BIASGATE);
+    constexpr bool CONV = AM == 1;
     GemmNTB p = pin;
     if (gridDim.y > 1) {
         const int64_t b = blockIdx.y;
@@ -58,11 +59,18 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
     const int n0 = (lin % tilesN) * (GATE ? 128 : 256);
     const int nlo = n0, nhi = GATE ? Ch + n0 : n0 + 128;   // first weight row of the two B halves
 
-    const i32x4 rsA = make_rsrc_dma(p.A + (m0 < p.M ? m0 : 0) * (int64_t)p.lda);
+    // conv3: the window starts one image row + one pixel before the tile's first pixel (clipped at the tensor start)
+    int64_t apix0 = (m0 < p.M ? m0 : 0);
+    if constexpr (CONV) {
+        apix0 -= p.gW + 1;
+        if (apix0 < 0) apix0 = 0;
+    }
+    const i32x4 rsA = make_rsrc_dma(p.A + apix0 * (int64_t)(CONV ? p.gC : p.lda));
     const i32x4 rsB = make_rsrc_dma(p.Bw);
     // staging map of a half-tile (16 DMAs of 8 rows): wave w issues rows 8 w .. 8 w + 7 and 64 + 8 w .. ; lane -> row (lane >> 3),
     // LDS slot lane & 7 = logical 16-byte chunk ^ ((row >> 1) & 7)
     uint32_t voffA[2][2], voffB[2][2];
+    uint32_t tapok[2][2];   // conv3: bit t set = tap t of this thread's row lies inside the image
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         const int row = 8 * wave + (lane >> 3) + 64 * ps;
@@ -70,10 +78,26 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = h * 128 + row;
-            voffA[h][ps] = (m0 + r < p.M) ? (uint32_t)r * (uint32_t)p.lda * 2u + ch : ROW_SENT;
+            if constexpr (CONV) {
+                const int64_t m = m0 + r;
+                const bool ok = m < p.M;
+                const int64_t mm = ok ? m : 0;
+                const int pw = (int)(mm % p.gW), ph = (int)((mm / p.gW) % p.gH);
+                uint32_t bits = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hh = ph + t / 3 - 1, ww = pw + t % 3 - 1;
+                    if (ok && hh >= 0 && hh < p.gH && ww >= 0 && ww < p.gW) bits |= 1u << t;
+                }
+                tapok[h][ps] = bits;
+                voffA[h][ps] = (uint32_t)((mm - apix0) * p.gC) * 2u + ch;
+            } else {
+                voffA[h][ps] = (m0 + r < p.M) ? (uint32_t)r * (uint32_t)p.lda * 2u + ch : ROW_SENT;
+            }
             voffB[h][ps] = (uint32_t)((h ? nhi : nlo) + row) * (uint32_t)p.K * 2u + ch;
         }
     }
+    const uint32_t tapinv = CONV ? 65536u / (uint32_t)(p.gC / 64) + 1u : 0u;   // tap of k-tile kt = (kt * tapinv) >> 16   (kt < 2048)
     const uint32_t lds0 = lds_addr(reinterpret_cast<const float*>(smem));
     const uint32_t lds_w = lds0 + (uint32_t)wave * 1024u;
     // X: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
@@ -87,8 +111,18 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
         if (X >= 2) dead = ROW_SENT;
 #endif
         if (X < 2) {
-            dma16(rsA, dst, voffA[X][0] | dead, soff);
-            dma16(rsA, dst + 8192u, voffA[X][1] | dead, soff);
+            if constexpr (CONV) {
+                // k-tile kt = 64 channels of ONE tap: the same shift for every row, per-row validity from the tap masks
+                const uint32_t tap = ((uint32_t)kt * tapinv) >> 16;
+                const int ch0 = kt * 64 - (int)tap * p.gC;
+                const int ky = (int)((tap * 11u) >> 5), kx = (int)tap - 3 * ky;
+                const uint32_t shift = (uint32_t)((((ky - 1) * p.gW + (kx - 1)) * p.gC + ch0) * 2);
+                dma16(rsA, dst, (((tapok[X][0] >> tap) & 1u) ? voffA[X][0] + shift : ROW_SENT) | dead, 0);
+                dma16(rsA, dst + 8192u, (((tapok[X][1] >> tap) & 1u) ? voffA[X][1] + shift : ROW_SENT) | dead, 0);
+            } else {
+                dma16(rsA, dst, voffA[X][0] | dead, soff);
+                dma16(rsA, dst + 8192u, voffA[X][1] | dead, soff);
+            }
         } else {
             dma16(rsB, dst, voffB[X - 2][0] | dead, soff);
             dma16(rsB, dst + 8192u, voffB[X - 2][1] | dead, soff);
@@ -247,7 +281,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 // Eligibility of a launch for the 256 x 256 kernel: plain operands, full 256-column tiles (128 per gate half), k-tiles in pairs, and
 // enough tiles to fill most of the 256 CUs (one block per CU).
 bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles) {
-    if (p.conv3 || p.gather2 || epi == EB_SCATTER || epi == EB_SCATTER_ADD || epi == EB_LNBWD2) return false;
+    if (p.gather2 || epi == EB_SCATTER || epi == EB_SCATTER_ADD || epi == EB_LNBWD2) return false;
+    if (p.conv3 && (epi != EB_PLAIN || p.gC % 64 != 0 || p.K != 9 * p.gC || p.K / 64 >= 2048 || (p.nb > 1))) return false;
     if (p.K % 128 != 0 || p.K < 128) return false;
     if (p.N % 256 != 0) return false;   // (gate: 128 columns of each half)
     const int nb = p.nb > 0 ? p.nb : 1;
@@ -258,6 +293,11 @@ bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles) {
 int launch_gemm_nt_bf16_256(const GemmNTB& p, int epi, hipStream_t s) {
     const unsigned nb = (unsigned)(p.nb > 0 ? p.nb : 1);
     const dim3 grid((unsigned)(cdiv64(p.M, 256) * (p.N / 256)), nb);
+    if (p.conv3) {
+        gemm_nt_bf16_256_kernel<EB_PLAIN, 1><<<grid, dim3(512), 0, s>>>(p);
+        DCPT_CHECK_LAUNCH("gemm_nt_bf16_256 conv3");
+        return DCPT_OK;
+    }
     switch (epi) {
         case EB_PLAIN: gemm_nt_bf16_256_kernel<EB_PLAIN><<<grid, dim3(512), 0, s>>>(p); break;
         case EB_BIAS: gemm_nt_bf16_256_kernel<EB_BIAS><<<grid, dim3(512), 0, s>>>(p); break;

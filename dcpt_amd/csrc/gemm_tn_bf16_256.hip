@@ -57,6 +57,7 @@ __device__ __forceinline__ float dot_ones(bf16x8 f, float c) {   // c + sum of t
     return c;
 }
 
+template <bool YCONV>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,7 +85,14 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
     const int64_t mw = mbeg < p.M ? mbeg : 0;
 
     const i32x4 rsX = make_rsrc_dma(p.X + mw * (int64_t)p.ldx + n0);
-    const i32x4 rsY = make_rsrc_dma(p.Y + mw * (int64_t)p.ldy + k0);
+    // gathered Y (weight gradient of a dense 3 x 3): the window starts one image row + one pixel before the block's first pixel (clipped at
+    // the tensor start); a 128-column half of the tile lies inside ONE tap (gC % 128 == 0)
+    int64_t ypix0 = mw;
+    if constexpr (YCONV) {
+        ypix0 -= p.gW + 1;
+        if (ypix0 < 0) ypix0 = 0;
+    }
+    const i32x4 rsY = make_rsrc_dma(YCONV ? p.Y + ypix0 * (int64_t)p.gC : p.Y + mw * (int64_t)p.ldy + k0);
     // staging map of a half-tile (two passes of 32 pixel rows): wave w issues rows 4 w .. 4 w + 3 of each pass; lane -> row (lane >> 4),
     // chunk POSITION lane & 15, which holds source chunk (lane & 15) ^ 4 (row & 3)
     int srow[2];
@@ -97,9 +105,27 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             voffX[h][ps] = ((uint32_t)row * (uint32_t)p.ldx + (uint32_t)(128 * h + 8 * c)) * 2u;
-            voffY[h][ps] = ((uint32_t)row * (uint32_t)p.ldy + (uint32_t)(128 * h + 8 * c)) * 2u;
+            if constexpr (YCONV) {   // (tap, channel) of the half's first column; offset relative to the row's own pixel (may be negative: wraps)
+                const int kk = k0 + 128 * h, tap = kk / p.gC, ch = kk - tap * p.gC;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                voffY[h][ps] = (uint32_t)(((int)(mw - ypix0) + row) * p.gC + ch + 8 * c + ((ky - 1) * p.gW + (kx - 1)) * p.gC) * 2u;
+            } else {
+                voffY[h][ps] = ((uint32_t)row * (uint32_t)p.ldy + (uint32_t)(128 * h + 8 * c)) * 2u;
+            }
         }
     }
+    // gathered Y: pixel coordinates of this thread's two rows in the Y tile staged last (advanced by 64 pixels per tile), and the two halves' taps
+    int yh[2] = {0, 0}, yw[2] = {0, 0};
+    int ydy[2] = {0, 0}, ydx[2] = {0, 0};
+    if constexpr (YCONV) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tap = (k0 + 128 * h) / p.gC;
+            ydy[h] = tap / 3 - 1;
+            ydx[h] = tap - 3 * (tap / 3) - 1;
+        }
+    }
+    const int adv_h = YCONV ? 64 / p.gW : 0, adv_w = YCONV ? 64 % p.gW : 0;
     const uint32_t lds0 = lds_addr(reinterpret_cast<const float*>(smem));
     const uint32_t lds_w = lds0 + (uint32_t)wave * 1024u;
 
@@ -175,6 +201,37 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
                 const uint32_t soff = (uint32_t)(row0 + kt * 64) * 2u * (uint32_t)p.ldx;
                 dma16(rsX, dst, srow[0] < left ? voffX[Q][0] : ROW_SENT, soff);
                 dma16(rsX, dst + 8192u, srow[1] < left ? voffX[Q][1] : ROW_SENT, soff);
+            } else if constexpr (YCONV) {
+                // the Y stages come in the order lo(k), hi(k), lo(k + 1), hi(k + 1), ...: a lo stage moves the pixel coordinates to its tile
+                if (Q == 2) {
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        if (kt == 0) {
+                            const int64_t m = mw + row0 + srow[ps];
+                            yw[ps] = (int)(m % p.gW);
+                            yh[ps] = (int)((m / p.gW) % p.gH);
+                        } else {
+                            int w2 = yw[ps] + adv_w, h2 = yh[ps] + adv_h;
+                            if (w2 >= p.gW) {
+                                w2 -= p.gW;
+                                ++h2;
+                            }
+                            while (h2 >= p.gH) h2 -= p.gH;
+                            yw[ps] = w2;
+                            yh[ps] = h2;
+                        }
+                    }
+                }
+                const int dy = ydy[Q - 2], dx = ydx[Q - 2];
+                // (the tile's advance is added to the per-lane offset, not passed as the scalar offset: a tap above / left of the pixel makes
+                // the lane's own part negative, and the range check looks at the lane's part alone)
+                const uint32_t adv = (uint32_t)(row0 + kt * 64) * 2u * (uint32_t)p.gC;
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int hh = yh[ps] + dy, ww = yw[ps] + dx;
+                    const bool ok = srow[ps] < left && hh >= 0 && hh < p.gH && ww >= 0 && ww < p.gW;
+                    dma16(rsY, dst + 8192u * ps, ok ? voffY[Q - 2][ps] + adv : ROW_SENT, 0);
+                }
             } else {
                 const uint32_t soff = (uint32_t)(row0 + kt * 64) * 2u * (uint32_t)p.ldy;
                 dma16(rsY, dst, srow[0] < left ? voffY[Q - 2][0] : ROW_SENT, soff);
@@ -315,9 +372,14 @@ __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /*
         const float4 G = f4_add(f4_add(f4_add(gs[0], gs[1]), f4_add(gs[2], gs[3])), f4_add(f4_add(gs[4], gs[5]), f4_add(gs[6], gs[7])));
         const float ge[4] = {G.x, G.y, G.z, G.w};
         float de[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t ko = k;   // position of column k inside a row of dW
+        if (j.conv3) {     // packed k = tap * Ci + ic  ->  dW[n][ic][tap]
+            const int Ci = j.K / 9, tap = k / Ci;
+            ko = (int64_t)(k - tap * Ci) * 9 + tap;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int64_t o = (int64_t)(nbase + e) * j.K + k;
+            const int64_t o = (int64_t)(nbase + e) * j.K + ko;
             j.dW[o] = rsc[e] * ge[e];
             if (j.dgain) de[e] = j.W[o] * ge[e];
         }
@@ -432,7 +494,7 @@ __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const FinJobs jobs) 
 
 bool gemm_tn_bf16_256_ok(int N, int K) {
     static const int on = dcpt_tuning("DCPT_TN256", 1);
-    return on && N >= 256 && K >= 256 && N % 256 == 0 && K % 256 == 0 && N <= 4096 && K <= 4096;
+    return on && N >= 256 && K >= 256 && N % 256 == 0 && K % 256 == 0 && N <= 4096 && K <= 16384;
 }
 
 // Pixel ranges of a grouped launch: one block per CU in a single round.  Every tile of every problem gets about
@@ -506,7 +568,12 @@ int launch_gemm_tn_bf16_256(const GemmTNG& g, hipStream_t s) {
         const TnProb& p = g.p[i];
         DCPT_CHECK_ARG(p.X && p.Y && p.slab && p.M > 0 && gemm_tn_bf16_256_ok(p.N, p.K) && p.tiles_k == p.K / 256,
                        "gemm_tn_bf16_256: problem %d: null operand or N=%d / K=%d not multiples of 256", i, p.N, p.K);
-        DCPT_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.ldx >= p.N && p.ldy >= p.K, "gemm_tn_bf16_256: row strides must be multiples of 8");
+        DCPT_CHECK_ARG(p.ldx % 8 == 0 && p.ldx >= p.N && (p.yconv || (p.ldy % 8 == 0 && p.ldy >= p.K)), "gemm_tn_bf16_256: row strides must be multiples of 8");
+        DCPT_CHECK_ARG((p.yconv != 0) == (g.p[0].yconv != 0), "gemm_tn_bf16_256: gathered and plain Y operands cannot share a launch");
+        if (p.yconv)
+            DCPT_CHECK_ARG(p.gC % 128 == 0 && p.K == 9 * p.gC && p.seg_rows == 0 && p.colsum == nullptr && p.gW >= 1 && p.gH >= 1 &&
+                               (double)(p.rows_per_split + 192 + 2 * p.gW) * p.gC * 2.0 < 1.0e9,
+                           "gemm_tn_bf16_256: gathered Y needs K == 9 * gC, gC %% 128 == 0, no column sums, no image segments");
         DCPT_CHECK_ARG(p.splits >= 1 && p.rows_per_split >= 64 && p.rows_per_split % 64 == 0 && (int64_t)p.splits * p.rows_per_split >= p.M &&
                            p.blk0 == blocks && (p.seg_rows == 0 ? p.slots == p.splits
                                                                 : (p.seg_rows % 64 == 0 && p.rows_per_split % p.seg_rows == 0 && p.M % p.seg_rows == 0 &&
@@ -519,7 +586,8 @@ int launch_gemm_tn_bf16_256(const GemmTNG& g, hipStream_t s) {
         bytes += ((double)p.M * p.N + (double)p.M * p.K) * 2.0 + (double)gemm_tn_bf16_256_slab_floats(p) * 4.0;
     }
     ProfScope prof(s, PROF_TN + 257, g.p[0].M, g.p[0].N, g.p[0].K, flops, bytes);
-    gemm_tn_bf16_256_kernel<<<dim3((unsigned)blocks), dim3(512), 0, s>>>(g);
+    if (g.p[0].yconv) gemm_tn_bf16_256_kernel<true><<<dim3((unsigned)blocks), dim3(512), 0, s>>>(g);
+    else gemm_tn_bf16_256_kernel<false><<<dim3((unsigned)blocks), dim3(512), 0, s>>>(g);
     DCPT_CHECK_LAUNCH("gemm_tn_bf16_256");
     return DCPT_OK;
 }

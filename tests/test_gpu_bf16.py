@@ -311,7 +311,11 @@ def test_dcpt_step_with_bf16_encoder(dev):
 # ---- classifier head in bf16 storage ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,use_res,relu", [(2, 16, 32, 9, 7, 1, False, True), (2, 64, 64, 8, 8, 3, False, True),
                                                             (1, 128, 128, 16, 16, 3, True, True), (2, 64, 32, 6, 10, 1, True, False),
-                                                            (3, 256, 256, 8, 6, 3, False, False)])
+                                                            (3, 256, 256, 8, 6, 3, False, False),
+                                                            # the 256 x 256-tile kernels: weight gradient (N, K multiples of 256; gathered taps of a
+                                                            # dense 3 x 3, ragged pixel counts) and the implicit-GEMM forward / data gradient (>= 192 tiles)
+                                                            (1, 512, 256, 24, 20, 3, True, False), (2, 256, 512, 16, 16, 1, True, True),
+                                                            (3, 256, 256, 128, 128, 3, True, True)])
 def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     """conv (1x1 | dense 3x3 as implicit GEMM) -> channels-first LayerNorm -> [+res] -> [ReLU] with bf16 activations vs the same
     chain in fp32 with a bf16 rounding at the two stored tensors (degrad_classify_arch.py:69-103,227-243)."""
@@ -354,7 +358,16 @@ def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     torch.cuda.synchronize()
     errs = {"y": _rel(yd, yb), "dx": _rel(xd.grad, dxb), "dw": _rel(pd[0].grad, gb[0]), "dlnw": _rel(pd[1].grad, gb[1]), "dlnb": _rel(pd[2].grad, gb[2])}
     if use_res:
-        errs["dres"] = _rel(rd.grad, drb)
+        if relu:
+            # dres = gw * [pre-activation > 0]: a pre-activation within one bf16 ulp of zero may round to the other side in the two
+            # implementations, and then that ONE element differs by |gw| (max-relative error up to 1): bound the share of such elements
+            # (12.6 M elements in the largest case) and the error of all the others
+            a, b = rd.grad.detach().float().cpu(), drb.float()
+            flipped = ((a == 0) != (b == 0))
+            assert float(flipped.float().mean()) <= 2e-5, float(flipped.float().mean())
+            errs["dres"] = float(((a - b).abs() * (~flipped)).max() / b.abs().max())
+        else:
+            errs["dres"] = _rel(rd.grad, drb)
     bad = {k: v for k, v in errs.items() if not np.isfinite(v) or v > 2e-2}
     assert not bad, f"vs bf16-mode oracle: {bad} (all { {k: round(v, 4) for k, v in errs.items()} })"
     # vs fp32: a sanity bound only -- ReLU masks of values that round across zero flip whole gradient entries
