@@ -36,6 +36,7 @@ namespace {
 constexpr int HT = 16384;       // bytes of a half-tile
 constexpr int STG = 4 * HT;     // one k-tile: X-lo | X-hi | Y-lo | Y-hi
 constexpr int TILE_F = 65536;   // floats of one block's partial tile
+constexpr int FIN_THREADS = 512;   // threads of a finisher block
 
 typedef __attribute__((address_space(3))) bf16x4* lds_tr_p;
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
 //   cols job: out_j[c] = sum_r part[r][j][c]   (LayerNorm weight / bias gradients; the depthwise taps with their own output map)
 //   sca job : dWsca[n][k] = sum_b ds[b][n] pooled[b][k],  dbsca[n] = sum_b ds[b][n]
 __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /* [16][8] + [8] */) {
-    const int tid = threadIdx.x, lane = tid & 63, cgb = tid >> 6;   // 1024 threads: 16 column groups at a time
+    const int tid = threadIdx.x, lane = tid & 63, cgb = tid >> 6;   // 512 threads: 8 column groups at a time (two blocks per CU: the slab jobs
+                                                                     // of a wide NAFBlock -- 384 blocks -- are resident in one round)
     const int h = lane >> 5, kl = lane & 31;
     const int tile_n = rg >> 5, r32 = rg & 31;
     const int a = r32 >> 4, wm = (r32 >> 3) & 1, i = (r32 >> 2) & 1, q = r32 & 3;
@@ -345,7 +347,7 @@ __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /*
 #pragma unroll
     for (int e = 0; e < 4; ++e) rsc[e] = j.rowscale ? j.rowscale[nbase + e] : 1.f;
     float4 dot = f4_zero();
-    for (int cg = cgb; cg < (j.K >> 5); cg += 16) {
+    for (int cg = cgb; cg < (j.K >> 5); cg += FIN_THREADS / 64) {
         const int tile_k = cg >> 3, b = (cg >> 2) & 1, wn = cg & 3;
         const int chunk = (wm * 4 + wn) * 32 + ((a * 2 + b) * 2 + i) * 4 + q;
         const float* base = j.slab + (int64_t)(tile_n * j.tiles_k + tile_k) * TILE_F + chunk * 256 + lane * 4;
@@ -386,7 +388,7 @@ __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /*
         dot = f4_add(dot, make_float4(de[0], de[1], de[2], de[3]));
     }
     if (j.dgain == nullptr && j.dbias == nullptr) return;   // (uniform for the block)
-    // row dots: 32 lanes of a half wave, then the sixteen waves; column sums of X: 32 threads per row over the blocks' partial sums
+    // row dots: 32 lanes of a half wave, then the waves; column sums of X: 32 threads per row over the blocks' partial sums
     dot.x = group_sum(dot.x, 32);
     dot.y = group_sum(dot.y, 32);
     dot.z = group_sum(dot.z, 32);
@@ -403,21 +405,21 @@ __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /*
         if (j.colsum)
             for (int s = jj; s < j.cs_rows; s += 32) c += j.colsum[(int64_t)s * j.N + 8 * rg + row];
         c = group_sum(c, 32);
-        if (jj == 0) red[128 + row] = c;
+        if (jj == 0) red[FIN_THREADS / 8 + row] = c;
     }
     __syncthreads();
     if (tid < 8) {
         const int n = 8 * rg + tid;
         float d = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) d += red[w * 8 + tid];
-        const float c = red[128 + tid];
+        for (int w = 0; w < FIN_THREADS / 64; ++w) d += red[w * 8 + tid];
+        const float c = red[FIN_THREADS / 8 + tid];
         if (j.dgain) j.dgain[n] = d + (j.wbias ? j.wbias[n] * c : 0.f);
         if (j.dbias) j.dbias[n] = (j.rowscale ? j.rowscale[n] : 1.f) * c;
     }
 }
 
-__device__ __forceinline__ void fin_cols(const FinCols& j, int blk, float* red /* [64][16] */) {
+__device__ __forceinline__ void fin_cols(const FinCols& j, int blk, float* red /* [FIN_THREADS / 16][16] */) {
     const int nbx = (j.C + 15) >> 4;
     const int jj = blk / nbx, bx = blk - jj * nbx;
     const int cl = threadIdx.x & 15, rgp = threadIdx.x >> 4;
@@ -425,14 +427,14 @@ __device__ __forceinline__ void fin_cols(const FinCols& j, int blk, float* red /
     float s = 0.f;
     if (c < j.C) {
 #pragma unroll 4
-        for (int r = rgp; r < j.R; r += 64) s += j.part[((int64_t)r * j.nj + jj) * j.C + c];
+        for (int r = rgp; r < j.R; r += FIN_THREADS / 16) s += j.part[((int64_t)r * j.nj + jj) * j.C + c];
     }
     red[rgp * 16 + cl] = s;
     __syncthreads();
     if (rgp == 0 && c < j.C) {
         float t = red[cl];
 #pragma unroll
-        for (int i = 1; i < 64; ++i) t += red[i * 16 + cl];
+        for (int i = 1; i < FIN_THREADS / 16; ++i) t += red[i * 16 + cl];
         if (j.mode == 0) {
             float* o = jj == 0 ? j.out0 : j.out1;
             if (o) o[c] = t;
@@ -444,9 +446,9 @@ __device__ __forceinline__ void fin_cols(const FinCols& j, int blk, float* red /
 }
 
 __device__ __forceinline__ void fin_sca(const FinSca& j, int blk) {
-    const int nb0 = (int)(((int64_t)j.C * j.C + 1023) >> 10);
+    const int nb0 = (int)(((int64_t)j.C * j.C + FIN_THREADS - 1) / FIN_THREADS);
     if (blk < nb0) {
-        const int64_t i = (int64_t)blk * 1024 + threadIdx.x;
+        const int64_t i = (int64_t)blk * FIN_THREADS + threadIdx.x;
         if (i >= (int64_t)j.C * j.C) return;
         const int n = (int)(i / j.C), k = (int)(i % j.C);
         float s = 0.f;
@@ -454,7 +456,7 @@ __device__ __forceinline__ void fin_sca(const FinSca& j, int blk) {
         for (int b = 0; b < j.B; ++b) s = fmaf(j.ds[(int64_t)b * j.C + n], j.pooled[(int64_t)b * j.C + k], s);
         j.dW[i] = s;
     } else {
-        const int i = (blk - nb0) * 1024 + threadIdx.x;
+        const int i = (blk - nb0) * FIN_THREADS + threadIdx.x;
         if (i >= j.C) return;
         float s = 0.f;
         for (int b = 0; b < j.B; ++b) s += j.ds[(int64_t)b * j.C + i];
@@ -462,8 +464,8 @@ __device__ __forceinline__ void fin_sca(const FinSca& j, int blk) {
     }
 }
 
-__global__ __launch_bounds__(1024) void wgrad_finish_kernel(const FinJobs jobs) {
-    __shared__ float red[1024];
+__global__ __launch_bounds__(FIN_THREADS) void wgrad_finish_kernel(const FinJobs jobs) {
+    __shared__ float red[FIN_THREADS];
     const int blk = blockIdx.x;
     if (blk < jobs.slab_end) {
         FinSlab q = jobs.slab[0];
@@ -617,10 +619,10 @@ int launch_wgrad_finish(FinJobs& j, hipStream_t s) {
     j.cols_end = blk;
     if (j.sca.ds) {
         DCPT_CHECK_ARG(j.sca.pooled && j.sca.dW && j.sca.db && j.sca.B >= 1 && j.sca.C >= 1, "wgrad_finish: sca job");
-        blk += (int)cdiv64((int64_t)j.sca.C * j.sca.C, 1024) + cdiv(j.sca.C, 1024);
+        blk += (int)cdiv64((int64_t)j.sca.C * j.sca.C, FIN_THREADS) + cdiv(j.sca.C, FIN_THREADS);
     }
     if (blk == 0) return DCPT_OK;
-    wgrad_finish_kernel<<<dim3((unsigned)blk), dim3(1024), 0, s>>>(j);
+    wgrad_finish_kernel<<<dim3((unsigned)blk), dim3(FIN_THREADS), 0, s>>>(j);
     DCPT_CHECK_LAUNCH("wgrad_finish");
     return DCPT_OK;
 }

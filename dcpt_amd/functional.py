@@ -1403,19 +1403,34 @@ def concat_channels(a, b):
 # set_restormer_save() / DCPT_RESTORMER_SAVE select the mode.
 import os as _os  # noqa: E402
 
-_RESTORMER_MODES = ("full", "balanced", "lean")
-_RESTORMER_SAVE = _os.environ.get("DCPT_RESTORMER_SAVE", "balanced")
+_RESTORMER_MODES = ("auto", "full", "balanced", "lean")
+_RESTORMER_SAVE = _os.environ.get("DCPT_RESTORMER_SAVE", "auto")
 if _RESTORMER_SAVE not in _RESTORMER_MODES:
     raise ValueError(f"DCPT_RESTORMER_SAVE={_RESTORMER_SAVE!r}: expected one of {_RESTORMER_MODES}")
+_DEV_TOTAL: Dict[int, int] = {}
 
 
 def set_restormer_save(mode: str) -> str:
-    """'full', 'balanced' or 'lean'; returns the previous mode"""
+    """'auto' (default), 'full', 'balanced' or 'lean'; returns the previous mode.  'auto' decides per block and forward pass from the
+    memory the process holds on the device at that moment: 'full' (fastest) while less than 55 % of the device memory is allocated,
+    'balanced' up to 75 %, 'lean' beyond -- 288 GB of HBM3E take the default configuration (B = 64, 128 x 128: 118 GB in 'full') whole,
+    and a batch that does not fit sheds saved tensors block by block instead of failing (every mode gives bit-identical results)."""
     global _RESTORMER_SAVE
     if mode not in _RESTORMER_MODES:
         raise ValueError(mode)
     prev, _RESTORMER_SAVE = _RESTORMER_SAVE, mode
     return prev
+
+
+def _restormer_mode(dev) -> str:
+    if _RESTORMER_SAVE != "auto":
+        return _RESTORMER_SAVE
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    total = _DEV_TOTAL.get(idx)
+    if total is None:
+        total = _DEV_TOTAL[idx] = torch.cuda.get_device_properties(idx).total_memory
+    used = torch.cuda.memory_allocated(idx) / total
+    return "full" if used < 0.55 else "balanced" if used < 0.75 else "lean"
 
 
 @_remember_gemm_mode
@@ -1433,7 +1448,7 @@ class _MDTAFn(torch.autograd.Function):
         M, ch = B * H * W, Cc // heads
         y = _empty_nhwc(B, Cc, H, W, dev)
         stats = torch.empty((2, M), dtype=torch.float32, device=dev)
-        mode = _RESTORMER_SAVE
+        mode = _restormer_mode(dev)
         qkv1 = None if mode == "lean" else _empty_nhwc(B, 3 * Cc, H, W, dev)
         qkv = _empty_nhwc(B, 3 * Cc, H, W, dev)
         nrm = torch.empty((B, 2 * Cc), dtype=torch.float32, device=dev)
@@ -1506,7 +1521,7 @@ class _GDFNFn(torch.autograd.Function):
         hp = (hidden + 3) // 4 * 4
         y = _empty_nhwc(B, Cc, H, W, dev)
         stats = torch.empty((2, M), dtype=torch.float32, device=dev)
-        full = _RESTORMER_SAVE == "full"
+        full = _restormer_mode(dev) == "full"
         u = _empty_nhwc(B, 2 * hp, H, W, dev)
         t = _empty_nhwc(B, hp, H, W, dev) if full else None
         xn = _empty_nhwc(B, Cc, H, W, dev) if full else None
