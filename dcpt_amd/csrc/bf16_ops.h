@@ -18,7 +18,7 @@ int launch_ln_act_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, c
 int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
 
-constexpr int WPACKB_MAX_JOBS = 8;
+constexpr int WPACKB_MAX_JOBS = 9;
 struct WpackBJobs {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
                       // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
                       // 4 / 5 / 6 / 7: misc.hip's WP_DOWN / WP_DOWN_T / WP_UP / WP_UP_T (2x2 stride-2 conv, 1x1 conv + PixelShuffle(2))

@@ -247,15 +247,20 @@ DwrGeom dwr_geom(const DwGeom& g, int es) {
     const int PH = g.C * es / 8;
     int lp = 2;
     while (lp < PH && lp < 64) lp <<= 1;
+    static const int force_lp = dcpt_tuning("DCPT_DWR_FWD_LP", 0);   // experiments
+    static const int force_nrp = dcpt_tuning("DCPT_DWR_FWD_NRP", 0);
+    if (force_lp >= 2 && force_lp <= lp) lp = force_lp;
     d.LP = lp;
     d.nqc = cdiv(PH, lp);
     const int PB = 2 * (256 / lp);
     d.nwc = cdiv(g.W, PB);
-    // row parts: enough blocks to fill the chip (>= 1024), at least 8 rows each so that the two halo rows stay a small fraction
+    // row parts: enough blocks to fill the chip (>= 1024), at least 16 rows each so that the two halo rows stay a small fraction (8-row parts
+    // at level 3 -- 32 x 32 images -- measured 41.8 us against 30.6 us with 16-row parts: profiles/r4/dwring_fwd_geometry.txt)
     int64_t nrp = cdiv64(cdiv64(1024, (int64_t)g.B * d.nqc), d.nwc);
-    const int64_t maxp = g.H / 8 > 0 ? g.H / 8 : 1;
+    const int64_t maxp = g.H / 16 > 0 ? g.H / 16 : 1;
     if (nrp > maxp) nrp = maxp;
     if (nrp < 1) nrp = 1;
+    if (force_nrp > 0) nrp = force_nrp < g.H ? force_nrp : g.H;
     d.nrp = (int)nrp;
     return d;
 }

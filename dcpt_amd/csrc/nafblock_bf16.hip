@@ -32,9 +32,14 @@ bool ffn_fused(int C) {
 struct FwdWsB {
     float* w2p;
     float* pool_part;
-    bf16_t *W1, *W4, *W5, *W3s;
+    bf16_t *W1, *W4, *W5, *W3s, *W3, *t2s;
     int nblk_pool;
+    bool scale_act;   // conv3's SCA scale on the activations (t2 * s, one GEMM) instead of in per-image weights: images smaller than 2 C pixels
 };
+
+// Per-image weight copies W3 * s[b] are C x C each; an image of P pixels brings P x C activations: below P = 2 C the weight copies (written
+// by the pack, read by the GEMM) are the larger traffic and the per-image GEMMs have fewer rows than a tile -- scale the activations instead.
+bool conv3_scale_activations(int P, int C) { return P < 2 * C; }
 
 size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* out) {
     WsAlloc a(base, base ? bytes : (size_t)-1);
@@ -46,7 +51,10 @@ size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* 
     w.W1 = a.get<bf16_t>((size_t)2 * C * C);
     w.W4 = a.get<bf16_t>((size_t)2 * C * C);
     w.W5 = a.get<bf16_t>((size_t)C * C);
-    w.W3s = a.get<bf16_t>((size_t)B * C * C);
+    w.scale_act = conv3_scale_activations(H * W, C);
+    w.W3s = w.scale_act ? nullptr : a.get<bf16_t>((size_t)B * C * C);
+    w.W3 = w.scale_act ? a.get<bf16_t>((size_t)C * C) : nullptr;
+    w.t2s = w.scale_act ? a.get<bf16_t>((size_t)B * H * W * C) : nullptr;
     if (out) *out = w;
     return a.off;
 }
@@ -203,7 +211,7 @@ bool shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C 
 // keeps this buffer per block and refreshes it when the parameters change (once per optimizer step) saves the per-call packs:
 // 5 launches per block and step (dcpt_nafblock_wpack_bf16 / *_packed entry points).
 struct PackB {
-    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1;
+    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3;
     float* w2p;
 };
 size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
@@ -217,13 +225,15 @@ size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
     k.wT3 = a.get<bf16_t>((size_t)C * C);
     k.wT1 = a.get<bf16_t>((size_t)2 * C * C);
     k.w2p = a.get<float>((size_t)18 * C);
+    k.W3 = a.get<bf16_t>((size_t)C * C);
     if (out) *out = k;
     return a.off;
 }
 int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
     const int C2 = 2 * C;
     WpackBJobs j{};
-    j.n = 8;
+    j.n = 9;
+    j.in[8] = p->conv3_w; j.out[8] = k.W3; j.N[8] = C; j.K[8] = C;
     j.in[0] = p->conv1_w; j.out[0] = k.W1; j.N[0] = C2; j.K[0] = C;
     j.in[1] = p->conv4_w; j.out[1] = k.W4; j.N[1] = C2; j.K[1] = C;
     j.in[2] = p->conv5_w; j.out[2] = k.W5; j.N[2] = C; j.K[2] = C;
@@ -276,8 +286,13 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         PackB k;
         DCPT_CHECK_ARG(pack_layout(C, const_cast<void*>(packed), packed_bytes, &k) <= packed_bytes, "nafblock_fwd_bf16: packed weights buffer too small");
         w.W1 = k.W1; w.W4 = k.W4; w.W5 = k.W5; w.w2p = k.w2p;
+        if (w.scale_act) w.W3 = k.W3;
     } else {
         j.n = 3;
+        if (w.scale_act) {
+            j.n = 4;
+            j.in[3] = p->conv3_w; j.out[3] = w.W3; j.N[3] = C; j.K[3] = C;
+        }
         j.in[0] = p->conv1_w; j.out[0] = w.W1; j.N[0] = 2 * C; j.K[0] = C;
         j.in[1] = p->conv4_w; j.out[1] = w.W4; j.N[1] = 2 * C; j.K[1] = C;
         j.in[2] = p->conv5_w; j.out[2] = w.W5; j.N[2] = C; j.K[2] = C;
@@ -299,15 +314,22 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     if (dw_ring_usable(dg, 2)) DCPT_TRY(launch_dw_ring_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     else DCPT_TRY(launch_dw_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
-    // y = inp + (conv3(t2 * s) + b3) * beta: the per-image scale lives in the weights, one GEMM problem per image
-    j = WpackBJobs{};
-    j.n = 1;
-    j.in[0] = p->conv3_w; j.out[0] = w.W3s; j.N[0] = C; j.K[0] = C; j.kscale[0] = sv->s; j.nimg[0] = B;
-    DCPT_TRY(launch_wpack_bf16(j, s));
     g = GemmNTB{};
-    g.M = P; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = w.W3s; g.N = C; g.C = sv->y; g.ldc = C; g.bias = p->conv3_b;
-    g.res = inp; g.ldres = C; g.cscale = p->beta;
-    g.nb = B; g.sA = (int64_t)P * C; g.sB = (int64_t)C * C; g.sC = (int64_t)P * C; g.sR = (int64_t)P * C;
+    if (w.scale_act) {
+        // y = inp + (conv3(t2 * s) + b3) * beta with the scale on the activations (small images): one pass over t2, one GEMM
+        DCPT_TRY(launch_scale_rows_bf16(sv->t2, sv->s, w.t2s, M, C, P, s));
+        g.M = M; g.A = w.t2s; g.lda = C; g.K = C; g.Bw = w.W3; g.N = C; g.C = sv->y; g.ldc = C; g.bias = p->conv3_b;
+        g.res = inp; g.ldres = C; g.cscale = p->beta;
+    } else {
+        // ... with the per-image scale in the weights, one GEMM problem per image
+        j = WpackBJobs{};
+        j.n = 1;
+        j.in[0] = p->conv3_w; j.out[0] = w.W3s; j.N[0] = C; j.K[0] = C; j.kscale[0] = sv->s; j.nimg[0] = B;
+        DCPT_TRY(launch_wpack_bf16(j, s));
+        g.M = P; g.A = sv->t2; g.lda = C; g.K = C; g.Bw = w.W3s; g.N = C; g.C = sv->y; g.ldc = C; g.bias = p->conv3_b;
+        g.res = inp; g.ldres = C; g.cscale = p->beta;
+        g.nb = B; g.sA = (int64_t)P * C; g.sB = (int64_t)C * C; g.sC = (int64_t)P * C; g.sR = (int64_t)P * C;
+    }
     DCPT_TRY(launch_gemm_nt_bf16(g, EB_RESID, s));
     if (ffn_fused(C)) {   // narrow levels: LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual in one pass over y (ffn_bf16.hip)
         FfnFwdB f{};

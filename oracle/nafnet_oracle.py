@@ -100,8 +100,14 @@ def nafblock_bf16(inp, P: dict, pre: str):
     pooled = t2u.mean(dim=(2, 3))                                                    # pooling sums the unrounded gate outputs
     t2 = _rf(t2u)                                                                    # (dt2 = dts * s + dpool stays on chip)
     s = F.linear(pooled, g("sca.1.weight").flatten(1), g("sca.1.bias"))             # [B][C]
-    w3s = _rf(g("conv3.weight").flatten(1)[None] * s[:, None, :])                   # per-image weights W3[n][k] * s[b][k]
-    x3 = torch.einsum("bnk,bkhw->bnhw", w3s, _rb(t2)) + g("conv3.bias").view(1, -1, 1, 1)   # (dts is stored in bf16)
+    if t2.shape[2] * t2.shape[3] < 2 * c:
+        # small images (fewer pixels than 2 x channels): the HIP path scales the ACTIVATIONS, t2 * s stored in bf16 (its gradient too),
+        # and runs one GEMM with the shared bf16 weights -- per-image weight copies would be larger than the activations they multiply
+        t2s = _rr(t2 * s[:, :, None, None])
+        x3 = F.conv2d(t2s, _rf(g("conv3.weight")), g("conv3.bias"))
+    else:
+        w3s = _rf(g("conv3.weight").flatten(1)[None] * s[:, None, :])               # per-image weights W3[n][k] * s[b][k]
+        x3 = torch.einsum("bnk,bkhw->bnhw", w3s, _rb(t2)) + g("conv3.bias").view(1, -1, 1, 1)   # (dts is stored in bf16)
     y = _rr(inp + x3 * g("beta"))
     xn2 = _rr(layernorm2d(y, g("norm2.weight"), g("norm2.bias")))
     vu = F.conv2d(xn2, _rf(g("conv4.weight")), g("conv4.bias"))
