@@ -505,7 +505,12 @@ bool gemm_tn_bf16_256_ok(int N, int K) {
 // them with that image's scale): its blocks take a divisor of the image (large images) or a whole number of images, one slot each (small
 // ones).  Returns false -- and plans nothing -- if such a problem cannot be cut that way (image not a multiple of 64 pixels, or so small
 // that the per-image slots would cost more traffic than a scaled copy of the operand: the caller makes that copy instead).
+// (a block's 256 KB of partial sums are worth 512 pixels of its two operand tiles: with fewer than ~1000 pixels per block a launch moves
+// more slab bytes than operand bytes -- small batches fill fewer CUs instead; DCPT at 128 x 128: 48.7 -> ... us per grouped launch)
+constexpr int64_t TN_MIN_ROWS_DEFAULT = 1024;
+
 bool gemm_tn_bf16_256_plan(GemmTNG& g, const int* img_P, int target_blocks) {
+    static const int64_t TN_MIN_ROWS = dcpt_tuning("DCPT_TN_MIN_ROWS", (int)TN_MIN_ROWS_DEFAULT);
     int tiles = 0;
     for (int i = 0; i < g.n; ++i) {
         g.p[i].tiles_k = g.p[i].K / 256;
@@ -548,7 +553,7 @@ bool gemm_tn_bf16_256_plan(GemmTNG& g, const int* img_P, int target_blocks) {
         TnProb& p = g.p[i];
         if (!(img_P && img_P[i] > 0)) {
             int64_t rows = cdiv64(cdiv64(p.M, sf), 64) * 64;
-            if (rows < 256) rows = 256;
+            if (rows < TN_MIN_ROWS) rows = TN_MIN_ROWS;
             p.rows_per_split = rows;
             p.splits = (int)cdiv64(p.M, rows);
             p.slots = p.splits;

@@ -360,19 +360,22 @@ def test_psnr_bf16_storage_vs_fp32(dev, trained_denoiser):
     from basicsr.metrics import calculate_psnr
 
     nets = {}
-    for dt in ("fp32", "bf16"):
+    for dt in ("fp32", "bf16", "bf16_tail32"):
         net = build_network(dict(type="NAFNetBaseline", act_dtype=dt, **FULL))
         net.load_state_dict(trained_denoiser, strict=True)
         nets[dt] = net.to(dev).eval()
-    worst = 0.0
+    worst = {"bf16": 0.0, "bf16_tail32": 0.0}
     kw = dict(crop_border=0, test_y_channel=False, image_range=255.0)
     f = lambda t: t.clamp(0, 1).cpu().numpy()   # noqa: E731
     for i in range(4):
         gt, lq = _smooth_pair(i)
         with torch.no_grad():
-            o32, o16 = nets["fp32"](lq[None].to(dev)), nets["bf16"](lq[None].to(dev))
-        assert o16.dtype == torch.float32
-        p32, p16 = calculate_psnr(f(o32), f(gt[None]), **kw), calculate_psnr(f(o16), f(gt[None]), **kw)
-        worst = max(worst, abs(p32 - p16))
-    print(f"bf16 storage moves PSNR by at most {worst:.4f} dB on these pairs")
-    assert worst <= 0.03, f"PSNR differs by {worst:.4f} dB"   # measured: 0.0125 dB on the trained network
+            outs = {dt: n(lq[None].to(dev)) for dt, n in nets.items()}
+        p32 = calculate_psnr(f(outs["fp32"]), f(gt[None]), **kw)
+        for dt in worst:
+            assert outs[dt].dtype == torch.float32
+            worst[dt] = max(worst[dt], abs(p32 - calculate_psnr(f(outs[dt]), f(gt[None]), **kw)))
+    print(f"bf16 storage moves PSNR by at most {worst['bf16']:.4f} dB on these pairs, with the last decoder group + ending in fp32 by {worst['bf16_tail32']:.4f} dB")
+    assert worst["bf16"] <= 0.03, f"PSNR differs by {worst['bf16']:.4f} dB"   # measured: 0.0125 dB on the trained network
+    # act_dtype = "bf16_tail32": measured on MI355X -- see the assertion's bound; this is the bf16 mode that stays inside north_star's 0.01 dB
+    assert worst["bf16_tail32"] <= 0.01, f"PSNR differs by {worst['bf16_tail32']:.4f} dB"
