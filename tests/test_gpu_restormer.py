@@ -181,8 +181,9 @@ def test_directional_derivative_full_size(dev):
 
 
 def test_saved_tensor_modes_equal_full(dev):
-    """The save modes of the Restormer halves (functional.set_restormer_save / DCPT_RESTORMER_SAVE) -- "balanced" (default: LN(x), attn @ v and
-    the GDFN gate product recomputed in backward) and "lean" (also the qkv conv output) -- give bit-identical outputs
+    """The save modes of the Restormer halves (functional.set_restormer_save / DCPT_RESTORMER_SAVE) -- "balanced" (LN(x), attn @ v and
+    the GDFN gate product recomputed in backward), "lean" (also the qkv conv output) and the default "auto" (one of the three per block,
+    by the device memory in use) -- give bit-identical outputs
     and gradients to "full": the recomputation runs the same kernels on the same inputs; each keeps fewer bytes alive between
     forward and backward than the one before."""
     from basicsr.archs import build_network
@@ -193,9 +194,9 @@ def test_saved_tensor_modes_equal_full(dev):
     x = keyed_input("lean.x", (2, 3, 32, 32)).to(dev)
     res = {}
     prev = DF.set_restormer_save("full")
-    assert prev == "balanced"   # the default
+    assert prev == "auto"   # the default
     try:
-        for mode in ("full", "balanced", "lean"):
+        for mode in ("full", "balanced", "lean", "auto"):
             DF.set_restormer_save(mode)
             net = build_network(dict(type="Restormer", **R_CFG))
             net.load_state_dict(sd, strict=True)
@@ -211,7 +212,7 @@ def test_saved_tensor_modes_equal_full(dev):
             del net, y
     finally:
         DF.set_restormer_save(prev)
-    for mode in ("balanced", "lean"):
+    for mode in ("balanced", "lean", "auto"):
         assert torch.equal(res["full"][0], res[mode][0])
         for k in res["full"][1]:
             assert torch.equal(res["full"][1][k], res[mode][1][k]), (mode, k)
