@@ -13,6 +13,16 @@ __device__ __forceinline__ f8 ld8(const bf16_t* p, bool ok) {
     const u32x4 w = *reinterpret_cast<const u32x4*>(p);
     return f8{make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y)), make_float4(bf_lo(w.z), bf_hi(w.z), bf_lo(w.w), bf_hi(w.w))};
 }
+// the same load kept PACKED (4 registers instead of 8): what the LayerNorm kernels prefetch for their next row
+__device__ __forceinline__ u32x4 ld8raw(const bf16_t* p, bool ok) {
+    u32x4 w;
+    w.x = w.y = w.z = w.w = 0u;
+    if (ok) w = *reinterpret_cast<const u32x4*>(p);
+    return w;
+}
+__device__ __forceinline__ f8 unpack8(u32x4 w) {
+    return f8{make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y)), make_float4(bf_lo(w.z), bf_hi(w.z), bf_lo(w.w), bf_hi(w.w))};
+}
 __device__ __forceinline__ void st8(bf16_t* p, bool ok, f8 v) {
     if (!ok) return;
     u32x4 w;
@@ -43,17 +53,28 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_kernel(const bf16_t* __restri
         ww[i] = q < nq ? f8_ld(w + 8 * q) : f8_zero();
         bb[i] = q < nq ? f8_ld(b + 8 * q) : f8_zero();
     }
+    // the row of the NEXT iteration is loaded before this one's reductions (a row is one 16-byte load per lane: without the prefetch a wave has
+    // 1 KB in flight and the kernel is latency-bound beyond the Infinity Cache -- 2.7 TB/s at 65 536 x 512 -- tools/ubench/stream_mix.hip)
+    u32x4 nxt[NQ];
+    {
+        const int64_t row0 = (int64_t)blockIdx.x * gpb + tid / G;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) nxt[i] = ld8raw(x + (row0 < M ? row0 : 0) * (int64_t)C + 8 * (lig + i * G), row0 < M && lig + i * G < nq);
+    }
     for (int64_t rb = blockIdx.x; rb * gpb < M; rb += gridDim.x) {
         const int64_t row = rb * gpb + tid / G;
         const bool valid = row < M;
-        const bf16_t* xr = x + (valid ? row : 0) * (int64_t)C;
         f8 v[NQ];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = lig + i * G;
-            v[i] = ld8(xr + 8 * q, valid && q < nq);
+            v[i] = unpack8(nxt[i]);
             sum += f8_sum(v[i]);
+        }
+        {
+            const int64_t row2 = (rb + gridDim.x) * gpb + tid / G;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) nxt[i] = ld8raw(x + (row2 < M ? row2 : 0) * (int64_t)C + 8 * (lig + i * G), row2 < M && lig + i * G < nq);
         }
         sum = group_sum(sum, G);
         const float mean = sum / (float)C;
@@ -108,28 +129,54 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const bf16_t* __restri
         ab[i] = f8_zero();
     }
     const float invC = 1.0f / (float)C;
+    // operands of the NEXT iteration are loaded before this one's reductions and stores (two rows in flight per wave: see ln_fwd_bf16_kernel)
+    u32x4 ng[NQ], nx[NQ], nd[NQ], nm[NQ];
+    float nmean, nrs;
+    auto fetch = [&](int64_t it) {
+        const int64_t row = (it * gridDim.x + blockIdx.x) * gpb + gid;
+        const bool valid = it < iters && row < M;
+        const int64_t ro = (valid ? row : 0) * (int64_t)C;
+        nmean = valid ? mu[row] : 0.f;
+        nrs = valid ? rstd[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lig + i * G;
+            const bool ok = valid && q < nq;
+            ng[i] = ld8raw(gy + ro + 8 * q, ok);
+            nm[i] = ld8raw(ymask + ro + 8 * q, ok && ymask != nullptr);
+            nx[i] = ld8raw(x + ro + 8 * q, ok);
+            nd[i] = ld8raw(dres + ro + 8 * q, ok && dres != nullptr);
+        }
+    };
+    fetch(0);
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t row = (it * gridDim.x + blockIdx.x) * gpb + gid;
         const bool valid = row < M;
         const int64_t ro = (valid ? row : 0) * (int64_t)C;
-        const float mean = valid ? mu[row] : 0.f, rs = valid ? rstd[row] : 0.f;
-        f8 g[NQ], xh[NQ], dr[NQ];
+        const float mean = nmean, rs = nrs;
+        f8 g[NQ], xh[NQ], dr[NQ], xraw[NQ], ymk[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            g[i] = unpack8(ng[i]);
+            xraw[i] = unpack8(nx[i]);
+            dr[i] = unpack8(nd[i]);
+            ymk[i] = unpack8(nm[i]);
+        }
+        fetch(it + 1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = lig + i * G;
             const bool ok = valid && q < nq;
-            g[i] = ld8(gy + ro + 8 * q, ok);
             if (ymask) {   // ReLU behind the LayerNorm: the gradient passes where the (post-ReLU) output is > 0
-                const f8 ym = ld8(ymask + ro + 8 * q, ok);
+                const f8 ym = ymk[i];
                 g[i].lo = make_float4(ym.lo.x > 0.f ? g[i].lo.x : 0.f, ym.lo.y > 0.f ? g[i].lo.y : 0.f, ym.lo.z > 0.f ? g[i].lo.z : 0.f,
                                       ym.lo.w > 0.f ? g[i].lo.w : 0.f);
                 g[i].hi = make_float4(ym.hi.x > 0.f ? g[i].hi.x : 0.f, ym.hi.y > 0.f ? g[i].hi.y : 0.f, ym.hi.z > 0.f ? g[i].hi.z : 0.f,
                                       ym.hi.w > 0.f ? g[i].hi.w : 0.f);
             }
             if (gmasked) st8(gmasked + ro + 8 * q, ok, g[i]);   // the shortcut branch receives the masked gradient
-            const f8 xv = ld8(x + ro + 8 * q, ok);
-            dr[i] = dres ? ld8(dres + ro + 8 * q, ok) : f8_zero();
+            const f8 xv = xraw[i];
             xh[i].lo = make_float4((xv.lo.x - mean) * rs, (xv.lo.y - mean) * rs, (xv.lo.z - mean) * rs, (xv.lo.w - mean) * rs);
             xh[i].hi = make_float4((xv.hi.x - mean) * rs, (xv.hi.y - mean) * rs, (xv.hi.z - mean) * rs, (xv.hi.w - mean) * rs);
             if (!ok) xh[i] = f8_zero();
