@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (the metric is quoted at 32)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even with one rank (path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path-check-shared-device", action="store_true",
+                    help="PATH CHECK ONLY, never a measurement: the ranks share the visible GPU(s) and the collectives go over gloo, so that the "
+                         "multi-rank code path can be exercised on a one-GPU box (the line is marked invalid)")
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32: the exact fp32 MFMA kernels (the headline); bf16x3: the wide GEMMs on the bf16 pipe with split operands "
                          "(fp32-class, reported as its own line -- never the headline)")
@@ -214,8 +217,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
-    if torch.cuda.device_count() < world:
+    if torch.cuda.device_count() < world and not args.path_check_shared_device:
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible on this node")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -226,7 +230,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
+        if args.path_check_shared_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
 
     from basicsr.archs import build_network
     from dcpt_amd import _lib
@@ -329,6 +336,8 @@ def main():
     def step_fb():
         opt.zero_grad(set_to_none=True)
         (model(lq) - gt).abs().mean().backward()
+        if use_ddp:   # (what the optimizer's post-step hook does in a full step: the bucket views may be written in place again)
+            dcpt_ddp.refresh_views(net.parameters())
 
     step_fb()
     barrier()
@@ -454,6 +463,8 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         res["lib_digest"] = lib_digest()
+        if args.path_check_shared_device:
+            res["invalid"] = "path check: the ranks shared a device and the collectives went over gloo -- not a measurement"
         if world == 1 and not args.no_secondary:
             sec = {}
             if args.gemm_precision == "fp32":
