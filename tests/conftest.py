@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+if os.environ.get("DCPT_TOOL_LIB"):   # development only: run the suite against a variant build (tools/build_variant.sh) instead of the product library
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _variant  # noqa: E402,F401
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
