@@ -61,3 +61,11 @@ def test_product_never_imports_oracle():
                 if f.endswith(".py"):
                     src = open(os.path.join(d, f)).read()
                     assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{d}/{f} mentions the oracle"
+
+
+def test_graft_entry_build_runs():
+    """the driver's build check (__graft_entry__.build): compiles / loads the library, checks the ABI version against the binding table and
+    imports the package -- it once pinned a literal ABI number and broke when the ABI grew"""
+    import __graft_entry__ as g
+
+    g.build()
