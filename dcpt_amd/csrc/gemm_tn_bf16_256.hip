@@ -1,14 +1,15 @@
 // Grouped bf16 weight-gradient GEMM with 256 x 256 output tiles:  G_p[n][k] = sum_m X_p[m][n] * Y_p[m][k]  for up to TNG_MAX problems
-// in ONE launch (the weight gradients of a wide NAFBlock: conv5 + conv4 after dv exists, conv3 + conv1 after dt1 exists; reference
-// basicsr/archs/nafnet_arch.py:165-186), and the FINISHER that turns the partial sums into parameter gradients together with every
-// other small parameter-gradient reduction of the block -- one launch instead of ten.
+// in ONE launch (the four weight gradients of a wide NAFBlock -- conv5, conv4, conv3, conv1 -- once dt1 exists; a dense 3 x 3 of the
+// classifier head with its gathered-tap Y operand; reference basicsr/archs/nafnet_arch.py:165-186, degrad_classify_arch.py:132-243), and
+// the FINISHER that turns the partial sums into parameter gradients together with every other small parameter-gradient reduction of the
+// block -- one launch instead of ten.
 //
 // Why grouped, why 256.  A CU holds one 256 x 256 fp32 tile in its accumulators, the chip 256 of them; a single 1024 x 512 weight
 // gradient has 8 such tiles, so all CUs working on it means 32 partial sums per output element (64 MB of fp32 slabs written and read
 // back for 96 MB of operands).  The 128 x 128 kernel (gemm_bf16.hip) has the same slab bytes and twice the operand traffic from L2
-// (every X element K/128 times, every Y element N/128 times): 614-688 TF/s + a 9.6-us reducer per problem.  Four problems in two
-// launches of 12 tiles each are 21 partial sums per element: a third less slab traffic per flop, half the L2 -> LDS fill per flop,
-// 2 + 1 launches instead of 4 + 8.
+// (every X element K/128 times, every Y element N/128 times): 614-688 TF/s + a 9.6-us reducer per problem.  The four problems of a block
+// in one launch are 24 tiles at C = 512, i.e. 10 partial sums per element (86 MB of slabs per block backward instead of 256 MB), half the
+// L2 -> LDS fill per flop, 1 + 1 launches instead of 4 + 8 (847 TF/s for the grouped launch at level 3).
 //
 // Kernel = the schedule of the NT kernel (gemm_bf16_256.hip: 8 waves in two groups one barrier apart, a SIMD alternates between one
 // wave issuing 8 MFMAs and its partner reading fragments + feeding the LDS-DMA queue; half-tile ring, counted vmcnt, DMAs never

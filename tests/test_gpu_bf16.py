@@ -315,7 +315,9 @@ def test_dcpt_step_with_bf16_encoder(dev):
                                                             # the 256 x 256-tile kernels: weight gradient (N, K multiples of 256; gathered taps of a
                                                             # dense 3 x 3, ragged pixel counts) and the implicit-GEMM forward / data gradient (>= 192 tiles)
                                                             (1, 512, 256, 24, 20, 3, True, False), (2, 256, 512, 16, 16, 1, True, True),
-                                                            (3, 256, 256, 128, 128, 3, True, True)])
+                                                            (3, 256, 256, 128, 128, 3, True, True),
+                                                            # found by tests/fuzz_shapes.py: one ReLU flip, nine pixels of the input gradient
+                                                            (5, 256, 64, 47, 63, 3, True, True)])
 def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     """conv (1x1 | dense 3x3 as implicit GEMM) -> channels-first LayerNorm -> [+res] -> [ReLU] with bf16 activations vs the same
     chain in fp32 with a bf16 rounding at the two stored tensors (degrad_classify_arch.py:69-103,227-243)."""
@@ -357,6 +359,16 @@ def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     yd.backward(gw.to(dev).bfloat16())
     torch.cuda.synchronize()
     errs = {"y": _rel(yd, yb), "dx": _rel(xd.grad, dxb), "dw": _rel(pd[0].grad, gb[0]), "dlnw": _rel(pd[1].grad, gb[1]), "dlnb": _rel(pd[2].grad, gb[2])}
+    if relu:
+        # a pre-activation within one bf16 ulp of zero may round to the other side of the ReLU in the two implementations: the input
+        # gradient of that pixel (and, for a 3 x 3, of its eight neighbours) then differs by a whole term of the sum -- with 64 output
+        # channels a few per cent of the maximum (tests/fuzz_shapes.py finds such shapes).  Such pixels are counted, not compared.
+        fl = ((yd.detach().float().cpu() == 0) != (yb == 0)).any(dim=1, keepdim=True).float()
+        assert float(fl.mean()) <= 1e-3, float(fl.mean())
+        if ks == 3:
+            fl = F.max_pool2d(fl, 3, 1, 1)
+        a, b = xd.grad.detach().float().cpu(), dxb.float()
+        errs["dx"] = float(((a - b).abs() * (fl == 0)).max() / b.abs().max())
     if use_res:
         if relu:
             # dres = gw * [pre-activation > 0]: a pre-activation within one bf16 ulp of zero may round to the other side in the two
@@ -371,7 +383,8 @@ def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     bad = {k: v for k, v in errs.items() if not np.isfinite(v) or v > 2e-2}
     assert not bad, f"vs bf16-mode oracle: {bad} (all { {k: round(v, 4) for k, v in errs.items()} })"
     # vs fp32: a sanity bound only -- ReLU masks of values that round across zero flip whole gradient entries
-    assert _rel(yd, yf) <= 4e-2 and _rel(xd.grad, dxf) <= 0.15 and _rel(pd[0].grad, gf[0]) <= 0.15
+    assert _rel(yd, yf) <= 4e-2 and _rel(pd[0].grad, gf[0]) <= 0.15
+    assert relu or _rel(xd.grad, dxf) <= 0.15
 
 
 def test_dc_head_bf16_oracle(dev):
