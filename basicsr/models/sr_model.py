@@ -208,26 +208,56 @@ class SRModel(BaseModel):
                 groups.setdefault((yp1 - yp0, xp1 - xp0), []).append((x0, y0, x1, y1, xp0, yp0, xp1, yp1))
         shard = self._tile_shard()
         world, rank = (self.opt["world_size"], self.opt["rank"]) if shard else (1, 0)
-        nbatch = 0
-        for tiles in groups.values():
-            for i in range(0, len(tiles), max(1, max_batch // b)):
-                nbatch += 1
-                if (nbatch - 1) % world != rank:
-                    continue
-                chunk = tiles[i:i + max(1, max_batch // b)]
-                inp = torch.cat([self.lq[:, :, t[5]:t[7], t[4]:t[6]] for t in chunk], 0)
-                with torch.no_grad():
-                    out = net(inp)
-                for j, (x0, y0, x1, y1, xp0, yp0, xp1, yp1) in enumerate(chunk):
-                    ox, oy = (x0 - xp0) * sc, (y0 - yp0) * sc
-                    self.output[:, :, y0 * sc:y1 * sc, x0 * sc:x1 * sc] = \
-                        out[j * b:(j + 1) * b, :, oy:oy + (y1 - y0) * sc, ox:ox + (x1 - x0) * sc]
+        per = max(1, max_batch // b)
+        batches = [tiles[i:i + per] for tiles in groups.values() for i in range(0, len(tiles), per)]
+        batches = [chunk for k, chunk in enumerate(batches) if k % world == rank]
+
+        def run(chunk):
+            inp = torch.cat([self.lq[:, :, t[5]:t[7], t[4]:t[6]] for t in chunk], 0)
+            with torch.no_grad():
+                out = net(inp)
+            for j, (x0, y0, x1, y1, xp0, yp0, xp1, yp1) in enumerate(chunk):
+                ox, oy = (x0 - xp0) * sc, (y0 - yp0) * sc
+                self.output[:, :, y0 * sc:y1 * sc, x0 * sc:x1 * sc] = \
+                    out[j * b:(j + 1) * b, :, oy:oy + (y1 - y0) * sc, ox:ox + (x1 - x0) * sc]
+
+        streams = self._tile_streams(len(batches), net)
+        if not streams:
+            for chunk in batches:
+                run(chunk)
+        else:
+            # the shape classes are independent and each is too small to fill the chip (4 tiles of 544 x 544: 146 of 256 workgroups in the
+            # level-3 GEMMs, hundreds of latency-bound small launches): one HIP stream per batch in flight, disjoint regions of the output
+            cur = torch.cuda.current_stream(self.lq.device)
+            for st in streams:
+                st.wait_stream(cur)
+            for k, chunk in enumerate(batches):
+                with torch.cuda.stream(streams[k % len(streams)]):
+                    run(chunk)
+            for st in streams:
+                cur.wait_stream(st)
         if shard:
             import torch.distributed as dist
 
             dist.reduce(self.output, dst=0, op=dist.ReduceOp.SUM)   # disjoint tiles: the sum is the assembled image (valid on rank 0)
         if net is self.net_g:
             net.train()
+
+    def _tile_streams(self, nbatches, net):
+        """HIP streams for the tile batches of ``test_tile`` (``tile.streams``, default 2 -- the measured optimum, 4 is slower again; 1 = the caller's stream only).  One stream when
+        there is nothing to overlap, off the GPU, or when the network runs its GEMMs in the split-operand mode (one process-wide scratch
+        buffer, dcpt_amd/csrc/gemm_x3.hip)."""
+        n = min(int(self.opt["tile"].get("streams", 2)), nbatches)
+        if n <= 1 or not self.lq.is_cuda:
+            return []
+        from dcpt_amd import functional as DF
+
+        if getattr(net, "gemm_precision", None) not in (None, "fp32") or DF.get_gemm_precision() != "fp32":
+            return []
+        pool = getattr(self, "_tile_stream_pool", None)
+        if pool is None or len(pool) < n or pool[0].device != self.lq.device:
+            pool = self._tile_stream_pool = [torch.cuda.Stream(self.lq.device) for _ in range(n)]
+        return pool[:n]
 
     def _tile_shard(self):
         return bool(self.opt.get("dist")) and self.opt.get("world_size", 1) > 1 and "tile" in self.opt and \

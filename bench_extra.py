@@ -63,7 +63,7 @@ def run_restormer(dev, save="auto", steps=5, warmup=2, B=64, S=128):
                 peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
 
 
-def run_infer2k(dev, dtype="fp32", steps=5, warmup=2, S=2048):
+def run_infer2k(dev, dtype="fp32", steps=5, warmup=2, S=2048, streams=2):
     """BASELINE.json configs[4]: one S x S image through SRModel.test_tile (reference sr_model.py:273-361), 512-pixel tiles with 16 pixels
     of context, NAFNet-64 inference."""
     from basicsr.models import build_model
@@ -74,7 +74,7 @@ def run_infer2k(dev, dtype="fp32", steps=5, warmup=2, S=2048):
     peak = 2.5e15 if dtype == "bf16" else 157.3e12
     opt = dict(name="b", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
                network_g=dict(type="NAFNetBaseline", window_size=16, **dict(NAF, act_dtype=dtype)), path=dict(),
-               tile=dict(infer_size=512, tile_pad=16), val=dict(save_img=False))
+               tile=dict(infer_size=512, tile_pad=16, streams=streams), val=dict(save_img=False))
     m = build_model(opt)
     fill_module_(m.net_g)
     img = torch.rand((1, 3, S, S), generator=g, device=dev)
@@ -88,7 +88,7 @@ def run_infer2k(dev, dtype="fp32", steps=5, warmup=2, S=2048):
     dt = timed(run, steps, warmup)
     flops = (S / 256.0) ** 2 * 126.11e9 * (544 / 512.0) ** 2
     return dict(workload=f"NAFNet-64 tiled inference, {S}x{S}, test_tile infer_size 512 / tile_pad 16, feature maps {dtype} "
-                         "(BASELINE.json configs[4])",
+                         f"(BASELINE.json configs[4]), tile batches on {streams} stream(s)",
                 ms_per_image=round(dt * 1e3, 2), megapixels_per_s=round(S * S / 1e6 / dt, 3), steps=steps, warmup=warmup,
                 alg_tflops=round(flops / dt / 1e12, 2), mfma_peak_tflops=peak / 1e12, mfma_frac=round(flops / dt / peak, 4),
                 peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--restormer-save", default="auto", choices=["auto", "lean", "balanced", "full"], help="what the Restormer halves keep for backward")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tile-streams", type=int, default=2, help="infer2k: HIP streams the tile batches run on (tile.streams)")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--side-stream", type=int, default=1, choices=[0, 1], help="0: weight-gradient work on the caller's stream (serialized kernel times)")
@@ -182,7 +183,7 @@ def main():
     elif args.workload == "restormer":
         res = run_restormer(dev, args.restormer_save, args.steps, args.warmup, args.batch or 64, args.size or 128)
     else:
-        res = run_infer2k(dev, args.dtype, args.steps, args.warmup, args.size or 2048)
+        res = run_infer2k(dev, args.dtype, args.steps, args.warmup, args.size or 2048, args.tile_streams)
     res["peak_mem_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
     print(json.dumps(res), flush=True)
 

@@ -417,9 +417,15 @@ class PackedWeightsBf16:
     def __init__(self):
         self.key = None
         self.buf = None
+        self.stream = None   # the stream the pack was made on, and the event behind it: another stream waits before it reads the pack
+        self.event = None    # (tiled inference runs its tile batches on several streams, basicsr/models/sr_model.py::test_tile)
 
     def get(self, params: Dict[str, torch.Tensor]) -> torch.Tensor:
         key = (_PACK_GENERATION,) + tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
+        if key == self.key:
+            if self.stream != _stream(self.buf.device):
+                torch.cuda.current_stream(self.buf.device).wait_event(self.event)
+            return self.buf
         if key != self.key:
             lib = _lib.load()
             ps = tuple(_contig(params[k].detach()) for k in PARAM_FIELDS)
@@ -432,6 +438,9 @@ class PackedWeightsBf16:
             pp = NafBlockParams(*[p.data_ptr() for p in ps])
             check(lib.dcpt_nafblock_wpack_bf16(C.byref(pp), self.buf.data_ptr(), self.buf.numel(), Cc, _stream(dev)), "dcpt_nafblock_wpack_bf16")
             self.key = key
+            self.stream = _stream(dev)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(dev))
         return self.buf
 
 

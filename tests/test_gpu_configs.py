@@ -103,6 +103,38 @@ def test_tiled_2k_inference_vs_oracle(dev):
         assert e <= 1e-3, f"tile ({ty},{tx}) vs oracle: {e:.3e}"
 
 
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_tile_batches_on_several_streams_equal_one_stream(dev, act_dtype):
+    """configs[4]: ``test_tile`` runs its shape classes on ``tile.streams`` HIP streams (default 2).  Same batches, same kernels, disjoint
+    output regions: the result is bit-identical to the single-stream run, repeatedly (a race on the shared weight packs, a workspace or
+    the output would show as run-to-run differences), and the packed weights made on one stream are waited for by the others."""
+    from basicsr.models import build_model
+    from dcpt_amd import functional as DF
+
+    outs = {}
+    for streams in (1, 4):
+        opt = dict(name="t", model_type="SRModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=False,
+                   network_g=dict(type="NAFNetBaseline", window_size=16, act_dtype=act_dtype, **FULL), path=dict(),
+                   tile=dict(infer_size=512, tile_pad=16, streams=streams), val=dict(save_img=False))
+        m = build_model(opt)
+        m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**FULL), seed=0), strict=True)
+        img = torch.rand((1, 3, 1536, 1280), generator=torch.Generator().manual_seed(7))
+        runs = []
+        for rep in range(3):
+            if rep == 1:
+                DF.invalidate_packed_weights()   # the next first batch re-packs on ITS stream while the others start behind it
+            m.feed_data({"lq": img})
+            m.pre_test()
+            m.test_tile()
+            m.post_test()
+            runs.append(m.output.cpu())
+        # (the split-operand GEMM mode shares one scratch buffer process-wide: one stream there)
+        assert len(m._tile_streams(9, m.net_g)) == (4 if streams == 4 and DF.get_gemm_precision() == "fp32" else 0)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        outs[streams] = runs[0]
+    assert bool(torch.isfinite(outs[1]).all()) and torch.equal(outs[1], outs[4])
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 def test_dcpt_step_full_size_directional_derivative(dev):
     """BASELINE.json configs[2] in fp32: the analytic gradients left in `.grad` by DCPTModel.optimize_parameters (lr = 0), contracted
