@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const ST* __restrict__
         // them.  Without them this kernel -- and, of everything in the library, only this kernel -- returned a handful of wrong elements
         // per launch (always the first output channel of the last 16 lanes' pixel, i.e. the first sums formed from the new registers)
         // whenever bf16 MFMA GEMMs of ANOTHER stream shared its SIMDs; alone on the chip it is exact.  Forcing every s_waitcnt to zero
-        // did not help, any change of this instruction neighbourhood did (tests/stream_stress.py; DESIGN.md 6 has the measurements).
+        // did not help, any change of this instruction neighbourhood did (tests/stream_stress.py; DESIGN.md 4h has the measurements).
         asm volatile("s_nop 1"
                      : "+v"(xl.x), "+v"(xl.y), "+v"(xl.z), "+v"(xl.w), "+v"(xc.x), "+v"(xc.y), "+v"(xc.z), "+v"(xc.w), "+v"(xr.x), "+v"(xr.y),
                        "+v"(xr.z), "+v"(xr.w));

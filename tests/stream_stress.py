@@ -4,7 +4,7 @@
 
 For each victim (a layer's forward under no_grad, or its forward + backward) the quiet result is taken first; then the victim runs
 ``reps`` times on one stream while a second stream runs bf16 NAFBlocks back to back, and every result must equal the quiet one bit
-for bit.  Found with this: the bf16 ending conv (conv3x3_b2s_kernel<3, bf16>) next to the bf16 GEMM kernels -- see DESIGN.md 6."""
+for bit.  Found with this: the bf16 ending conv (conv3x3_b2s_kernel<3, bf16>) next to the bf16 GEMM kernels -- see DESIGN.md 4h."""
 import argparse
 import os
 import sys
