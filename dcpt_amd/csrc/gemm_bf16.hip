@@ -434,7 +434,7 @@ void tn_shape(int N, int K, int* bn, int* bk) {
 int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     GemmNTB p = pin;
     if (p.nb < 1) p.nb = 1;
-    DCPT_CHECK_ARG(p.A && p.Bw && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt_bf16: null operand or empty problem");
+    DCPT_CHECK_ARG(p.A && p.Bw && (p.C || epi == EB_BIASGATE) && p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt_bf16: null operand or empty problem");
     DCPT_CHECK_ARG(p.K % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldc % 8 == 0 && p.ldres % 8 == 0,
                    "gemm_nt_bf16: K=%d, N=%d and the row strides must be multiples of 8 (16-byte rows)", p.K, p.N);
     if (p.conv3)

@@ -108,8 +108,10 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
                 v2.hi = *reinterpret_cast<const float4*>(&Cs[rl * BN + W + 8 * q + 4]);
                 v = f8_add(v, bias);
                 v2 = f8_add(v2, bias2);
-                bbuf_st8(rsC, o, v);
-                bbuf_st8(rsC, o + 2u * (uint32_t)Ch, v2);
+                if (p.C) {   // (null: inference -- only the gate output is kept)
+                    bbuf_st8(rsC, o, v);
+                    bbuf_st8(rsC, o + 2u * (uint32_t)Ch, v2);
+                }
                 bbuf_st8(rsX, ok ? ((uint32_t)rl * (uint32_t)Ch + (uint32_t)n) * 2u : ROW_SENT, f8_mul(v, v2));
             } else if constexpr (EK == EB_PLAIN || EK == EB_SCATTER) {
                 bbuf_st8(rsC, o, v);

@@ -269,8 +269,10 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     DCPT_CHECK_ARG(shape_ok(B, H, W, C), "nafblock_fwd_bf16: bad shape B=%d H=%d W=%d C=%d (C %% 8 == 0, C <= 1024)", B, H, W, C);
     DCPT_CHECK_ARG(sv->t1 && sv->t2 && sv->y && sv->xn1 && sv->mu1 && sv->rstd1 && sv->pooled && sv->s, "nafblock_fwd_bf16: saved buffers missing");
     const bool infer = !sv->v && !sv->xn2 && !sv->g && !sv->mu2 && !sv->rstd2;   // inference with the fused second half: nothing of it is kept
-    DCPT_CHECK_ARG((sv->v && sv->xn2 && sv->g && sv->mu2 && sv->rstd2) || (infer && ffn_fused(C)),
-                   "nafblock_fwd_bf16: saved v / xn2 / g / mu2 / rstd2 missing (all five may be null only where dcpt_nafblock_bf16_fused_ffn(C) is 1)");
+    // (v alone may be null anywhere: a caller that runs no backward -- the bias+gate epilogue then writes SimpleGate(v) only)
+    DCPT_CHECK_ARG((sv->xn2 && sv->g && sv->mu2 && sv->rstd2) || (infer && ffn_fused(C)),
+                   "nafblock_fwd_bf16: saved xn2 / g / mu2 / rstd2 missing (all of v / xn2 / g / mu2 / rstd2 may be null only where "
+                   "dcpt_nafblock_bf16_fused_ffn(C) is 1; v alone may be null when no backward pass follows)");
     FwdWsB w;
     const size_t need = fwd_layout(B, H, W, C, ws, ws_bytes, &w);
     if (need > ws_bytes || ws == nullptr) {

@@ -285,7 +285,8 @@ def _saved_bf16(t1, v, acts, stats, sca, infer):
     if infer:
         return _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), 0, stats[0].data_ptr(), stats[1].data_ptr(), 0, 0,
                                       sca[0].data_ptr(), sca[1].data_ptr(), acts[2].data_ptr(), 0, 0)
-    return _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), v.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+    # (v None: no backward follows at a width whose second half is three kernels -- the bias + gate epilogue then keeps the gate only)
+    return _lib.NafBlockSavedBf16(t1.data_ptr(), acts[0].data_ptr(), acts[1].data_ptr(), 0 if v is None else v.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                                   stats[2 if full else 0].data_ptr(), stats[3 if full else 1].data_ptr(), sca[0].data_ptr(), sca[1].data_ptr(),
                                   acts[2].data_ptr(), acts[3 if full else 2].data_ptr(), acts[4 if full else 2].data_ptr())
 
@@ -312,9 +313,10 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         # tensors only that backward reads (v, LN2(y), SimpleGate(v), LN2's statistics) are neither allocated nor written
         # where the block's second half is one kernel, its backward recomputes LN2(y), the gate and LN2's statistics: never allocated
         fused = bool(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
-        infer = fused and not (grad_mode and any(ctx.needs_input_grad))
+        nograd = not (grad_mode and any(ctx.needs_input_grad))
+        infer = fused and nograd
         _NAFBlockBf16Fn.last_infer = infer
-        v = None if infer else _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)
+        v = None if nograd else _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)   # (conv4's output is read by the backward only)
         acts = torch.empty((3 if fused else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
         stats = torch.empty((2 if fused else 4, M), dtype=torch.float32, device=dev)
         sca = torch.empty((2, B, Cc), dtype=torch.float32, device=dev)           # pooled, s
@@ -328,7 +330,7 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
             check(lib.dcpt_nafblock_fwd_bf16_packed(C.byref(ps), packed.data_ptr(), packed.numel(), inp.data_ptr(), out.data_ptr(), C.byref(sv),
                                                     ws.data_ptr(), ws.numel(), B, H, W, Cc, _stream(dev)), "dcpt_nafblock_fwd_bf16_packed")
         ctx.packed = packed   # (a plain byte buffer owned by the module; the backward of THIS forward reads the same pack)
-        if not infer:
+        if not nograd:
             ctx.save_for_backward(inp, t1, v, acts, stats, sca, *params)
         return out
 

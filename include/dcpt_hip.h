@@ -155,7 +155,9 @@ size_t dcpt_nafblock_wpack_bf16_bytes(int C);
  * nafnet_arch.py:180-186) as ONE kernel (ffn_bf16.hip, the narrow levels): a caller that will not run the backward pass (inference)
  * may then pass saved->v = xn2 = g = mu2 = rstd2 = NULL -- all five or none -- and the forward skips v as well (4 -> 2 tensor passes for
  * that half).  With 1 the library never reads or writes saved->xn2 / g / mu2 / rstd2 in either pass (its backward kernels recompute
- * LayerNorm2, the gate and the statistics from y and v): in training they only have to be non-null.  0: every saved buffer is used. */
+ * LayerNorm2, the gate and the statistics from y and v): in training they only have to be non-null.  0: every saved buffer is used --
+ * except that saved->v ALONE may be NULL at any width when no backward pass follows: conv4's bias + gate epilogue then writes
+ * SimpleGate(v) only (one tensor pass instead of three for that launch). */
 int dcpt_nafblock_bf16_fused_ffn(int C);
 int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream);
 /* Weight (and bias) gradient of a 1 x 1 convolution in bf16 storage (ABI 9; the conv1 / conv3 / conv4 / conv5 weight gradients of

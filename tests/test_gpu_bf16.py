@@ -749,6 +749,27 @@ def test_fused_second_half_inference_drops_saved_tensors(dev):
         assert DF._NAFBlockBf16Fn.last_infer is True and torch.equal(y_inf2, y_inf)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 128, 12, 10), (3, 256, 17, 9), (24, 512, 32, 32)])
+def test_wide_level_inference_skips_conv4_output(dev, shape):
+    """At the widths whose second half is three kernels a forward that no backward follows passes saved->v = NULL: conv4's bias + gate
+    epilogue (128-row and 256 x 256-tile kernels; the last shape is large enough for the latter) writes SimpleGate(v) only.  Same bits
+    as the training forward."""
+    from dcpt_amd import functional as DF
+
+    c = shape[1]
+    tag = f"bf.infw.{c}.{shape[2]}."
+    P = _params(c, tag)
+    Pd = {k: P[v].to(dev).requires_grad_(True) for k, v in FUSED.items()}
+    x = keyed_input(tag + "x", shape, lo=-1.5, hi=1.5).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    y_train = DF.nafblock_bf16(x.clone().requires_grad_(True), Pd)
+    assert y_train.grad_fn is not None and y_train.grad_fn.saved_tensors[2] is not None   # (v kept for the backward)
+    with torch.no_grad():
+        y_inf = DF.nafblock_bf16(x, Pd)
+    torch.cuda.synchronize()
+    assert DF._NAFBlockBf16Fn.last_infer is False and torch.equal(y_train.detach(), y_inf)
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 256), (1000, 256, 256), (8192 + 77, 1024, 512), (64 * 33, 512, 512), (300, 256, 512),
                                    (2048, 128, 64), (513, 64, 128)])
 def test_conv1x1_wgrad_bf16(dev, M, N, K):
