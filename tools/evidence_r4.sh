@@ -28,5 +28,9 @@ tools/level_kernels.sh 0 bf16 $O/bf16_block_level0_kernels.txt
 (timeout 300 python tools/ddp_probe.py 2>&1 | grep -v INFO | tail -6) > $O/ddp_probe.txt
 tools/extras_all.sh gpurun_out/evidence_$TAG > $O/extras.log 2>&1
 (timeout 300 python bench_extra.py --workload restormer 2>&1 | tail -1) > $O/extra_restormer_auto.json
+tools/kernel_table.sh $O/infer2k_bf16_kernels_two_streams.txt 4 python $R/bench_extra.py --workload infer2k --dtype bf16 --steps 3 --warmup 1
+(for d in bf16 fp32; do for n in 1 2 4; do python bench_extra.py --workload infer2k --dtype $d --tile-streams $n --steps 5 --warmup 2 2>/dev/null | tail -1; done; done) > $O/infer2k_streams.txt
+(timeout 600 python tests/stream_stress.py --reps 30 2>&1 | grep "differing\|FAILED\|stable") > $O/stream_stress.txt
+(timeout 900 python tests/fuzz_shapes.py --seed 3 --n 40 2>&1 | tail -5) > $O/fuzz_seed3_tail.txt
 find $R/gpurun_out/prof_$TAG -name "*.csv" -size +2M -delete
 tail -3 $O/pytest_gpu_full.log; cat $O/bench_default_command.json | cut -c1-300
