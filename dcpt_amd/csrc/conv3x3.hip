@@ -159,15 +159,9 @@ __global__ __launch_bounds__(256) void conv3x3_b2s_kernel(const ST* __restrict__
     for (int s = 0; s < CS; ++s) a0[s] = a1[s] = 0.f;
     for (int r = k.y0 - 1; r <= k.y1; ++r) {
         const uint32_t o = (r >= 0 && r < H) ? ((uint32_t)((r - rb) * W + k.x) * (uint32_t)Cb + 4u * (uint32_t)k.q) * ES : ROW_SENT;
-        float4 xl = big_ld4<ST>(rs_x, (o - st) | cl), xc = big_ld4<ST>(rs_x, o | cc), xr = big_ld4<ST>(rs_x, (o + st) | cr);
-        // Two idle issue slots between the arrival (and bf16 unpack) of the three pixels and the first packed-fp32 operation that reads
-        // them.  Without them this kernel -- and, of everything in the library, only this kernel -- returned a handful of wrong elements
-        // per launch (always the first output channel of the last 16 lanes' pixel, i.e. the first sums formed from the new registers)
-        // whenever bf16 MFMA GEMMs of ANOTHER stream shared its SIMDs; alone on the chip it is exact.  Forcing every s_waitcnt to zero
-        // did not help, any change of this instruction neighbourhood did (tests/stream_stress.py; DESIGN.md 4h has the measurements).
-        asm volatile("s_nop 1"
-                     : "+v"(xl.x), "+v"(xl.y), "+v"(xl.z), "+v"(xl.w), "+v"(xc.x), "+v"(xc.y), "+v"(xc.z), "+v"(xc.w), "+v"(xr.x), "+v"(xr.y),
-                       "+v"(xr.z), "+v"(xr.w));
+        // (this loop is where the packed-fp32 operand-select problem was found: the whole library is built without packed fp32,
+        // dcpt_amd/build.py NO_PACKED_FP32 and DESIGN.md 4h)
+        const float4 xl = big_ld4<ST>(rs_x, (o - st) | cl), xc = big_ld4<ST>(rs_x, o | cc), xr = big_ld4<ST>(rs_x, (o + st) | cr);
         float a2[CS];
 #pragma unroll
         for (int s = 0; s < CS; ++s) {

@@ -11,7 +11,7 @@ mkdir -p experiments/build/$SUF experiments/lib
 OBJS=""
 for s in $(python -c "from dcpt_amd.build import SOURCES; print(' '.join(SOURCES))"); do
   if [[ " $RE " == *" $s "* ]]; then
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-value -DDCPT_TUNING "$@" -c dcpt_amd/csrc/$s -o experiments/build/$SUF/${s%.hip}.o &
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-value -Xclang -target-feature -Xclang -packed-fp32-ops -DDCPT_TUNING "$@" -c dcpt_amd/csrc/$s -o experiments/build/$SUF/${s%.hip}.o &
     OBJS="$OBJS experiments/build/$SUF/${s%.hip}.o"
   else
     OBJS="$OBJS dcpt_amd/build/${s%.hip}.o"
