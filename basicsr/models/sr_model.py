@@ -28,6 +28,9 @@ def tensor2img_rgb(t: torch.Tensor) -> np.ndarray:
     return (t.permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)
 
 
+_TILE_STREAMS = {}   # device -> HIP streams of SRModel.test_tile (process-wide, see _tile_streams)
+
+
 @MODEL_REGISTRY.register()
 class SRModel(BaseModel):
     def __init__(self, opt):
@@ -254,9 +257,12 @@ class SRModel(BaseModel):
 
         if getattr(net, "gemm_precision", None) not in (None, "fp32") or DF.get_gemm_precision() != "fp32":
             return []
-        pool = getattr(self, "_tile_stream_pool", None)
-        if pool is None or len(pool) < n or pool[0].device != self.lq.device:
-            pool = self._tile_stream_pool = [torch.cuda.Stream(self.lq.device) for _ in range(n)]
+        # one pool per device for the whole process: every torch.cuda.Stream() is another runtime stream, the runtime multiplexes them onto a
+        # few hardware queues, and two streams that land on one queue do not overlap (a second model's own pair of streams measured 95 ms
+        # where the first model's pair gave 83 on the same image)
+        pool = _TILE_STREAMS.setdefault(self.lq.device, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(self.lq.device))
         return pool[:n]
 
     def _tile_shard(self):
