@@ -95,6 +95,10 @@ class NAFBlock(nn.Module):
     # the groups and the forward hooks on ``decoder{i}`` (the DCPT taps) see bf16 feature maps (module docstring)
     act_bf16 = False
 
+    def local_sca(self):
+        pool = self.sca[0]
+        return isinstance(pool, AvgPool2d) and pool.kernel_size is not None
+
     def forward(self, inp):
         pool = self.sca[0]
         if isinstance(pool, AvgPool2d) and pool.kernel_size is not None:
@@ -170,6 +174,7 @@ class NAFNetBaseline(nn.Module):
             # 16-byte bf16 rows at every level (the up layers' 2c -> c/2 PixelShuffle cells included: c = width * 2^k)
             raise ValueError(f"act_dtype='bf16' needs width % 8 == 0 (16-byte bf16 channel vectors), got width={self._width}")
         self.act_dtype = act_dtype
+        self.__dict__.pop("_bf16_blocks", None)
         for m in self.modules():
             if isinstance(m, NAFBlock):
                 m.act_bf16 = act_dtype != "fp32"
@@ -184,6 +189,17 @@ class NAFNetBaseline(nn.Module):
     def _forward(self, inp, hook=False):
         # bf16 storage: the intro conv emits bf16 features and every layer up to the ending conv's input stays bf16 (forward hooks on
         # the block groups then see bf16 feature maps; the classifier head takes either dtype)
+        if self.act_dtype != "fp32" and inp.is_cuda:
+            # the operand copies of every bf16 block's weights in one go where they are stale (after an optimizer step: 5 launches
+            # instead of 36); the blocks then find their pack current
+            blocks = self.__dict__.get("_bf16_blocks")
+            if blocks is None:   # (a plain attribute, not a registered submodule list; rebuilt by set_act_dtype)
+                blocks = [m for m in self.modules() if isinstance(m, NAFBlock) and m.act_bf16 and not m.local_sca()]
+                for m in blocks:
+                    if getattr(m, "_packed_bf16", None) is None:
+                        m._packed_bf16 = DF.PackedWeightsBf16()
+                self.__dict__["_bf16_blocks"] = blocks
+            DF.pack_blocks_bf16([(m._packed_bf16, m.fused_params()) for m in blocks])
         x = DF.conv3x3_in(inp, self.intro.weight, self.intro.bias, out_bf16=self.act_dtype != "fp32")
         encs = []
         for encoder, down in zip(self.encoders, self.downs):

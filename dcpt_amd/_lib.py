@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 _lock = threading.Lock()
 
@@ -95,6 +95,7 @@ SIGNATURES = {
     "dcpt_nafblock_bf16_fused_ffn": (cint, [cint]),
     "dcpt_nafblock_fused_ffn": (cint, [cint]),
     "dcpt_nafblock_wpack_bf16": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, cint, stream_t]),
+    "dcpt_nafblock_wpack_bf16_multi": (cint, [C.POINTER(NafBlockParams), C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(cint), cint, stream_t]),
     "dcpt_nafblock_fwd_bf16_packed": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, f32p, f32p, C.POINTER(NafBlockSavedBf16), C.c_void_p, sz,
                                              cint, cint, cint, cint, stream_t]),
     "dcpt_nafblock_bwd_bf16_packed": (cint, [C.POINTER(NafBlockParams), C.c_void_p, sz, C.POINTER(NafBlockGrads), f32p,

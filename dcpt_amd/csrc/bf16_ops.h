@@ -19,18 +19,23 @@ int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
 
 constexpr int WPACKB_MAX_JOBS = 9;
-struct WpackBJobs {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
-                      // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
-                      // 4 / 5 / 6 / 7: misc.hip's WP_DOWN / WP_DOWN_T / WP_UP / WP_UP_T (2x2 stride-2 conv, 1x1 conv + PixelShuffle(2))
-                      // 8: depthwise taps [N = 2C][K = 9] -> FP32 [9][2C] (dw_pack layout; `out` points at floats)
-    const float* in[WPACKB_MAX_JOBS];
-    bf16_t* out[WPACKB_MAX_JOBS];
-    const float* rs[WPACKB_MAX_JOBS];
-    const float* kscale[WPACKB_MAX_JOBS];
-    int N[WPACKB_MAX_JOBS], K[WPACKB_MAX_JOBS], nimg[WPACKB_MAX_JOBS], transpose[WPACKB_MAX_JOBS];
+constexpr int WPACKB_MAX_JOBS_L = 72;   // the multi-block form (8 NAFBlocks per launch; 72 x 48 B of kernel arguments)
+template <int MAXJ>
+struct WpackBJobsT {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
+                       // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
+                       // 4 / 5 / 6 / 7: misc.hip's WP_DOWN / WP_DOWN_T / WP_UP / WP_UP_T (2x2 stride-2 conv, 1x1 conv + PixelShuffle(2))
+                       // 8: depthwise taps [N = 2C][K = 9] -> FP32 [9][2C] (dw_pack layout; `out` points at floats)
+    const float* in[MAXJ];
+    bf16_t* out[MAXJ];
+    const float* rs[MAXJ];
+    const float* kscale[MAXJ];
+    int N[MAXJ], K[MAXJ], nimg[MAXJ], transpose[MAXJ];
     int n;
 };
+using WpackBJobs = WpackBJobsT<WPACKB_MAX_JOBS>;
+using WpackBJobsL = WpackBJobsT<WPACKB_MAX_JOBS_L>;
 int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s);
+int launch_wpack_bf16(const WpackBJobsL& jobs, hipStream_t s);
 int launch_scale_rows_bf16(const bf16_t* x, const float* simg, bf16_t* out, int64_t M, int C, int P, hipStream_t s);
 int launch_sca_ds_part_bf16(const bf16_t* dts, const bf16_t* t2, float* ds_part, int B, int C, int P, int nslices, hipStream_t s);
 

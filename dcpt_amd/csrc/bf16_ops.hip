@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* __restrict_
 }
 
 // weight packs: one launch, grid.y = job
-__global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobs jobs) {
+template <int MAXJ>
+__global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ> jobs) {
     const int j = blockIdx.y;
     const float* __restrict__ in = jobs.in[j];
     bf16_t* __restrict__ out = jobs.out[j];
@@ -461,8 +462,9 @@ int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s) {
     return DCPT_OK;
 }
 
-int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s) {
-    DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= WPACKB_MAX_JOBS, "wpack_bf16: bad job count");
+template <int MAXJ>
+static int launch_wpack_bf16_t(const WpackBJobsT<MAXJ>& jobs, hipStream_t s) {
+    DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= MAXJ, "wpack_bf16: bad job count");
     int64_t mx = 0;
     for (int j = 0; j < jobs.n; ++j) {
         const int64_t t = (int64_t)(jobs.nimg[j] > 0 ? jobs.nimg[j] : 1) * jobs.N[j] * jobs.K[j];
@@ -470,10 +472,13 @@ int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s) {
     }
     int g = grid_for(mx);
     if (g > 512) g = 512;
-    wpack_bf16_kernel<<<dim3(g, jobs.n), dim3(256), 0, s>>>(jobs);
+    if (MAXJ > WPACKB_MAX_JOBS && g > 64) g = 64;   // (many jobs: the grid's y extent fills the chip, x strides over a job)
+    wpack_bf16_kernel<MAXJ><<<dim3(g, jobs.n), dim3(256), 0, s>>>(jobs);
     DCPT_CHECK_LAUNCH("wpack_bf16");
     return DCPT_OK;
 }
+int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s) { return launch_wpack_bf16_t(jobs, s); }
+int launch_wpack_bf16(const WpackBJobsL& jobs, hipStream_t s) { return launch_wpack_bf16_t(jobs, s); }
 
 int launch_scale_rows_bf16(const bf16_t* x, const float* simg, bf16_t* out, int64_t M, int C, int P, hipStream_t s) {
     DCPT_CHECK_ARG(C % 8 == 0, "scale_rows_bf16: C=%d", C);

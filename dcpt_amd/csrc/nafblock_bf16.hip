@@ -229,19 +229,23 @@ size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
     if (out) *out = k;
     return a.off;
 }
-int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
+template <typename J>
+void pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b) {   // the block's nine jobs at j[b .. b + 8]
     const int C2 = 2 * C;
+    j.in[b + 8] = p->conv3_w; j.out[b + 8] = k.W3; j.N[b + 8] = C; j.K[b + 8] = C;
+    j.in[b + 0] = p->conv1_w; j.out[b + 0] = k.W1; j.N[b + 0] = C2; j.K[b + 0] = C;
+    j.in[b + 1] = p->conv4_w; j.out[b + 1] = k.W4; j.N[b + 1] = C2; j.K[b + 1] = C;
+    j.in[b + 2] = p->conv5_w; j.out[b + 2] = k.W5; j.N[b + 2] = C; j.K[b + 2] = C;
+    j.in[b + 3] = p->conv5_w; j.out[b + 3] = k.wT5; j.rs[b + 3] = p->gamma; j.N[b + 3] = C;  j.K[b + 3] = C; j.transpose[b + 3] = 1;
+    j.in[b + 4] = p->conv4_w; j.out[b + 4] = k.wT4; j.rs[b + 4] = nullptr;  j.N[b + 4] = C2; j.K[b + 4] = C; j.transpose[b + 4] = 1;
+    j.in[b + 5] = p->conv3_w; j.out[b + 5] = k.wT3; j.rs[b + 5] = p->beta;  j.N[b + 5] = C;  j.K[b + 5] = C; j.transpose[b + 5] = 1;
+    j.in[b + 6] = p->conv1_w; j.out[b + 6] = k.wT1; j.rs[b + 6] = nullptr;  j.N[b + 6] = C2; j.K[b + 6] = C; j.transpose[b + 6] = 1;
+    j.in[b + 7] = p->conv2_w; j.out[b + 7] = reinterpret_cast<bf16_t*>(k.w2p); j.N[b + 7] = C2; j.K[b + 7] = 9; j.transpose[b + 7] = 8;
+}
+int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
     WpackBJobs j{};
     j.n = 9;
-    j.in[8] = p->conv3_w; j.out[8] = k.W3; j.N[8] = C; j.K[8] = C;
-    j.in[0] = p->conv1_w; j.out[0] = k.W1; j.N[0] = C2; j.K[0] = C;
-    j.in[1] = p->conv4_w; j.out[1] = k.W4; j.N[1] = C2; j.K[1] = C;
-    j.in[2] = p->conv5_w; j.out[2] = k.W5; j.N[2] = C; j.K[2] = C;
-    j.in[3] = p->conv5_w; j.out[3] = k.wT5; j.rs[3] = p->gamma; j.N[3] = C;  j.K[3] = C; j.transpose[3] = 1;
-    j.in[4] = p->conv4_w; j.out[4] = k.wT4; j.rs[4] = nullptr;  j.N[4] = C2; j.K[4] = C; j.transpose[4] = 1;
-    j.in[5] = p->conv3_w; j.out[5] = k.wT3; j.rs[5] = p->beta;  j.N[5] = C;  j.K[5] = C; j.transpose[5] = 1;
-    j.in[6] = p->conv1_w; j.out[6] = k.wT1; j.rs[6] = nullptr;  j.N[6] = C2; j.K[6] = C; j.transpose[6] = 1;
-    j.in[7] = p->conv2_w; j.out[7] = reinterpret_cast<bf16_t*>(k.w2p); j.N[7] = C2; j.K[7] = 9; j.transpose[7] = 8;
+    pack_jobs(p, k, C, j, 0);
     return launch_wpack_bf16(j, s);
 }
 
@@ -252,6 +256,27 @@ extern "C" size_t dcpt_nafblock_bwd_bf16_ws_bytes(int B, int H, int W, int C) { 
 
 extern "C" size_t dcpt_nafblock_wpack_bf16_bytes(int C) { return pack_layout(C, nullptr, 0, nullptr); }
 extern "C" int dcpt_nafblock_bf16_fused_ffn(int C) { return ffn_fused(C) ? 1 : 0; }
+
+// the packs of n blocks (any mix of widths) in ceil(n / 8) launches instead of n: what a network does once per optimizer step
+extern "C" int dcpt_nafblock_wpack_bf16_multi(const dcpt_nafblock_params* ps, void* const* packed, const size_t* packed_bytes, const int* C,
+                                              int n, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(ps && packed && packed_bytes && C && n >= 1, "nafblock_wpack_bf16_multi: null argument or n=%d", n);
+    constexpr int PER = WPACKB_MAX_JOBS_L / 9;
+    for (int b0 = 0; b0 < n; b0 += PER) {
+        WpackBJobsL j{};
+        const int nb = n - b0 < PER ? n - b0 : PER;
+        for (int b = 0; b < nb; ++b) {
+            const int i = b0 + b;
+            DCPT_CHECK_ARG(packed[i] && C[i] > 0 && C[i] % 8 == 0 && C[i] <= 1024, "nafblock_wpack_bf16_multi: block %d: null buffer or bad C=%d", i, C[i]);
+            PackB k;
+            DCPT_CHECK_ARG(pack_layout(C[i], packed[i], packed_bytes[i], &k) <= packed_bytes[i], "nafblock_wpack_bf16_multi: block %d: buffer too small", i);
+            pack_jobs(ps + i, k, C[i], j, 9 * b);
+        }
+        j.n = 9 * nb;
+        DCPT_TRY(launch_wpack_bf16(j, (hipStream_t)stream));
+    }
+    return DCPT_OK;
+}
 
 extern "C" int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream) {
     DCPT_CHECK_ARG(p && packed && C > 0 && C % 8 == 0 && C <= 1024, "nafblock_wpack_bf16: null argument or bad C=%d", C);

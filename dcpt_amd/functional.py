@@ -422,8 +422,12 @@ class PackedWeightsBf16:
         self.stream = None   # the stream the pack was made on, and the event behind it: another stream waits before it reads the pack
         self.event = None    # (tiled inference runs its tile batches on several streams, basicsr/models/sr_model.py::test_tile)
 
+    @staticmethod
+    def key_of(params: Dict[str, torch.Tensor]):
+        return (_PACK_GENERATION,) + tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
+
     def get(self, params: Dict[str, torch.Tensor]) -> torch.Tensor:
-        key = (_PACK_GENERATION,) + tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
+        key = self.key_of(params)
         if key == self.key:
             if self.stream != _stream(self.buf.device):
                 torch.cuda.current_stream(self.buf.device).wait_event(self.event)
@@ -444,6 +448,41 @@ class PackedWeightsBf16:
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(dev))
         return self.buf
+
+
+def pack_blocks_bf16(blocks) -> int:
+    """Refresh the weight packs of several NAFBlocks in ceil(n / 8) launches (dcpt_nafblock_wpack_bf16_multi) instead of one per block:
+    ``blocks`` = [(PackedWeightsBf16, params dict), ...] of a network, called before its forward; only the stale ones are packed, and
+    ``PackedWeightsBf16.get`` then finds them current.  Returns how many were packed."""
+    stale = []
+    for pk, params in blocks:
+        key = pk.key_of(params)
+        if key != pk.key:
+            stale.append((pk, params, key))
+    if len(stale) < 2:
+        return 0   # (a single block packs itself in get())
+    lib = _lib.load()
+    n = len(stale)
+    ps_arr = (NafBlockParams * n)()
+    bufs, nbytes, widths, keep = (C.c_void_p * n)(), (C.c_size_t * n)(), (C.c_int * n)(), []
+    dev = None
+    for i, (pk, params, key) in enumerate(stale):
+        ps = tuple(_contig(params[k].detach()) for k in PARAM_FIELDS)
+        _require_gpu(*ps)
+        keep.append(ps)
+        dev = ps[0].device
+        Cc = params["conv3_w"].shape[0]
+        need = lib.dcpt_nafblock_wpack_bf16_bytes(Cc)
+        if pk.buf is None or pk.buf.numel() != need or pk.buf.device != dev:
+            pk.buf = torch.empty(need, dtype=torch.uint8, device=dev)
+        ps_arr[i] = NafBlockParams(*[p.data_ptr() for p in ps])
+        bufs[i], nbytes[i], widths[i] = pk.buf.data_ptr(), need, Cc
+    check(lib.dcpt_nafblock_wpack_bf16_multi(ps_arr, bufs, nbytes, widths, n, _stream(dev)), "dcpt_nafblock_wpack_bf16_multi")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    for pk, params, key in stale:
+        pk.key, pk.stream, pk.event = key, _stream(dev), ev
+    return n
 
 
 def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor], packed: PackedWeightsBf16 = None) -> torch.Tensor:

@@ -160,6 +160,10 @@ size_t dcpt_nafblock_wpack_bf16_bytes(int C);
  * SimpleGate(v) only (one tensor pass instead of three for that launch). */
 int dcpt_nafblock_bf16_fused_ffn(int C);
 int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream);
+/* The same for n blocks at once (ABI 10; ps / packed / packed_bytes / C are arrays of n, any mix of widths): ceil(n / 8) launches
+ * instead of n -- a network's packs once per optimizer step.  Bit-identical to n calls of dcpt_nafblock_wpack_bf16. */
+int dcpt_nafblock_wpack_bf16_multi(const dcpt_nafblock_params* ps, void* const* packed, const size_t* packed_bytes, const int* C, int n,
+                                   dcpt_stream_t stream);
 /* Weight (and bias) gradient of a 1 x 1 convolution in bf16 storage (ABI 9; the conv1 / conv3 / conv4 / conv5 weight gradients of
  * nafnet_arch.py:170-186 as an operator of its own): dW[n][k] = sum_m dY[m][n] * X[m][k], db[n] = sum_m dY[m][n] (db may be NULL).
  * dY: [M][N] bf16, X: [M][K] bf16, dW: [N][K] fp32.  N, K multiples of 8; where both are multiples of 256 the 256 x 256-tile grouped

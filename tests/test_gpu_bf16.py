@@ -792,3 +792,33 @@ def test_conv1x1_wgrad_bf16(dev, M, N, K):
     assert float((db.double().cpu() - refb).abs().max()) <= 2e-5 * float(refb.abs().max()) + 1e-3
     dW3 = DF.conv1x1_wgrad_bf16(dy.to(dev), x.to(dev), with_bias=False)
     assert torch.equal(dW3, dW)
+
+
+@pytest.mark.gpu
+def test_network_packs_all_blocks_in_a_few_launches_bit_identically(dev):
+    """dcpt_nafblock_wpack_bf16_multi (functional.pack_blocks_bf16, called by NAFNetBaseline.forward): the packs of blocks of mixed widths
+    made together equal the per-block packs bit for bit; after an optimizer step the network re-packs all of them, and its output equals
+    that of a network whose blocks pack themselves."""
+    from basicsr.archs import build_network
+    from dcpt_amd import functional as DF
+    from dcpt_amd.keyed_init import fill_module_
+
+    cfg = dict(type="NAFNetBaseline", img_channel=3, width=32, middle_blk_num=1, enc_blk_nums=[1, 2, 9], dec_blk_nums=[1, 1, 1], act_dtype="bf16")
+    net = fill_module_(build_network(cfg)).to(dev)
+    blocks = [m for m in net.modules() if type(m).__name__ == "NAFBlock"]
+    assert len(blocks) == 16   # two launches of the multi form (8 blocks each)
+    x = keyed_input("multipack.x", (2, 3, 32, 32)).to(dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, fused=True)
+    for it in range(2):
+        n = DF.pack_blocks_bf16([(DF.PackedWeightsBf16(), b.fused_params()) for b in blocks[:3]])
+        assert n == 3
+        y = net(x)
+        together = [b._packed_bf16.buf.clone() for b in blocks]
+        for b in blocks:   # the per-block form into fresh caches
+            alone = DF.PackedWeightsBf16().get(b.fused_params())
+            assert torch.equal(alone, together[blocks.index(b)])
+        assert DF.pack_blocks_bf16([(b._packed_bf16, b.fused_params()) for b in blocks]) == 0   # all current
+        y.abs().mean().backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        assert all(b._packed_bf16.key != DF.PackedWeightsBf16.key_of(b.fused_params()) for b in blocks)   # stale after the step
