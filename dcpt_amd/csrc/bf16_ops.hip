@@ -282,6 +282,27 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ>
         }
         return;
     }
+    if (jobs.transpose[j] == 1) {   // out[k][n] = in[n][k] * rs[n]: 32 x 32 tiles through LDS, reads coalesced along k, writes along n
+        __shared__ float tile[32][33];
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+        const int tn = (N + 31) / 32, tk = (K + 31) / 32;
+        for (int t = blockIdx.x; t < tn * tk; t += gridDim.x) {
+            const int n0 = (t / tk) * 32, k0 = (t % tk) * 32;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + ty + 8 * r, k = k0 + tx;
+                tile[ty + 8 * r][tx] = (n < N && k < K) ? in[(int64_t)n * K + k] * (rs ? rs[n] : 1.f) : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + ty + 8 * r, n = n0 + tx;
+                if (k < K && n < N) out[(int64_t)k * N + n] = (bf16_t)(bf_pack(tile[tx][ty + 8 * r], 0.f) & 0xffffu);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         // i indexes the OUTPUT
         const int64_t img = i / ((int64_t)N * K);
@@ -472,7 +493,7 @@ static int launch_wpack_bf16_t(const WpackBJobsT<MAXJ>& jobs, hipStream_t s) {
     }
     int g = grid_for(mx);
     if (g > 512) g = 512;
-    if (MAXJ > WPACKB_MAX_JOBS && g > 64) g = 64;   // (many jobs: the grid's y extent fills the chip, x strides over a job)
+    if (MAXJ > WPACKB_MAX_JOBS && g > 256) g = 256;
     wpack_bf16_kernel<MAXJ><<<dim3(g, jobs.n), dim3(256), 0, s>>>(jobs);
     DCPT_CHECK_LAUNCH("wpack_bf16");
     return DCPT_OK;
