@@ -408,15 +408,36 @@ int launch_sca_wgrad(const float* ds_part, int nslices, float* ds, const float* 
 }
 
 // several row-scaled transposes in one launch: out_j[k][n] = in_j[n][k] * (rs_j ? rs_j[n] : 1)
-__global__ void wpack_multi_kernel(const WpackJobs jobs) {
+// (32 x 32 tiles through LDS: reads coalesced along k, writes along n -- the element-per-thread form read with stride K)
+__global__ __launch_bounds__(256) void wpack_multi_kernel(const WpackJobs jobs) {
+    __shared__ float tile[32][33];
     const int y = blockIdx.y;
     const int N = jobs.N[y], K = jobs.K[y];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)N * K) return;
-    const int k = (int)(i / N), n = (int)(i % N);
-    const float v = jobs.in[y][(int64_t)n * K + k];
-    const float* rs = jobs.rs[y];
-    jobs.out[y][i] = rs ? v * rs[n] : v;
+    const float* __restrict__ in = jobs.in[y];
+    float* __restrict__ out = jobs.out[y];
+    const float* __restrict__ rs = jobs.rs[y];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tn = (N + 31) / 32, tk = (K + 31) / 32;
+    for (int t = blockIdx.x; t < tn * tk; t += gridDim.x) {
+        const int n0 = (t / tk) * 32, k0 = (t % tk) * 32;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + ty + 8 * r, k = k0 + tx;
+            float v = 0.f;
+            if (n < N && k < K) {
+                v = in[(int64_t)n * K + k];
+                if (rs) v = v * rs[n];
+            }
+            tile[ty + 8 * r][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + ty + 8 * r, n = n0 + tx;
+            if (k < K && n < N) out[(int64_t)k * N + n] = tile[tx][ty + 8 * r];
+        }
+        __syncthreads();
+    }
 }
 
 // one wave per output j: u[j] = W[j][:] . lnw,  cvec[j] = bz[j] + W[j][:] . lnb
@@ -458,7 +479,9 @@ int launch_wpack_multi(const WpackJobs& jobs, hipStream_t s) {
     DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= WPACK_MAX_JOBS, "wpack_multi: %d jobs", jobs.n);
     int64_t mx = 0;
     for (int j = 0; j < jobs.n; ++j) mx = (int64_t)jobs.N[j] * jobs.K[j] > mx ? (int64_t)jobs.N[j] * jobs.K[j] : mx;
-    wpack_multi_kernel<<<dim3((unsigned)cdiv64(mx, 256), jobs.n), dim3(256), 0, s>>>(jobs);
+    int64_t g = cdiv64(mx, 1024);   // one 32 x 32 tile per block and iteration
+    if (g > 256) g = 256;
+    wpack_multi_kernel<<<dim3((unsigned)g, jobs.n), dim3(256), 0, s>>>(jobs);
     DCPT_CHECK_LAUNCH("wpack_multi");
     return DCPT_OK;
 }
