@@ -67,11 +67,30 @@ def convln_shapes(rng, n):
     return out
 
 
+def block32_shapes(rng, n):
+    out = []
+    while len(out) < n:
+        c = rng.choice([8, 16, 24, 32, 64, 64, 96, 128, 256, 512, 1024])
+        h, w = rng.randint(3, 40), rng.randint(3, 40)
+        cap = 2 * 1024 * 1024
+        b = rng.randint(1, max(1, min(cap // (c * h * w), 12)))
+        out.append((b, c, h, w))
+    return out
+
+
+def edge_shapes(rng, n):
+    return [(rng.randint(1, 4), rng.choice([1, 3, 4]), rng.choice([8, 16, 32, 64, 128]), rng.randint(3, 40), rng.randint(3, 40)) for _ in range(n)]
+
+
+def downup_shapes(rng, n):
+    return [(rng.randint(1, 4), rng.choice([8, 16, 24, 64, 128, 256]), 2 * rng.randint(1, 16), 2 * rng.randint(1, 16)) for _ in range(n)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--n", type=int, default=40)
-    ap.add_argument("--what", default="block,wgrad,convln")
+    ap.add_argument("--what", default="block,wgrad,convln,fp32")
     args = ap.parse_args()
     import test_gpu_bf16 as T
 
@@ -85,6 +104,12 @@ def main():
         cases += [("wgrad", T.test_conv1x1_wgrad_bf16, s) for s in wgrad_shapes(rng, args.n)]
     if "convln" in what:
         cases += [("convln", T.test_conv_ln_bf16_oracle, s) for s in convln_shapes(rng, max(4, args.n // 2))]
+    if "fp32" in what:   # the fp32 path's parity tests (tests/test_gpu_parity.py) on drawn shapes
+        import test_gpu_parity as TP
+
+        cases += [("block32", TP.test_nafblock_oracle, s) for s in block32_shapes(rng, args.n)]
+        cases += [("edge", TP.test_edge_convs, s) for s in edge_shapes(rng, max(4, args.n // 2))]
+        cases += [("downup", TP.test_down_up, s) for s in downup_shapes(rng, max(4, args.n // 2))]
     failed = []
     for name, fn, a in cases:
         t0 = time.time()
