@@ -303,6 +303,43 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ>
         }
         return;
     }
+    if (jobs.transpose[j] == 2) {   // dense 3x3: out[oc][tap * Ci + ic] = in[(oc * Ci + ic) * 9 + tap].  A tile = one oc x 64 ic: 576
+        __shared__ float buf2[576];   // contiguous floats in, nine runs of 64 bf16 out (the element-per-thread form reads with stride 9)
+        const int Ci = K / 9, nch = (Ci + 63) / 64;
+        for (int t = blockIdx.x; t < N * nch; t += gridDim.x) {
+            const int oc = t / nch, ic0 = (t % nch) * 64;
+            const int nic = Ci - ic0 < 64 ? Ci - ic0 : 64;
+            const float* src = in + ((int64_t)oc * Ci + ic0) * 9;
+            for (int q = threadIdx.x; q < nic * 9; q += 256) buf2[q] = src[q];
+            __syncthreads();
+            for (int q = threadIdx.x; q < 576; q += 256) {
+                const int tap = q >> 6, i = q & 63;
+                if (i < nic) out[(int64_t)oc * K + tap * Ci + ic0 + i] = (bf16_t)(bf_pack(buf2[i * 9 + tap], 0.f) & 0xffffu);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    if (jobs.transpose[j] == 3) {   // its transposed conv: out[ic][tap * Co + oc] = in[(oc * Ci + ic) * 9 + 8 - tap].  A tile = 8 ic x 32 oc:
+        __shared__ float buf3[32 * 73];   // 32 runs of 72 contiguous floats in, 72 runs of 32 bf16 out
+        const int Ci = K / 9, Co = N, nic = (Ci + 7) / 8, noc = (Co + 31) / 32;
+        for (int t = blockIdx.x; t < nic * noc; t += gridDim.x) {
+            const int ic0 = (t / noc) * 8, oc0 = (t % noc) * 32;
+            for (int q = threadIdx.x; q < 32 * 72; q += 256) {
+                const int ol = q / 72, r = q - ol * 72;
+                const int oc = oc0 + ol, ic = ic0 + r / 9;
+                buf3[ol * 73 + r] = (oc < Co && ic < Ci) ? in[((int64_t)oc * Ci + ic0) * 9 + r] : 0.f;
+            }
+            __syncthreads();
+            for (int q = threadIdx.x; q < 8 * 9 * 32; q += 256) {
+                const int ol = q & 31, tap = (q >> 5) % 9, il = q / 288;
+                if (oc0 + ol < Co && ic0 + il < Ci)
+                    out[(int64_t)(ic0 + il) * (9 * Co) + tap * Co + oc0 + ol] = (bf16_t)(bf_pack(buf3[ol * 73 + il * 9 + 8 - tap], 0.f) & 0xffffu);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         // i indexes the OUTPUT
         const int64_t img = i / ((int64_t)N * K);
@@ -492,7 +529,7 @@ static int launch_wpack_bf16_t(const WpackBJobsT<MAXJ>& jobs, hipStream_t s) {
         if (t > mx) mx = t;
     }
     int g = grid_for(mx);
-    if (g > 512) g = 512;
+    if (g > 4096) g = 4096;   // (a tile of the gathered 3 x 3 packs is ~1 us of latency: the largest has 16 384 of them)
     if (MAXJ > WPACKB_MAX_JOBS && g > 256) g = 256;
     wpack_bf16_kernel<MAXJ><<<dim3(g, jobs.n), dim3(256), 0, s>>>(jobs);
     DCPT_CHECK_LAUNCH("wpack_bf16");
