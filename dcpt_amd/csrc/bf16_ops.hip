@@ -4,6 +4,7 @@
 // GEMM epilogue.  A lane owns 8 consecutive channels (one 16-byte access); a row lives in G = pow2 >= C / 8 lanes of one wave.
 #include "bf16.h"
 #include "bf16_ops.h"
+#include "chain_bf16.h"
 
 namespace {
 
@@ -263,6 +264,37 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ>
     if (jobs.transpose[j] == 8) {   // the depthwise conv's [N = 2C][K = 9] taps -> fp32 [9][2C] (dwconv.hip's dw_pack layout); `out` holds floats
         float* __restrict__ of = reinterpret_cast<float*>(out);
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) of[(i % 9) * N + i / 9] = in[i];
+        return;
+    }
+    if (jobs.transpose[j] == 9) {   // conv4 + conv5 of a wide NAFBlock as the chain kernel's fragment-order weight stream (chain_bf16.hip):
+        // in = conv4_w [2C][C], rs = conv5_w [C][C] (the second matrix rides in the row-scale slot), N = 3 C, K = C.  Wave w of the chain
+        // kernel reads FR fragments of 1 KB in the order it consumes them: conv4 pass p, k-step ks -> the v1 tile (gate channels
+        // w CW + 32 p ..+31) then its v2 partner (+C); after all passes conv5, k-step ks -> output tiles t = 0 .. NT-1.  A fragment = A operand
+        // of v_mfma_f32_32x32x16_bf16: lane (rho = lane & 31, kg = lane >> 5) holds W[row(rho)][16 ks + 8 kg ..+7], and the MFMA row rho
+        // stands for channel 16 ((rho >> 2) & 1) + (rho & 3) + 4 (rho >> 3) of the tile, which makes the 16 accumulator registers of a lane
+        // 16 CONSECUTIVE channels (32 contiguous bytes of a bf16 row).
+        const int C = K, CW = C / CHAIN_NW, NT = CW / 32, KS = C / 16, F4 = 2 * NT * KS, FR = F4 + NT * KS;
+        const float* __restrict__ W5 = rs;
+        const int64_t nq = (int64_t)CHAIN_NW * FR * 64;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+            const int lane = (int)(q & 63), fi = (int)((q >> 6) % FR), w = (int)((q >> 6) / FR);
+            const int rho = lane & 31, kg = lane >> 5, cc = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+            const float* src;
+            if (fi < F4) {
+                const int rec = fi >> 1, f = fi & 1, pp = rec / KS, ks = rec % KS;
+                src = in + (int64_t)(f * C + w * CW + 32 * pp + cc) * C + 16 * ks + 8 * kg;
+            } else {
+                const int f5 = fi - F4, ks = f5 / NT, t = f5 % NT;
+                src = W5 + (int64_t)(w * CW + 32 * t + cc) * C + 16 * ks + 8 * kg;
+            }
+            const f8 v = f8_ld(src);
+            u32x4 o;
+            o.x = bf_pack(v.lo.x, v.lo.y);
+            o.y = bf_pack(v.lo.z, v.lo.w);
+            o.z = bf_pack(v.hi.x, v.hi.y);
+            o.w = bf_pack(v.hi.z, v.hi.w);
+            *reinterpret_cast<u32x4*>(out + q * 8) = o;
+        }
         return;
     }
     if (jobs.transpose[j] == 0 && K % 8 == 0) {   // the big one (per-image scaled weights, nimg * N * K elements): 8 per thread, 16-byte stores

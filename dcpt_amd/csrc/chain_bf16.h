@@ -1,0 +1,26 @@
+// Fused 1x1-conv chains of a NAFBlock at the WIDE levels (C = 256 / 512) in bf16 storage (chain_bf16.hip).  The narrow level's chains
+// (C = 64) keep their weights in registers (ffn_bf16.hip); here a weight matrix is 0.5 - 1 MB, so the roles are turned around: the
+// PIXEL TILE stays on the CU (128 pixels x C channels in LDS) and the weights stream past it, L2 -> registers, every wave its own rows.
+#pragma once
+#include "bf16.h"
+
+// Second half of the block, reference basicsr/archs/nafnet_arch.py:180-186:
+//   out = y + gamma * (conv5(SimpleGate(conv4(LayerNorm2(y)))) + b5)
+struct ChainFwdB {
+    const bf16_t* y;         // [M][C]
+    const float *lnw, *lnb;  // [C]
+    const bf16_t* Wf;        // fragment-order weight stream of conv4 + conv5 (chain_wstream_elems(C) elements, launch_wpack_bf16 mode 9)
+    const float *b4, *b5, *gamma;
+    bf16_t* out;             // [M][C]
+    bf16_t* v;               // [M][2C] conv4 output, or null (no backward pass follows)
+    bf16_t *xn2, *g;         // [M][C] LayerNorm2(y), SimpleGate(v): operands of the weight-gradient GEMMs, or null (both)
+    float *mu, *rstd;        // [M] or null (both)
+    int64_t M;
+    float eps;
+};
+bool chain_fwd_bf16_ok(int C, int64_t M);
+size_t chain_wstream_elems(int C);   // bf16 elements of Wf (3 C^2), 0 if the width has no chain kernel
+int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s);
+
+// geometry shared with the pack (bf16_ops.hip, mode 9): 8 waves per block, wave w owns gate channels [w C/8, (w+1) C/8)
+constexpr int CHAIN_NW = 8;

@@ -1,0 +1,440 @@
+// Second half of a NAFBlock at the WIDE levels (C = 256 / 512) as ONE kernel in bf16 storage:
+//     out = y + gamma * (conv5(SimpleGate(conv4(LayerNorm2(y)) + b4)) + b5)          reference basicsr/archs/nafnet_arch.py:180-186
+// It replaces three launches of the unfused schedule (ln_fwd_bf16, conv4 with the bias + gate epilogue, conv5 with the residual epilogue:
+// 19 + 52 + 44 us per level-3 block at B = 32, 256^2) and the HBM round trips of LN2(y), v and the gate between them.
+//
+// How the work is laid out (SURVEY.md 8d's canonical schedule for C >= 128: the chain per pixel tile, the weights streamed):
+//   * A block owns a tile of TM = 128 pixels.  The tile's CURRENT operand -- LN2(y), later the gate -- lives in LDS as [128][C] bf16
+//     (128 KB at C = 512), 16-byte chunks XOR-swizzled by row so that MFMA fragment reads, row reads and fragment-layout writes are all
+//     conflict-free.  It is rewritten IN PLACE between the two GEMMs (a chain is sequential anyway: conv5 cannot start before the gate is
+//     complete), so one buffer serves the whole chain and a CU holds a whole tile of rows.
+//   * The products are computed TRANSPOSED, D[n][m] = sum_k W[n][k] x[m][k]: weights are the A operand, pixels the B operand.  Wave w of
+//     the 8 owns the output channels [w C/8, (w+1) C/8) of every GEMM, so a weight element is used by exactly ONE wave: weights never
+//     touch LDS.  They come L2 -> registers as ready-made MFMA fragments from a per-wave stream packed in consumption order
+//     (bf16_ops.hip, pack mode 9; 1 KB per fragment, fully coalesced), eight fragments ahead of their use; the k-loops have no barriers
+//     and no LDS writes.  Per k-step a wave issues 2 fragment loads + 4 ds_read_b128 for 8 MFMAs (32x32x16, 4 pixel tiles x 2 channel
+//     tiles); a 128-pixel tile needs every weight once, i.e. 1.5 MB of L2 reads per 268 MFLOP -- 32 B/clk/CU at the MFMA peak.
+//   * In the accumulator layout a lane holds ONE pixel and (the pack permutes the MFMA rows) 16 CONSECUTIVE channels per 32 x 32 tile:
+//     bias, gate, gamma and the residual are per-lane arithmetic, a lane's results are 32 contiguous bytes of a bf16 row.
+//   * conv4's 2C outputs do not fit the registers at once (128 x 1024 fp32 = the whole register file): a wave takes its gate channels in
+//     passes of 32, each pass the v1 tile and its v2 partner (8 accumulator tiles = 128 registers), applies bias + gate at the end of the
+//     pass, stores v, and keeps the gate as packed bf16 (32 registers per pass) until every wave is done reading LN2(y).
+//   * LayerNorm2: a wave normalises 16 rows.  Rows come in coalesced (16 B per lane), go to LDS raw, and are re-read 16 rows x 4 lanes
+//     (a lane holds a quarter row: lane-local sums + two shuffles), normalised in place; two-pass statistics in fp32 over the bf16
+//     inputs exactly as ln_fwd_bf16.
+// Rounding points are the unfused path's (nafblock_bf16.hip / oracle nafblock_bf16): LN2(y) -> bf16, v -> bf16 on store, the gate =
+// product of the UNROUNDED halves rounded once, out rounded once.  Only the summation order inside a dot product differs.
+#include "bf16_ops.h"
+#include "chain_bf16.h"
+
+namespace {
+
+constexpr int NW = CHAIN_NW;
+
+template <int C, int TM>
+struct Geo {
+    static_assert(TM == 128 && (C == 256 || C == 512), "chain_bf16: TM = 128, C = 256 / 512");
+    static constexpr int MT = TM / 32;       // pixel tiles
+    static constexpr int CW = C / NW;        // channels of a wave
+    static constexpr int NT = CW / 32;       // its 32-channel tiles: conv4 passes (a v1 and a v2 tile each) and conv5 tiles
+    static constexpr int KS = C / 16;        // k-steps of a GEMM
+    static constexpr int F4 = 2 * NT * KS;   // conv4 fragments of a wave
+    static constexpr int FRAGS = F4 + NT * KS;
+    static constexpr uint32_t WTOT = FRAGS * 1024u;   // bytes of a wave's stream (a multiple of 8 KB)
+    static constexpr int PITCH = C * 2;      // bytes of a tile row
+    static constexpr int XB = TM * PITCH;
+    static constexpr int CPR = C / 8;        // 16-byte chunks of a row
+    static constexpr int RPI = 64 / CPR;     // rows one coalesced wave access covers
+    static constexpr int RW = TM / NW;       // rows a wave normalises (16)
+    static constexpr int NI = RW / RPI;      // coalesced accesses per wave for its rows
+    static constexpr int NJ = CPR / 4;       // chunks per lane in the (row, quarter) layout
+    // LDS: the fp32 parameter tables first (ds offsets below 64 KB are immediates), then the tile
+    static constexpr int T_LW = 0, T_LB = C, T_B4 = 2 * C, T_B5 = 4 * C, T_GM = 5 * C, T_N = 6 * C;
+    static constexpr int XOFF = T_N * 4;
+    static constexpr int SMEM = XOFF + XB;
+    static_assert(XOFF % 1024 == 0, "tile base alignment (the fragment addresses XOR bits 5..7)");
+    static_assert(WTOT % 8192 == 0 && F4 % 8 == 0, "ring alignment");
+};
+
+// Compile-time ablations for tools/build_variant.sh (never in the product): CHAIN_ABL_NOW no weight loads in the k-loops, CHAIN_ABL_NOMFMA
+// no MFMAs, CHAIN_ABL_NOLDS no pixel-fragment reads, CHAIN_ABL_NOST every global store dropped by the range check.
+__device__ __forceinline__ bf16x8 ldfrag(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void st16(u32x4 v, rsrc_t r, uint32_t voff) {
+#ifdef CHAIN_ABL_NOST
+    voff |= ROW_SENT;
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 o;
+    o.x = bf_pack(f[0], f[1]);
+    o.y = bf_pack(f[2], f[3]);
+    o.z = bf_pack(f[4], f[5]);
+    o.w = bf_pack(f[6], f[7]);
+    return o;
+}
+__device__ __forceinline__ void unpack8(u32x4 w, float* f) {
+    f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y);
+    f[4] = bf_lo(w.z); f[5] = bf_hi(w.z); f[6] = bf_lo(w.w); f[7] = bf_hi(w.w);
+}
+#ifdef CHAIN_TIMELINE   // diagnostic builds: shader-clock stamps of wave 0 / wave 4 of every block at the phase boundaries (tools/chain_timeline.py)
+__device__ unsigned long long g_chain_tl[512 * 2 * 16];
+#define TL(i) do { if (lane == 0 && (wave & 3) == 0) g_chain_tl[(blockIdx.x * 2 + (wave >> 2)) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TL(i) do { } while (0)
+#endif
+// LDS is shared by the eight waves: their LDS traffic must have landed before the barrier, the weight stream (vmcnt) stays in flight
+__device__ __forceinline__ void block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One GEMM of the chain for this wave: acc[f][mt] += W-tile f (32 channels) x pixel tile mt over all k.  The fragment ring holds the next
+// eight 1-KB fragments of the wave's stream; a slot is refilled right after its last use (the stream wraps: after the tile's last
+// fragment come the first ones of the next tile).
+// Rows of the tile that leave for HBM WHILE a GEMM runs (LN2(y) during conv4, the gate during conv5: both sit in LDS as that GEMM's
+// operand).  vmcnt retires in issue order, so a wave that has just issued a burst of stores cannot take its next weight fragment until
+// the burst has drained -- with every CU storing at once that is the HBM write time of the whole tensor, exposed (measured: 40 of 97 us).
+// One coalesced row access every PER k-steps instead: ds_read in one step, the store in the next, never more than one in flight.
+struct Trickle {
+    rsrc_t dst;
+    uint32_t lds0, glb0;   // lane constants: (RW wave + crow) PITCH [+ chunk 16 for glb0]
+    int cchunk, rbase;     // rbase = (RW wave + crow) & 15
+    int j0;                // first access of this GEMM
+    bool on;
+};
+template <int NF, int PER, class G>
+__device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)[8], rsrc_t wrs, uint32_t l16, uint32_t& wnext,
+                                      const unsigned char* X, uint32_t xlane, const Trickle& tr) {
+    static_assert(8 % NF == 0, "fragments per k-step must divide the ring");
+    static_assert(PER >= 2 && 8 % PER == 0, "trickle period");
+    constexpr int MT = G::MT, NO = G::KS / 8;
+    u32x4 pend = {0, 0, 0, 0};
+    asm volatile("" : "+v"(xlane));   // (keeps the fragment addresses of a GEMM from being hoisted out of the tile loop and spilled)
+    // The schedule is pinned per k-step (sched_barrier): pixel fragments of step k + 1 are requested BEFORE the MFMAs of step k, a ring
+    // slot is refilled right after its last use -- left alone, hipcc reads fragments just in time and sinks the refills until the ring
+    // is drained (s_waitcnt vmcnt(0) inside the loop).
+    bf16x8 b[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b[0][mt] = *reinterpret_cast<const bf16x8*>(X + xlane + mt * 32 * G::PITCH);
+#pragma unroll 1
+    for (int o = 0; o < NO; ++o) {
+        const uint32_t xo = xlane + (uint32_t)o * 256u;
+        const uint32_t xwrap = o + 1 < NO ? xo + 256u : xlane;   // (the last step's look-ahead re-reads step 0: harmless, in range)
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const uint32_t xn = k8 < 7 ? (xo ^ (uint32_t)((k8 + 1) << 5)) : xwrap;
+#pragma unroll
+#ifndef CHAIN_ABL_NOLDS
+            for (int mt = 0; mt < MT; ++mt) b[(k8 + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(X + xn + mt * 32 * G::PITCH);
+#else
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(b[(k8 + 1) & 1][mt]));
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int slot = (k8 * NF + f) & 7;
+                const bf16x8 a = ring[slot];
+#pragma unroll
+#ifndef CHAIN_ABL_NOMFMA
+                for (int mt = 0; mt < MT; ++mt) acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[k8 & 1][mt], acc[f][mt], 0, 0, 0);
+#else
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[f][mt]) : "v"(a), "v"(b[k8 & 1][mt]));
+#endif
+#ifndef CHAIN_ABL_NOW
+                ring[slot] = ldfrag(wrs, l16, wnext + (uint32_t)slot * 1024u);
+#else
+                asm volatile("" : "+v"(ring[slot]));
+#endif
+                if (slot == 7) {
+                    wnext += 8192u;
+                    if (wnext >= G::WTOT) wnext = 0;
+                }
+            }
+            {   // (unconditional: with nothing to store the window is empty and the range check drops the store -- no branch in the loop)
+                const int j = tr.j0 + (o * 8 + k8) / PER;   // coalesced access j of the wave's rows: row (RW wave + crow) + j RPI
+                if (k8 % PER == 0)
+                    pend = *reinterpret_cast<const u32x4*>(X + tr.lds0 + (uint32_t)(j * G::RPI) * G::PITCH +
+                                                           (uint32_t)(((tr.cchunk & ~15) | ((tr.cchunk ^ (tr.rbase + j * G::RPI)) & 15)) << 4));
+                if (k8 % PER == 1) st16(pend, tr.dst, tr.glb0 + (uint32_t)(j * G::RPI) * G::PITCH);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int C, int TM>
+__global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) {
+    using G = Geo<C, TM>;
+    constexpr int MT = G::MT, NT = G::NT, PITCH = G::PITCH, CW = G::CW;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
+    unsigned char* const X = smem + G::XOFF;
+    float* const tab = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < G::T_N; i += 512)
+        tab[i] = i < G::T_LB ? p.lnw[i] : i < G::T_B4 ? p.lnb[i - G::T_LB] : i < G::T_B5 ? p.b4[i - G::T_B4] : i < G::T_GM ? p.b5[i - G::T_B5] : p.gamma[i - G::T_GM];
+
+    TL(0);
+    block_sync();   // (the parameter tables)
+    TL(1);
+
+    // this wave's weight stream; the first eight fragments are on their way while the tile is normalised
+    const rsrc_t wrs = make_rsrc(p.Wf + (size_t)wave * G::FRAGS * 512);
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    bf16x8 ring[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring[i] = ldfrag(wrs, l16, (uint32_t)i * 1024u);
+    uint32_t wnext = 8192u % G::WTOT;
+
+    const int64_t ntiles = (p.M + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // Every per-lane address of the tile derives from this copy of the lane id, opaque to the optimiser: otherwise the ~150 loop-invariant
+        // addresses of the phases below are hoisted out of the tile loop and live in scratch.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // accumulator layout: pixel m of a pixel tile, channel half h of a channel tile
+        const int m = ln & 31, h = ln >> 5;
+        const uint32_t xlane = (uint32_t)m * PITCH + (uint32_t)((((m & 14) | (h ^ (m & 1)))) << 4);   // fragment reads: chunk (2 ks + h) ^ (m & 15)
+        // coalesced row layout: RPI rows per access, lane -> (row, chunk)
+        const int crow = ln / G::CPR, cchunk = ln % G::CPR;
+        // LayerNorm layout: 16 rows x 4 lanes
+        const int rl = ln & 15, q = ln >> 4;
+        const int64_t row0 = tile * TM;
+        const uint32_t nrows = (uint32_t)((p.M - row0) < TM ? (p.M - row0) : TM);
+        // windows at the tile's first row, as long as its valid rows: rows past M read 0 and their stores are dropped
+        const rsrc_t yr = make_rsrc(p.y + row0 * C, nrows * PITCH);
+        const rsrc_t outr = make_rsrc(p.out + row0 * C, nrows * PITCH);
+
+        // ---- the wave's 16 rows: HBM -> registers -> LDS (raw), coalesced ----
+        {
+            u32x4 raw[G::NI];
+#pragma unroll
+            for (int j = 0; j < G::NI; ++j) {
+                const int R = G::RW * wave + j * G::RPI + crow;
+                raw[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, (uint32_t)R * PITCH + (uint32_t)cchunk * 16u, 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < G::NI; ++j) {
+                const int R = G::RW * wave + j * G::RPI + crow;
+                *reinterpret_cast<u32x4*>(X + R * PITCH + (((cchunk & ~15) | ((cchunk ^ R) & 15)) << 4)) = raw[j];
+            }
+        }
+        TL(2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // ---- LayerNorm2 in place: lane (rl, q) holds chunks 4 j + q of row RW wave + rl ----
+        {
+            const int R = G::RW * wave + rl;
+            unsigned char* const xr = X + R * PITCH;
+            u32x4 xw[G::NJ];
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j) xw[j] = *reinterpret_cast<const u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j) {
+                float f[8];
+                unpack8(xw[j], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += f[e];
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j) {
+                float f[8];
+                unpack8(xw[j], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = f[e] - mean;
+                    sq += d * d;
+                }
+            }
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            const float rs = 1.0f / sqrtf(sq * (1.0f / C) + p.eps);
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j) {
+                const int ch = 8 * (4 * j + q);
+                float f[8], o[8];
+                unpack8(xw[j], f);
+                const float4 w0 = *reinterpret_cast<const float4*>(tab + G::T_LW + ch), w1 = *reinterpret_cast<const float4*>(tab + G::T_LW + ch + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(tab + G::T_LB + ch), b1 = *reinterpret_cast<const float4*>(tab + G::T_LB + ch + 4);
+                o[0] = (f[0] - mean) * rs * w0.x + b0.x; o[1] = (f[1] - mean) * rs * w0.y + b0.y;
+                o[2] = (f[2] - mean) * rs * w0.z + b0.z; o[3] = (f[3] - mean) * rs * w0.w + b0.w;
+                o[4] = (f[4] - mean) * rs * w1.x + b1.x; o[5] = (f[5] - mean) * rs * w1.y + b1.y;
+                o[6] = (f[6] - mean) * rs * w1.z + b1.z; o[7] = (f[7] - mean) * rs * w1.w + b1.w;
+                *reinterpret_cast<u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4)) = pack8(o);
+            }
+            if (p.mu && q == 0 && (uint32_t)R < nrows) {
+                p.mu[row0 + R] = mean;
+                p.rstd[row0 + R] = rs;
+            }
+        }
+        // LN2(y) is conv4's weight-gradient operand, the gate conv5's: the wave's 16 rows of each leave coalesced during the GEMM that reads them
+        Trickle tr;
+        tr.lds0 = (uint32_t)(G::RW * wave + crow) * PITCH;
+        tr.glb0 = tr.lds0 + (uint32_t)cchunk * 16u;
+        tr.cchunk = cchunk;
+        tr.rbase = (G::RW * wave + crow) & 15;
+        tr.on = p.xn2 != nullptr;
+        tr.dst = make_rsrc(tr.on ? p.xn2 + row0 * C : p.out, tr.on ? nrows * PITCH : 0);
+        TL(3);
+        block_sync();   // LN2(y) of all 128 rows is in LDS
+        TL(4);
+
+        // ---- conv4 + bias + SimpleGate, a pass per 32 gate channels ----
+        u32x4 greg[NT][MT][2];
+#pragma unroll
+        for (int ps = 0; ps < NT; ++ps) {
+            floatx16 acc[2][MT];
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
+            tr.j0 = ps * (G::NI / NT);
+            kloop<2, G::KS / (G::NI / NT), G>(acc, ring, wrs, l16, wnext, X, xlane, tr);
+            TL(5 + 2 * ps);
+            const int cb = CW * wave + 32 * ps + 16 * h;   // the lane's 16 consecutive channels (v1; the v2 partner is C + cb)
+            const rsrc_t vr = make_rsrc(p.v ? p.v + row0 * 2 * C : p.out, p.v ? nrows * 2 * PITCH : 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {   // 8 channels at a time: the bias values are transient (LDS broadcast reads)
+                    const float4 ba = *reinterpret_cast<const float4*>(tab + G::T_B4 + cb + 8 * hf), bb = *reinterpret_cast<const float4*>(tab + G::T_B4 + cb + 8 * hf + 4);
+                    const float4 ca = *reinterpret_cast<const float4*>(tab + G::T_B4 + C + cb + 8 * hf), cc = *reinterpret_cast<const float4*>(tab + G::T_B4 + C + cb + 8 * hf + 4);
+                    const float b1[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w}, b2[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
+                    float u1[8], u2[8], gv[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        u1[r] = acc[0][mt][8 * hf + r] + b1[r];
+                        u2[r] = acc[1][mt][8 * hf + r] + b2[r];
+                        gv[r] = u1[r] * u2[r];
+                    }
+                    if (p.v) {
+                        const uint32_t vo = (uint32_t)(32 * mt + m) * (2 * PITCH) + (uint32_t)cb * 2u + 16u * hf;
+                        st16(pack8(u1), vr, vo);
+                        st16(pack8(u2), vr, vo + PITCH);
+                    }
+                    greg[ps][mt][hf] = pack8(gv);
+                    asm volatile("" : "+v"(greg[ps][mt][hf]));   // (pack NOW: otherwise the fp32 products stay live across the next pass and spill)
+                }
+            TL(6 + 2 * ps);
+        }
+        block_sync();   // every wave has read LN2(y) for the last time: the gate takes its place
+        TL(9);
+        {
+#pragma unroll
+            for (int ps = 0; ps < NT; ++ps)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int R = 32 * mt + m, ch0 = (CW * wave + 32 * ps + 16 * h) >> 3;   // chunks ch0, ch0 + 1 (ch0 even)
+                    unsigned char* const xr = X + R * PITCH + ((ch0 & ~15) << 4);
+                    *reinterpret_cast<u32x4*>(xr + (((ch0 ^ R) & 15) << 4)) = greg[ps][mt][0];
+                    *reinterpret_cast<u32x4*>(xr + ((((ch0 + 1) ^ R) & 15) << 4)) = greg[ps][mt][1];
+                }
+        }
+        TL(10);
+        block_sync();   // the gate of all 128 rows is in LDS
+        TL(11);
+
+        // ---- conv5 + bias, gamma, residual ----
+        {
+            floatx16 acc[NT][MT];
+#pragma unroll
+            for (int f = 0; f < NT; ++f)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
+            tr.j0 = 0;
+            tr.on = p.g != nullptr;
+            tr.dst = make_rsrc(tr.on ? p.g + row0 * C : p.out, tr.on ? nrows * PITCH : 0);
+            // the residual in the accumulator layout: the tile's rows of y again (read once already: L2 / Infinity Cache).  The first channel
+            // tile's share is requested before the GEMM, the rest while the first is finished (registers: 128 accumulators + 32 here)
+            u32x4 yv[MT][2];
+            const int cb0 = CW * wave + 16 * h;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint32_t yo = (uint32_t)(32 * mt + m) * PITCH + (uint32_t)cb0 * 2u;
+                yv[mt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo, 0, 0));
+                yv[mt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo + 16, 0, 0));
+            }
+            kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, X, xlane, tr);
+            TL(12);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int cb = CW * wave + 32 * t + 16 * h;
+                if (t > 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const uint32_t yo = (uint32_t)(32 * mt + m) * PITCH + (uint32_t)cb * 2u;
+                        yv[mt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo, 0, 0));
+                        yv[mt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo + 16, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const float4 ba = *reinterpret_cast<const float4*>(tab + G::T_B5 + cb + 8 * hf), bb = *reinterpret_cast<const float4*>(tab + G::T_B5 + cb + 8 * hf + 4);
+                        const float4 ga = *reinterpret_cast<const float4*>(tab + G::T_GM + cb + 8 * hf), gb = *reinterpret_cast<const float4*>(tab + G::T_GM + cb + 8 * hf + 4);
+                        const float b5[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w}, gm[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                        float yf[8], o[8];
+                        unpack8(yv[mt][hf], yf);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o[r] = yf[r] + (acc[t][mt][8 * hf + r] + b5[r]) * gm[r];
+                        st16(pack8(o), outr, (uint32_t)(32 * mt + m) * PITCH + (uint32_t)cb * 2u + 16u * hf);
+                    }
+            }
+        }
+        TL(13);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TL(14);
+        if (tile + gridDim.x < ntiles) block_sync();   // the next tile's rows overwrite the gate
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <int C>
+int launch_t(const ChainFwdB& p, hipStream_t s) {
+    const int64_t ntiles = (p.M + 127) / 128;
+    const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
+    chain_fwd_bf16_kernel<C, 128><<<dim3(grid), dim3(512), 0, s>>>(p);
+    DCPT_CHECK_LAUNCH("chain_fwd_bf16");
+    return DCPT_OK;
+}
+
+}  // namespace
+
+#ifdef CHAIN_TIMELINE
+extern "C" int dcpt_chain_timeline_read(void* host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chain_tl), bytes < sizeof(g_chain_tl) ? bytes : sizeof(g_chain_tl)) == hipSuccess ? 0 : 3;
+}
+#endif
+bool chain_fwd_bf16_ok(int C, int64_t M) {
+    static const int on = dcpt_tuning("DCPT_FFN_CHAIN", 1);
+    // (32-bit window offsets: a tile's window starts at its first row, so only a row's bytes matter)
+    return on && (C == 256 || C == 512) && M >= 128;
+}
+size_t chain_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)3 * C * C : 0; }
+
+int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(p.y && p.Wf && p.out && p.lnw && p.lnb && p.b4 && p.b5 && p.gamma && p.M > 0, "chain_fwd_bf16: null argument");
+    DCPT_CHECK_ARG((p.xn2 == nullptr) == (p.g == nullptr) && (p.mu == nullptr) == (p.rstd == nullptr), "chain_fwd_bf16: xn2 / g and mu / rstd come in pairs");
+    if (C == 512) return launch_t<512>(p, s);
+    if (C == 256) return launch_t<256>(p, s);
+    dcpt_set_error("chain_fwd_bf16: no kernel for C=%d", C);
+    return DCPT_ERR_ARG;
+}

@@ -18,6 +18,7 @@
 // the same side stream as the fp32 block.
 #include "bf16_ops.h"
 #include "ffn_bf16.h"
+#include "chain_bf16.h"
 #include "side.h"
 #include "../../include/dcpt_hip.h"
 
@@ -29,10 +30,13 @@ bool ffn_fused(int C) {
     return on && ffn_fwd_bf16_ok(C);
 }
 
+// wide levels: LayerNorm2 -> conv4 -> gate -> conv5 -> residual as one kernel per 128-pixel tile, weights streamed (chain_bf16.hip)
+bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 128); }
+
 struct FwdWsB {
     float* w2p;
     float* pool_part;
-    bf16_t *W1, *W4, *W5, *W3s, *W3, *t2s;
+    bf16_t *W1, *W4, *W5, *W3s, *W3, *t2s, *Wf;
     int nblk_pool;
     bool scale_act;   // conv3's SCA scale on the activations (t2 * s, one GEMM) instead of in per-image weights: images smaller than 2 C pixels
 };
@@ -51,6 +55,7 @@ size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* 
     w.W1 = a.get<bf16_t>((size_t)2 * C * C);
     w.W4 = a.get<bf16_t>((size_t)2 * C * C);
     w.W5 = a.get<bf16_t>((size_t)C * C);
+    w.Wf = ffn_chain(C) ? a.get<bf16_t>(chain_wstream_elems(C)) : nullptr;
     w.scale_act = conv3_scale_activations(H * W, C);
     w.W3s = w.scale_act ? nullptr : a.get<bf16_t>((size_t)B * C * C);
     w.W3 = w.scale_act ? a.get<bf16_t>((size_t)C * C) : nullptr;
@@ -211,7 +216,7 @@ bool shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C 
 // keeps this buffer per block and refreshes it when the parameters change (once per optimizer step) saves the per-call packs:
 // 5 launches per block and step (dcpt_nafblock_wpack_bf16 / *_packed entry points).
 struct PackB {
-    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3;
+    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3, *Wf;
     float* w2p;
 };
 size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
@@ -226,12 +231,17 @@ size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
     k.wT1 = a.get<bf16_t>((size_t)2 * C * C);
     k.w2p = a.get<float>((size_t)18 * C);
     k.W3 = a.get<bf16_t>((size_t)C * C);
+    k.Wf = ffn_chain(C) ? a.get<bf16_t>(chain_wstream_elems(C)) : nullptr;   // conv4 + conv5 in the chain kernel's fragment order
     if (out) *out = k;
     return a.off;
 }
+constexpr int PACK_JOBS = 10;   // jobs of one block at most
 template <typename J>
-void pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b) {   // the block's nine jobs at j[b .. b + 8]
+int pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b) {   // the block's nine or ten jobs at j[b ..]; returns their number
     const int C2 = 2 * C;
+    if (k.Wf) {
+        j.in[b + 9] = p->conv4_w; j.rs[b + 9] = p->conv5_w; j.out[b + 9] = k.Wf; j.N[b + 9] = 3 * C; j.K[b + 9] = C; j.transpose[b + 9] = 9;
+    }
     j.in[b + 8] = p->conv3_w; j.out[b + 8] = k.W3; j.N[b + 8] = C; j.K[b + 8] = C;
     j.in[b + 0] = p->conv1_w; j.out[b + 0] = k.W1; j.N[b + 0] = C2; j.K[b + 0] = C;
     j.in[b + 1] = p->conv4_w; j.out[b + 1] = k.W4; j.N[b + 1] = C2; j.K[b + 1] = C;
@@ -241,11 +251,11 @@ void pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b
     j.in[b + 5] = p->conv3_w; j.out[b + 5] = k.wT3; j.rs[b + 5] = p->beta;  j.N[b + 5] = C;  j.K[b + 5] = C; j.transpose[b + 5] = 1;
     j.in[b + 6] = p->conv1_w; j.out[b + 6] = k.wT1; j.rs[b + 6] = nullptr;  j.N[b + 6] = C2; j.K[b + 6] = C; j.transpose[b + 6] = 1;
     j.in[b + 7] = p->conv2_w; j.out[b + 7] = reinterpret_cast<bf16_t*>(k.w2p); j.N[b + 7] = C2; j.K[b + 7] = 9; j.transpose[b + 7] = 8;
+    return k.Wf ? 10 : 9;
 }
 int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
     WpackBJobs j{};
-    j.n = 9;
-    pack_jobs(p, k, C, j, 0);
+    j.n = pack_jobs(p, k, C, j, 0);
     return launch_wpack_bf16(j, s);
 }
 
@@ -255,24 +265,27 @@ extern "C" size_t dcpt_nafblock_fwd_bf16_ws_bytes(int B, int H, int W, int C) { 
 extern "C" size_t dcpt_nafblock_bwd_bf16_ws_bytes(int B, int H, int W, int C) { return bwd_layout(B, H, W, C, nullptr, 0, nullptr); }
 
 extern "C" size_t dcpt_nafblock_wpack_bf16_bytes(int C) { return pack_layout(C, nullptr, 0, nullptr); }
-extern "C" int dcpt_nafblock_bf16_fused_ffn(int C) { return ffn_fused(C) ? 1 : 0; }
+// 1: LN2(y), SimpleGate(v) and LN2's statistics are never touched at this width (the fused backward recomputes them);
+// 2: they are written for the backward pass but may be NULL (like v) when none follows -- the chain kernel of the wide levels
+extern "C" int dcpt_nafblock_bf16_fused_ffn(int C) { return ffn_fused(C) ? 1 : ffn_chain(C) ? 2 : 0; }
 
 // the packs of n blocks (any mix of widths) in ceil(n / 8) launches instead of n: what a network does once per optimizer step
 extern "C" int dcpt_nafblock_wpack_bf16_multi(const dcpt_nafblock_params* ps, void* const* packed, const size_t* packed_bytes, const int* C,
                                               int n, dcpt_stream_t stream) {
     DCPT_CHECK_ARG(ps && packed && packed_bytes && C && n >= 1, "nafblock_wpack_bf16_multi: null argument or n=%d", n);
-    constexpr int PER = WPACKB_MAX_JOBS_L / 9;
+    constexpr int PER = WPACKB_MAX_JOBS_L / PACK_JOBS;
     for (int b0 = 0; b0 < n; b0 += PER) {
         WpackBJobsL j{};
         const int nb = n - b0 < PER ? n - b0 : PER;
+        int nj = 0;
         for (int b = 0; b < nb; ++b) {
             const int i = b0 + b;
             DCPT_CHECK_ARG(packed[i] && C[i] > 0 && C[i] % 8 == 0 && C[i] <= 1024, "nafblock_wpack_bf16_multi: block %d: null buffer or bad C=%d", i, C[i]);
             PackB k;
             DCPT_CHECK_ARG(pack_layout(C[i], packed[i], packed_bytes[i], &k) <= packed_bytes[i], "nafblock_wpack_bf16_multi: block %d: buffer too small", i);
-            pack_jobs(ps + i, k, C[i], j, 9 * b);
+            nj += pack_jobs(ps + i, k, C[i], j, nj);
         }
-        j.n = 9 * nb;
+        j.n = nj;
         DCPT_TRY(launch_wpack_bf16(j, (hipStream_t)stream));
     }
     return DCPT_OK;
@@ -295,7 +308,7 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     DCPT_CHECK_ARG(sv->t1 && sv->t2 && sv->y && sv->xn1 && sv->mu1 && sv->rstd1 && sv->pooled && sv->s, "nafblock_fwd_bf16: saved buffers missing");
     const bool infer = !sv->v && !sv->xn2 && !sv->g && !sv->mu2 && !sv->rstd2;   // inference with the fused second half: nothing of it is kept
     // (v alone may be null anywhere: a caller that runs no backward -- the bias+gate epilogue then writes SimpleGate(v) only)
-    DCPT_CHECK_ARG((sv->xn2 && sv->g && sv->mu2 && sv->rstd2) || (infer && ffn_fused(C)),
+    DCPT_CHECK_ARG((sv->xn2 && sv->g && sv->mu2 && sv->rstd2) || (infer && (ffn_fused(C) || ffn_chain(C))),
                    "nafblock_fwd_bf16: saved xn2 / g / mu2 / rstd2 missing (all of v / xn2 / g / mu2 / rstd2 may be null only where "
                    "dcpt_nafblock_bf16_fused_ffn(C) is 1; v alone may be null when no backward pass follows)");
     FwdWsB w;
@@ -312,13 +325,17 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     if (packed) {
         PackB k;
         DCPT_CHECK_ARG(pack_layout(C, const_cast<void*>(packed), packed_bytes, &k) <= packed_bytes, "nafblock_fwd_bf16: packed weights buffer too small");
-        w.W1 = k.W1; w.W4 = k.W4; w.W5 = k.W5; w.w2p = k.w2p;
+        w.W1 = k.W1; w.W4 = k.W4; w.W5 = k.W5; w.w2p = k.w2p; w.Wf = k.Wf;
         if (w.scale_act) w.W3 = k.W3;
     } else {
         j.n = 3;
         if (w.scale_act) {
-            j.n = 4;
-            j.in[3] = p->conv3_w; j.out[3] = w.W3; j.N[3] = C; j.K[3] = C;
+            j.in[j.n] = p->conv3_w; j.out[j.n] = w.W3; j.N[j.n] = C; j.K[j.n] = C;
+            ++j.n;
+        }
+        if (w.Wf) {
+            j.in[j.n] = p->conv4_w; j.rs[j.n] = p->conv5_w; j.out[j.n] = w.Wf; j.N[j.n] = 3 * C; j.K[j.n] = C; j.transpose[j.n] = 9;
+            ++j.n;
         }
         j.in[0] = p->conv1_w; j.out[0] = w.W1; j.N[0] = 2 * C; j.K[0] = C;
         j.in[1] = p->conv4_w; j.out[1] = w.W4; j.N[1] = 2 * C; j.K[1] = C;
@@ -364,6 +381,12 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         // (LN2(y), the gate and the statistics are recomputed by the backward kernels: sv->xn2 / g / mu2 / rstd2 stay unwritten)
         f.out = out; f.v = sv->v; f.M = M; f.eps = eps;
         return launch_ffn_fwd_bf16(f, C, s);
+    }
+    if (ffn_chain(C)) {   // wide levels: the same chain per 128-pixel tile with the weights streamed past it (chain_bf16.hip)
+        ChainFwdB f{};
+        f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.Wf = w.Wf; f.b4 = p->conv4_b; f.b5 = p->conv5_b; f.gamma = p->gamma;
+        f.out = out; f.v = sv->v; f.xn2 = sv->xn2; f.g = sv->g; f.mu = sv->mu2; f.rstd = sv->rstd2; f.M = M; f.eps = eps;
+        return launch_chain_fwd_bf16(f, C, s);
     }
     DCPT_TRY(launch_ln_fwd_bf16(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
     g = GemmNTB{};

@@ -312,13 +312,16 @@ class _NAFBlockBf16Fn(torch.autograd.Function):
         # no backward coming (torch.no_grad / nothing requires grad) and the block's second half is one kernel at this width: the five
         # tensors only that backward reads (v, LN2(y), SimpleGate(v), LN2's statistics) are neither allocated nor written
         # where the block's second half is one kernel, its backward recomputes LN2(y), the gate and LN2's statistics: never allocated
-        fused = bool(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
+        # (1: C = 64, ffn_bf16.hip -- never touched; 2: C = 256 / 512, chain_bf16.hip -- written for the backward pass only)
+        ffn = int(lib.dcpt_nafblock_bf16_fused_ffn(Cc))
+        fused = ffn == 1
         nograd = not (grad_mode and any(ctx.needs_input_grad))
-        infer = fused and nograd
+        infer = ffn != 0 and nograd
         _NAFBlockBf16Fn.last_infer = infer
         v = None if nograd else _empty_nhwc_bf16(B, 2 * Cc, H, W, dev)   # (conv4's output is read by the backward only)
-        acts = torch.empty((3 if fused else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
-        stats = torch.empty((2 if fused else 4, M), dtype=torch.float32, device=dev)
+        slim = fused or infer
+        acts = torch.empty((3 if slim else 5, B, H, W, Cc), dtype=torch.bfloat16, device=dev)   # t2, y, LN1(inp) [, LN2(y), SimpleGate(v)]
+        stats = torch.empty((2 if slim else 4, M), dtype=torch.float32, device=dev)
         sca = torch.empty((2, B, Cc), dtype=torch.float32, device=dev)           # pooled, s
         ps = NafBlockParams(*[p.data_ptr() for p in params])
         sv = _saved_bf16(t1, v, acts, stats, sca, infer)

@@ -157,7 +157,10 @@ size_t dcpt_nafblock_wpack_bf16_bytes(int C);
  * that half).  With 1 the library never reads or writes saved->xn2 / g / mu2 / rstd2 in either pass (its backward kernels recompute
  * LayerNorm2, the gate and the statistics from y and v): in training they only have to be non-null.  0: every saved buffer is used --
  * except that saved->v ALONE may be NULL at any width when no backward pass follows: conv4's bias + gate epilogue then writes
- * SimpleGate(v) only (one tensor pass instead of three for that launch). */
+ * SimpleGate(v) only (one tensor pass instead of three for that launch).
+ * 2 (ABI 11; C = 256 / 512, chain_bf16.hip: the same chain per 128-pixel tile with the weights streamed past it): the forward WRITES
+ * xn2 / g / mu2 / rstd2 (the unfused backward reads them), but a caller that will not run the backward pass may pass all five of
+ * v / xn2 / g / mu2 / rstd2 as NULL exactly as with 1. */
 int dcpt_nafblock_bf16_fused_ffn(int C);
 int dcpt_nafblock_wpack_bf16(const dcpt_nafblock_params* p, void* packed, size_t packed_bytes, int C, dcpt_stream_t stream);
 /* The same for n blocks at once (ABI 10; ps / packed / packed_bytes / C are arrays of n, any mix of widths): ceil(n / 8) launches

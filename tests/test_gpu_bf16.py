@@ -730,7 +730,8 @@ def test_fused_second_half_inference_drops_saved_tensors(dev):
     from dcpt_amd import _lib, functional as DF
 
     lib = _lib.load()
-    assert lib.dcpt_nafblock_bf16_fused_ffn(64) == 1 and lib.dcpt_nafblock_bf16_fused_ffn(512) == 0
+    assert lib.dcpt_nafblock_bf16_fused_ffn(64) == 1 and lib.dcpt_nafblock_bf16_fused_ffn(128) == 0
+    assert lib.dcpt_nafblock_bf16_fused_ffn(512) == 2 and lib.dcpt_nafblock_bf16_fused_ffn(256) == 2   # the chain kernel of the wide levels
     for shape in [(3, 64, 5, 7), (2, 64, 32, 32)]:
         c = shape[1]
         tag = f"bf.inf.{c}.{shape[2]}."
@@ -752,9 +753,9 @@ def test_fused_second_half_inference_drops_saved_tensors(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 128, 12, 10), (3, 256, 17, 9), (24, 512, 32, 32)])
 def test_wide_level_inference_skips_conv4_output(dev, shape):
-    """At the widths whose second half is three kernels a forward that no backward follows passes saved->v = NULL: conv4's bias + gate
-    epilogue (128-row and 256 x 256-tile kernels; the last shape is large enough for the latter) writes SimpleGate(v) only.  Same bits
-    as the training forward."""
+    """A forward that no backward follows passes saved->v = NULL: at C = 128 (second half = three kernels) conv4's bias + gate epilogue
+    writes SimpleGate(v) only; at C = 256 / 512 (second half = the chain kernel, chain_bf16.hip, dcpt_nafblock_bf16_fused_ffn = 2) LN2(y),
+    the gate and LN2's statistics are not written either.  Same bits as the training forward."""
     from dcpt_amd import functional as DF
 
     c = shape[1]
@@ -767,7 +768,7 @@ def test_wide_level_inference_skips_conv4_output(dev, shape):
     with torch.no_grad():
         y_inf = DF.nafblock_bf16(x, Pd)
     torch.cuda.synchronize()
-    assert DF._NAFBlockBf16Fn.last_infer is False and torch.equal(y_train.detach(), y_inf)
+    assert DF._NAFBlockBf16Fn.last_infer is (c != 128) and torch.equal(y_train.detach(), y_inf)
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 256), (1000, 256, 256), (8192 + 77, 1024, 512), (64 * 33, 512, 512), (300, 256, 512),
