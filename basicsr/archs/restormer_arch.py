@@ -133,6 +133,14 @@ def _trunc_normal_(t, std=0.02):
 
 
 class _RestormerBase(nn.Module):
+    def _set_save_mode(self, save_mode):
+        # ``network_g.save_mode`` (this repo's extension): what the transformer blocks keep for backward -- "full" | "balanced" | "lean" |
+        # "auto" (dcpt_amd/functional.py, "What the Restormer halves keep"); None = the process default ("balanced").  Results are
+        # bit-identical in every mode; only step time and peak memory differ.
+        if save_mode not in (None, "auto", "full", "balanced", "lean"):
+            raise ValueError(f"save_mode must be 'full', 'balanced', 'lean' or 'auto', got {save_mode!r}")
+        self.save_mode = save_mode
+
     def _build(self, inp_channels, out_channels, dim, num_blocks, num_refinement_blocks, heads, ffn_expansion_factor, bias,
                LayerNorm_type, make_level):
         if bias:
@@ -179,8 +187,9 @@ class _RestormerBase(nn.Module):
 class Restormer(_RestormerBase):
     def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
                  heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type="BiasFree", dual_pixel_task=False,
-                 scale=1, window_size=8):
+                 scale=1, window_size=8, save_mode=None):
         super().__init__()
+        self._set_save_mode(save_mode)
         if dual_pixel_task or scale != 1:
             raise NotImplementedError("dual_pixel_task / scale > 1 are not on the DCPT path")
         self.dual_pixel_task, self.scale = dual_pixel_task, scale
@@ -189,9 +198,10 @@ class Restormer(_RestormerBase):
                     lambda d, h, n: SequentialTransformerBlock(d, h, n, ffn_expansion_factor, bias, LayerNorm_type))
 
     def forward(self, inp_img, hook=None):
-        d1 = self._features(inp_img)
-        if not hook:
-            return self._tail(d1, inp_img)
+        with DF.restormer_save(self.save_mode, inp_img.device):
+            d1 = self._features(inp_img)
+            if not hook:
+                return self._tail(d1, inp_img)
         return None
 
 
@@ -200,8 +210,9 @@ class Restormer_origin(_RestormerBase):
     """reference :425-517: plain nn.Sequential levels, WithBias LayerNorm default, no ``hook`` argument."""
 
     def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
-                 heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias", dual_pixel_task=False):
+                 heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias", dual_pixel_task=False, save_mode=None):
         super().__init__()
+        self._set_save_mode(save_mode)
         if dual_pixel_task:
             raise NotImplementedError("dual_pixel_task is not on the DCPT path")
         self.dual_pixel_task = dual_pixel_task
@@ -210,4 +221,5 @@ class Restormer_origin(_RestormerBase):
                     lambda d, h, n: nn.Sequential(*[TransformerBlock(d, h, ffn_expansion_factor, bias, LayerNorm_type) for _ in range(n)]))
 
     def forward(self, inp_img):
-        return self._tail(self._features(inp_img), inp_img)
+        with DF.restormer_save(self.save_mode, inp_img.device):
+            return self._tail(self._features(inp_img), inp_img)

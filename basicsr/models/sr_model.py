@@ -255,7 +255,9 @@ class SRModel(BaseModel):
             return []
         from dcpt_amd import functional as DF
 
-        if getattr(net, "gemm_precision", None) not in (None, "fp32") or DF.get_gemm_precision() != "fp32":
+        # (``net`` may be the DDP / DataParallel wrapper, which has no ``gemm_precision``: ask the bare network and every submodule)
+        bare = self.get_bare_model(net)
+        if DF.get_gemm_precision() != "fp32" or any(getattr(mod, "gemm_precision", None) not in (None, "fp32") for mod in bare.modules()):
             return []
         # one pool per device for the whole process: every torch.cuda.Stream() is another runtime stream, the runtime multiplexes them onto a
         # few hardware queues, and two streams that land on one queue do not overlap (a second model's own pair of streams measured 95 ms

@@ -35,7 +35,7 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def run_restormer(dev, save="auto", steps=5, warmup=2, B=64, S=128):
+def run_restormer(dev, save="balanced", steps=5, warmup=2, B=64, S=128):
     """BASELINE.json configs[3]: Restormer defaults (reference restormer_arch.py:234-422), fwd + L1 + bwd + AdamW, fp32."""
     from basicsr.archs import build_network
     from dcpt_amd import functional as DF
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--workload", required=True, choices=["dcpt", "restormer", "infer2k", "naf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--head-dtype", default=None, choices=["fp32", "bf16"], help="dcpt: classifier-head activations (default: --dtype)")
-    ap.add_argument("--restormer-save", default="auto", choices=["auto", "lean", "balanced", "full"], help="what the Restormer halves keep for backward")
+    ap.add_argument("--restormer-save", default="balanced", choices=["auto", "lean", "balanced", "full"], help="what the Restormer halves keep for backward")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tile-streams", type=int, default=2, help="infer2k: HIP streams the tile batches run on (tile.streams)")

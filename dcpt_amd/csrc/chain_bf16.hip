@@ -225,30 +225,23 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
         {
             const int R = G::RW * wave + rl;
             unsigned char* const xr = X + R * PITCH;
-            u32x4 xw[G::NJ];
-#pragma unroll
-            for (int j = 0; j < G::NJ; ++j) xw[j] = *reinterpret_cast<const u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4));
+            // (the row quarter is unpacked ONCE into fp32 registers: the three passes over it are VALU-bound -- 128 elements per lane)
+            float xf[G::NJ * 8];
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < G::NJ; ++j) {
-                float f[8];
-                unpack8(xw[j], f);
+                unpack8(*reinterpret_cast<const u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4)), xf + 8 * j);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum += f[e];
+                for (int e = 0; e < 8; ++e) sum += xf[8 * j + e];
             }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             const float mean = sum * (1.0f / C);
             float sq = 0.f;
 #pragma unroll
-            for (int j = 0; j < G::NJ; ++j) {
-                float f[8];
-                unpack8(xw[j], f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = f[e] - mean;
-                    sq += d * d;
-                }
+            for (int e = 0; e < G::NJ * 8; ++e) {
+                xf[e] -= mean;
+                sq += xf[e] * xf[e];
             }
             sq += __shfl_xor(sq, 16);
             sq += __shfl_xor(sq, 32);
@@ -256,14 +249,12 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
 #pragma unroll
             for (int j = 0; j < G::NJ; ++j) {
                 const int ch = 8 * (4 * j + q);
-                float f[8], o[8];
-                unpack8(xw[j], f);
                 const float4 w0 = *reinterpret_cast<const float4*>(tab + G::T_LW + ch), w1 = *reinterpret_cast<const float4*>(tab + G::T_LW + ch + 4);
                 const float4 b0 = *reinterpret_cast<const float4*>(tab + G::T_LB + ch), b1 = *reinterpret_cast<const float4*>(tab + G::T_LB + ch + 4);
-                o[0] = (f[0] - mean) * rs * w0.x + b0.x; o[1] = (f[1] - mean) * rs * w0.y + b0.y;
-                o[2] = (f[2] - mean) * rs * w0.z + b0.z; o[3] = (f[3] - mean) * rs * w0.w + b0.w;
-                o[4] = (f[4] - mean) * rs * w1.x + b1.x; o[5] = (f[5] - mean) * rs * w1.y + b1.y;
-                o[6] = (f[6] - mean) * rs * w1.z + b1.z; o[7] = (f[7] - mean) * rs * w1.w + b1.w;
+                const float* f = xf + 8 * j;
+                float o[8];
+                o[0] = f[0] * rs * w0.x + b0.x; o[1] = f[1] * rs * w0.y + b0.y; o[2] = f[2] * rs * w0.z + b0.z; o[3] = f[3] * rs * w0.w + b0.w;
+                o[4] = f[4] * rs * w1.x + b1.x; o[5] = f[5] * rs * w1.y + b1.y; o[6] = f[6] * rs * w1.z + b1.z; o[7] = f[7] * rs * w1.w + b1.w;
                 *reinterpret_cast<u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4)) = pack8(o);
             }
             if (p.mu && q == 0 && (uint32_t)R < nrows) {
@@ -323,6 +314,19 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
                 }
             TL(6 + 2 * ps);
         }
+        // the residual in the accumulator layout: the tile's rows of y again (read once already: L2 / Infinity Cache).  The first channel
+        // tile's share is requested HERE -- it arrives while the block waits at the two barriers below (a load issued right before the
+        // GEMM would hold up its first weight fragment: vmcnt retires in order) --, the rest while the first is finished
+        u32x4 yv[MT][2];
+        {
+            const int cb0 = CW * wave + 16 * h;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint32_t yo = (uint32_t)(32 * mt + m) * PITCH + (uint32_t)cb0 * 2u;
+                yv[mt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo, 0, 0));
+                yv[mt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo + 16, 0, 0));
+            }
+        }
         block_sync();   // every wave has read LN2(y) for the last time: the gate takes its place
         TL(9);
         {
@@ -352,16 +356,6 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
             tr.j0 = 0;
             tr.on = p.g != nullptr;
             tr.dst = make_rsrc(tr.on ? p.g + row0 * C : p.out, tr.on ? nrows * PITCH : 0);
-            // the residual in the accumulator layout: the tile's rows of y again (read once already: L2 / Infinity Cache).  The first channel
-            // tile's share is requested before the GEMM, the rest while the first is finished (registers: 128 accumulators + 32 here)
-            u32x4 yv[MT][2];
-            const int cb0 = CW * wave + 16 * h;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const uint32_t yo = (uint32_t)(32 * mt + m) * PITCH + (uint32_t)cb0 * 2u;
-                yv[mt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo, 0, 0));
-                yv[mt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, yo + 16, 0, 0));
-            }
             kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, X, xlane, tr);
             TL(12);
 #pragma unroll
@@ -391,7 +385,9 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
             }
         }
         TL(13);
+#ifdef CHAIN_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         TL(14);
         if (tile + gridDim.x < ntiles) block_sync();   // the next tile's rows overwrite the gate
     }
@@ -425,8 +421,9 @@ extern "C" int dcpt_chain_timeline_read(void* host, size_t bytes) {
 #endif
 bool chain_fwd_bf16_ok(int C, int64_t M) {
     static const int on = dcpt_tuning("DCPT_FFN_CHAIN", 1);
-    // (32-bit window offsets: a tile's window starts at its first row, so only a row's bytes matter)
-    return on && (C == 256 || C == 512) && M >= 128;
+    // a block = one CU for a 128-pixel tile: taken when the last round of tiles fills at least 3/4 of the chip (nafblock_bf16.hip)
+    const int64_t nt = (M + 127) / 128, cus = num_cus(), rounds = (nt + cus - 1) / cus;
+    return on && (C == 256 || C == 512) && nt * 4 >= rounds * cus * 3;
 }
 size_t chain_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)3 * C * C : 0; }
 

@@ -31,12 +31,19 @@ bool ffn_fused(int C) {
 }
 
 // wide levels: LayerNorm2 -> conv4 -> gate -> conv5 -> residual as one kernel per 128-pixel tile, weights streamed (chain_bf16.hip)
-bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 128); }
+// ffn_chain(C): the width has the kernel (what dcpt_nafblock_bf16_fused_ffn reports: a caller may then leave xn2 / g / mu2 / rstd2 NULL when
+// no backward follows); ffn_chain_use(C, M): this launch takes it -- a block owns a whole CU for a 128-pixel tile, so a pixel count that
+// fills less than 3/4 of the last round of 256 tiles (tiled inference: 4 tiles of 528 x 528 are 137 tiles at level 3; DCPT at 128 x 128:
+// 128) keeps the three-kernel chain, which scales with M (measured: 2K tiled inference 25.9 -> 58 ms with the chain kernel forced).
+bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 1 << 20); }
+bool ffn_chain_use(int C, int64_t M) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, M); }
 
 struct FwdWsB {
     float* w2p;
     float* pool_part;
     bf16_t *W1, *W4, *W5, *W3s, *W3, *t2s, *Wf;
+    bf16_t *xn2, *g;   // stand-ins for saved->xn2 / g / mu2 / rstd2 where a caller left them NULL (allowed at the chain widths) and the launch
+    float *mu2, *rstd2;   // runs the three-kernel chain after all
     int nblk_pool;
     bool scale_act;   // conv3's SCA scale on the activations (t2 * s, one GEMM) instead of in per-image weights: images smaller than 2 C pixels
 };
@@ -56,6 +63,14 @@ size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* 
     w.W4 = a.get<bf16_t>((size_t)2 * C * C);
     w.W5 = a.get<bf16_t>((size_t)C * C);
     w.Wf = ffn_chain(C) ? a.get<bf16_t>(chain_wstream_elems(C)) : nullptr;
+    w.xn2 = w.g = nullptr;
+    w.mu2 = w.rstd2 = nullptr;
+    if (ffn_chain(C) && !ffn_chain_use(C, (int64_t)B * H * W)) {
+        w.xn2 = a.get<bf16_t>((size_t)B * H * W * C);
+        w.g = a.get<bf16_t>((size_t)B * H * W * C);
+        w.mu2 = a.get<float>((size_t)B * H * W);
+        w.rstd2 = a.get<float>((size_t)B * H * W);
+    }
     w.scale_act = conv3_scale_activations(H * W, C);
     w.W3s = w.scale_act ? nullptr : a.get<bf16_t>((size_t)B * C * C);
     w.W3 = w.scale_act ? a.get<bf16_t>((size_t)C * C) : nullptr;
@@ -382,18 +397,21 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         f.out = out; f.v = sv->v; f.M = M; f.eps = eps;
         return launch_ffn_fwd_bf16(f, C, s);
     }
-    if (ffn_chain(C)) {   // wide levels: the same chain per 128-pixel tile with the weights streamed past it (chain_bf16.hip)
+    if (ffn_chain_use(C, M)) {   // wide levels: the same chain per 128-pixel tile with the weights streamed past it (chain_bf16.hip)
         ChainFwdB f{};
         f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.Wf = w.Wf; f.b4 = p->conv4_b; f.b5 = p->conv5_b; f.gamma = p->gamma;
         f.out = out; f.v = sv->v; f.xn2 = sv->xn2; f.g = sv->g; f.mu = sv->mu2; f.rstd = sv->rstd2; f.M = M; f.eps = eps;
         return launch_chain_fwd_bf16(f, C, s);
     }
-    DCPT_TRY(launch_ln_fwd_bf16(sv->y, p->norm2_w, p->norm2_b, sv->xn2, sv->mu2, sv->rstd2, M, C, eps, s));
+    // (inference at a chain width with a pixel count the chain kernel is not used for: LN2(y) / the gate / the statistics live in the workspace)
+    bf16_t* const xn2 = sv->xn2 ? sv->xn2 : w.xn2;
+    bf16_t* const gt = sv->g ? sv->g : w.g;
+    DCPT_TRY(launch_ln_fwd_bf16(sv->y, p->norm2_w, p->norm2_b, xn2, sv->mu2 ? sv->mu2 : w.mu2, sv->rstd2 ? sv->rstd2 : w.rstd2, M, C, eps, s));
     g = GemmNTB{};
-    g.M = M; g.A = sv->xn2; g.lda = C; g.K = C; g.Bw = w.W4; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b; g.gate = sv->g;
+    g.M = M; g.A = xn2; g.lda = C; g.K = C; g.Bw = w.W4; g.N = 2 * C; g.C = sv->v; g.ldc = 2 * C; g.bias = p->conv4_b; g.gate = gt;
     DCPT_TRY(launch_gemm_nt_bf16(g, EB_BIASGATE, s));
     g = GemmNTB{};
-    g.M = M; g.A = sv->g; g.lda = C; g.K = C; g.Bw = w.W5; g.N = C; g.C = out; g.ldc = C; g.bias = p->conv5_b; g.res = sv->y; g.ldres = C;
+    g.M = M; g.A = gt; g.lda = C; g.K = C; g.Bw = w.W5; g.N = C; g.C = out; g.ldc = C; g.bias = p->conv5_b; g.res = sv->y; g.ldres = C;
     g.cscale = p->gamma;
     return launch_gemm_nt_bf16(g, EB_RESID, s);
 }

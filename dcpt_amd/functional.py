@@ -88,14 +88,23 @@ def _contig(t):
 _X3_SCRATCH: Dict[int, torch.Tensor] = {}       # device index -> scratch for the split weight images
 _GEMM_DEFAULT = ("fp32", 0)                     # the process default: (mode, min_tiles)
 _GEMM_ACTIVE = ("fp32", 0)                      # what the library is switched to right now
+_GEMM_ACTIVE_BUF = (None, 0)                    # (device index, bytes) of the scratch registered with the library while bf16x3 is on
 _GEMM_SCRATCH_MB = 256
 _SIDE_BEFORE_X3 = None                          # the side-stream setting the mode found when it was switched on
 
 
 def _activate_gemm_mode(mode: str, min_tiles: int = 0, device=None):
-    global _GEMM_ACTIVE, _SIDE_BEFORE_X3
+    global _GEMM_ACTIVE, _GEMM_ACTIVE_BUF, _SIDE_BEFORE_X3
     if (mode, min_tiles) == _GEMM_ACTIVE:
-        return
+        if mode == "fp32":
+            return
+        # already on: still re-register when the scratch has to grow (a later set_gemm_precision(scratch_mb=...)) or to move to
+        # another device -- otherwise large launches would silently fall back to the fp32 kernels (round-4 advisor finding)
+        want = torch.device(device).index if device is not None else _GEMM_ACTIVE_BUF[0]
+        if want is None:
+            want = torch.cuda.current_device()
+        if want == _GEMM_ACTIVE_BUF[0] and _GEMM_ACTIVE_BUF[1] >= (_GEMM_SCRATCH_MB << 20):
+            return
     lib = _lib.load()
     if mode == "fp32":
         check(lib.dcpt_set_gemm_x3(None, 0, 0), "dcpt_set_gemm_x3")
@@ -110,6 +119,7 @@ def _activate_gemm_mode(mode: str, min_tiles: int = 0, device=None):
         if buf is None or buf.numel() < (_GEMM_SCRATCH_MB << 20):
             buf = _X3_SCRATCH[idx] = torch.empty(_GEMM_SCRATCH_MB << 20, dtype=torch.uint8, device=torch.device("cuda", idx))
         check(lib.dcpt_set_gemm_x3(buf.data_ptr(), buf.numel(), int(min_tiles)), "dcpt_set_gemm_x3")
+        _GEMM_ACTIVE_BUF = (idx, buf.numel())
         # the split-operand kernels take the whole CU (160 KB of LDS, 8 waves): a weight-gradient block of the side stream cannot share a
         # CU with them (measured: 107.0 ms serialized vs 109.2 ms with it), so the side stream is off while the mode is on
         prev = lib.dcpt_set_side_stream(0)
@@ -1448,42 +1458,66 @@ def concat_channels(a, b):
 
 # What the Restormer halves keep for backward (every saved pointer of dcpt_mdta_saved / dcpt_gdfn_saved may be NULL on its own; the
 # backward entry points recompute what is missing with the forward kernels, bit-identical results):
-#   "full"      everything the backward pass reads: 19 [M][C] units per block;
-#   "balanced"  (default) LN(x) of both halves, attn @ v and the GDFN gate product gelu(x1) * x2 are NOT kept -- two bandwidth passes,
-#               one small batched GEMM and one depthwise-gate pass per block in backward: 13.3 units;
-#   "lean"      additionally the qkv conv output (one more C x 3C GEMM in backward): 10.3 units.
-# Measured on MI355X, Restormer B = 64, 128 x 128 (profiles/r3/extra_restormer_*.json).
-# set_restormer_save() / DCPT_RESTORMER_SAVE select the mode.
+#   "full"      everything the backward pass reads: 19 [M][C] units per block (fastest; B = 64, 128 x 128: 118-125 GB);
+#   "balanced"  (DEFAULT) LN(x) of both halves, attn @ v and the GDFN gate product gelu(x1) * x2 are NOT kept -- two bandwidth passes,
+#               one small batched GEMM and one depthwise-gate pass per block in backward: 13.3 units (86 GB, +6 % time);
+#   "lean"      additionally the qkv conv output (one more C x 3C GEMM in backward): 10.3 units (69 GB);
+#   "auto"      opt-in: ONE choice per network forward from the memory the process holds on the device when the forward starts
+#               ('full' below 40 % of the device memory, 'balanced' up to 70 %, 'lean' beyond).
+# The mode is explicit: ``network_g.save_mode`` in the options (ctor kwarg of Restormer / Restormer_origin) or the process default
+# (set_restormer_save / DCPT_RESTORMER_SAVE); the default does NOT look at free memory -- a DDP rank or a co-resident model gets the same
+# schedule, step time and peak memory as a process that has the device to itself (round-4 verdict / advisor finding).
+# Measured on MI355X, Restormer B = 64, 128 x 128 (profiles/r3/extra_restormer_*.json, profiles/r5/).
+import contextlib as _contextlib  # noqa: E402
 import os as _os  # noqa: E402
 
 _RESTORMER_MODES = ("auto", "full", "balanced", "lean")
-_RESTORMER_SAVE = _os.environ.get("DCPT_RESTORMER_SAVE", "auto")
+_RESTORMER_SAVE = _os.environ.get("DCPT_RESTORMER_SAVE", "balanced")
 if _RESTORMER_SAVE not in _RESTORMER_MODES:
     raise ValueError(f"DCPT_RESTORMER_SAVE={_RESTORMER_SAVE!r}: expected one of {_RESTORMER_MODES}")
+_RESTORMER_SCOPED = None          # the resolved mode of the network forward that is running (restormer_save), or None
 _DEV_TOTAL: Dict[int, int] = {}
 
 
 def set_restormer_save(mode: str) -> str:
-    """'auto' (default), 'full', 'balanced' or 'lean'; returns the previous mode.  'auto' decides per block and forward pass from the
-    memory the process holds on the device at that moment: 'full' (fastest) while less than 55 % of the device memory is allocated,
-    'balanced' up to 75 %, 'lean' beyond -- 288 GB of HBM3E take the default configuration (B = 64, 128 x 128: 118 GB in 'full') whole,
-    and a batch that does not fit sheds saved tensors block by block instead of failing (every mode gives bit-identical results)."""
+    """Process default: 'balanced' (initially), 'full', 'lean' or 'auto'; returns the previous default."""
     global _RESTORMER_SAVE
     if mode not in _RESTORMER_MODES:
-        raise ValueError(mode)
+        raise ValueError(f"restormer save mode {mode!r}: expected one of {_RESTORMER_MODES}")
     prev, _RESTORMER_SAVE = _RESTORMER_SAVE, mode
     return prev
 
 
-def _restormer_mode(dev) -> str:
-    if _RESTORMER_SAVE != "auto":
-        return _RESTORMER_SAVE
+def _resolve_restormer_mode(mode, dev) -> str:
+    if mode != "auto":
+        return mode
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     total = _DEV_TOTAL.get(idx)
     if total is None:
         total = _DEV_TOTAL[idx] = torch.cuda.get_device_properties(idx).total_memory
     used = torch.cuda.memory_allocated(idx) / total
-    return "full" if used < 0.55 else "balanced" if used < 0.75 else "lean"
+    return "full" if used < 0.40 else "balanced" if used < 0.70 else "lean"
+
+
+@_contextlib.contextmanager
+def restormer_save(mode, dev):
+    """Scope of one network forward: ``mode`` (None = the process default) is resolved ONCE here -- 'auto' looks at the device memory now,
+    not block by block -- and every MDTA / GDFN half inside the scope keeps the same set of tensors."""
+    global _RESTORMER_SCOPED
+    mode = _RESTORMER_SAVE if mode is None else mode
+    if mode not in _RESTORMER_MODES:
+        raise ValueError(f"restormer save mode {mode!r}: expected one of {_RESTORMER_MODES}")
+    prev, _RESTORMER_SCOPED = _RESTORMER_SCOPED, _resolve_restormer_mode(mode, dev)
+    try:
+        yield _RESTORMER_SCOPED
+    finally:
+        _RESTORMER_SCOPED = prev
+
+
+def _restormer_mode(dev) -> str:
+    if _RESTORMER_SCOPED is not None:
+        return _RESTORMER_SCOPED
+    return _resolve_restormer_mode(_RESTORMER_SAVE, dev)   # a bare MDTA / GDFN call outside a network
 
 
 @_remember_gemm_mode

@@ -132,6 +132,16 @@ def test_tile_batches_on_several_streams_equal_one_stream(dev, act_dtype):
         assert len(m._tile_streams(9, m.net_g)) == (4 if streams == 4 and DF.get_gemm_precision() == "fp32" else 0)
         assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
         outs[streams] = runs[0]
+        if streams == 4:
+            # a network built for the split-operand mode keeps ONE stream also behind a DataParallel / DDP wrapper (which hides the
+            # attribute the guard reads: round-4 advisor finding) -- the mode's scratch buffer is process-wide
+            wrapped = torch.nn.DataParallel(m.net_g, device_ids=[m.lq.device.index or 0])
+            assert len(m._tile_streams(9, wrapped)) == len(m._tile_streams(9, m.net_g))
+            m.net_g.gemm_precision = "bf16x3"
+            try:
+                assert m._tile_streams(9, m.net_g) == [] and m._tile_streams(9, wrapped) == []
+            finally:
+                m.net_g.gemm_precision = None
     assert bool(torch.isfinite(outs[1]).all()) and torch.equal(outs[1], outs[4])
 
 
@@ -392,11 +402,11 @@ def test_psnr_bf16_storage_vs_fp32(dev, trained_denoiser):
     from basicsr.metrics import calculate_psnr
 
     nets = {}
-    for dt in ("fp32", "bf16", "bf16_tail32"):
+    for dt in ("fp32", "bf16", "bf16_tail32", "bf16_edge32"):
         net = build_network(dict(type="NAFNetBaseline", act_dtype=dt, **FULL))
         net.load_state_dict(trained_denoiser, strict=True)
         nets[dt] = net.to(dev).eval()
-    worst = {"bf16": 0.0, "bf16_tail32": 0.0}
+    worst = {"bf16": 0.0, "bf16_tail32": 0.0, "bf16_edge32": 0.0}
     psnr = {dt: [] for dt in nets}
     kw = dict(crop_border=0, test_y_channel=False, image_range=255.0)
     f = lambda t: t.clamp(0, 1).cpu().numpy()   # noqa: E731
@@ -418,3 +428,6 @@ def test_psnr_bf16_storage_vs_fp32(dev, trained_denoiser):
     # act_dtype = "bf16_tail32" is the bf16 mode that stays inside north_star's 0.01 dB
     assert mean["bf16_tail32"] <= 0.01, f"set PSNR differs by {mean['bf16_tail32']:.4f} dB"
     assert worst["bf16_tail32"] <= 0.015, f"PSNR of one image differs by {worst['bf16_tail32']:.4f} dB"
+    # act_dtype = "bf16_edge32" (everything at full resolution in fp32): EVERY held-out image inside the gate (round-4 verdict, item 6b)
+    print(f"bf16_edge32: set PSNR moves by {mean['bf16_edge32']:.4f} dB, single image at most {worst['bf16_edge32']:.4f} dB")
+    assert worst["bf16_edge32"] <= 0.01, f"PSNR of one image differs by {worst['bf16_edge32']:.4f} dB"

@@ -182,8 +182,8 @@ def test_directional_derivative_full_size(dev):
 
 def test_saved_tensor_modes_equal_full(dev):
     """The save modes of the Restormer halves (functional.set_restormer_save / DCPT_RESTORMER_SAVE) -- "balanced" (LN(x), attn @ v and
-    the GDFN gate product recomputed in backward), "lean" (also the qkv conv output) and the default "auto" (one of the three per block,
-    by the device memory in use) -- give bit-identical outputs
+    the GDFN gate product recomputed in backward; the DEFAULT: it does not depend on free memory), "lean" (also the qkv conv output) and
+    the opt-in "auto" (one of the three per network forward, by the device memory in use when it starts) -- give bit-identical outputs
     and gradients to "full": the recomputation runs the same kernels on the same inputs; each keeps fewer bytes alive between
     forward and backward than the one before."""
     from basicsr.archs import build_network
@@ -194,7 +194,7 @@ def test_saved_tensor_modes_equal_full(dev):
     x = keyed_input("lean.x", (2, 3, 32, 32)).to(dev)
     res = {}
     prev = DF.set_restormer_save("full")
-    assert prev == "auto"   # the default
+    assert prev == "balanced"   # the default: explicit, the same on every rank / next to any co-resident model
     try:
         for mode in ("full", "balanced", "lean", "auto"):
             DF.set_restormer_save(mode)
@@ -218,3 +218,15 @@ def test_saved_tensor_modes_equal_full(dev):
             assert torch.equal(res["full"][1][k], res[mode][1][k]), (mode, k)
     assert res["balanced"][2] < 0.85 * res["full"][2], (res["balanced"][2], res["full"][2])
     assert res["lean"][2] < 0.7 * res["full"][2], (res["lean"][2], res["full"][2])
+    # the mode is also a per-network key (``network_g.save_mode``): it scopes one forward and wins over the process default
+    net = build_network(dict(type="Restormer", save_mode="lean", **R_CFG))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    y = net(x)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - base
+    assert torch.equal(y.detach(), res["full"][0]) and abs(held - res["lean"][2]) <= 0.02 * res["lean"][2], (held, res["lean"][2])
+    with pytest.raises(ValueError):
+        build_network(dict(type="Restormer", save_mode="everything", **R_CFG))

@@ -722,3 +722,110 @@ def test_ddp_bucket_order_is_backward_completion_order_gloo(tmp_path):
                            "encoders.0", "intro"], blocks_only
     enc3 = [int(k.split(".")[2]) for k in ready if k.startswith("encoders.3.") and k.endswith("conv1.weight")]
     assert enc3 == list(range(27, -1, -1))
+
+
+# ------------------------------------------------------------------------------------------------
+def _ddp_fallback_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from dcpt_amd import ddp as DD, functional as DF
+
+    class _Emu(torch.autograd.Function):
+        """stands in for a fused HIP block on the CPU: y = x w^T + b with its parameter gradients written into the buffers
+        functional._grad_buffers hands out -- DDP's bucket views where they are known and unused, fresh tensors otherwise"""
+
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.owners = (w, b)
+            ctx.save_for_backward(x, w.detach(), b.detach())
+            return x @ w.detach().t() + b.detach()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w, b = ctx.saved_tensors
+            gw, gb = DF._grad_buffers((w, b), ctx.owners)
+            gw.copy_(dy.t() @ x)
+            gb.copy_(dy.sum(0))
+            return dy @ w, gw, gb
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.w1 = torch.nn.Parameter(torch.randn(16, 8, generator=g))
+            self.b1 = torch.nn.Parameter(torch.randn(16, generator=g))
+            self.w2 = torch.nn.Parameter(torch.randn(4, 16, generator=g))
+            self.b2 = torch.nn.Parameter(torch.randn(4, generator=g))
+
+        def forward(self, x):
+            return _Emu.apply(torch.tanh(_Emu.apply(x, self.w1, self.b1)), self.w2, self.b2)
+
+    class NoBuiltin(DistributedDataParallel):   # a torch without the private hook registration dcpt_amd.ddp prefers
+        def __getattribute__(self, name):
+            if name == "_register_builtin_comm_hook":
+                raise AttributeError(name)
+            return super().__getattribute__(name)
+
+    g = torch.Generator().manual_seed(100 + rank)
+    xa, xb = torch.randn(6, 8, generator=g), torch.randn(6, 8, generator=g)
+    res = {}
+    for variant in ("builtin", "fallback"):
+        net = Net()
+        model = (DistributedDataParallel if variant == "builtin" else NoBuiltin)(net, gradient_as_bucket_view=True)
+        assert hasattr(model, "_register_builtin_comm_hook") == (variant == "builtin")
+        DD.prepare(model)
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)   # lr 0: the parameters stay put, the post-step hook still records the bucket views
+        hits0 = DF._grad_buffers.hits
+        grads = []
+        for it in range(3):   # iteration 0: fresh tensors (no views known yet); from 1 on: the kernels' outputs ARE the bucket views
+            opt.zero_grad(set_to_none=True)
+            model(xa).square().mean().backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+            opt.step()
+        res[variant] = dict(grads=grads, hits=DF._grad_buffers.hits - hits0)
+        # gradient accumulation: micro-batch a under no_sync(), micro-batch b synchronised -> mean over ranks of the SUM of both
+        opt.zero_grad(set_to_none=True)
+        with model.no_sync():
+            model(xa).square().mean().backward()
+        model(xb).square().mean().backward()
+        res[variant]["accum"] = [p.grad.clone() for p in net.parameters()]
+    # what the ranks should have: plain autograd on an unwrapped copy
+    ref = Net()
+    own = {}
+    for name, x in (("a", xa), ("b", xb)):
+        ref.zero_grad(set_to_none=True)
+        ref(x).square().mean().backward()
+        own[name] = [p.grad.clone() for p in ref.parameters()]
+    torch.save(dict(res=res, own=own), os.path.join(out, f"f{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ddp_zero_copy_gradients_fallback_hook_and_no_sync_gloo(tmp_path):
+    """dcpt_amd/ddp.py on 2 gloo ranks (reference base_model.py:108-115 wraps the network in DDP): (1) with torch's private
+    ``_register_builtin_comm_hook`` ABSENT ``prepare`` falls back to the public Python all-reduce hook and the averaged gradients are the
+    same; (2) gradients written straight into DDP's bucket views (functional._grad_buffers, from the second iteration on) equal the mean
+    of the ranks' own gradients; (3) accumulation over two micro-batches, the first under ``no_sync()``, equals the mean over ranks of the
+    sum of both micro-batches' gradients -- a view is used at most once between two optimizer steps, the second backward falls back to
+    a fresh tensor that autograd accumulates."""
+    import torch.multiprocessing as mp
+
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_fallback_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"f{i}.pt")) for i in range(2)]
+    mean_a = [(x + y) / 2 for x, y in zip(r[0]["own"]["a"], r[1]["own"]["a"])]
+    mean_ab = [(xa + xb + ya + yb) / 2 for xa, xb, ya, yb in zip(r[0]["own"]["a"], r[0]["own"]["b"], r[1]["own"]["a"], r[1]["own"]["b"])]
+    for rank in range(2):
+        for variant in ("builtin", "fallback"):
+            v = r[rank]["res"][variant]
+            for it in range(3):
+                for g, want in zip(v["grads"][it], mean_a):
+                    assert torch.allclose(g, want, rtol=1e-6, atol=1e-7), (rank, variant, it)
+            assert v["hits"] >= 4, (variant, v["hits"])   # the zero-copy path was taken (4 parameters, iterations 1 and 2)
+            for g, want in zip(v["accum"], mean_ab):
+                assert torch.allclose(g, want, rtol=1e-6, atol=1e-7), (rank, variant, "no_sync accumulation")
+        for a, b in zip(r[rank]["res"]["builtin"]["grads"][2], r[rank]["res"]["fallback"]["grads"][2]):
+            assert torch.equal(a, b)

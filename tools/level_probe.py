@@ -17,21 +17,25 @@ for lvl, (c, hw, nblk) in enumerate([(64, 256, 2), (128, 128, 2), (256, 64, 2), 
     blk = fill_module_(NAFBlock(c)).to(dev)
     x = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     go = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
-    if BF:
+    if BF:   # through the MODULE, as the network runs it: the per-block packed-weights cache on (round-4 verdict: the bare call re-packed per call)
         x, go = x.bfloat16(), go.bfloat16()
-        fwd = lambda t: DF.nafblock_bf16(t, blk.fused_params())
-    else:
-        fwd = blk
+        blk.act_bf16 = True
+    fwd = blk
     x.requires_grad_(True)
     for _ in range(3):
         y = fwd(x); y.backward(go)
     n = 10
     e0, e1, e2 = ev(), ev(), ev()
     tf = tb = 0.0
-    for _ in range(n):
-        e0.record(); y = fwd(x); e1.record(); y.backward(go); e2.record(); torch.cuda.synchronize()
-        tf += e0.elapsed_time(e1); tb += e1.elapsed_time(e2)
-    tf /= n; tb /= n
+    ys = []
+    e0.record()
+    for _ in range(n):   # (no synchronisation inside the loops: back-to-back launches, as in a step)
+        ys.append(fwd(x))
+    e1.record()
+    for y in ys:
+        y.backward(go)
+    e2.record(); torch.cuda.synchronize()
+    tf = e0.elapsed_time(e1) / n; tb = e1.elapsed_time(e2) / n
     M = 32 * hw * hw
     gf = 36.0 * M * c * c / 1e9   # fwd+bwd GEMM flops of a block (6 c^2 MACs per pixel forward, x3)
     unit = M * c * ES / 1e6       # MB of one [M][C] tensor

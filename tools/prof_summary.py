@@ -4,7 +4,7 @@ in KiB and reads 1/2 of a wide coalesced stream -> x2; WRITE_SIZE in KiB, uncali
 import csv, glob, os, re, sys
 from collections import defaultdict
 
-root = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+root = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "auto" else 0.0   # 0 / "auto": counted from the trace
 
 def short(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n)
@@ -17,6 +17,11 @@ for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recur
         k = short(r['Kernel_Name']); d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         ktime[k][0] += 1; ktime[k][1] += d
 tot = sum(v[1] for v in ktime.values())
+if steps <= 0:
+    # one ending conv (conv3x3_b2s: features -> 3-channel image; the s2b kernel also serves the ending conv's data gradient) per network
+    # forward = per step, whatever passes bench.py has grown (round-4 verdict: a literal 3 made every per-step figure of
+    # profiles/r4/rocprofv3_summary_serialized.txt 2x)
+    steps = float(max(1, sum(c for k, (c, _) in ktime.items() if k.startswith('conv3x3_b2s_kernel'))))
 print(f"== kernel trace: {tot/1e3:.2f} ms total over {steps:g} steps = {tot/1e3/steps:.2f} ms/step")
 top = sorted(ktime.items(), key=lambda kv: -kv[1][1])
 for k, (c, us) in top[:30]:

@@ -14,7 +14,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES G
   timeout 900 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1
 done
 cd $ROOT
-python tools/prof_summary.py $OUT 3 > $OUT/summary.txt 2>&1
+python tools/prof_summary.py $OUT auto > $OUT/summary.txt 2>&1   # (steps = intro-conv launches in the trace)
 tail -60 $OUT/summary.txt
 # keep only the small files (the raw traces are big)
 find $OUT -name "*.csv" -size +20M -delete
