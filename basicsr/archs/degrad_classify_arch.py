@@ -109,12 +109,18 @@ class _DCHead(nn.Module):
     def _run_stages(self, x, features):
         bf = self.act_dtype == "bf16"
         for i, feature in enumerate(features):
-            x = DF.mix(None if x is None else DF.to_f32(x), DF.to_f32(feature), self.mixing_weights, i)   # fp32: one pass per stage
-            if bf:
-                x = DF.to_bf16(x)
+            if bf and feature.is_cuda and feature.dtype == torch.bfloat16 and (x is None or x.dtype == torch.bfloat16):
+                # taps and stage outputs both bf16 (the all-bf16 DCPT step): mixed in fp32, stored once -- no cast passes
+                x = DF.mix(x, feature, self.mixing_weights, i)
+            else:
+                x = DF.mix(None if x is None else DF.to_f32(x), DF.to_f32(feature), self.mixing_weights, i)   # fp32: one pass per stage
+                if bf:
+                    x = DF.to_bf16(x)
             x = self.bottleneck_layers[i](x)
             x = self.downsample_layers[i](x)
         x = self.last_stage(x)
+        if bf and x.is_cuda and x.dtype == torch.bfloat16:
+            return DF.meanpool_fc(x, self.fc.weight, self.fc.bias)   # pooled in fp32 straight from the bf16 map
         return DF.meanpool_fc(DF.to_f32(x), self.fc.weight, self.fc.bias)
 
 

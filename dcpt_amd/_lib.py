@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 _lock = threading.Lock()
 
@@ -154,6 +154,10 @@ SIGNATURES = {
     "dcpt_meanpool_fc_ws_bytes": (sz, [cint, cint, cint]),
     "dcpt_meanpool_fc_fwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_meanpool_fc_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_mix_fwd_bf16": (cint, [f32p, f32p, f32p, cint, cint, f32p, i64, stream_t]),
+    "dcpt_mix_bwd_bf16": (cint, [f32p, f32p, f32p, cint, cint, f32p, f32p, C.c_void_p, sz, i64, stream_t]),
+    "dcpt_meanpool_fc_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_meanpool_fc_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_patch_unfold": (cint, [f32p, f32p, cint, cint, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_patch_fold": (cint, [f32p, f32p, cint, cint, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint, cint]),

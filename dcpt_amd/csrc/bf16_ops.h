@@ -18,7 +18,7 @@ int launch_ln_act_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, c
 int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
 
-constexpr int WPACKB_MAX_JOBS = 10;
+constexpr int WPACKB_MAX_JOBS = 11;
 constexpr int WPACKB_MAX_JOBS_L = 80;   // the multi-block form (8 NAFBlocks per launch; 80 x 48 B of kernel arguments)
 template <int MAXJ>
 struct WpackBJobsT {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];

@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ>
         // of v_mfma_f32_32x32x16_bf16: lane (rho = lane & 31, kg = lane >> 5) holds W[row(rho)][16 ks + 8 kg ..+7], and the MFMA row rho
         // stands for channel 16 ((rho >> 2) & 1) + (rho & 3) + 4 (rho >> 3) of the tile, which makes the 16 accumulator registers of a lane
         // 16 CONSECUTIVE channels (32 contiguous bytes of a bf16 row).
-        const int C = K, CW = C / CHAIN_NW, NT = CW / 32, KS = C / 16, F4 = 2 * NT * KS, FR = F4 + NT * KS;
+        // (rs == null: the [2C][C] matrix alone -- conv1 for the kernel's LayerNorm1 -> conv1 form)
         const float* __restrict__ W5 = rs;
+        const int C = K, CW = C / CHAIN_NW, NT = CW / 32, KS = C / 16, F4 = 2 * NT * KS, FR = W5 ? F4 + NT * KS : F4;
         const int64_t nq = (int64_t)CHAIN_NW * FR * 64;
         for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
             const int lane = (int)(q & 63), fi = (int)((q >> 6) % FR), w = (int)((q >> 6) / FR);

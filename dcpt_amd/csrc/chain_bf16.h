@@ -21,6 +21,11 @@ struct ChainFwdB {
 bool chain_fwd_bf16_ok(int C, int64_t M);
 size_t chain_wstream_elems(int C);   // bf16 elements of Wf (3 C^2), 0 if the width has no chain kernel
 int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s);
+// First two links of the block on the same kernel, t1 = conv1(LayerNorm1(inp)) + b1 (nafnet_arch.py:169-170): y = inp, Wf = conv1's stream
+// (chain_head_wstream_elems(C) = 2 C^2 elements, pack mode 9 with no second matrix), b4 = conv1's bias, v = t1, xn2 / mu / rstd =
+// LayerNorm1's output and statistics (null: inference); b5 / gamma / out / g unused.
+size_t chain_head_wstream_elems(int C);
+int launch_chain_head_bf16(const ChainFwdB& p, int C, hipStream_t s);
 
 // geometry shared with the pack (bf16_ops.hip, mode 9): 8 waves per block, wave w owns gate channels [w C/8, (w+1) C/8)
 constexpr int CHAIN_NW = 8;

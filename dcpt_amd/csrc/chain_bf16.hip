@@ -103,7 +103,7 @@ struct Trickle {
     bool on;
 };
 template <int NF, int PER, class G>
-__device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)[8], rsrc_t wrs, uint32_t l16, uint32_t& wnext,
+__device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)[8], rsrc_t wrs, uint32_t l16, uint32_t& wnext, uint32_t wtot,
                                       const unsigned char* X, uint32_t xlane, const Trickle& tr) {
     static_assert(8 % NF == 0, "fragments per k-step must divide the ring");
     static_assert(PER >= 2 && 8 % PER == 0, "trickle period");
@@ -147,7 +147,7 @@ __device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)
 #endif
                 if (slot == 7) {
                     wnext += 8192u;
-                    if (wnext >= G::WTOT) wnext = 0;
+                    if (wnext >= wtot) wnext = 0;
                 }
             }
             {   // (unconditional: with nothing to store the window is empty and the range check drops the store -- no branch in the loop)
@@ -162,29 +162,34 @@ __device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)
     }
 }
 
-template <int C, int TM>
+// HEAD = 1: the first two links of the block instead, t1 = conv1(LayerNorm1(inp)) + b1 (reference nafnet_arch.py:169-170): `y` is the block
+// input, the weight stream holds conv1 only (its 2C outputs in the same passes of a lower and an upper 32-channel tile; b4 = conv1's
+// bias), `v` receives t1, `xn2` / `mu` / `rstd` LayerNorm1's output and statistics (conv1's weight-gradient operand; null in inference);
+// b5 / gamma / out / g are not touched.
+template <int C, int TM, int HEAD>
 __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) {
     using G = Geo<C, TM>;
     constexpr int MT = G::MT, NT = G::NT, PITCH = G::PITCH, CW = G::CW;
+    constexpr uint32_t WTOT = HEAD ? G::F4 * 1024u : G::WTOT;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
     unsigned char* const X = smem + G::XOFF;
     float* const tab = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < G::T_N; i += 512)
-        tab[i] = i < G::T_LB ? p.lnw[i] : i < G::T_B4 ? p.lnb[i - G::T_LB] : i < G::T_B5 ? p.b4[i - G::T_B4] : i < G::T_GM ? p.b5[i - G::T_B5] : p.gamma[i - G::T_GM];
+        tab[i] = i < G::T_LB ? p.lnw[i] : i < G::T_B4 ? p.lnb[i - G::T_LB] : i < G::T_B5 ? p.b4[i - G::T_B4] : HEAD ? 0.f : i < G::T_GM ? p.b5[i - G::T_B5] : p.gamma[i - G::T_GM];
 
     TL(0);
     block_sync();   // (the parameter tables)
     TL(1);
 
     // this wave's weight stream; the first eight fragments are on their way while the tile is normalised
-    const rsrc_t wrs = make_rsrc(p.Wf + (size_t)wave * G::FRAGS * 512);
+    const rsrc_t wrs = make_rsrc(p.Wf + (size_t)wave * (WTOT / 2));
     const uint32_t l16 = (uint32_t)lane * 16u;
     bf16x8 ring[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) ring[i] = ldfrag(wrs, l16, (uint32_t)i * 1024u);
-    uint32_t wnext = 8192u % G::WTOT;
+    uint32_t wnext = 8192u % WTOT;
 
     const int64_t ntiles = (p.M + TM - 1) / TM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
         const uint32_t nrows = (uint32_t)((p.M - row0) < TM ? (p.M - row0) : TM);
         // windows at the tile's first row, as long as its valid rows: rows past M read 0 and their stores are dropped
         const rsrc_t yr = make_rsrc(p.y + row0 * C, nrows * PITCH);
-        const rsrc_t outr = make_rsrc(p.out + row0 * C, nrows * PITCH);
+        const rsrc_t outr = make_rsrc(HEAD ? p.y : p.out + row0 * C, HEAD ? 0 : nrows * PITCH);
 
         // ---- the wave's 16 rows: HBM -> registers -> LDS (raw), coalesced ----
         {
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
         tr.cchunk = cchunk;
         tr.rbase = (G::RW * wave + crow) & 15;
         tr.on = p.xn2 != nullptr;
-        tr.dst = make_rsrc(tr.on ? p.xn2 + row0 * C : p.out, tr.on ? nrows * PITCH : 0);
+        tr.dst = make_rsrc(tr.on ? p.xn2 + row0 * C : p.y, tr.on ? nrows * PITCH : 0);
         TL(3);
         block_sync();   // LN2(y) of all 128 rows is in LDS
         TL(4);
@@ -286,10 +291,10 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
             tr.j0 = ps * (G::NI / NT);
-            kloop<2, G::KS / (G::NI / NT), G>(acc, ring, wrs, l16, wnext, X, xlane, tr);
+            kloop<2, G::KS / (G::NI / NT), G>(acc, ring, wrs, l16, wnext, WTOT, X, xlane, tr);
             TL(5 + 2 * ps);
             const int cb = CW * wave + 32 * ps + 16 * h;   // the lane's 16 consecutive channels (v1; the v2 partner is C + cb)
-            const rsrc_t vr = make_rsrc(p.v ? p.v + row0 * 2 * C : p.out, p.v ? nrows * 2 * PITCH : 0);
+            const rsrc_t vr = make_rsrc(p.v ? p.v + row0 * 2 * C : p.y, p.v ? nrows * 2 * PITCH : 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -309,11 +314,14 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
                         st16(pack8(u1), vr, vo);
                         st16(pack8(u2), vr, vo + PITCH);
                     }
-                    greg[ps][mt][hf] = pack8(gv);
-                    asm volatile("" : "+v"(greg[ps][mt][hf]));   // (pack NOW: otherwise the fp32 products stay live across the next pass and spill)
+                    if constexpr (!HEAD) {
+                        greg[ps][mt][hf] = pack8(gv);
+                        asm volatile("" : "+v"(greg[ps][mt][hf]));   // (pack NOW: otherwise the fp32 products stay live across the next pass and spill)
+                    }
                 }
             TL(6 + 2 * ps);
         }
+        if constexpr (!HEAD) {
         // the residual in the accumulator layout: the tile's rows of y again (read once already: L2 / Infinity Cache).  The first channel
         // tile's share is requested HERE -- it arrives while the block waits at the two barriers below (a load issued right before the
         // GEMM would hold up its first weight fragment: vmcnt retires in order) --, the rest while the first is finished
@@ -355,8 +363,8 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
                     for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
             tr.j0 = 0;
             tr.on = p.g != nullptr;
-            tr.dst = make_rsrc(tr.on ? p.g + row0 * C : p.out, tr.on ? nrows * PITCH : 0);
-            kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, X, xlane, tr);
+            tr.dst = make_rsrc(tr.on ? p.g + row0 * C : p.y, tr.on ? nrows * PITCH : 0);
+            kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, WTOT, X, xlane, tr);
             TL(12);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -384,6 +392,7 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
                     }
             }
         }
+        }
         TL(13);
 #ifdef CHAIN_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -403,11 +412,11 @@ int num_cus() {
     return n;
 }
 
-template <int C>
+template <int C, int HEAD>
 int launch_t(const ChainFwdB& p, hipStream_t s) {
     const int64_t ntiles = (p.M + 127) / 128;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
-    chain_fwd_bf16_kernel<C, 128><<<dim3(grid), dim3(512), 0, s>>>(p);
+    chain_fwd_bf16_kernel<C, 128, HEAD><<<dim3(grid), dim3(512), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("chain_fwd_bf16");
     return DCPT_OK;
 }
@@ -430,8 +439,19 @@ size_t chain_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)3 * 
 int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s) {
     DCPT_CHECK_ARG(p.y && p.Wf && p.out && p.lnw && p.lnb && p.b4 && p.b5 && p.gamma && p.M > 0, "chain_fwd_bf16: null argument");
     DCPT_CHECK_ARG((p.xn2 == nullptr) == (p.g == nullptr) && (p.mu == nullptr) == (p.rstd == nullptr), "chain_fwd_bf16: xn2 / g and mu / rstd come in pairs");
-    if (C == 512) return launch_t<512>(p, s);
-    if (C == 256) return launch_t<256>(p, s);
+    if (C == 512) return launch_t<512, 0>(p, s);
+    if (C == 256) return launch_t<256, 0>(p, s);
     dcpt_set_error("chain_fwd_bf16: no kernel for C=%d", C);
+    return DCPT_ERR_ARG;
+}
+
+size_t chain_head_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)2 * C * C : 0; }
+
+int launch_chain_head_bf16(const ChainFwdB& p, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(p.y && p.Wf && p.v && p.lnw && p.lnb && p.b4 && p.M > 0, "chain_head_bf16: null argument");
+    DCPT_CHECK_ARG((p.mu == nullptr) == (p.rstd == nullptr) && !p.g, "chain_head_bf16: mu / rstd come in pairs, g is not written");
+    if (C == 512) return launch_t<512, 1>(p, s);
+    if (C == 256) return launch_t<256, 1>(p, s);
+    dcpt_set_error("chain_head_bf16: no kernel for C=%d", C);
     return DCPT_ERR_ARG;
 }

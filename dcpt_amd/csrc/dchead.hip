@@ -5,6 +5,7 @@
 //   mean over H,W -> Linear                                                                 (:639-640)
 // The convolutions are MFMA GEMMs (gemm_nt/gemm_tn with the implicit-GEMM 3x3 loader); channels-first
 // LayerNorm on an NCHW tensor is a per-pixel row LayerNorm in NHWC, i.e. the ln.hip kernels.
+#include "bf16.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "../../include/dcpt_hip.h"
@@ -75,6 +76,18 @@ __global__ __launch_bounds__(256) void pool_relu_bwd_kernel(const float* __restr
 }
 
 // ---- mixing -------------------------------------------------------------------------------------
+// (the mixing step and the mean + Linear are templated on the STORAGE type of the feature maps: float, or bf16_t for the all-bf16 head --
+// arithmetic and reductions are fp32 either way, so the bf16 entry points give exactly what the fp32 ones gave behind casts)
+template <typename ST>
+__device__ __forceinline__ float4 ld4s(const ST* p) {
+    if constexpr (sizeof(ST) == 2) return bf4_unpack(*reinterpret_cast<const u32x2*>(p));
+    else return ldg4(p);
+}
+template <typename ST>
+__device__ __forceinline__ void st4s(ST* p, float4 v) {
+    if constexpr (sizeof(ST) == 2) *reinterpret_cast<u32x2*>(p) = bf4_pack(v);
+    else stg4(p, v);
+}
 __device__ __forceinline__ float softmax_i(const float* w, int n, int i) {
     float m = w[0];
     for (int j = 1; j < n; ++j) m = fmaxf(m, w[j]);
@@ -83,29 +96,31 @@ __device__ __forceinline__ float softmax_i(const float* w, int n, int i) {
     return expf(w[i] - m) / s;
 }
 
-__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ prev, const float* __restrict__ feat,
-                                                      const float* __restrict__ mw, int n, int idx, float* __restrict__ out,
+template <typename ST>
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const ST* __restrict__ prev, const ST* __restrict__ feat,
+                                                      const float* __restrict__ mw, int n, int idx, ST* __restrict__ out,
                                                       int64_t nq) {
     const float s = softmax_i(mw, n, idx);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
-        const float4 f = ldg4(feat + 4 * i);
+        const float4 f = ld4s(feat + 4 * i);
         float4 o = f4_scale(f, s);
-        if (prev) o = f4_add(o, ldg4(prev + 4 * i));
-        stg4(out + 4 * i, o);
+        if (prev) o = f4_add(o, ld4s(prev + 4 * i));
+        st4s(out + 4 * i, o);
     }
 }
 
 // dfeat = s*dout ; part[block] = sum dout*feat
-__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ feat,
-                                                      const float* __restrict__ mw, int n, int idx, float* __restrict__ dfeat,
+template <typename ST>
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const ST* __restrict__ dout, const ST* __restrict__ feat,
+                                                      const float* __restrict__ mw, int n, int idx, ST* __restrict__ dfeat,
                                                       float* __restrict__ part, int64_t nq) {
     __shared__ float red[256];
     const float s = softmax_i(mw, n, idx);
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
-        const float4 g = ldg4(dout + 4 * i), f = ldg4(feat + 4 * i);
+        const float4 g = ld4s(dout + 4 * i), f = ld4s(feat + 4 * i);
         acc += f4_sum(f4_mul(g, f));
-        stg4(dfeat + 4 * i, f4_scale(g, s));
+        st4s(dfeat + 4 * i, f4_scale(g, s));
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -137,7 +152,8 @@ __global__ __launch_bounds__(256) void mix_bwd_final_kernel(const float* __restr
 
 // ---- mean over pixels + linear ------------------------------------------------------------------
 // part[b][j][c] = sum over pixel slice j
-__global__ __launch_bounds__(256) void meanpool_part_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int P,
+template <typename ST>
+__global__ __launch_bounds__(256) void meanpool_part_kernel(const ST* __restrict__ x, float* __restrict__ part, int C, int P,
                                                             int nsl) {
     __shared__ float4 red[256];
     const int b = blockIdx.z, j = blockIdx.y;
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(256) void meanpool_part_kernel(const float* __restr
     if (pend > P) pend = P;
     float4 acc = f4_zero();
     if (qok)
-        for (int px = pbeg + pl; px < pend; px += pb) acc = f4_add(acc, ldg4(x + ((int64_t)b * P + px) * C + 4 * q));
+        for (int px = pbeg + pl; px < pend; px += pb) acc = f4_add(acc, ld4s(x + ((int64_t)b * P + px) * C + 4 * q));
     red[tid] = acc;
     __syncthreads();
     if (pl == 0 && qok) {
@@ -215,14 +231,15 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float* __restrict__ g
 }
 
 // dx[b][p][c] = dxrow[b][c]
-__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ dxrow, float* __restrict__ dx, int B, int P,
+template <typename ST>
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ dxrow, ST* __restrict__ dx, int B, int P,
                                                          int C) {
     const int nq = C / 4;
     const int64_t total = (int64_t)B * P * nq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int q = (int)(i % nq);
         const int64_t b = i / nq / P;
-        stg4(dx + 4 * i, ldg4(dxrow + b * C + 4 * q));
+        st4s(dx + 4 * i, ldg4(dxrow + b * C + 4 * q));
     }
 }
 
@@ -410,30 +427,46 @@ extern "C" int dcpt_conv1x1_pool_relu_bwd(const float* dy, const float* x, const
 }
 
 // ---------------------------------------------------------------------------------------------
-extern "C" int dcpt_mix_fwd(const float* prev, const float* feat, const float* mixing_weights, int n, int idx, float* out,
-                            int64_t numel, dcpt_stream_t stream) {
+template <typename ST>
+static int mix_fwd_t(const ST* prev, const ST* feat, const float* mixing_weights, int n, int idx, ST* out, int64_t numel, hipStream_t s) {
     DCPT_CHECK_ARG(feat && mixing_weights && out && n >= 1 && n <= 64 && idx >= 0 && idx < n && numel % 4 == 0, "mix_fwd: bad argument");
-    mix_fwd_kernel<<<dim3(grid_for(numel / 4)), dim3(256), 0, (hipStream_t)stream>>>(prev, feat, mixing_weights, n, idx, out, numel / 4);
+    mix_fwd_kernel<ST><<<dim3(grid_for(numel / 4)), dim3(256), 0, s>>>(prev, feat, mixing_weights, n, idx, out, numel / 4);
     DCPT_CHECK_LAUNCH("mix_fwd");
     return DCPT_OK;
+}
+extern "C" int dcpt_mix_fwd(const float* prev, const float* feat, const float* mixing_weights, int n, int idx, float* out,
+                            int64_t numel, dcpt_stream_t stream) {
+    return mix_fwd_t<float>(prev, feat, mixing_weights, n, idx, out, numel, (hipStream_t)stream);
+}
+extern "C" int dcpt_mix_fwd_bf16(const uint16_t* prev, const uint16_t* feat, const float* mixing_weights, int n, int idx, uint16_t* out,
+                                 int64_t numel, dcpt_stream_t stream) {
+    return mix_fwd_t<bf16_t>(prev, feat, mixing_weights, n, idx, out, numel, (hipStream_t)stream);
 }
 
 extern "C" size_t dcpt_mix_bwd_ws_bytes(int64_t numel) { return align_up((size_t)grid_for(numel / 4) * sizeof(float), 256); }
 
-extern "C" int dcpt_mix_bwd(const float* dout, const float* feat, const float* mixing_weights, int n, int idx, float* dfeat,
-                            float* dmix, void* ws, size_t ws_bytes, int64_t numel, dcpt_stream_t stream) {
-    hipStream_t s = (hipStream_t)stream;
+template <typename ST>
+static int mix_bwd_t(const ST* dout, const ST* feat, const float* mixing_weights, int n, int idx, ST* dfeat, float* dmix, void* ws,
+                     size_t ws_bytes, int64_t numel, hipStream_t s) {
     DCPT_CHECK_ARG(dout && feat && mixing_weights && dfeat && dmix && n >= 1 && n <= 64 && numel % 4 == 0, "mix_bwd: bad argument");
     if (ws == nullptr || ws_bytes < dcpt_mix_bwd_ws_bytes(numel)) {
         dcpt_set_error("mix_bwd: workspace too small");
         return DCPT_ERR_WS;
     }
     const unsigned nb = grid_for(numel / 4);
-    mix_bwd_kernel<<<dim3(nb), dim3(256), 0, s>>>(dout, feat, mixing_weights, n, idx, dfeat, (float*)ws, numel / 4);
+    mix_bwd_kernel<ST><<<dim3(nb), dim3(256), 0, s>>>(dout, feat, mixing_weights, n, idx, dfeat, (float*)ws, numel / 4);
     DCPT_CHECK_LAUNCH("mix_bwd");
     mix_bwd_final_kernel<<<dim3(1), dim3(256), 0, s>>>((float*)ws, (int)nb, mixing_weights, n, idx, dmix);
     DCPT_CHECK_LAUNCH("mix_bwd_final");
     return DCPT_OK;
+}
+extern "C" int dcpt_mix_bwd(const float* dout, const float* feat, const float* mixing_weights, int n, int idx, float* dfeat,
+                            float* dmix, void* ws, size_t ws_bytes, int64_t numel, dcpt_stream_t stream) {
+    return mix_bwd_t<float>(dout, feat, mixing_weights, n, idx, dfeat, dmix, ws, ws_bytes, numel, (hipStream_t)stream);
+}
+extern "C" int dcpt_mix_bwd_bf16(const uint16_t* dout, const uint16_t* feat, const float* mixing_weights, int n, int idx, uint16_t* dfeat,
+                                 float* dmix, void* ws, size_t ws_bytes, int64_t numel, dcpt_stream_t stream) {
+    return mix_bwd_t<bf16_t>(dout, feat, mixing_weights, n, idx, dfeat, dmix, ws, ws_bytes, numel, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -448,9 +481,9 @@ extern "C" size_t dcpt_meanpool_fc_ws_bytes(int B, int P, int C) {
     return align_up((size_t)B * pool_slices(P) * C * sizeof(float), 256) + align_up((size_t)B * C * sizeof(float), 256);
 }
 
-extern "C" int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float* fb, float* pooled, float* logits, void* ws,
-                                    size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream) {
-    hipStream_t s = (hipStream_t)stream;
+template <typename ST>
+static int meanpool_fc_fwd_t(const ST* x, const float* fw, const float* fb, float* pooled, float* logits, void* ws, size_t ws_bytes, int B,
+                             int P, int C, int NC, hipStream_t s) {
     DCPT_CHECK_ARG(x && fw && pooled && logits && C % 4 == 0 && B <= 65535 && C * 4 <= 65536, "meanpool_fc_fwd: bad argument");
     if (ws == nullptr || ws_bytes < dcpt_meanpool_fc_ws_bytes(B, P, C)) {
         dcpt_set_error("meanpool_fc_fwd: workspace too small");
@@ -459,16 +492,24 @@ extern "C" int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float
     const int nsl = pool_slices(P), nq = C / 4;
     int qb = 1;
     while (qb < nq && qb < 256) qb <<= 1;
-    meanpool_part_kernel<<<dim3(cdiv(nq, qb), nsl, B), dim3(256), 0, s>>>(x, (float*)ws, C, P, nsl);
+    meanpool_part_kernel<ST><<<dim3(cdiv(nq, qb), nsl, B), dim3(256), 0, s>>>(x, (float*)ws, C, P, nsl);
     DCPT_CHECK_LAUNCH("meanpool_part");
     fc_fwd_kernel<<<dim3(B), dim3(256), C * sizeof(float), s>>>((float*)ws, nsl, fw, fb, pooled, logits, C, NC, 1.0f / (float)P);
     DCPT_CHECK_LAUNCH("fc_fwd");
     return DCPT_OK;
 }
+extern "C" int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float* fb, float* pooled, float* logits, void* ws,
+                                    size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream) {
+    return meanpool_fc_fwd_t<float>(x, fw, fb, pooled, logits, ws, ws_bytes, B, P, C, NC, (hipStream_t)stream);
+}
+extern "C" int dcpt_meanpool_fc_fwd_bf16(const uint16_t* x, const float* fw, const float* fb, float* pooled, float* logits, void* ws,
+                                         size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream) {
+    return meanpool_fc_fwd_t<bf16_t>(x, fw, fb, pooled, logits, ws, ws_bytes, B, P, C, NC, (hipStream_t)stream);
+}
 
-extern "C" int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, const float* fw, float* dx, float* dfw, float* dfb,
-                                    void* ws, size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream) {
-    hipStream_t s = (hipStream_t)stream;
+template <typename ST>
+static int meanpool_fc_bwd_t(const float* dlogits, const float* pooled, const float* fw, ST* dx, float* dfw, float* dfb, void* ws,
+                             size_t ws_bytes, int B, int P, int C, int NC, hipStream_t s) {
     DCPT_CHECK_ARG(dlogits && pooled && fw && dx && dfw && dfb && C % 4 == 0, "meanpool_fc_bwd: bad argument");
     if (ws == nullptr || ws_bytes < dcpt_meanpool_fc_ws_bytes(B, P, C)) {
         dcpt_set_error("meanpool_fc_bwd: workspace too small");
@@ -478,9 +519,17 @@ extern "C" int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, c
     const int64_t mx = (int64_t)B * C > (int64_t)NC * C ? (int64_t)B * C : (int64_t)NC * C;
     fc_bwd_kernel<<<dim3((unsigned)cdiv64(mx, 256), 3), dim3(256), 0, s>>>(dlogits, pooled, fw, dxrow, dfw, dfb, B, C, NC, 1.0f / (float)P);
     DCPT_CHECK_LAUNCH("fc_bwd");
-    bcast_rows_kernel<<<dim3(grid_for((int64_t)B * P * (C / 4))), dim3(256), 0, s>>>(dxrow, dx, B, P, C);
+    bcast_rows_kernel<ST><<<dim3(grid_for((int64_t)B * P * (C / 4))), dim3(256), 0, s>>>(dxrow, dx, B, P, C);
     DCPT_CHECK_LAUNCH("bcast_rows");
     return DCPT_OK;
+}
+extern "C" int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, const float* fw, float* dx, float* dfw, float* dfb,
+                                    void* ws, size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream) {
+    return meanpool_fc_bwd_t<float>(dlogits, pooled, fw, dx, dfw, dfb, ws, ws_bytes, B, P, C, NC, (hipStream_t)stream);
+}
+extern "C" int dcpt_meanpool_fc_bwd_bf16(const float* dlogits, const float* pooled, const float* fw, uint16_t* dx, float* dfw, float* dfb,
+                                         void* ws, size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream) {
+    return meanpool_fc_bwd_t<bf16_t>(dlogits, pooled, fw, dx, dfw, dfb, ws, ws_bytes, B, P, C, NC, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

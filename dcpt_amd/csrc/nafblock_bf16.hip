@@ -37,11 +37,15 @@ bool ffn_fused(int C) {
 // 128) keeps the three-kernel chain, which scales with M (measured: 2K tiled inference 25.9 -> 58 ms with the chain kernel forced).
 bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 1 << 20); }
 bool ffn_chain_use(int C, int64_t M) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, M); }
+bool chain_head_on() {
+    static const int on = dcpt_tuning("DCPT_CHAIN_HEAD", 1);
+    return on != 0;
+}
 
 struct FwdWsB {
     float* w2p;
     float* pool_part;
-    bf16_t *W1, *W4, *W5, *W3s, *W3, *t2s, *Wf;
+    bf16_t *W1, *W4, *W5, *W3s, *W3, *t2s, *Wf, *Wf1;
     bf16_t *xn2, *g;   // stand-ins for saved->xn2 / g / mu2 / rstd2 where a caller left them NULL (allowed at the chain widths) and the launch
     float *mu2, *rstd2;   // runs the three-kernel chain after all
     int nblk_pool;
@@ -63,6 +67,7 @@ size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* 
     w.W4 = a.get<bf16_t>((size_t)2 * C * C);
     w.W5 = a.get<bf16_t>((size_t)C * C);
     w.Wf = ffn_chain(C) ? a.get<bf16_t>(chain_wstream_elems(C)) : nullptr;
+    w.Wf1 = ffn_chain(C) ? a.get<bf16_t>(chain_head_wstream_elems(C)) : nullptr;   // conv1 for the LayerNorm1 -> conv1 form of the kernel
     w.xn2 = w.g = nullptr;
     w.mu2 = w.rstd2 = nullptr;
     if (ffn_chain(C) && !ffn_chain_use(C, (int64_t)B * H * W)) {
@@ -231,7 +236,7 @@ bool shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C 
 // keeps this buffer per block and refreshes it when the parameters change (once per optimizer step) saves the per-call packs:
 // 5 launches per block and step (dcpt_nafblock_wpack_bf16 / *_packed entry points).
 struct PackB {
-    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3, *Wf;
+    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3, *Wf, *Wf1;
     float* w2p;
 };
 size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
@@ -247,15 +252,17 @@ size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
     k.w2p = a.get<float>((size_t)18 * C);
     k.W3 = a.get<bf16_t>((size_t)C * C);
     k.Wf = ffn_chain(C) ? a.get<bf16_t>(chain_wstream_elems(C)) : nullptr;   // conv4 + conv5 in the chain kernel's fragment order
+    k.Wf1 = ffn_chain(C) ? a.get<bf16_t>(chain_head_wstream_elems(C)) : nullptr;   // conv1 likewise
     if (out) *out = k;
     return a.off;
 }
-constexpr int PACK_JOBS = 10;   // jobs of one block at most
+constexpr int PACK_JOBS = 11;   // jobs of one block at most
 template <typename J>
 int pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b) {   // the block's nine or ten jobs at j[b ..]; returns their number
     const int C2 = 2 * C;
     if (k.Wf) {
         j.in[b + 9] = p->conv4_w; j.rs[b + 9] = p->conv5_w; j.out[b + 9] = k.Wf; j.N[b + 9] = 3 * C; j.K[b + 9] = C; j.transpose[b + 9] = 9;
+        j.in[b + 10] = p->conv1_w; j.rs[b + 10] = nullptr; j.out[b + 10] = k.Wf1; j.N[b + 10] = 2 * C; j.K[b + 10] = C; j.transpose[b + 10] = 9;
     }
     j.in[b + 8] = p->conv3_w; j.out[b + 8] = k.W3; j.N[b + 8] = C; j.K[b + 8] = C;
     j.in[b + 0] = p->conv1_w; j.out[b + 0] = k.W1; j.N[b + 0] = C2; j.K[b + 0] = C;
@@ -266,7 +273,7 @@ int pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b)
     j.in[b + 5] = p->conv3_w; j.out[b + 5] = k.wT3; j.rs[b + 5] = p->beta;  j.N[b + 5] = C;  j.K[b + 5] = C; j.transpose[b + 5] = 1;
     j.in[b + 6] = p->conv1_w; j.out[b + 6] = k.wT1; j.rs[b + 6] = nullptr;  j.N[b + 6] = C2; j.K[b + 6] = C; j.transpose[b + 6] = 1;
     j.in[b + 7] = p->conv2_w; j.out[b + 7] = reinterpret_cast<bf16_t*>(k.w2p); j.N[b + 7] = C2; j.K[b + 7] = 9; j.transpose[b + 7] = 8;
-    return k.Wf ? 10 : 9;
+    return k.Wf ? 11 : 9;
 }
 int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
     WpackBJobs j{};
@@ -340,7 +347,7 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     if (packed) {
         PackB k;
         DCPT_CHECK_ARG(pack_layout(C, const_cast<void*>(packed), packed_bytes, &k) <= packed_bytes, "nafblock_fwd_bf16: packed weights buffer too small");
-        w.W1 = k.W1; w.W4 = k.W4; w.W5 = k.W5; w.w2p = k.w2p; w.Wf = k.Wf;
+        w.W1 = k.W1; w.W4 = k.W4; w.W5 = k.W5; w.w2p = k.w2p; w.Wf = k.Wf; w.Wf1 = k.Wf1;
         if (w.scale_act) w.W3 = k.W3;
     } else {
         j.n = 3;
@@ -350,6 +357,8 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         }
         if (w.Wf) {
             j.in[j.n] = p->conv4_w; j.rs[j.n] = p->conv5_w; j.out[j.n] = w.Wf; j.N[j.n] = 3 * C; j.K[j.n] = C; j.transpose[j.n] = 9;
+            ++j.n;
+            j.in[j.n] = p->conv1_w; j.rs[j.n] = nullptr; j.out[j.n] = w.Wf1; j.N[j.n] = 2 * C; j.K[j.n] = C; j.transpose[j.n] = 9;
             ++j.n;
         }
         j.in[0] = p->conv1_w; j.out[0] = w.W1; j.N[0] = 2 * C; j.K[0] = C;
@@ -363,6 +372,11 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         f.y = inp; f.lnw = p->norm1_w; f.lnb = p->norm1_b; f.W4 = w.W1; f.b4 = p->conv1_b; f.v = sv->t1; f.xn2 = sv->xn1; f.mu = sv->mu1;
         f.rstd = sv->rstd1; f.M = M; f.eps = eps;
         DCPT_TRY(launch_ln_conv_bf16(f, C, s));
+    } else if (ffn_chain_use(C, M) && chain_head_on()) {   // wide levels: the same pair on the chain kernel (chain_bf16.hip, HEAD form)
+        ChainFwdB f{};
+        f.y = inp; f.lnw = p->norm1_w; f.lnb = p->norm1_b; f.Wf = w.Wf1; f.b4 = p->conv1_b; f.v = sv->t1; f.xn2 = sv->xn1; f.mu = sv->mu1;
+        f.rstd = sv->rstd1; f.M = M; f.eps = eps;
+        DCPT_TRY(launch_chain_head_bf16(f, C, s));
     } else {
         DCPT_TRY(launch_ln_fwd_bf16(inp, p->norm1_w, p->norm1_b, sv->xn1, sv->mu1, sv->rstd1, M, C, eps, s));
         g.M = M; g.A = sv->xn1; g.lda = C; g.K = C; g.Bw = w.W1; g.N = 2 * C; g.C = sv->t1; g.ldc = 2 * C; g.bias = p->conv1_b;

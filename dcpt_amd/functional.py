@@ -279,6 +279,17 @@ def _empty_nhwc_bf16(n, c, h, w, dev) -> torch.Tensor:
     return torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=torch.bfloat16, device=dev)
 
 
+def _require_gpu_feat(*ts):
+    """feature maps of the ops that exist in both storage types: fp32 or bf16, on the device"""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DcptHipError("dcpt_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.DcptHipError(f"feature maps are fp32 or bf16 (got {t.dtype})")
+
+
 def _require_gpu_bf16(*ts):
     for t in ts:
         if not t.is_cuda:
@@ -1256,13 +1267,19 @@ class _MixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prev, feat, mixing_weights, idx):
         lib = _lib.load()
-        _require_gpu(prev, feat, mixing_weights)
+        _require_gpu_feat(prev, feat)
+        _require_gpu(mixing_weights)
         feat = _nhwc(feat)
         prev_ = None if prev is None else _nhwc(prev)
         mw = _contig(mixing_weights.detach())
-        out = _empty_nhwc(*feat.shape, feat.device)
-        check(lib.dcpt_mix_fwd(_p(prev_), feat.data_ptr(), mw.data_ptr(), mw.numel(), int(idx), out.data_ptr(), feat.numel(),
-                               _stream(feat.device)), "dcpt_mix_fwd")
+        # bf16 storage (the all-bf16 head: taps and the previous stage's output both bf16): the same arithmetic without cast passes
+        bf = feat.dtype == torch.bfloat16
+        if bf and prev_ is not None and prev_.dtype != torch.bfloat16:
+            raise _lib.DcptHipError("mix: prev and feat must have the same storage dtype")
+        out = (_empty_nhwc_bf16 if bf else _empty_nhwc)(*feat.shape, feat.device)
+        fn = lib.dcpt_mix_fwd_bf16 if bf else lib.dcpt_mix_fwd
+        check(fn(_p(prev_), feat.data_ptr(), mw.data_ptr(), mw.numel(), int(idx), out.data_ptr(), feat.numel(), _stream(feat.device)),
+              "dcpt_mix_fwd")
         ctx.save_for_backward(feat, mw)
         ctx.idx, ctx.has_prev = int(idx), prev is not None
         return out
@@ -1271,13 +1288,15 @@ class _MixFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         feat, mw = ctx.saved_tensors
-        dout = _nhwc(dout)
+        bf = feat.dtype == torch.bfloat16
+        dout = _nhwc(dout if dout.dtype == feat.dtype else dout.to(feat.dtype))
         dev = feat.device
-        dfeat = _empty_nhwc(*feat.shape, dev)
+        dfeat = (_empty_nhwc_bf16 if bf else _empty_nhwc)(*feat.shape, dev)
         dmix = torch.empty_like(mw)
         ws = _workspace(dev, lib.dcpt_mix_bwd_ws_bytes(feat.numel()))
-        check(lib.dcpt_mix_bwd(dout.data_ptr(), feat.data_ptr(), mw.data_ptr(), mw.numel(), ctx.idx, dfeat.data_ptr(),
-                               dmix.data_ptr(), ws.data_ptr(), ws.numel(), feat.numel(), _stream(dev)), "dcpt_mix_bwd")
+        fn = lib.dcpt_mix_bwd_bf16 if bf else lib.dcpt_mix_bwd
+        check(fn(dout.data_ptr(), feat.data_ptr(), mw.data_ptr(), mw.numel(), ctx.idx, dfeat.data_ptr(), dmix.data_ptr(), ws.data_ptr(),
+                 ws.numel(), feat.numel(), _stream(dev)), "dcpt_mix_bwd")
         return (dout if ctx.has_prev else None), dfeat, dmix, None
 
 
@@ -1292,7 +1311,8 @@ class _MeanPoolFCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, fw, fb):
         lib = _lib.load()
-        _require_gpu(x, fw, fb)
+        _require_gpu_feat(x)
+        _require_gpu(fw, fb)
         x = _nhwc(x)
         fw_, fb_ = _contig(fw.detach()), (None if fb is None else _contig(fb.detach()))
         B, Cc, H, W = x.shape
@@ -1301,10 +1321,12 @@ class _MeanPoolFCFn(torch.autograd.Function):
         pooled = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         logits = torch.empty((B, NC), dtype=torch.float32, device=dev)
         ws = _workspace(dev, lib.dcpt_meanpool_fc_ws_bytes(B, H * W, Cc))
-        check(lib.dcpt_meanpool_fc_fwd(x.data_ptr(), fw_.data_ptr(), _p(fb_), pooled.data_ptr(), logits.data_ptr(), ws.data_ptr(),
-                                       ws.numel(), B, H * W, Cc, NC, _stream(dev)), "dcpt_meanpool_fc_fwd")
+        bf = x.dtype == torch.bfloat16   # bf16-storage feature map: pooled in fp32 straight from it, its gradient stored in bf16
+        fn = lib.dcpt_meanpool_fc_fwd_bf16 if bf else lib.dcpt_meanpool_fc_fwd
+        check(fn(x.data_ptr(), fw_.data_ptr(), _p(fb_), pooled.data_ptr(), logits.data_ptr(), ws.data_ptr(), ws.numel(), B, H * W, Cc, NC,
+                 _stream(dev)), "dcpt_meanpool_fc_fwd")
         ctx.save_for_backward(pooled, fw_)
-        ctx.shape, ctx.has_bias = (B, Cc, H, W), fb is not None
+        ctx.shape, ctx.has_bias, ctx.bf = (B, Cc, H, W), fb is not None, bf
         return logits
 
     @staticmethod
@@ -1315,13 +1337,13 @@ class _MeanPoolFCFn(torch.autograd.Function):
         NC = fw_.shape[0]
         dev = pooled.device
         dl = _contig(dlogits)
-        dx = _empty_nhwc(B, Cc, H, W, dev)
+        dx = (_empty_nhwc_bf16 if ctx.bf else _empty_nhwc)(B, Cc, H, W, dev)
         dfw = torch.empty_like(fw_)
         dfb = torch.empty((NC,), dtype=torch.float32, device=dev)
         ws = _workspace(dev, lib.dcpt_meanpool_fc_ws_bytes(B, H * W, Cc))
-        check(lib.dcpt_meanpool_fc_bwd(dl.data_ptr(), pooled.data_ptr(), fw_.data_ptr(), dx.data_ptr(), dfw.data_ptr(),
-                                       dfb.data_ptr(), ws.data_ptr(), ws.numel(), B, H * W, Cc, NC, _stream(dev)),
-              "dcpt_meanpool_fc_bwd")
+        fn = lib.dcpt_meanpool_fc_bwd_bf16 if ctx.bf else lib.dcpt_meanpool_fc_bwd
+        check(fn(dl.data_ptr(), pooled.data_ptr(), fw_.data_ptr(), dx.data_ptr(), dfw.data_ptr(), dfb.data_ptr(), ws.data_ptr(), ws.numel(),
+                 B, H * W, Cc, NC, _stream(dev)), "dcpt_meanpool_fc_bwd")
         return dx, dfw, (dfb if ctx.has_bias else None)
 
 

@@ -295,6 +295,17 @@ int dcpt_meanpool_fc_fwd(const float* x, const float* fw, const float* fb, float
                          int B, int P, int C, int NC, dcpt_stream_t stream);
 int dcpt_meanpool_fc_bwd(const float* dlogits, const float* pooled, const float* fw, float* dx, float* dfw, float* dfb, void* ws,
                          size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream);
+/* ABI 11: the same four with the feature maps (prev / feat / out, dout / dfeat; x, dx) in bf16 storage -- the all-bf16 head
+ * (degrad_classify_arch.py:632-640 with act_dtype "bf16") mixes and pools without cast passes.  Arithmetic and reductions are fp32, one
+ * rounding on store: the results equal the fp32 entry points' behind casts, bit for bit.  Workspaces as above. */
+int dcpt_mix_fwd_bf16(const uint16_t* prev, const uint16_t* feat, const float* mixing_weights, int n, int idx, uint16_t* out, int64_t numel,
+                      dcpt_stream_t stream);
+int dcpt_mix_bwd_bf16(const uint16_t* dout, const uint16_t* feat, const float* mixing_weights, int n, int idx, uint16_t* dfeat, float* dmix,
+                      void* ws, size_t ws_bytes, int64_t numel, dcpt_stream_t stream);
+int dcpt_meanpool_fc_fwd_bf16(const uint16_t* x, const float* fw, const float* fb, float* pooled, float* logits, void* ws, size_t ws_bytes,
+                              int B, int P, int C, int NC, dcpt_stream_t stream);
+int dcpt_meanpool_fc_bwd_bf16(const float* dlogits, const float* pooled, const float* fw, uint16_t* dx, float* dfw, float* dfb, void* ws,
+                              size_t ws_bytes, int B, int P, int C, int NC, dcpt_stream_t stream);
 /* PromptIR_DC.conv_embed (:491-494, Conv2d(3, dim, 7, 2, 3) + bias -> LayerNorm): the strided conv over the NCHW image is
  * unfolded into patch rows A[(b,oy,ox)][Kp], column k = (c*ksize + ky)*ksize + kx (the weight's own order), column
  * Cin*ksize*ksize = 1 (the bias column), the rest 0 up to Kp (a multiple of 4); the product + LayerNorm then run through

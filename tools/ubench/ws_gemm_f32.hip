@@ -21,7 +21,7 @@ __device__ __forceinline__ void block_sync() { asm volatile("s_waitcnt lgkmcnt(0
 // Wf: per wave FR = (K / 8) * NF fragments of 1 KB: q-group q (k = kk K/2 + 4q .. 4q + 3), then channel tile f
 template <int K, int N>
 __global__ __launch_bounds__(512) void ws_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Wf, const float* __restrict__ bias,
-                                                     float* __restrict__ Cout, int64_t M) {
+                                                     float* __restrict__ Cout, int64_t M, int reps) {
     constexpr int CW = N / NW, NF = CW / 32, PITCH = K * 4, NQ = K / 8, FRAGS = NQ * NF;
     constexpr uint32_t WTOT = FRAGS * 1024u;
     constexpr int RING = 8, QPR = RING / NF;   // q-groups per turn of the ring
@@ -73,6 +73,10 @@ __global__ __launch_bounds__(512) void ws_gemm_kernel(const float* __restrict__ 
         floatx4 b[2][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) b[0][mt] = *reinterpret_cast<const floatx4*>(X + xlane + mt * 32 * PITCH);
+        // reps > 1: the k-loop over and over on the same tile (the result is reps x the product) -- the loop alone, without the tile load and
+        // the epilogue: what the matrix pipe sustains when NOTHING else is in the way (MfmaUtil and clock by tools/pmc_cmd.sh)
+#pragma unroll 1
+        for (int rp = 0; rp < reps; ++rp)
 #pragma unroll 1
         for (int o = 0; o < NQ / 16; ++o) {
             const uint32_t xo = xlane + (uint32_t)o * 256u;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(512) void ws_gemm_kernel(const float* __restrict__ 
 }
 
 template <int K, int N>
-void run(int64_t M, int grid) {
+void run(int64_t M, int grid, int kreps = 1) {
     constexpr int CW = N / NW, NF = CW / 32, NQ = K / 8, FRAGS = NQ * NF;
     std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N), hWf((size_t)NW * FRAGS * 256);
     srand(1);
@@ -141,10 +145,10 @@ void run(int64_t M, int grid) {
     (void)hipMemcpy(b, hb.data(), N * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) ws_gemm_kernel<K, N><<<grid, 512>>>(A, Wf, b, C, M);
+    for (int i = 0; i < 3; ++i) ws_gemm_kernel<K, N><<<grid, 512>>>(A, Wf, b, C, M, kreps);
     const int reps = 20;
     (void)hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) ws_gemm_kernel<K, N><<<grid, 512>>>(A, Wf, b, C, M);
+    for (int i = 0; i < reps; ++i) ws_gemm_kernel<K, N><<<grid, 512>>>(A, Wf, b, C, M, kreps);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -158,19 +162,22 @@ void run(int64_t M, int grid) {
         const int n = rand() % N;
         double ref = hb[n];
         for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)mi * K + k] * hW[(size_t)n * K + k];
-        worst = fmax(worst, fabs(ref - hC[(size_t)mi * N + n]));
+        if (kreps == 1) worst = fmax(worst, fabs(ref - hC[(size_t)mi * N + n]));
     }
-    const double gf = 2.0 * M * N * K / 1e9;
-    printf("M %lld K %d N %d grid %d: %8.1f us  %6.1f TF/s  (%.3f of 157.3)   max |err| vs fp64 %.2e\n", (long long)M, K, N, grid, ms * 1e3, gf / ms, gf / ms / 157.3, worst);
+    const double gf = 2.0 * M * N * K / 1e9 * kreps;
+    printf("M %lld K %d N %d grid %d k-loop x%d: %8.1f us  %6.1f TF/s  (%.3f of 157.3)   max |err| vs fp64 %.2e\n", (long long)M, K, N, grid, kreps, ms * 1e3, gf / ms, gf / ms / 157.3, worst);
     fflush(stdout);
     (void)hipFree(A); (void)hipFree(Wf); (void)hipFree(b); (void)hipFree(C);
 }
 
-int main() {
-    run<512, 512>(32768, 256);
-    run<512, 512>(32768, 512);
-    run<512, 1024>(32768, 256);
-    run<512, 1024>(32768, 512);
-    run<512, 512>(65536, 256);
+int main(int argc, char** argv) {
+    const int only = argc > 1 ? atoi(argv[1]) : -1;   // one configuration (for the PMC passes: tools/pmc_cmd.sh groups launches by kernel name and grid)
+    if (only < 0 || only == 0) run<512, 512>(32768, 256);
+    if (only < 0) run<512, 512>(32768, 512);
+    if (only < 0 || only == 1) run<512, 1024>(32768, 256);
+    if (only < 0) run<512, 1024>(32768, 512);
+    if (only < 0) run<512, 512>(65536, 256);
+    if (only < 0 || only == 2) run<512, 512>(16384, 256, 16);   // one tile per CU, its k-loop 16 times: the loop alone
+    if (only < 0 || only == 3) run<512, 1024>(16384, 256, 8);
     return 0;
 }
