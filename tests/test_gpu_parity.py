@@ -189,7 +189,9 @@ def test_edge_convs(dev, B, Cs, Cb, H, W):
     check("ending y", y, yr, 1e-5)
     check("ending dx", fg.grad, fr.grad, 1e-5)
     check("ending dw", wg.grad, wr.grad, 1e-5)
-    check("ending db", bg.grad, br.grad, 1e-5)
+    # (Cs numbers, each a sum of B H W gradient values of both signs: with Cs = 1 the "tensor's scale" is ONE cancelling sum -- randomized
+    # shapes, tests/fuzz_shapes.py seed 6, found 1.3e-5 on (1, 1, 128, 38, 31) from the summation order alone)
+    check("ending db", bg.grad, br.grad, 1e-5 if Cs > 1 else 5e-5)
     check("ending dres", rg.grad, rr.grad, 1e-6)
 
 
