@@ -18,13 +18,14 @@ int launch_ln_act_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, c
 int launch_cast_f32_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s);
 
-constexpr int WPACKB_MAX_JOBS = 11;
+constexpr int WPACKB_MAX_JOBS = 12;
 constexpr int WPACKB_MAX_JOBS_L = 80;   // the multi-block form (8 NAFBlocks per launch; 80 x 48 B of kernel arguments)
 template <int MAXJ>
 struct WpackBJobsT {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] = in[n][k] * kscale[img][k]; 1: out[k][n] = in[n][k] * rs[n];
                        // 2 / 3: the dense-3x3 packs [Co][9 Ci] / [Ci][9 Co] (flipped taps) of misc.hip's WP_CONV3 / WP_CONV3_T (N = Co, K = 9 Ci)
                        // 4 / 5 / 6 / 7: misc.hip's WP_DOWN / WP_DOWN_T / WP_UP / WP_UP_T (2x2 stride-2 conv, 1x1 conv + PixelShuffle(2))
                        // 8: depthwise taps [N = 2C][K = 9] -> FP32 [9][2C] (dw_pack layout; `out` points at floats)
+                       // 10: the chain kernels' stream of one transposed, row-scaled [C][C] matrix (in[c][r] * rs[c]): N = K = C (chain_bf16.h)
                        // 9: the chain kernel's fragment-order stream of conv4 (in, [2C][C]) + conv5 (rs, [C][C]): N = 3 C, K = C (chain_bf16.h)
     const float* in[MAXJ];
     bf16_t* out[MAXJ];

@@ -298,6 +298,27 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ>
         }
         return;
     }
+    if (jobs.transpose[j] == 10) {   // the chain kernels' stream of ONE transposed, row-scaled [C][C] matrix: out row r, column c = in[c][r] * rs[c]
+        // (conv3 for the backward kernel: dts = dy (beta W3)^T).  Per wave NT * KS fragments: k-step ks, then output tile t (as conv5's part of mode 9).
+        const int C = K, CW = C / CHAIN_NW, NT = CW / 32, KS = C / 16, FR = NT * KS;
+        const int64_t nq = (int64_t)CHAIN_NW * FR * 64;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+            const int lane = (int)(q & 63), fi = (int)((q >> 6) % FR), w = (int)((q >> 6) / FR);
+            const int rho = lane & 31, kg = lane >> 5, cc = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+            const int ks = fi / NT, t = fi % NT;
+            const int r = w * CW + 32 * t + cc, c0 = 16 * ks + 8 * kg;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = in[(int64_t)(c0 + e) * C + r] * (rs ? rs[c0 + e] : 1.f);
+            u32x4 o;
+            o.x = bf_pack(v[0], v[1]);
+            o.y = bf_pack(v[2], v[3]);
+            o.z = bf_pack(v[4], v[5]);
+            o.w = bf_pack(v[6], v[7]);
+            *reinterpret_cast<u32x4*>(out + q * 8) = o;
+        }
+        return;
+    }
     if (jobs.transpose[j] == 0 && K % 8 == 0) {   // the big one (per-image scaled weights, nimg * N * K elements): 8 per thread, 16-byte stores
         const int64_t nk = (int64_t)N * K;
         for (int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x; i8 * 8 < total; i8 += (int64_t)gridDim.x * 256) {

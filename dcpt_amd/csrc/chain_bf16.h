@@ -27,5 +27,19 @@ int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s);
 size_t chain_head_wstream_elems(int C);
 int launch_chain_head_bf16(const ChainFwdB& p, int C, hipStream_t s);
 
+// Backward, the middle of the block (nafnet_arch.py:178-180 under autograd): dy = dout + LayerNorm2'(gln; y) and dts = dy (beta W3)^T with
+// SCA's per-tile channel sums, one kernel per 128-pixel tile (replaces ln_bwd_bf16 + the conv3^T data-gradient GEMM with the column-dot epilogue).
+struct ChainMidB {
+    const bf16_t *gln, *y, *dout, *t2;   // [M][C]: gradient of LN2's output, LN2's input, the residual path's gradient, SimpleGate output
+    const float *mu, *rstd, *lnw;        // [M], [M], [C]
+    const bf16_t* Wf;                    // fragment-order stream of (beta W3)^T (chain_mid_wstream_elems(C) = C^2 elements, pack mode 10)
+    bf16_t *dy, *dts;                    // [M][C]
+    float* lnpart;                       // [ceil(M / 128)][2][C]: per-tile sum_rows gln xhat, sum_rows gln
+    float* dspart;                       // [ceil(M / 128)][C]:   per-tile sum_rows dts t2
+    int64_t M;
+};
+size_t chain_mid_wstream_elems(int C);
+int launch_chain_bwd_mid_bf16(const ChainMidB& p, int C, hipStream_t s);
+
 // geometry shared with the pack (bf16_ops.hip, mode 9): 8 waves per block, wave w owns gate channels [w C/8, (w+1) C/8)
 constexpr int CHAIN_NW = 8;

@@ -402,6 +402,204 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
     }
 }
 
+// ---- backward, the middle of the block: dy = dout + LayerNorm2'(gln; y), dts = dy (beta W3)^T, SCA's channel sums -------------------------
+// (reference nafnet_arch.py:178-180 under autograd.)  The unfused schedule runs ln_bwd_bf16 (reads gln, y, dout, writes dy: 25 us at level 3,
+// 88 us once B = 64 stacked batches leave the Infinity Cache) and the conv3^T data-gradient GEMM with the column-dot epilogue (36 us).  Here the
+// LayerNorm backward IS the tile load of the GEMM: a wave computes dy for its 16 rows in the coalesced layout (a lane = 8 channels of a row;
+// row sums by shuffles, the column partials of dLN2.weight / bias accumulate per lane over the rows), writes them to the LDS tile and lets
+// them trickle out to HBM during the GEMM; the product leaves THROUGH the tile (accumulator layout -> LDS -> whole rows): coalesced 1-KB
+// stores instead of 16-byte pieces, and SCA's sums  ds[img][k] = sum_px dts t2  are taken on the way out in the same row layout, t2 read
+// coalesced.  (The unfused epilogue multiplies t2 with the fp32 accumulator, this one with the bf16-rounded dts it stores: 1e-4 relative
+// on a sum over >= 128 pixels.)
+template <int LANES>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < LANES; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int C, int TM>
+__global__ __launch_bounds__(512) void chain_bwd_mid_bf16_kernel(const ChainMidB p) {
+    using G = Geo<C, TM>;
+    constexpr int MT = G::MT, NT = G::NT, PITCH = G::PITCH, CW = G::CW;
+    constexpr uint32_t WTOT = NT * G::KS * 1024u;
+    constexpr int RED = 2 * NW * C * 4;   // bytes: [plane][wave][C] fp32 partial column sums
+    static_assert(RED % 1024 == 0 && WTOT % 8192 == 0, "layout");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RED + G::XB];
+    float* const red = reinterpret_cast<float*>(smem);
+    unsigned char* const X = smem + RED;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const rsrc_t wrs = make_rsrc(p.Wf + (size_t)wave * (WTOT / 2));
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    bf16x8 ring[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring[i] = ldfrag(wrs, l16, (uint32_t)i * 1024u);
+    uint32_t wnext = 8192u % WTOT;
+    const float invC = 1.0f / (float)C;
+
+    const int64_t ntiles = (p.M + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int m = ln & 31, h = ln >> 5;
+        const uint32_t xlane = (uint32_t)m * PITCH + (uint32_t)((((m & 14) | (h ^ (m & 1)))) << 4);
+        const int crow = ln / G::CPR, cchunk = ln % G::CPR;
+        const int64_t row0 = tile * TM;
+        const uint32_t nrows = (uint32_t)((p.M - row0) < TM ? (p.M - row0) : TM);
+        const rsrc_t gr = make_rsrc(p.gln + row0 * C, nrows * PITCH), yr = make_rsrc(p.y + row0 * C, nrows * PITCH);
+        const rsrc_t dr = make_rsrc(p.dout + row0 * C, nrows * PITCH), tr2 = make_rsrc(p.t2 + row0 * C, nrows * PITCH);
+        const rsrc_t mur = make_rsrc(p.mu + row0, nrows * 4), rsr = make_rsrc(p.rstd + row0, nrows * 4);
+        const rsrc_t dtsr = make_rsrc(p.dts + row0 * C, nrows * PITCH);
+
+        // ---- LayerNorm2 backward of the wave's rows, coalesced: dy -> LDS tile; column partials per lane ----
+        float ww[8], aw[8], ab[8];
+        {
+            const float4 w0 = ldg4(p.lnw + 8 * cchunk), w1 = ldg4(p.lnw + 8 * cchunk + 4);
+            ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aw[e] = ab[e] = 0.f;
+        constexpr int GRP = 4;   // accesses in flight together (3 tensors each)
+#pragma unroll 1
+        for (int j0 = 0; j0 < G::NI; j0 += GRP) {
+            u32x4 rg[GRP], rx[GRP], rd[GRP];
+            float rmean[GRP], rrs[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const int R = G::RW * wave + (j0 + u) * G::RPI + crow;
+                const uint32_t off = (uint32_t)R * PITCH + (uint32_t)cchunk * 16u;
+                rg[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0));
+                rx[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0));
+                rd[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
+                rmean[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mur, (uint32_t)R * 4u, 0, 0));
+                rrs[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, (uint32_t)R * 4u, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const int R = G::RW * wave + (j0 + u) * G::RPI + crow;
+                float g[8], x[8], d[8], gw[8];
+                unpack8(rg[u], g);
+                unpack8(rx[u], x);
+                unpack8(rd[u], d);
+                const float mean = rmean[u], rs = rrs[u];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = (x[e] - mean) * rs;   // xhat
+                    gw[e] = g[e] * ww[e];
+                    s1 += gw[e];
+                    s2 += gw[e] * x[e];
+                    aw[e] = fmaf(g[e], x[e], aw[e]);
+                    ab[e] += g[e];
+                }
+                s1 = row_sum<G::CPR>(s1) * invC;
+                s2 = row_sum<G::CPR>(s2) * invC;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (gw[e] - x[e] * s2 - s1) + d[e];
+                *reinterpret_cast<u32x4*>(X + R * PITCH + (((cchunk & ~15) | ((cchunk ^ R) & 15)) << 4)) = pack8(o);
+            }
+        }
+        if constexpr (G::RPI == 2) {   // two rows per access: lanes l and l ^ 32 hold the same channels
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                aw[e] += __shfl_xor(aw[e], 32);
+                ab[e] += __shfl_xor(ab[e], 32);
+            }
+        }
+        if (ln < G::CPR) {
+            float* r0 = red + wave * C + 8 * cchunk;
+            float* r1 = red + NW * C + wave * C + 8 * cchunk;
+            *reinterpret_cast<float4*>(r0) = make_float4(aw[0], aw[1], aw[2], aw[3]);
+            *reinterpret_cast<float4*>(r0 + 4) = make_float4(aw[4], aw[5], aw[6], aw[7]);
+            *reinterpret_cast<float4*>(r1) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+            *reinterpret_cast<float4*>(r1 + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+        }
+        block_sync();   // dy of all 128 rows and the eight waves' column partials are in LDS
+        for (int c = tid; c < 2 * C; c += 512) {   // sum_rows gln xhat (-> dLN2.weight), sum_rows gln (-> dLN2.bias) of this tile, fixed order
+            const int pl = c / C, ch = c - pl * C;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[(pl * NW + w) * C + ch];
+            p.lnpart[(tile * 2 + pl) * C + ch] = a;
+        }
+
+        // ---- dts^T = (beta W3)^T-stream x dy^T; dy leaves for HBM row by row meanwhile ----
+        Trickle tr;
+        tr.lds0 = (uint32_t)(G::RW * wave + crow) * PITCH;
+        tr.glb0 = tr.lds0 + (uint32_t)cchunk * 16u;
+        tr.cchunk = cchunk;
+        tr.rbase = (G::RW * wave + crow) & 15;
+        tr.on = true;
+        tr.dst = make_rsrc(p.dy + row0 * C, nrows * PITCH);
+        tr.j0 = 0;
+        floatx16 acc[NT][MT];
+#pragma unroll
+        for (int f = 0; f < NT; ++f)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
+        kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, WTOT, X, xlane, tr);
+        block_sync();   // every wave is done with dy (fragment reads and the trickle): the product takes its place
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int R = 32 * mt + m, ch0 = (CW * wave + 32 * t + 16 * h) >> 3;
+                unsigned char* const xr = X + R * PITCH + ((ch0 & ~15) << 4);
+                float o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = acc[t][mt][r];
+                *reinterpret_cast<u32x4*>(xr + (((ch0 ^ R) & 15) << 4)) = pack8(o);
+                *reinterpret_cast<u32x4*>(xr + ((((ch0 + 1) ^ R) & 15) << 4)) = pack8(o + 8);
+            }
+        block_sync();   // dts of all 128 rows is in LDS
+        // ---- whole rows out, SCA's channel sums on the way ----
+        float ds[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds[e] = 0.f;
+#pragma unroll 1
+        for (int j0 = 0; j0 < G::NI; j0 += GRP) {
+            u32x4 rt[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const int R = G::RW * wave + (j0 + u) * G::RPI + crow;
+                rt[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(tr2, (uint32_t)R * PITCH + (uint32_t)cchunk * 16u, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const int R = G::RW * wave + (j0 + u) * G::RPI + crow;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(X + R * PITCH + (((cchunk & ~15) | ((cchunk ^ R) & 15)) << 4));
+                st16(v, dtsr, (uint32_t)R * PITCH + (uint32_t)cchunk * 16u);
+                float a[8], b[8];
+                unpack8(v, a);
+                unpack8(rt[u], b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds[e] = fmaf(a[e], b[e], ds[e]);
+            }
+        }
+        if constexpr (G::RPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ds[e] += __shfl_xor(ds[e], 32);
+        }
+        if (ln < G::CPR) {
+            float* r0 = red + wave * C + 8 * cchunk;
+            *reinterpret_cast<float4*>(r0) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+            *reinterpret_cast<float4*>(r0 + 4) = make_float4(ds[4], ds[5], ds[6], ds[7]);
+        }
+        block_sync();
+        for (int ch = tid; ch < C; ch += 512) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[w * C + ch];
+            p.dspart[tile * C + ch] = a;
+        }
+        if (tile + gridDim.x < ntiles) block_sync();   // the next tile's rows overwrite the tile and the partials
+    }
+}
+
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -443,6 +641,23 @@ int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s) {
     if (C == 256) return launch_t<256, 0>(p, s);
     dcpt_set_error("chain_fwd_bf16: no kernel for C=%d", C);
     return DCPT_ERR_ARG;
+}
+
+size_t chain_mid_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)C * C : 0; }
+
+int launch_chain_bwd_mid_bf16(const ChainMidB& p, int C, hipStream_t s) {
+    DCPT_CHECK_ARG(p.gln && p.y && p.dout && p.t2 && p.mu && p.rstd && p.lnw && p.Wf && p.dy && p.dts && p.lnpart && p.dspart && p.M > 0,
+                   "chain_bwd_mid_bf16: null argument");
+    const int64_t ntiles = (p.M + 127) / 128;
+    const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
+    if (C == 512) chain_bwd_mid_bf16_kernel<512, 128><<<dim3(grid), dim3(512), 0, s>>>(p);
+    else if (C == 256) chain_bwd_mid_bf16_kernel<256, 128><<<dim3(grid), dim3(512), 0, s>>>(p);
+    else {
+        dcpt_set_error("chain_bwd_mid_bf16: no kernel for C=%d", C);
+        return DCPT_ERR_ARG;
+    }
+    DCPT_CHECK_LAUNCH("chain_bwd_mid_bf16");
+    return DCPT_OK;
 }
 
 size_t chain_head_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)2 * C * C : 0; }

@@ -37,6 +37,10 @@ bool ffn_fused(int C) {
 // 128) keeps the three-kernel chain, which scales with M (measured: 2K tiled inference 25.9 -> 58 ms with the chain kernel forced).
 bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 1 << 20); }
 bool ffn_chain_use(int C, int64_t M) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, M); }
+bool chain_mid_on() {
+    static const int on = dcpt_tuning("DCPT_CHAIN_MID", 1);
+    return on != 0;
+}
 bool chain_head_on() {
     static const int on = dcpt_tuning("DCPT_CHAIN_HEAD", 1);
     return on != 0;
@@ -85,7 +89,8 @@ size_t fwd_layout(int B, int H, int W, int C, void* base, size_t bytes, FwdWsB* 
 }
 
 struct BwdWsB {
-    bf16_t *wT5, *wT4, *wT3, *wT1;
+    bf16_t *wT5, *wT4, *wT3, *wT1, *WfT3;
+    bool mid;   // LayerNorm2 backward + the conv3^T data gradient + SCA's sums as one kernel per pixel tile (chain_bf16.hip)
     float* w2p;
     bf16_t *dv, *gln, *dy, *dts, *dt1, *t2s;
     float *slab, *colsum;
@@ -135,6 +140,7 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
     w.wT4 = a.get<bf16_t>((size_t)2 * C * C);
     w.wT3 = a.get<bf16_t>((size_t)C * C);
     w.wT1 = a.get<bf16_t>((size_t)2 * C * C);
+    w.WfT3 = ffn_chain(C) ? a.get<bf16_t>(chain_mid_wstream_elems(C)) : nullptr;
     w.w2p = a.get<float>((size_t)18 * C);
     w.dv = a.get<bf16_t>((size_t)M * 2 * C);
     w.gln = a.get<bf16_t>((size_t)M * C);
@@ -204,6 +210,7 @@ size_t bwd_layout(int B, int H, int W, int C, void* base, size_t bytes, BwdWsB* 
             w.lnpart2 = a.get<float>(need);
         }
     }
+    w.mid = ffn_chain_use(C, M) && chain_mid_on() && w.ds_fused && w.tn256 && !w.lrs;
     w.ffn_part = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
     w.ffn_part1 = ffn_fused(C) ? a.get<float>((size_t)ffn_bwd_bf16_waves(M) * 2 * C) : nullptr;
     w.ffn_g5 = w.ffn_g4 = w.ffn_cs5 = w.ffn_cs4 = nullptr;
@@ -236,7 +243,7 @@ bool shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C 
 // keeps this buffer per block and refreshes it when the parameters change (once per optimizer step) saves the per-call packs:
 // 5 launches per block and step (dcpt_nafblock_wpack_bf16 / *_packed entry points).
 struct PackB {
-    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3, *Wf, *Wf1;
+    bf16_t *W1, *W4, *W5, *wT5, *wT4, *wT3, *wT1, *W3, *Wf, *Wf1, *WfT3;
     float* w2p;
 };
 size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
@@ -253,16 +260,18 @@ size_t pack_layout(int C, void* base, size_t bytes, PackB* out) {
     k.W3 = a.get<bf16_t>((size_t)C * C);
     k.Wf = ffn_chain(C) ? a.get<bf16_t>(chain_wstream_elems(C)) : nullptr;   // conv4 + conv5 in the chain kernel's fragment order
     k.Wf1 = ffn_chain(C) ? a.get<bf16_t>(chain_head_wstream_elems(C)) : nullptr;   // conv1 likewise
+    k.WfT3 = ffn_chain(C) ? a.get<bf16_t>(chain_mid_wstream_elems(C)) : nullptr;   // (beta conv3)^T for the backward kernel
     if (out) *out = k;
     return a.off;
 }
-constexpr int PACK_JOBS = 11;   // jobs of one block at most
+constexpr int PACK_JOBS = 12;   // jobs of one block at most
 template <typename J>
 int pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b) {   // the block's nine or ten jobs at j[b ..]; returns their number
     const int C2 = 2 * C;
     if (k.Wf) {
         j.in[b + 9] = p->conv4_w; j.rs[b + 9] = p->conv5_w; j.out[b + 9] = k.Wf; j.N[b + 9] = 3 * C; j.K[b + 9] = C; j.transpose[b + 9] = 9;
         j.in[b + 10] = p->conv1_w; j.rs[b + 10] = nullptr; j.out[b + 10] = k.Wf1; j.N[b + 10] = 2 * C; j.K[b + 10] = C; j.transpose[b + 10] = 9;
+        j.in[b + 11] = p->conv3_w; j.rs[b + 11] = p->beta; j.out[b + 11] = k.WfT3; j.N[b + 11] = C; j.K[b + 11] = C; j.transpose[b + 11] = 10;
     }
     j.in[b + 8] = p->conv3_w; j.out[b + 8] = k.W3; j.N[b + 8] = C; j.K[b + 8] = C;
     j.in[b + 0] = p->conv1_w; j.out[b + 0] = k.W1; j.N[b + 0] = C2; j.K[b + 0] = C;
@@ -273,7 +282,7 @@ int pack_jobs(const dcpt_nafblock_params* p, const PackB& k, int C, J& j, int b)
     j.in[b + 5] = p->conv3_w; j.out[b + 5] = k.wT3; j.rs[b + 5] = p->beta;  j.N[b + 5] = C;  j.K[b + 5] = C; j.transpose[b + 5] = 1;
     j.in[b + 6] = p->conv1_w; j.out[b + 6] = k.wT1; j.rs[b + 6] = nullptr;  j.N[b + 6] = C2; j.K[b + 6] = C; j.transpose[b + 6] = 1;
     j.in[b + 7] = p->conv2_w; j.out[b + 7] = reinterpret_cast<bf16_t*>(k.w2p); j.N[b + 7] = C2; j.K[b + 7] = 9; j.transpose[b + 7] = 8;
-    return k.Wf ? 11 : 9;
+    return k.Wf ? 12 : 9;
 }
 int pack_all(const dcpt_nafblock_params* p, const PackB& k, int C, hipStream_t s) {
     WpackBJobs j{};
@@ -462,10 +471,14 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
     if (packed) {
         PackB k;
         DCPT_CHECK_ARG(pack_layout(C, const_cast<void*>(packed), packed_bytes, &k) <= packed_bytes, "nafblock_bwd_bf16: packed weights buffer too small");
-        w.wT5 = k.wT5; w.wT4 = k.wT4; w.wT3 = k.wT3; w.wT1 = k.wT1; w.w2p = k.w2p;
+        w.wT5 = k.wT5; w.wT4 = k.wT4; w.wT3 = k.wT3; w.wT1 = k.wT1; w.w2p = k.w2p; w.WfT3 = k.WfT3;
     } else {
         WpackBJobs j{};
         j.n = 4;
+        if (w.mid) {
+            j.in[4] = p->conv3_w; j.rs[4] = p->beta; j.out[4] = w.WfT3; j.N[4] = C; j.K[4] = C; j.transpose[4] = 10;
+            j.n = 5;
+        }
         j.in[0] = p->conv5_w; j.out[0] = w.wT5; j.rs[0] = p->gamma; j.N[0] = C;  j.K[0] = C; j.transpose[0] = 1;
         j.in[1] = p->conv4_w; j.out[1] = w.wT4; j.rs[1] = nullptr;  j.N[1] = C2; j.K[1] = C; j.transpose[1] = 1;
         j.in[2] = p->conv3_w; j.out[2] = w.wT3; j.rs[2] = p->beta;  j.N[2] = C;  j.K[2] = C; j.transpose[2] = 1;
@@ -529,15 +542,20 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
         }
         // B4: conv4 gradients
         if (!w.tn256) DCPT_TRY(wgrad_b(w.dv, C2, sv->xn2, C, M, w.slab, w.colsum, nullptr, nullptr, nullptr, gr->conv4_w, nullptr, gr->conv4_b, sw));
-        // B5: dy = dout + LN2-backward
-        if (!w.lrs) DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
+        // B5: dy = dout + LN2-backward  (with the chain kernel: part of B6 below)
+        if (!w.lrs && !w.mid) DCPT_TRY(launch_ln_bwd_bf16(w.gln, sv->y, sv->mu2, sv->rstd2, p->norm2_w, dout, w.dy, w.lnpart, w.ln_nblk, M, C, s));
         DCPT_TRY(side_fork(sd, 2, s));
-        if (!w.tn256) DCPT_TRY(launch_colpart_reduce(w.lnpart, w.lrs ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
+        if (!w.tn256) DCPT_TRY(launch_colpart_reduce(w.lnpart, (w.lrs || w.mid) ? ln_tiles : w.ln_nblk, 2, C, gr->norm2_w, gr->norm2_b, nullptr, sw));
     }
     // B6: dts = d(t2 * s) (+ SCA's per-image channel sums out of the epilogue when an image is a whole number of 128-pixel tiles)
     g = GemmNTB{};
     g.M = M; g.A = w.dy; g.lda = C; g.K = C; g.Bw = w.wT3; g.N = C; g.C = w.dts; g.ldc = C;
-    if (w.ds_fused) {
+    if (w.mid && !ffn) {   // B5 + B6 per 128-pixel tile, the LayerNorm backward as the GEMM's tile load (chain_bf16.hip)
+        ChainMidB q{};
+        q.gln = w.gln; q.y = sv->y; q.dout = dout; q.t2 = sv->t2; q.mu = sv->mu2; q.rstd = sv->rstd2; q.lnw = p->norm2_w; q.Wf = w.WfT3;
+        q.dy = w.dy; q.dts = w.dts; q.lnpart = w.lnpart; q.dspart = w.ds_part; q.M = M;
+        DCPT_TRY(launch_chain_bwd_mid_bf16(q, C, s));
+    } else if (w.ds_fused) {
         g.res = sv->t2; g.ldres = C; g.colpart = w.ds_part;
         DCPT_TRY(launch_gemm_nt_bf16(g, EB_DOTCOL, s));
     } else {
@@ -627,7 +645,7 @@ static int nafblock_bwd_bf16_impl(const dcpt_nafblock_params* p, const dcpt_nafb
             f.slab[3].dW = gr->conv1_w; f.slab[3].dbias = gr->conv1_b;
             const int lnR = w.lrs ? ln_tiles : w.ln_nblk;
             f.ncols = 3;
-            f.cols[0] = FinCols{w.lnpart, gr->norm2_w, gr->norm2_b, lnR, 2, C, 0};
+            f.cols[0] = FinCols{w.lnpart, gr->norm2_w, gr->norm2_b, w.mid ? ln_tiles : lnR, 2, C, 0};
             f.cols[1] = FinCols{w.lnpart2, gr->norm1_w, gr->norm1_b, lnR, 2, C, 0};
             f.cols[2] = FinCols{w.wpart, gr->conv2_w, gr->conv2_b, B * nblk_b, 10, C2, 1};
             f.sca = FinSca{w.ds, sv->pooled, gr->sca_w, gr->sca_b, B, C};
