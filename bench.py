@@ -38,6 +38,15 @@ EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_
 
 
 def prof_class_name(cls: int) -> str:
+    if cls >= 1024:   # the chain kernels of the wide levels (chain_bf16.hip)
+        return {1024: "chain_fwd_bf16<ffn: LN2+conv4+gate+conv5+residual>", 1025: "chain_fwd_bf16<head: LN1+conv1>",
+                1026: "chain_bwd_mid_bf16<LN2'+conv3^T+sca sums>"}.get(cls, f"chain<{cls - 1024}>")
+    if cls == 512 + 257:
+        return "gemm_tn_bf16_256<grouped weight gradients of a block>"
+    if cls == 512 + 256:
+        return "gemm_tn_bf16"
+    if 256 <= cls < 512:
+        return f"gemm_nt_bf16<epi={ {0: 'plain', 1: 'bias', 2: 'resid', 3: 'sgbwd', 4: 'biasgate', 5: 'dotcol', 6: 'lnbwd2', 7: 'scatter', 8: 'scatter_add'}.get(cls - 256, cls - 256)}>"
     if cls >= 512:
         c = cls - 512
         return f"gemm_tn<x={ALOAD.get(c // 8, c // 8)},y={ALOAD.get(c % 8, c % 8)}>"
@@ -123,6 +132,36 @@ def secondary_dcpt_bf16(dev, steps=5, warmup=3):
             m.optimize_parameters(1)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        # the dominant GEMM-class kernel of THIS step, live: one more step with every launch bracketed by HIP events on its stream
+        # (libdcpt_hip's prof.hip; the wide bf16 levels run single-stream, so a bracket spans exactly its launch)
+        roof = None
+        try:
+            from dcpt_amd import _lib
+            import ctypes
+
+            lib = _lib.load()
+            lib.dcpt_prof_enable(1)
+            m.optimize_parameters(1)
+            torch.cuda.synchronize()
+            buf = (ctypes.c_double * (8 * 512))()
+            n = lib.dcpt_prof_read(buf, 512)
+            lib.dcpt_prof_enable(0)
+            rows = [dict(kernel=prof_class_name(int(buf[i * 8])), MNK=[int(buf[i * 8 + 1]), int(buf[i * 8 + 2]), int(buf[i * 8 + 3])],
+                         launches=int(buf[i * 8 + 4]), ms=buf[i * 8 + 5], flops=buf[i * 8 + 6], bytes=buf[i * 8 + 7]) for i in range(n)]
+            by = {}
+            for r in rows:   # per kernel family (the shapes of a family differ by level)
+                a = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                for k in ("ms", "flops", "bytes", "launches"):
+                    a[k] += r[k]
+            name, a = max(by.items(), key=lambda kv: kv[1]["ms"])
+            tf = a["flops"] / a["ms"] / 1e9
+            roof = {"kernel": name, "bound": "hbm" if a["bytes"] / 8e12 > a["flops"] / 2.5e15 else "mfma", "launches_per_step": a["launches"],
+                    "ms_per_step": round(a["ms"], 3), "achieved_tflops": round(tf, 1), "peak_tflops": 2500.0, "mfma_frac": round(tf / 2500.0, 4),
+                    "achieved_gbs": round(a["bytes"] / a["ms"] / 1e6, 1), "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / 8000.0, 4),
+                    "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 1),
+                    "measured": "live, HIP events around every launch of the family in one extra step (algorithmic flops / bytes of the launches)"}
+        except Exception as e:   # noqa: BLE001  (the roofline object is extra: never lose the timing over it)
+            roof = {"error": str(e)[:200]}
         sc = B * (S / 256.0) ** 2
         flops = sc * 1.315e12          # 2 x 378.3 GF (encoder, fwd+bwd) + 558.9 GF (head) per 256^2 image
         log = m.get_current_log()
@@ -134,6 +173,7 @@ def secondary_dcpt_bf16(dev, steps=5, warmup=3):
             "hbm_frac": round(sc * 2 * naf_bytes_bf16 / dt / (PEAK_HBM_TBS * 1e12), 4),
             "hbm_frac_note": "encoder's algorithmic bf16 bytes only (SURVEY 8d has no byte count for the head): a lower bound",
             "l_pix": round(float(log["l_pix"]), 6), "l_classify": round(float(log["l_classify"]), 6),
+            "roofline": roof,
         }
         del m
         torch.cuda.empty_cache()

@@ -26,6 +26,7 @@
 // product of the UNROUNDED halves rounded once, out rounded once.  Only the summation order inside a dot product differs.
 #include "bf16_ops.h"
 #include "chain_bf16.h"
+#include "prof.h"
 
 namespace {
 
@@ -614,6 +615,9 @@ template <int C, int HEAD>
 int launch_t(const ChainFwdB& p, hipStream_t s) {
     const int64_t ntiles = (p.M + 127) / 128;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
+    // (live timing for bench.py: flops of the GEMMs, algorithmic bytes of what the launch reads and writes)
+    const double units = HEAD ? 1.0 + 2.0 + (p.xn2 ? 1.0 : 0.0) : 2.0 + 1.0 + (p.v ? 2.0 : 0.0) + (p.xn2 ? 2.0 : 0.0);
+    ProfScope prof(s, PROF_OTHER + HEAD, p.M, HEAD ? 2 * C : 3 * C, C, (HEAD ? 4.0 : 6.0) * (double)p.M * C * C, units * (double)p.M * C * 2.0);
     chain_fwd_bf16_kernel<C, 128, HEAD><<<dim3(grid), dim3(512), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("chain_fwd_bf16");
     return DCPT_OK;
@@ -650,6 +654,7 @@ int launch_chain_bwd_mid_bf16(const ChainMidB& p, int C, hipStream_t s) {
                    "chain_bwd_mid_bf16: null argument");
     const int64_t ntiles = (p.M + 127) / 128;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
+    ProfScope prof(s, PROF_OTHER + 2, p.M, C, C, 2.0 * (double)p.M * C * C, 6.0 * (double)p.M * C * 2.0);
     if (C == 512) chain_bwd_mid_bf16_kernel<512, 128><<<dim3(grid), dim3(512), 0, s>>>(p);
     else if (C == 256) chain_bwd_mid_bf16_kernel<256, 128><<<dim3(grid), dim3(512), 0, s>>>(p);
     else {

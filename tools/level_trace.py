@@ -11,8 +11,9 @@ lvl = int(sys.argv[1]); c, hw = [(64, 256), (128, 128), (256, 64), (512, 32), (1
 bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 dev = torch.device('cuda:0')
 blk = fill_module_(NAFBlock(c)).to(dev)
-x = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
-go = torch.randn(32, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+B = int(os.environ.get('B', '32'))
+x = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+go = torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
 if bf:
     x, go = x.bfloat16(), go.bfloat16()
 if len(sys.argv) > 2 and sys.argv[2] == "x3":
