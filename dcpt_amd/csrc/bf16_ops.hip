@@ -298,6 +298,25 @@ __global__ __launch_bounds__(256) void wpack_bf16_kernel(const WpackBJobsT<MAXJ>
         }
         return;
     }
+    if (jobs.transpose[j] == 11) {   // conv3 with SCA's per-image scale as the chain kernel's streams: out[img][wave][NT * KS fragments] of W3[n][k] * kscale[img][k]
+        const int C = K, CW = C / CHAIN_NW, NT = CW / 32, KS = C / 16, FR = NT * KS;
+        const int64_t per = (int64_t)CHAIN_NW * FR * 64, nq = per * nimg;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+            const int64_t img = q / per, qi = q - img * per;
+            const int lane = (int)(qi & 63), fi = (int)((qi >> 6) % FR), w = (int)((qi >> 6) / FR);
+            const int rho = lane & 31, kg = lane >> 5, cc = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+            const int kst = fi / NT, t = fi % NT, k0 = 16 * kst + 8 * kg;
+            f8 v = f8_ld(in + (int64_t)(w * CW + 32 * t + cc) * C + k0);
+            if (ks) v = f8_mul(v, f8_ld(ks + img * C + k0));
+            u32x4 o;
+            o.x = bf_pack(v.lo.x, v.lo.y);
+            o.y = bf_pack(v.lo.z, v.lo.w);
+            o.z = bf_pack(v.hi.x, v.hi.y);
+            o.w = bf_pack(v.hi.z, v.hi.w);
+            *reinterpret_cast<u32x4*>(out + q * 8) = o;
+        }
+        return;
+    }
     if (jobs.transpose[j] == 10) {   // the chain kernels' stream of ONE transposed, row-scaled [C][C] matrix: out row r, column c = in[c][r] * rs[c]
         // (conv3 for the backward kernel: dts = dy (beta W3)^T).  Per wave NT * KS fragments: k-step ks, then output tile t (as conv5's part of mode 9).
         const int C = K, CW = C / CHAIN_NW, NT = CW / 32, KS = C / 16, FR = NT * KS;

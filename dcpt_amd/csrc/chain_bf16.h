@@ -17,6 +17,12 @@ struct ChainFwdB {
     float *mu, *rstd;        // [M] or null (both)
     int64_t M;
     float eps;
+    // conv3 in front of the chain (t2 != null; nafnet_arch.py:174-178): y = inp + beta (conv3(t2 s) + b3) is computed HERE (y is written,
+    // not read): t2 [M][C] SimpleGate output, inp [M][C] the block input, W3f the per-image fragment-order streams of W3[n][k] s[img][k]
+    // (B x C^2 elements, pack mode 11), b3 / beta [C], P pixels per image (a multiple of 128: a tile lies inside one image)
+    const bf16_t *t2, *inp, *W3f;
+    const float *b3, *beta;
+    int P;
 };
 bool chain_fwd_bf16_ok(int C, int64_t M);
 size_t chain_wstream_elems(int C);   // bf16 elements of Wf (3 C^2), 0 if the width has no chain kernel

@@ -50,7 +50,7 @@ struct Geo {
     static constexpr int NI = RW / RPI;      // coalesced accesses per wave for its rows
     static constexpr int NJ = CPR / 4;       // chunks per lane in the (row, quarter) layout
     // LDS: the fp32 parameter tables first (ds offsets below 64 KB are immediates), then the tile
-    static constexpr int T_LW = 0, T_LB = C, T_B4 = 2 * C, T_B5 = 4 * C, T_GM = 5 * C, T_N = 6 * C;
+    static constexpr int T_LW = 0, T_LB = C, T_B4 = 2 * C, T_B5 = 4 * C, T_GM = 5 * C, T_B3 = 6 * C, T_BT = 7 * C, T_N = 8 * C;
     static constexpr int XOFF = T_N * 4;
     static constexpr int SMEM = XOFF + XB;
     static_assert(XOFF % 1024 == 0, "tile base alignment (the fragment addresses XOR bits 5..7)");
@@ -81,8 +81,8 @@ __device__ __forceinline__ void unpack8(u32x4 w, float* f) {
     f[4] = bf_lo(w.z); f[5] = bf_hi(w.z); f[6] = bf_lo(w.w); f[7] = bf_hi(w.w);
 }
 #ifdef CHAIN_TIMELINE   // diagnostic builds: shader-clock stamps of wave 0 / wave 4 of every block at the phase boundaries (tools/chain_timeline.py)
-__device__ unsigned long long g_chain_tl[512 * 2 * 16];
-#define TL(i) do { if (lane == 0 && (wave & 3) == 0) g_chain_tl[(blockIdx.x * 2 + (wave >> 2)) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_chain_tl[512 * 2 * 24];
+#define TL(i) do { if (lane == 0 && (wave & 3) == 0) g_chain_tl[(blockIdx.x * 2 + (wave >> 2)) * 24 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TL(i) do { } while (0)
 #endif
@@ -96,6 +96,13 @@ __device__ __forceinline__ void block_sync() { asm volatile("s_waitcnt lgkmcnt(0
 // operand).  vmcnt retires in issue order, so a wave that has just issued a burst of stores cannot take its next weight fragment until
 // the burst has drained -- with every CU storing at once that is the HBM write time of the whole tensor, exposed (measured: 40 of 97 us).
 // One coalesced row access every PER k-steps instead: ds_read in one step, the store in the next, never more than one in flight.
+// A wave's weight stream: fragments of 1 KB at r + next, next + 1024, ...; after `tot` bytes the stream that FOLLOWS takes over (the same
+// one again for the next tile, or -- with conv3 in front of the chain -- conv3's per-image stream after conv5 and the shared conv4 / conv5
+// stream after conv3): the ring never runs dry across the seams.
+struct Stream {
+    rsrc_t r;
+    uint32_t next, tot;
+};
 struct Trickle {
     rsrc_t dst;
     uint32_t lds0, glb0;   // lane constants: (RW wave + crow) PITCH [+ chunk 16 for glb0]
@@ -104,7 +111,7 @@ struct Trickle {
     bool on;
 };
 template <int NF, int PER, class G>
-__device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)[8], rsrc_t wrs, uint32_t l16, uint32_t& wnext, uint32_t wtot,
+__device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)[8], Stream& st, const Stream& after, uint32_t l16,
                                       const unsigned char* X, uint32_t xlane, const Trickle& tr) {
     static_assert(8 % NF == 0, "fragments per k-step must divide the ring");
     static_assert(PER >= 2 && 8 % PER == 0, "trickle period");
@@ -142,13 +149,13 @@ __device__ __forceinline__ void kloop(floatx16 (&acc)[NF][G::MT], bf16x8 (&ring)
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[f][mt]) : "v"(a), "v"(b[k8 & 1][mt]));
 #endif
 #ifndef CHAIN_ABL_NOW
-                ring[slot] = ldfrag(wrs, l16, wnext + (uint32_t)slot * 1024u);
+                ring[slot] = ldfrag(st.r, l16, st.next + (uint32_t)slot * 1024u);
 #else
                 asm volatile("" : "+v"(ring[slot]));
 #endif
                 if (slot == 7) {
-                    wnext += 8192u;
-                    if (wnext >= wtot) wnext = 0;
+                    st.next += 8192u;
+                    if (st.next >= st.tot) st = after;   // (after.next = 0; wave-uniform: four scalar selects)
                 }
             }
             {   // (unconditional: with nothing to store the window is empty and the range check drops the store -- no branch in the loop)
@@ -171,28 +178,36 @@ template <int C, int TM, int HEAD>
 __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) {
     using G = Geo<C, TM>;
     constexpr int MT = G::MT, NT = G::NT, PITCH = G::PITCH, CW = G::CW;
-    constexpr uint32_t WTOT = HEAD ? G::F4 * 1024u : G::WTOT;
+    constexpr bool HD = HEAD == 1, C3 = HEAD == 2;   // HEAD = 2: the second half WITH conv3 in front (below)
+    constexpr uint32_t WTOT = HD ? G::F4 * 1024u : G::WTOT, W3TOT = NT * G::KS * 1024u;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
     unsigned char* const X = smem + G::XOFF;
     float* const tab = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < G::T_N; i += 512)
-        tab[i] = i < G::T_LB ? p.lnw[i] : i < G::T_B4 ? p.lnb[i - G::T_LB] : i < G::T_B5 ? p.b4[i - G::T_B4] : HEAD ? 0.f : i < G::T_GM ? p.b5[i - G::T_B5] : p.gamma[i - G::T_GM];
+        tab[i] = i < G::T_LB ? p.lnw[i] : i < G::T_B4 ? p.lnb[i - G::T_LB] : i < G::T_B5 ? p.b4[i - G::T_B4] : HD ? 0.f : i < G::T_GM ? p.b5[i - G::T_B5]
+               : i < G::T_B3 ? p.gamma[i - G::T_GM] : !C3 ? 0.f : i < G::T_BT ? p.b3[i - G::T_B3] : p.beta[i - G::T_BT];
 
     TL(0);
     block_sync();   // (the parameter tables)
     TL(1);
 
     // this wave's weight stream; the first eight fragments are on their way while the tile is normalised
-    const rsrc_t wrs = make_rsrc(p.Wf + (size_t)wave * (WTOT / 2));
+    const int64_t ntiles = (p.M + TM - 1) / TM;
+    const Stream smain{make_rsrc(p.Wf + (size_t)wave * (WTOT / 2)), 0u, WTOT};
+    // conv3's weights carry SCA's per-image scale (W3[n][k] s[img][k], wpack mode 11): one stream per (image, wave); a tile lies inside an image
+    auto stream3 = [&](int64_t tile) {
+        const int64_t img = tile * TM / (p.P > 0 ? p.P : 1);
+        return Stream{make_rsrc(p.W3f + ((size_t)img * NW + wave) * (W3TOT / 2)), 0u, W3TOT};
+    };
     const uint32_t l16 = (uint32_t)lane * 16u;
+    Stream st = C3 ? stream3(blockIdx.x < ntiles ? blockIdx.x : 0) : smain;
     bf16x8 ring[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ring[i] = ldfrag(wrs, l16, (uint32_t)i * 1024u);
-    uint32_t wnext = 8192u % WTOT;
+    for (int i = 0; i < 8; ++i) ring[i] = ldfrag(st.r, l16, (uint32_t)i * 1024u);
+    st.next = 8192u % st.tot;
 
-    const int64_t ntiles = (p.M + TM - 1) / TM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // Every per-lane address of the tile derives from this copy of the lane id, opaque to the optimiser: otherwise the ~150 loop-invariant
         // addresses of the phases below are hoisted out of the tile loop and live in scratch.
@@ -209,7 +224,10 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
         const uint32_t nrows = (uint32_t)((p.M - row0) < TM ? (p.M - row0) : TM);
         // windows at the tile's first row, as long as its valid rows: rows past M read 0 and their stores are dropped
         const rsrc_t yr = make_rsrc(p.y + row0 * C, nrows * PITCH);
-        const rsrc_t outr = make_rsrc(HEAD ? p.y : p.out + row0 * C, HEAD ? 0 : nrows * PITCH);
+        const rsrc_t t2r = make_rsrc(C3 ? p.t2 + row0 * C : p.y, C3 ? nrows * PITCH : 0);
+        const rsrc_t outr = make_rsrc(HD ? p.y : p.out + row0 * C, HD ? 0 : nrows * PITCH);
+        // what follows the shared conv4 / conv5 stream: itself (next tile), or the next tile's conv3 stream
+        const Stream after = C3 ? stream3(tile + gridDim.x < ntiles ? tile + gridDim.x : tile) : smain;
 
         // ---- the wave's 16 rows: HBM -> registers -> LDS (raw), coalesced ----
         {
@@ -217,13 +235,77 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
 #pragma unroll
             for (int j = 0; j < G::NI; ++j) {
                 const int R = G::RW * wave + j * G::RPI + crow;
-                raw[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, (uint32_t)R * PITCH + (uint32_t)cchunk * 16u, 0, 0));
+                raw[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(C3 ? t2r : yr, (uint32_t)R * PITCH + (uint32_t)cchunk * 16u, 0, 0));
             }
 #pragma unroll
             for (int j = 0; j < G::NI; ++j) {
                 const int R = G::RW * wave + j * G::RPI + crow;
                 *reinterpret_cast<u32x4*>(X + R * PITCH + (((cchunk & ~15) | ((cchunk ^ R) & 15)) << 4)) = raw[j];
             }
+        }
+        if constexpr (C3) {
+            // ---- conv3 in front (reference nafnet_arch.py:174-178): y = inp + beta (conv3(t2 s) + b3).  The tile in LDS is t2; the product
+            // comes back INTO the tile (accumulator layout -> LDS), leaves for HBM as whole rows, and is normalised where it lies ----
+            TL(16);
+            block_sync();   // t2 of all 128 rows is in LDS
+            TL(17);
+            floatx16 acc[NT][MT];
+#pragma unroll
+            for (int f = 0; f < NT; ++f)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
+            Trickle tn;
+            tn.lds0 = tn.glb0 = 0;
+            tn.cchunk = tn.rbase = tn.j0 = 0;
+            tn.on = false;
+            tn.dst = make_rsrc(p.y, 0);   // (nothing leaves during this GEMM: an empty window)
+            const rsrc_t inr = make_rsrc(p.inp + row0 * C, nrows * PITCH);
+            u32x4 iv[NT][MT][2];   // the residual in the accumulator layout: the first channel tile's share is requested before the GEMM, the
+            {                      // rest before the barrier behind it (it lands while the block waits)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint32_t io = (uint32_t)(32 * mt + m) * PITCH + (uint32_t)(CW * wave + 16 * h) * 2u;
+                    iv[0][mt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(inr, io, 0, 0));
+                    iv[0][mt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(inr, io + 16, 0, 0));
+                }
+            }
+            kloop<NT, G::KS / G::NI, G>(acc, ring, st, smain, l16, X, xlane, tn);
+            TL(18);
+#pragma unroll
+            for (int t = 1; t < NT; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint32_t io = (uint32_t)(32 * mt + m) * PITCH + (uint32_t)(CW * wave + 32 * t + 16 * h) * 2u;
+                    iv[t][mt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(inr, io, 0, 0));
+                    iv[t][mt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(inr, io + 16, 0, 0));
+                }
+            block_sync();   // every wave has read t2 for the last time
+            TL(19);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int cb = CW * wave + 32 * t + 16 * h;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int R = 32 * mt + m, ch0 = cb >> 3;
+                    unsigned char* const xr = X + R * PITCH + ((ch0 & ~15) << 4);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const float4 ba = *reinterpret_cast<const float4*>(tab + G::T_B3 + cb + 8 * hf), bb = *reinterpret_cast<const float4*>(tab + G::T_B3 + cb + 8 * hf + 4);
+                        const float4 ga = *reinterpret_cast<const float4*>(tab + G::T_BT + cb + 8 * hf), gb = *reinterpret_cast<const float4*>(tab + G::T_BT + cb + 8 * hf + 4);
+                        const float b3[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w}, bt[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                        float rf[8], o[8];
+                        unpack8(iv[t][mt][hf], rf);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o[r] = rf[r] + (acc[t][mt][8 * hf + r] + b3[r]) * bt[r];
+                        *reinterpret_cast<u32x4*>(xr + ((((ch0 + hf) ^ R) & 15) << 4)) = pack8(o);
+                    }
+                }
+            }
+            TL(20);
+            block_sync();   // y of all 128 rows is in LDS
+            TL(21);
         }
         TL(2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -236,7 +318,11 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < G::NJ; ++j) {
-                unpack8(*reinterpret_cast<const u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4)), xf + 8 * j);
+                const u32x4 rawy = *reinterpret_cast<const u32x4*>(xr + (j >> 2) * 256 + (((4 * (j & 3) + q) ^ rl) << 4));
+                // (conv3 in front: y exists only in this tile -- it leaves for HBM from the LayerNorm's own reads, 16 rows x 64 bytes per store,
+                // spread over the statistics pass so that the burst drains behind the arithmetic)
+                if constexpr (C3) st16(rawy, yr, (uint32_t)R * PITCH + (uint32_t)(4 * j + q) * 16u);
+                unpack8(rawy, xf + 8 * j);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += xf[8 * j + e];
             }
@@ -277,6 +363,9 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
         tr.on = p.xn2 != nullptr;
         tr.dst = make_rsrc(tr.on ? p.xn2 + row0 * C : p.y, tr.on ? nrows * PITCH : 0);
         TL(3);
+        // (conv3 in front: the rows of y this wave stored are re-read at the end of the tile by OTHER waves, in the accumulator layout -- they
+        // must have left this wave's queue before any wave passes the barrier; the LayerNorm above gave them the time)
+        if constexpr (C3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         block_sync();   // LN2(y) of all 128 rows is in LDS
         TL(4);
 
@@ -292,7 +381,7 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
             tr.j0 = ps * (G::NI / NT);
-            kloop<2, G::KS / (G::NI / NT), G>(acc, ring, wrs, l16, wnext, WTOT, X, xlane, tr);
+            kloop<2, G::KS / (G::NI / NT), G>(acc, ring, st, after, l16, X, xlane, tr);
             TL(5 + 2 * ps);
             const int cb = CW * wave + 32 * ps + 16 * h;   // the lane's 16 consecutive channels (v1; the v2 partner is C + cb)
             const rsrc_t vr = make_rsrc(p.v ? p.v + row0 * 2 * C : p.y, p.v ? nrows * 2 * PITCH : 0);
@@ -315,14 +404,14 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
                         st16(pack8(u1), vr, vo);
                         st16(pack8(u2), vr, vo + PITCH);
                     }
-                    if constexpr (!HEAD) {
+                    if constexpr (!HD) {
                         greg[ps][mt][hf] = pack8(gv);
                         asm volatile("" : "+v"(greg[ps][mt][hf]));   // (pack NOW: otherwise the fp32 products stay live across the next pass and spill)
                     }
                 }
             TL(6 + 2 * ps);
         }
-        if constexpr (!HEAD) {
+        if constexpr (!HD) {
         // the residual in the accumulator layout: the tile's rows of y again (read once already: L2 / Infinity Cache).  The first channel
         // tile's share is requested HERE -- it arrives while the block waits at the two barriers below (a load issued right before the
         // GEMM would hold up its first weight fragment: vmcnt retires in order) --, the rest while the first is finished
@@ -365,7 +454,7 @@ __global__ __launch_bounds__(512) void chain_fwd_bf16_kernel(const ChainFwdB p) 
             tr.j0 = 0;
             tr.on = p.g != nullptr;
             tr.dst = make_rsrc(tr.on ? p.g + row0 * C : p.y, tr.on ? nrows * PITCH : 0);
-            kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, WTOT, X, xlane, tr);
+            kloop<NT, G::KS / G::NI, G>(acc, ring, st, after, l16, X, xlane, tr);
             TL(12);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -431,12 +520,13 @@ __global__ __launch_bounds__(512) void chain_bwd_mid_bf16_kernel(const ChainMidB
     unsigned char* const X = smem + RED;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const rsrc_t wrs = make_rsrc(p.Wf + (size_t)wave * (WTOT / 2));
+    const Stream smain{make_rsrc(p.Wf + (size_t)wave * (WTOT / 2)), 0u, WTOT};
+    Stream st = smain;
     const uint32_t l16 = (uint32_t)lane * 16u;
     bf16x8 ring[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ring[i] = ldfrag(wrs, l16, (uint32_t)i * 1024u);
-    uint32_t wnext = 8192u % WTOT;
+    for (int i = 0; i < 8; ++i) ring[i] = ldfrag(st.r, l16, (uint32_t)i * 1024u);
+    st.next = 8192u % WTOT;
     const float invC = 1.0f / (float)C;
 
     const int64_t ntiles = (p.M + TM - 1) / TM;
@@ -542,7 +632,7 @@ __global__ __launch_bounds__(512) void chain_bwd_mid_bf16_kernel(const ChainMidB
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[f][mt][r] = 0.f;
-        kloop<NT, G::KS / G::NI, G>(acc, ring, wrs, l16, wnext, WTOT, X, xlane, tr);
+        kloop<NT, G::KS / G::NI, G>(acc, ring, st, smain, l16, X, xlane, tr);
         block_sync();   // every wave is done with dy (fragment reads and the trickle): the product takes its place
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -616,8 +706,9 @@ int launch_t(const ChainFwdB& p, hipStream_t s) {
     const int64_t ntiles = (p.M + 127) / 128;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
     // (live timing for bench.py: flops of the GEMMs, algorithmic bytes of what the launch reads and writes)
-    const double units = HEAD ? 1.0 + 2.0 + (p.xn2 ? 1.0 : 0.0) : 2.0 + 1.0 + (p.v ? 2.0 : 0.0) + (p.xn2 ? 2.0 : 0.0);
-    ProfScope prof(s, PROF_OTHER + HEAD, p.M, HEAD ? 2 * C : 3 * C, C, (HEAD ? 4.0 : 6.0) * (double)p.M * C * C, units * (double)p.M * C * 2.0);
+    const double units = HEAD == 1 ? 1.0 + 2.0 + (p.xn2 ? 1.0 : 0.0) : (HEAD == 2 ? 3.0 : 0.0) + 2.0 + 1.0 + (p.v ? 2.0 : 0.0) + (p.xn2 ? 2.0 : 0.0);
+    ProfScope prof(s, PROF_OTHER + (HEAD == 2 ? 3 : HEAD), p.M, HEAD == 1 ? 2 * C : HEAD == 2 ? 4 * C : 3 * C, C,
+                   (HEAD == 1 ? 4.0 : HEAD == 2 ? 8.0 : 6.0) * (double)p.M * C * C, units * (double)p.M * C * 2.0);
     chain_fwd_bf16_kernel<C, 128, HEAD><<<dim3(grid), dim3(512), 0, s>>>(p);
     DCPT_CHECK_LAUNCH("chain_fwd_bf16");
     return DCPT_OK;
@@ -641,6 +732,12 @@ size_t chain_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)3 * 
 int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s) {
     DCPT_CHECK_ARG(p.y && p.Wf && p.out && p.lnw && p.lnb && p.b4 && p.b5 && p.gamma && p.M > 0, "chain_fwd_bf16: null argument");
     DCPT_CHECK_ARG((p.xn2 == nullptr) == (p.g == nullptr) && (p.mu == nullptr) == (p.rstd == nullptr), "chain_fwd_bf16: xn2 / g and mu / rstd come in pairs");
+    if (p.t2) {   // conv3 in front: y is an OUTPUT
+        DCPT_CHECK_ARG(p.inp && p.W3f && p.b3 && p.beta && p.P >= 128 && p.P % 128 == 0 && p.M % p.P == 0,
+                       "chain_fwd_bf16 (conv3 in front): null argument or image size %d not a multiple of 128 pixels", p.P);
+        if (C == 512) return launch_t<512, 2>(p, s);
+        if (C == 256) return launch_t<256, 2>(p, s);
+    }
     if (C == 512) return launch_t<512, 0>(p, s);
     if (C == 256) return launch_t<256, 0>(p, s);
     dcpt_set_error("chain_fwd_bf16: no kernel for C=%d", C);

@@ -37,6 +37,10 @@ bool ffn_fused(int C) {
 // 128) keeps the three-kernel chain, which scales with M (measured: 2K tiled inference 25.9 -> 58 ms with the chain kernel forced).
 bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 1 << 20); }
 bool ffn_chain_use(int C, int64_t M) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, M); }
+bool chain_conv3_on() {
+    static const int on = dcpt_tuning("DCPT_CHAIN_CONV3", 1);
+    return on != 0;
+}
 bool chain_mid_on() {
     static const int on = dcpt_tuning("DCPT_CHAIN_MID", 1);
     return on != 0;
@@ -396,8 +400,15 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
     if (dw_ring_usable(dg, 2)) DCPT_TRY(launch_dw_ring_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     else DCPT_TRY(launch_dw_fwd_bf16(sv->t1, w.w2p, p->conv2_b, sv->t2, w.pool_part, dg, s));
     DCPT_TRY(launch_sca_fwd(w.pool_part, w.nblk_pool, p->sca_w, p->sca_b, sv->pooled, sv->s, B, C, P, s));
+    // wide levels, images of whole 128-pixel tiles: conv3 runs IN FRONT of the chain kernel below (its per-image weights as fragment streams)
+    const bool conv3_in_chain = ffn_chain_use(C, M) && chain_conv3_on() && !w.scale_act && P % 128 == 0;
     g = GemmNTB{};
-    if (w.scale_act) {
+    if (conv3_in_chain) {
+        j = WpackBJobs{};
+        j.n = 1;
+        j.in[0] = p->conv3_w; j.out[0] = w.W3s; j.N[0] = C; j.K[0] = C; j.kscale[0] = sv->s; j.nimg[0] = B; j.transpose[0] = 11;
+        DCPT_TRY(launch_wpack_bf16(j, s));
+    } else if (w.scale_act) {
         // y = inp + (conv3(t2 * s) + b3) * beta with the scale on the activations (small images): one pass over t2, one GEMM
         DCPT_TRY(launch_scale_rows_bf16(sv->t2, sv->s, w.t2s, M, C, P, s));
         g.M = M; g.A = w.t2s; g.lda = C; g.K = C; g.Bw = w.W3; g.N = C; g.C = sv->y; g.ldc = C; g.bias = p->conv3_b;
@@ -412,7 +423,7 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         g.res = inp; g.ldres = C; g.cscale = p->beta;
         g.nb = B; g.sA = (int64_t)P * C; g.sB = (int64_t)C * C; g.sC = (int64_t)P * C; g.sR = (int64_t)P * C;
     }
-    DCPT_TRY(launch_gemm_nt_bf16(g, EB_RESID, s));
+    if (!conv3_in_chain) DCPT_TRY(launch_gemm_nt_bf16(g, EB_RESID, s));
     if (ffn_fused(C)) {   // narrow levels: LayerNorm2 -> conv4 -> SimpleGate -> conv5 -> residual in one pass over y (ffn_bf16.hip)
         FfnFwdB f{};
         f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.W4 = w.W4; f.W5 = w.W5; f.b4 = p->conv4_b; f.b5 = p->conv5_b; f.gamma = p->gamma;
@@ -424,6 +435,9 @@ static int nafblock_fwd_bf16_impl(const dcpt_nafblock_params* p, const uint16_t*
         ChainFwdB f{};
         f.y = sv->y; f.lnw = p->norm2_w; f.lnb = p->norm2_b; f.Wf = w.Wf; f.b4 = p->conv4_b; f.b5 = p->conv5_b; f.gamma = p->gamma;
         f.out = out; f.v = sv->v; f.xn2 = sv->xn2; f.g = sv->g; f.mu = sv->mu2; f.rstd = sv->rstd2; f.M = M; f.eps = eps;
+        if (conv3_in_chain) {   // y = inp + beta (conv3(t2 s) + b3) is produced by the same kernel
+            f.t2 = sv->t2; f.inp = inp; f.W3f = w.W3s; f.b3 = p->conv3_b; f.beta = p->beta; f.P = P;
+        }
         return launch_chain_fwd_bf16(f, C, s);
     }
     // (inference at a chain width with a pixel count the chain kernel is not used for: LN2(y) / the gate / the statistics live in the workspace)

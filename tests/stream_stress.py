@@ -57,6 +57,22 @@ def victims(net, act, B=2, S=256):
             return [y.detach(), xx.grad] + [p.grad for p in blk.parameters()]
 
         out[f"block C={c} fwd+bwd"] = fb
+        if act == "bf16" and c in (256, 512):
+            # the same block on enough pixels for the chain kernels of the wide levels (chain_bf16.hip: LN -> 1 x 1 chains per 128-pixel tile,
+            # taken when the tiles fill 3/4 of the chip): 24 576 pixels = 192 tiles
+            xb = feat(act, 24576 // (s * s), c, s, s, 70 + c)
+            out[f"block C={c} (chain kernels) fwd"] = lambda blk=blk, x=xb: blk(x)
+
+            def fbc(blk=blk, x=xb):
+                xx = x.detach().clone().requires_grad_(True)
+                for p in blk.parameters():
+                    p.grad = None
+                with torch.enable_grad():
+                    y = blk(xx)
+                    y.backward(x)
+                return [y.detach(), xx.grad] + [p.grad for p in blk.parameters()]
+
+            out[f"block C={c} (chain kernels) fwd+bwd"] = fbc
     for i, (c, s) in enumerate(levels[:4]):
         x = feat(act, B, c, s, s, 40 + i)
         out[f"down{i}"] = lambda i=i, x=x: net.downs[i](x)
