@@ -38,7 +38,10 @@ bool ffn_fused(int C) {
 bool ffn_chain(int C) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, 1 << 20); }
 bool ffn_chain_use(int C, int64_t M) { return !ffn_fused(C) && chain_fwd_bf16_ok(C, M); }
 bool chain_conv3_on() {
-    static const int on = dcpt_tuning("DCPT_CHAIN_CONV3", 1);
+    // OFF: built, parity-green and measured (profiles/r5/bf16_block_level3_kernels_conv3_in_chain_negative.txt): the kernel with conv3 in front
+    // takes 120-123 us where the chain kernel + the separate conv3 launch take 86.5 + 35.4 -- one tile per CU serialises the extra tile load, GEMM,
+    // two barriers and the accumulator-layout round trip through LDS that the 256 x 256-tile GEMM overlaps across its tiles; same-box step +0.2 ms.
+    static const int on = dcpt_tuning("DCPT_CHAIN_CONV3", 0);
     return on != 0;
 }
 bool chain_mid_on() {
