@@ -68,7 +68,11 @@ def test_cast_roundtrip(dev):
 # (3, 64, 5, 7) / (1, 64, 9, 13) / (5, 64, 48, 40): the fused second half of the narrow levels (ffn_bf16.hip) with a ragged last group of
 # 32 pixels (M = 105, 117) and with more groups than one launch has waves (M = 9600: every wave walks its ring more than three times)
 @pytest.mark.parametrize("shape", [(2, 64, 32, 32), (3, 64, 5, 7), (1, 64, 9, 13), (5, 64, 48, 40), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8),
-                                   (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9), (24, 512, 32, 32), (25, 512, 31, 32), (6, 256, 64, 64)])
+                                   (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9), (24, 512, 32, 32), (25, 512, 31, 32), (6, 256, 64, 64),
+                                   # the chain kernels of the wide levels (chain_bf16.hip: taken when the 128-pixel tiles fill 3/4 of the chip's last
+                                   # round): images of 15 tiles (FFN + HEAD + the backward MID form, odd tile count per image), images that are no
+                                   # whole number of tiles (no MID form; M = 28 800), two rounds of tiles at C = 256 (M = 49 152)
+                                   (13, 512, 48, 40), (200, 512, 12, 12), (48, 256, 32, 32)])
 def test_nafblock_bf16_oracle(dev, shape):
     from dcpt_amd import functional as DF
 
