@@ -77,6 +77,15 @@ class BaseModel:
                  "Rprop": torch.optim.Rprop}
         if optim_type not in table:
             raise NotImplementedError(f"optimizer {optim_type} is not supported yet.")
+        if optim_type == "AdamW" and kwargs.get("fused") and not kwargs.get("amsgrad"):
+            # ``fused: true`` asks for a fused implementation: on fp32 CUDA parameters that is the library's multi-tensor kernel
+            # (dcpt_amd/optim.py: torch's update rule and state-dict layout, a handful of launches for the 664 tensors of NAFNet-64)
+            params = list(params)
+            flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
+            if flat and all(p.is_cuda and p.dtype == torch.float32 for p in flat):
+                from dcpt_amd.optim import FusedAdamW
+
+                return FusedAdamW(params, lr, **kwargs)
         return table[optim_type](params, lr, **kwargs)
 
     def setup_schedulers(self):

@@ -55,7 +55,17 @@ class DCPTModel(BaseModel):
     def hook_forward_fn(self, module, input, output):  # noqa: A002
         if isinstance(output, tuple):
             output = output[-1]
+        rng = getattr(self, "_tap_rows", None)
+        if rng is not None and not self.freeze_encoder and torch.is_tensor(output) and output.is_cuda:
+            # stacked encoder pass: the head taps samples rng[0]..rng[1]-1 of this feature map and the network goes on with all of it --
+            # one autograd node for both uses, so that the two gradients are merged in place instead of zero-padded and added
+            from dcpt_amd.functional import tap_split
+
+            through, tap = tap_split(output, rng[0], rng[1])
+            self.hook_outputs.append(tap)
+            return through
         self.hook_outputs.append(output.detach() if self.freeze_encoder else output)
+        return None
 
     def install_hooks(self):
         hook_names = self.opt.get("hook_names", None)
@@ -127,12 +137,18 @@ class DCPTModel(BaseModel):
                 else:
                     from dcpt_amd.functional import take_batch   # (stride-preserving slice gradients: no NCHW round trips)
 
-                    pix_output = take_batch(self.net_g(torch.cat([recon_in, self.lq], 0), hook=False), 0, nb)
+                    split = self.lq.is_cuda   # (the hooks hand back the second half of each tap themselves: hook_forward_fn)
+                    self._tap_rows = (nb, 2 * nb) if split else None
+                    try:
+                        pix_output = take_batch(self.net_g(torch.cat([recon_in, self.lq], 0), hook=False), 0, nb)
+                    finally:
+                        self._tap_rows = None
                     # one stacked forward must have fired every hook exactly once, on the full 2B batch
-                    if len(self.hook_outputs) != len(self.hooks) or any(t.shape[0] != 2 * nb for t in self.hook_outputs):
-                        raise RuntimeError(f"batched encoder pass: expected {len(self.hooks)} taps of batch {2 * nb}, got "
+                    want = nb if split else 2 * nb
+                    if len(self.hook_outputs) != len(self.hooks) or any(t.shape[0] != want for t in self.hook_outputs):
+                        raise RuntimeError(f"batched encoder pass: expected {len(self.hooks)} taps of batch {want}, got "
                                            f"{[tuple(t.shape) for t in self.hook_outputs]}")
-                    taps = [take_batch(t, nb, 2 * nb) for t in self.hook_outputs]
+                    taps = self.hook_outputs if split else [take_batch(t, nb, 2 * nb) for t in self.hook_outputs]
             else:
                 pix_output = self.net_g(recon_in, hook=False)
             self.hook_outputs = []  # drop the taps recorded by the reconstruction forward

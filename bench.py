@@ -40,7 +40,7 @@ EPI = {0: "plain", 1: "bias", 2: "resid", 3: "sgbwd", 4: "scatter", 5: "scatter_
 def prof_class_name(cls: int) -> str:
     if cls >= 1024:   # the chain kernels of the wide levels (chain_bf16.hip)
         return {1024: "chain_fwd_bf16<ffn: LN2+conv4+gate+conv5+residual>", 1025: "chain_fwd_bf16<head: LN1+conv1>",
-                1026: "chain_bwd_mid_bf16<LN2'+conv3^T+sca sums>"}.get(cls, f"chain<{cls - 1024}>")
+                1026: "chain_bwd_mid_bf16<LN2'+conv3^T+sca sums>", 1028: "adamw<all parameter tensors of a group>"}.get(cls, f"chain<{cls - 1024}>")
     if cls == 512 + 257:
         return "gemm_tn_bf16_256<grouped weight gradients of a block>"
     if cls == 512 + 256:
@@ -297,7 +297,9 @@ def main():
         from dcpt_amd import ddp as dcpt_ddp
 
         dcpt_ddp.prepare(model)   # per-bucket divide + the blocks' gradients written straight into the bucket views (no per-parameter copies)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0, fused=True)
+    from dcpt_amd.optim import FusedAdamW   # torch.optim.AdamW's update on the library's multi-tensor kernel (dcpt_adamw_step)
+
+    opt = FusedAdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0)
 
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)

@@ -45,7 +45,9 @@ def run_restormer(dev, save="balanced", steps=5, warmup=2, B=64, S=128):
     torch.cuda.reset_peak_memory_stats()
     DF.set_restormer_save(save)
     net = fill_module_(build_network(dict(type="Restormer"))).to(dev)
-    optm = torch.optim.AdamW(net.parameters(), lr=1e-4, fused=True)
+    from dcpt_amd.optim import FusedAdamW
+
+    optm = FusedAdamW(net.parameters(), lr=1e-4)
     lq = torch.rand((B, 3, S, S), generator=g, device=dev)
     gt = torch.rand((B, 3, S, S), generator=g, device=dev)
 
@@ -100,6 +102,7 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--head-dtype", default=None, choices=["fp32", "bf16"], help="dcpt: classifier-head activations (default: --dtype)")
     ap.add_argument("--restormer-save", default="balanced", choices=["auto", "lean", "balanced", "full"], help="what the Restormer halves keep for backward")
+    ap.add_argument("--optimizer", default="dcpt", choices=["dcpt", "torch"], help="A/B: torch = torch.optim.AdamW(fused=True) instead of dcpt_amd.optim.FusedAdamW")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tile-streams", type=int, default=2, help="infer2k: HIP streams the tile batches run on (tile.streams)")
@@ -115,6 +118,10 @@ def main():
     from basicsr.archs import build_network
     from dcpt_amd.keyed_init import fill_module_
 
+    if args.optimizer == "torch":   # A/B of the optimizer step: torch's fused kernel behind the same constructor
+        import dcpt_amd.optim as _O
+
+        _O.FusedAdamW = lambda params, lr=1e-3, **kw: torch.optim.AdamW(params, lr, **{**kw, "fused": True})
     g = torch.Generator(device=dev).manual_seed(1234)
     bf = args.dtype == "bf16"
     naf = dict(NAF, act_dtype=args.dtype)
@@ -133,7 +140,9 @@ def main():
         # configs[1]'s network and batch, as a bf16-vs-fp32 comparison line (the fp32 headline is bench.py's, never this one)
         B, S = args.batch or 32, args.size or 256
         net = fill_module_(build_network(dict(type="NAFNetBaseline", **naf))).to(dev)
-        optm = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0, fused=True)
+        from dcpt_amd.optim import FusedAdamW
+
+        optm = FusedAdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0)
         lq = torch.rand((B, 3, S, S), generator=g, device=dev)
         gt = torch.rand((B, 3, S, S), generator=g, device=dev)
 

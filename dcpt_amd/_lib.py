@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 _lock = threading.Lock()
 
@@ -183,6 +183,8 @@ SIGNATURES = {
     "dcpt_prof_enable": (cint, [cint]),
     "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
     "dcpt_set_side_stream": (cint, [cint]),
+    "dcpt_adamw_step": (cint, [cint, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_int64), C.c_void_p, stream_t]),
     "dcpt_allreduce_flat": (cint, [f32p, sz, C.c_void_p, C.c_float, stream_t]),
     "dcpt_nchw_to_nhwc": (cint, [f32p, f32p, cint, cint, cint, stream_t]),
     "dcpt_nhwc_to_nchw": (cint, [f32p, f32p, cint, cint, cint, stream_t]),

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libdcpt_hip.so")
 ARCH = "gfx950"
-SOURCES = ["gemm_nt.hip", "gemm_x3.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip", "prof.hip", "side.hip", "dchead.hip", "restormer.hip", "promptir.hip", "comm.hip", "gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_tn_bf16_256.hip", "bf16_ops.hip", "nafblock_bf16.hip", "dwring.hip", "dchead_bf16.hip", "edge_bf16.hip", "ffn_bf16.hip", "ffn_f32.hip", "chain_bf16.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_x3.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", "misc.hip", "conv3x3.hip", "nafblock.hip", "capi.hip", "prof.hip", "side.hip", "dchead.hip", "restormer.hip", "promptir.hip", "comm.hip", "gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_tn_bf16_256.hip", "bf16_ops.hip", "nafblock_bf16.hip", "dwring.hip", "dchead_bf16.hip", "edge_bf16.hip", "ffn_bf16.hip", "ffn_f32.hip", "chain_bf16.hip", "optim.hip"]
 # No packed-fp32 VALU instructions (v_pk_mul / fma / add_f32) in device code.  Their operand-select forms (op_sel / op_sel_hi: a result half
 # taking the other half of a source pair) returned wrong values in lanes 48-63 -- a few elements per launch -- whenever bf16 MFMA GEMMs of
 # ANOTHER stream shared the SIMD: found in the ending conv under two-stream tiled inference, pinned down by replacing exactly those

@@ -624,6 +624,38 @@ class _TakeBatchFn(torch.autograd.Function):
         return out, None, None
 
 
+class _TapSplitFn(torch.autograd.Function):
+    """(x, x[lo:hi]) for a feature map with TWO consumers -- the network goes on with x, a tap (the classifier head of the DCPT step,
+    reference ...pretrain_model.py:60-68,140-163) takes samples lo..hi-1.  With two separate uses autograd builds the tap's zero-padded
+    gradient (a fill + a copy of the feature map's size) and then ADDS the two gradients (three more passes, 18 bf16 `add` launches per
+    DCPT step at 256 x 256: 1.4 ms); here the tap's gradient is added INTO rows lo..hi-1 of the main path's gradient, in place: one read
+    of the slice and a read-modify-write of the same rows.  (The main path's gradient is the fresh output of the layer above's backward;
+    it has no other consumer in this graph.)"""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.meta = (tuple(x.shape), tuple(x.stride()), x.dtype, x.device, int(lo), int(hi))
+        return x.view(x.shape), x[lo:hi]
+
+    @staticmethod
+    def backward(ctx, g, gs):
+        shape, stride, dtype, dev, lo, hi = ctx.meta
+        if g is None:
+            if gs is None:
+                return None, None, None
+            return _TakeBatchFn.backward(ctx, gs)
+        if gs is not None:
+            if g.shape != tuple(shape) or not g.is_floating_point():
+                g = g.clone()
+            g[lo:hi].add_(gs.to(g.dtype))
+        return g, None, None
+
+
+def tap_split(x, lo, hi):
+    """-> (x, x[lo:hi]) with the two gradients merged in place on the way back (one use of x downstream, one tap)"""
+    return _TapSplitFn.apply(x, lo, hi)
+
+
 def take_batch(x, lo, hi):
     """samples lo..hi-1 of a batch (a view in forward, a stride-preserving zero-padded gradient in backward)"""
     return _TakeBatchFn.apply(x, lo, hi)

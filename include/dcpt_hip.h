@@ -427,6 +427,23 @@ int dcpt_prof_read(double* out, int max_rows);
  * environment, and automatically while `stream` is being captured into a graph).  Returns the previous setting. */
 int dcpt_set_side_stream(int on);
 
+/* ---- optimizer step --------------------------------------------------------------------------------------
+ * AdamW (decoupled weight decay) over a LIST of fp32 tensors, the update that closes every training step of the path: replaces
+ * torch.optim.AdamW(...).step() as built by basicsr/models/base_model.py:70-93 and called by sr_model.py:118 and
+ * degradation_classification_pretrain_model.py:170-173.  Per element, in fp32 and in the order of torch's fused kernel:
+ *     p -= lr wd p;  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+ * `params / grads / exp_avg / exp_avg_sq / numel` are HOST arrays of n entries (device pointers and element counts, tensor i dense in
+ * any layout shared by its four buffers; entries with numel 0 are skipped); bias_correction{1,2} = 1 - beta{1,2}^step for the step
+ * being taken (step >= 1).  maximize != 0 negates the gradients.  A few launches on `stream` for any n (80 tensors per launch, the
+ * pointers travel as kernel arguments: nothing is copied or allocated). */
+typedef struct {
+    double lr, beta1, beta2, eps, weight_decay;   /* doubles as the host holds them: 1 - beta is formed in double (1 - 0.999 in fp32 is off by 1e-5) */
+    double bias_correction1, bias_correction2;
+    int maximize;
+} dcpt_adamw_hparams;
+int dcpt_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numel, const dcpt_adamw_hparams* h, dcpt_stream_t stream);
+
 /* ---- gradient all-reduce (data-parallel step) -------------------------------------------------------
  * replaces what torch DistributedDataParallel does for the reference (basicsr/models/base_model.py:108-115: bucketed
  * all-reduce(SUM) / world of the gradients; :448 the loss reduce) for hosts that drive the collective themselves:
