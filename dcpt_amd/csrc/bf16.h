@@ -157,6 +157,14 @@ struct TnProb {
 struct GemmTNG {
     TnProb p[TNG_MAX];
     int n;
+    // XCD-aligned block order (filled by gemm_tn_bf16_256_plan; xcd_slots == 0: blocks in problem / pixel-range / tile order through
+    // xcd_remap).  The tiles of one pixel range share their operand columns, and they share them through ONE XCD's L2 only: a UNIT is
+    // min(tiles, 4) consecutive tiles of a pixel range, a problem's units in order are dealt to the 8 XCDs in contiguous runs --
+    // xq[i] packs, 6 bits each, the first unit of problem i on XCD 0..7 and (entry 8) its unit count; hardware block b runs slot b >> 3
+    // of XCD b & 7 (slots count through the problems' runs; past them the block is idle); the grid is 8 * xcd_slots blocks.
+    int xcd_slots;
+    int only;   // diagnostic builds (DCPT_TUNING): >= 0 = only this problem's blocks run; -1 otherwise
+    unsigned long long xq[TNG_MAX];
 };
 bool gemm_tn_bf16_256_ok(int N, int K);
 // img_P[i] > 0: problem i needs partial sums per image of img_P[i] pixels (false if that is not possible: no plan is made)

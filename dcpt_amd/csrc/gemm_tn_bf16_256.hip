@@ -21,7 +21,8 @@
 //     p0: read X-lo, Y-lo   stage Y-hi(t+1)   MFMA (lo,lo)        p2: read X-hi    stage X-lo(t+2)   MFMA (hi,hi)
 //     p1: read Y-hi         stage X-hi(t+1)   MFMA (lo,hi)        p3: --           stage Y-lo(t+2)   MFMA (hi,lo)
 // Bias gradients (column sums of X) ride along as v_dot2c_f32_bf16 on the X fragments a wave holds anyway: the four waves that share
-// an X strip take one 32-column tile each, only in the blocks of the first k tile column: 16 VALU instructions per k-tile.
+// an X strip take one 32-column tile each, the strip's lower 128 columns in the blocks of k tile column 0 and the upper 128 in those of
+// k tile column 1 (16 VALU instructions per k-tile in the load slot of a phase that reads few fragments, the same load on every sibling tile).
 //
 // Slabs are stored in the ACCUMULATORS' OWN LAYOUT (a block's 256 KB = 256 chunks of [64 lanes][4 floats]: fully coalesced 16-byte
 // stores straight from the registers, no LDS transpose); only the finisher knows the map back to (n, k): a lane's float4 is 4
@@ -31,6 +32,18 @@
 #include "bf16.h"
 #include "kernels.h"
 #include "prof.h"
+
+#ifdef TN256_TIMELINE
+// Diagnostic build only (tools/tn256_timeline.py): per-block wall-clock stamps (100 MHz) at the start, after the prologue, at each quarter
+// of the first segment's k-loop and at the end, plus the XCC id and the block's (problem, pixel range, tile)
+__device__ unsigned long long g_tl_tn256[1024][10];
+extern "C" int dcpt_timeline_read_tn256(unsigned long long* host, int nblk) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl_tn256), sizeof(unsigned long long) * 10 * (size_t)nblk);
+}
+#define TL256(i) if (threadIdx.x == 0 && blockIdx.x < 1024) g_tl_tn256[blockIdx.x][i] = wall_clock64();
+#else
+#define TL256(i)
+#endif
 
 namespace {
 
@@ -48,15 +61,14 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a) {   // rows r
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ float4 f4_bcast(float s) { return make_float4(s, s, s, s); }
-__device__ __forceinline__ float dot_ones(bf16x8 f, float c) {   // c + sum of the 8 values
-    bf16x2v one;
+__device__ __forceinline__ void dot_ones(bf16x8 f, float (&c)[2]) {   // c[0] + c[1] += the 8 values (two independent chains: the kernel has no
+    bf16x2v one;                                                       // register to spare for four)
     one.x = (__bf16)1.0f;
     one.y = (__bf16)1.0f;
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), one, c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), one, c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), one, c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), one, c, false);
-    return c;
+    c[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), one, c[0], false);
+    c[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), one, c[1], false);
+    c[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), one, c[0], false);
+    c[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), one, c[1], false);
 }
 
 template <bool YCONV>
@@ -66,14 +78,58 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;              // 0: leads, 1: one barrier behind
     const int wm = wave >> 2, wn = wave & 3;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
     TnProb p = g.p[0];   // (wave-uniform selects on kernel arguments: no dynamically indexed copy of the table)
+    int split, tile, tiles, pidx = 0;
+    if (g.xcd_slots > 0) {   // XCD-aligned order (GemmTNG): slot b >> 3 of XCD b & 7
+        const int sh = 6 * (int)(blockIdx.x & 7);
+        int slot = (int)(blockIdx.x >> 3), unit = -1, tin = 0, usz = 1;
 #pragma unroll
-    for (int i = 1; i < TNG_MAX; ++i)
-        if (i < g.n && lin >= g.p[i].blk0) p = g.p[i];
-    const int rel = lin - p.blk0;
-    const int tiles = (p.N >> 8) * p.tiles_k;
-    const int split = rel / tiles, tile = rel - split * tiles;   // (consecutive blocks = the tiles of one pixel range: one XCD's L2 serves them)
+        for (int i = 0; i < TNG_MAX; ++i) {
+            if (i < g.n && unit < 0) {
+                const int u0 = (int)((g.xq[i] >> sh) & 63ull), u1 = (int)((g.xq[i] >> (sh + 6)) & 63ull);
+                const int tl = (g.p[i].N >> 8) * g.p[i].tiles_k, us = tl < 4 ? tl : 4;
+                const int cnt = (u1 - u0) * us;
+                if (slot < cnt) {
+                    p = g.p[i];
+                    pidx = i;
+                    usz = us;
+                    unit = u0 + slot / us;
+                    tin = slot % us;
+                } else {
+                    slot -= cnt;
+                }
+            }
+        }
+        if (unit < 0) return;   // an idle slot of this XCD
+        tiles = (p.N >> 8) * p.tiles_k;
+        const int ups = tiles / usz;
+        split = unit / ups;
+        tile = (unit - split * ups) * usz + tin;
+    } else {
+        const int lin = xcd_remap(blockIdx.x, gridDim.x);
+#pragma unroll
+        for (int i = 1; i < TNG_MAX; ++i)
+            if (i < g.n && lin >= g.p[i].blk0) {
+                p = g.p[i];
+                pidx = i;
+            }
+        const int rel = lin - p.blk0;
+        tiles = (p.N >> 8) * p.tiles_k;
+        split = rel / tiles;   // (consecutive blocks = the tiles of one pixel range: one XCD's L2 serves them)
+        tile = rel - split * tiles;
+    }
+#ifdef DCPT_TUNING   // diagnostic builds: only the blocks of ONE problem of the group run (per-problem fabric traffic, tools/exp_r5f.sh)
+    if (g.only >= 0 && pidx != g.only) return;
+#endif
+    TL256(0)
+#ifdef TN256_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_tl_tn256[blockIdx.x][8] = ((unsigned long long)(xcc & 15u) << 48) | ((unsigned long long)pidx << 32) | ((unsigned long long)split << 16) | (unsigned)tile;
+        g_tl_tn256[blockIdx.x][9] = 1;
+    }
+#endif
     const int tile_n = tile / p.tiles_k, tile_k = tile - tile_n * p.tiles_k;
     const int n0 = tile_n * 256, k0 = tile_k * 256;
     const int64_t mbeg = (int64_t)split * p.rows_per_split;
@@ -147,8 +203,13 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
         const int c = wn * 32 + 16 * g16 + 4 * (t16 & 3);
         bbase = smem + 2 * HT + rowoff + (((c >> 3) ^ swz) << 4) + (c & 7) * 2;
     }
-    float cs = 0.f;
-    const bool do_cs = (p.colsum != nullptr) && tile_k == 0;   // wave (wm, wn) sums X columns  (wn >> 1) * 128 + wm * 64 + (wn & 1) * 32 + 0..31
+    // wave (wm, wn) sums X columns  (wn >> 1) * 128 + wm * 64 + (wn & 1) * 32 + 0..31 -- the two 128-column halves in DIFFERENT tiles of the
+    // strip where it has two or more (k tile columns 0 and 1): the sums are 16 VALU instructions per k-tile, and with all of them in the first
+    // tile column (and in the waves' load phase) those blocks ran 18 % longer than their siblings (95 us against 80 at level 3,
+    // tools/tn256_timeline.py) -- which stretches the launch AND takes the siblings out of step, so that the late ones find the shared operand
+    // columns evicted from the XCD's L2 (459 MB over the fabric for 335 MB of operands)
+    float cs[2] = {0.f, 0.f};
+    const bool do_cs = !YCONV && (p.colsum != nullptr) && (p.tiles_k == 1 ? tile_k == 0 : tile_k == (wn >> 1));   // (gathered Y: never with column sums)
 
 #ifdef TN_ABL_NOMFMA   // ablation build: operands stay live, no matrix work
 #define TN_MFMA_OP(ACC, FA, FB) asm volatile("" ::"v"(FA), "v"(FB))
@@ -166,14 +227,6 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
         fb[0][j] = tr_read8(bbase + (S)*STG + j * 4096);                                                                  \
         fa[1][j] = tr_read8(abase[1] + (S)*STG + j * 4096);                                                               \
     }
-#define TN_COLSUM(H)                                                                                                      \
-    if (do_cs && (wn >> 1) == (H)) {                                                                                      \
-        if (wn & 1) {                                                                                                     \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) cs = dot_ones(fa[1][j], cs);                                    \
-        } else {                                                                                                          \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) cs = dot_ones(fa[0][j], cs);                                    \
-        }                                                                                                                 \
-    }
 #define TN_MFMA(AH, BH)                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                                       \
@@ -182,6 +235,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
     __builtin_amdgcn_s_setprio(0);                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     __builtin_amdgcn_s_barrier();
+// column sums of X half H from the fragments in fa: issued in the load slot of the phase that has the FEWEST fragment reads while fa
+// still holds that half (phase 1 for the lower half, phase 3 for the upper one; phases 0 and 2 read 12 and 8 fragments, 1 and 3 read 4 and 0)
+#define TN_COLSUM(H)                                                                                                      \
+    if (do_cs && (wn >> 1) == (H)) {                                                                                      \
+        if (wn & 1) {                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) dot_ones(fa[1][j], cs);                                         \
+        } else {                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) dot_ones(fa[0][j], cs);                                         \
+        }                                                                                                                 \
+    }
 #define TN_PUBLISH()                                                                                                      \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                      \
     __builtin_amdgcn_s_barrier();
@@ -261,36 +324,46 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // X-lo(0), Y-lo(0) landed (this wave's part; the barrier publishes all)
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind from here on
+        if (seg == 0) { TL256(1) }
 
         for (int t = 0; t < nkt2; t += 2) {
+#ifdef TN256_TIMELINE
+            if (seg == 0 && nkt2 >= 8) {
+                const int qt = (nkt2 / 4) & ~1;
+                if (t == qt) { TL256(2) }
+                if (t == 2 * qt) { TL256(3) }
+                if (t == 3 * qt) { TL256(4) }
+            }
+#endif
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int kt = t + s;
                 // phase 0: (X-lo, Y-lo)
                 TN_LOAD_AB(s)
                 stage(3, s ^ 1, kt + 1);
-                TN_COLSUM(0)
                 TN_PUBLISH()
                 TN_MFMA(0, 0)
                 // phase 1: (X-lo, Y-hi)
                 TN_LOAD_B(s, 1)
                 stage(1, s ^ 1, kt + 1);
+                TN_COLSUM(0)
                 TN_PUBLISH()
                 TN_MFMA(0, 1)
                 // phase 2: (X-hi, Y-hi)
                 TN_LOAD_A(s, 1)
                 stage(0, s, kt + 2);
-                TN_COLSUM(1)
                 TN_PUBLISH()
                 TN_MFMA(1, 1)
                 // phase 3: (X-hi, Y-lo)
                 stage(2, s, kt + 2);
+                TN_COLSUM(1)
                 TN_PUBLISH()
                 TN_MFMA(1, 0)
             }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier: every wave is past its last fragment read
         dma_wait_all();                               // (the zero-filling DMAs past the last k-tile, before the next segment restages)
+        if (seg == 0) { TL256(5) }
 
 #ifdef TN_ABL_NOEPI   // ablation build: accumulators stay live, nothing is written
 #pragma unroll
@@ -323,8 +396,10 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_256_kernel(const GemmTNG g) 
 #undef TN_MFMA
 #undef TN_MFMA_OP
 #undef TN_PUBLISH
+    TL256(6)
     if (do_cs) {   // lanes l and l + 32 hold the two pixel halves of column l
-        const float tot = cs + __shfl_xor(cs, 32);
+        const float own = cs[0] + cs[1];
+        const float tot = own + __shfl_xor(own, 32);
         if (lane < 32) p.colsum[(int64_t)split * p.N + n0 + (wn >> 1) * 128 + wm * 64 + (wn & 1) * 32 + lane] = tot;
     }
 }
@@ -510,8 +585,81 @@ bool gemm_tn_bf16_256_ok(int N, int K) {
 // more slab bytes than operand bytes -- small batches fill fewer CUs instead; DCPT at 128 x 128: 48.7 -> ... us per grouped launch)
 constexpr int64_t TN_MIN_ROWS_DEFAULT = 1024;
 
+// The XCD-aligned block order of GemmTNG: units (<= 4 consecutive tiles of one pixel range) dealt to the 8 XCDs in contiguous runs of
+// about the same number of blocks; a run boundary that would fall between the two units of an 8-tile pixel range moves to the range's end
+// (or start) while the XCD keeps at most 32 blocks -- one per CU.  Left off (xcd_slots = 0) where a problem's tile count is no multiple of its unit or a
+// problem has more than 63 units.
+static void plan_xcd(GemmTNG& g) {
+    static const int on = dcpt_tuning("DCPT_TN_XCD", 1);
+    g.xcd_slots = 0;
+    g.only = dcpt_tuning("DCPT_TN_ONLY", -1);
+    for (int i = 0; i < TNG_MAX; ++i) g.xq[i] = 0;
+    if (!on) return;
+    int usz[TNG_MAX], ups[TNG_MAX], units[TNG_MAX], off[TNG_MAX + 1], total_blocks = 0;
+    off[0] = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tl = (g.p[i].N / 256) * g.p[i].tiles_k;
+        usz[i] = tl < 4 ? tl : 4;
+        if (tl % usz[i] != 0) return;
+        ups[i] = tl / usz[i];
+        units[i] = g.p[i].splits * ups[i];
+        if (units[i] > 63) return;
+        off[i + 1] = off[i] + units[i];
+        total_blocks += units[i] * usz[i];
+    }
+    const int U = off[g.n];
+    auto prob_of = [&](int u) {
+        int i = 0;
+        while (i + 1 < g.n && u >= off[i + 1]) ++i;
+        return i;
+    };
+    int cut[9];
+    cut[0] = 0;
+    int cum = 0, u = 0, slots = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int target = (int)(((int64_t)total_blocks * (x + 1) + 4) / 8);
+        int run = 0;
+        while (u < U) {
+            const int i = prob_of(u);
+            if (x < 7 && cum + usz[i] / 2 >= target && run > 0) break;   // (the last XCD takes what is left)
+            cum += usz[i];
+            run += usz[i];
+            ++u;
+        }
+        if (x < 7 && u < U) {   // boundary inside a pixel range's units?  move it to the range's end, else to its start
+            const int i = prob_of(u), r = (u - off[i]) % ups[i];
+            if (r != 0 && ups[i] == 2) {   // (larger tile sets share enough inside their units)
+                const int fwd = ups[i] - r;
+                if (run + fwd * usz[i] <= 32) {
+                    u += fwd;
+                    cum += fwd * usz[i];
+                    run += fwd * usz[i];
+                } else if (run - r * usz[i] > 0) {
+                    u -= r;
+                    cum -= r * usz[i];
+                    run -= r * usz[i];
+                }
+            }
+        }
+        cut[x + 1] = u;
+        if (run > slots) slots = run;
+    }
+    for (int i = 0; i < g.n; ++i) {
+        unsigned long long q = 0;
+        for (int x = 0; x <= 8; ++x) {
+            int v = cut[x] - off[i];
+            v = v < 0 ? 0 : (v > units[i] ? units[i] : v);
+            q |= (unsigned long long)v << (6 * x);
+        }
+        g.xq[i] = q;
+    }
+    g.xcd_slots = slots;
+}
+
 bool gemm_tn_bf16_256_plan(GemmTNG& g, const int* img_P, int target_blocks) {
     static const int64_t TN_MIN_ROWS = dcpt_tuning("DCPT_TN_MIN_ROWS", (int)TN_MIN_ROWS_DEFAULT);
+    static const int force_blocks = dcpt_tuning("DCPT_TN_BLOCKS", 0);   // experiments: blocks per launch (default: one per CU)
+    if (force_blocks > 0) target_blocks = force_blocks;
     int tiles = 0;
     for (int i = 0; i < g.n; ++i) {
         g.p[i].tiles_k = g.p[i].K / 256;
@@ -562,6 +710,7 @@ bool gemm_tn_bf16_256_plan(GemmTNG& g, const int* img_P, int target_blocks) {
         p.blk0 = blk;
         blk += p.splits * (p.N / 256) * p.tiles_k;
     }
+    plan_xcd(g);
     return true;
 }
 
@@ -594,8 +743,9 @@ int launch_gemm_tn_bf16_256(const GemmTNG& g, hipStream_t s) {
         bytes += ((double)p.M * p.N + (double)p.M * p.K) * 2.0 + (double)gemm_tn_bf16_256_slab_floats(p) * 4.0;
     }
     ProfScope prof(s, PROF_TN + 257, g.p[0].M, g.p[0].N, g.p[0].K, flops, bytes);
-    if (g.p[0].yconv) gemm_tn_bf16_256_kernel<true><<<dim3((unsigned)blocks), dim3(512), 0, s>>>(g);
-    else gemm_tn_bf16_256_kernel<false><<<dim3((unsigned)blocks), dim3(512), 0, s>>>(g);
+    const unsigned grid = g.xcd_slots > 0 ? 8u * (unsigned)g.xcd_slots : (unsigned)blocks;
+    if (g.p[0].yconv) gemm_tn_bf16_256_kernel<true><<<dim3(grid), dim3(512), 0, s>>>(g);
+    else gemm_tn_bf16_256_kernel<false><<<dim3(grid), dim3(512), 0, s>>>(g);
     DCPT_CHECK_LAUNCH("gemm_tn_bf16_256");
     return DCPT_OK;
 }

@@ -7,7 +7,10 @@ import torch
 from dcpt_amd import functional as DF
 
 dev = torch.device("cuda:0")
-for M, N, K in [(32768, 1024, 512), (32768, 512, 512), (131072, 512, 256), (131072, 256, 256), (8192, 2048, 1024), (65536, 1024, 512), (16384, 1024, 512)]:
+SHAPES = [(32768, 1024, 512), (32768, 512, 512), (131072, 512, 256), (131072, 256, 256), (8192, 2048, 1024), (65536, 1024, 512), (16384, 1024, 512)]
+if os.environ.get("SHAPE"):   # one shape only (PMC passes: tools/exp_r5e.sh)
+    SHAPES = [SHAPES[int(os.environ["SHAPE"])]]
+for M, N, K in SHAPES:
     R = 6   # operand sets in rotation: ~600 MB per round, beyond the 256 MB Infinity Cache
     dys = [torch.randn((M, N), device=dev).bfloat16() for _ in range(R)]
     xs = [torch.randn((M, K), device=dev).bfloat16() for _ in range(R)]
