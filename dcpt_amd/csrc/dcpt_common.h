@@ -137,4 +137,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
 }
+// The same for a BATCHED launch (grid.y = independent problems): the hardware deals the blocks of a 2-D grid to the XCDs in the linear order
+// x + y * gridDim.x, so a remap of blockIdx.x alone leaves the blocks of one problem on gridDim.x % 8 ... different XCDs -- with 8 blocks per
+// image (conv3 with per-image weights at level 3) every block of an image on its own XCD, the activations read 2 x and the image's weights
+// 4 x over the fabric (168 MB for 84: profiles/r5/nt_batched_xcd/).  Over the whole grid, a problem's blocks are neighbours on one XCD.
+__device__ __forceinline__ void xcd_remap_batched(int& lin, int& batch) {
+    const int gx = (int)gridDim.x;
+    if (gridDim.y == 1) {
+        lin = xcd_remap((int)blockIdx.x, gx);
+        batch = 0;
+        return;
+    }
+    const int lg = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), gx * (int)gridDim.y);
+    batch = lg / gx;
+    lin = lg - batch * gx;
+}
 #endif

@@ -28,8 +28,10 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr bool CONV = AM == 1, GATH = AM == 2;
     GemmNTB p = pin;
+    int lin, batch;
+    xcd_remap_batched(lin, batch);
     if (gridDim.y > 1) {
-        const int64_t b = blockIdx.y;
+        const int64_t b = batch;
         p.A += b * p.sA;
         p.Bw += b * p.sB;
         p.C += b * p.sC;
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmNTB pin) {
     const int wm = wave / WN, wn = wave % WN;
     const int Ch = p.N / 2;
     const int tilesN = GATE ? (Ch + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(lin / tilesN) * BM;
     const int n0 = (lin % tilesN) * (GATE ? BN / 2 : BN);
 

@@ -39,8 +39,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
     constexpr bool GATE = (EK == EB_BIASGATE);
     constexpr bool CONV = AM == 1;
     GemmNTB p = pin;
+    int lin, batch;
+    xcd_remap_batched(lin, batch);
     if (gridDim.y > 1) {
-        const int64_t b = blockIdx.y;
+        const int64_t b = batch;
         p.A += b * p.sA;
         p.Bw += b * p.sB;
         p.C += b * p.sC;
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
     const int wm = wave >> 2, wn = wave & 3;
     const int Ch = p.N / 2;
     const int tilesN = GATE ? Ch / 128 : p.N / 256;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(lin / tilesN) * 256;
     const int n0 = (lin % tilesN) * (GATE ? 128 : 256);
     const int nlo = n0, nhi = GATE ? Ch + n0 : n0 + 128;   // first weight row of the two B halves

@@ -56,8 +56,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
     constexpr bool A_DMA = (AK == A_PLAIN || AK == A_GATHER || AK == A_CONV3);  // pure data movement
     GemmNT p = pin;
     TL_STAMP(0) TL_HWID()
+    int lin, batch;
+    xcd_remap_batched(lin, batch);
     if (gridDim.y > 1) {  // batched: shift the base pointers of this problem
-        const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
+        const int b1 = batch / p.nb2, b2 = batch % p.nb2;
         p.A += b1 * p.sA1 + b2 * p.sA2;
         p.Bw += b1 * p.sB1 + b2 * p.sB2;
         p.C += b1 * p.sC1 + b2 * p.sC2;
@@ -78,7 +80,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNT pin)
     const int wm = wave / WN, wn = wave % WN;
     constexpr bool GATE = (EK == E_BIASGATE);
     const int tilesN = GATE ? (p.N / 2 + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(lin / tilesN) * BM;
     const int n0 = (lin % tilesN) * (GATE ? BN / 2 : BN);   // GATE: first column of the tile inside each half
 

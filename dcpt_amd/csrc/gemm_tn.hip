@@ -35,11 +35,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     static_assert(is_dma<XK>(), "X (the output gradient) is never transformed");
     GemmTN p = pin;
     TLT(0)
+    int lin, batch;
+    xcd_remap_batched(lin, batch);
     if (gridDim.y > 1) {
-        const int b1 = blockIdx.y / p.nb2, b2 = blockIdx.y % p.nb2;
+        const int b1 = batch / p.nb2, b2 = batch % p.nb2;
         p.X += b1 * p.sX1 + b2 * p.sX2;
         p.Y += b1 * p.sY1 + b2 * p.sY2;
-        p.slab += (int64_t)blockIdx.y * p.splits * p.N * p.K;
+        p.slab += (int64_t)batch * p.splits * p.N * p.K;
     }
     constexpr int TN = BN / (WN * 32), TK = BKo / (WK * 32);
     // staging: pass i of the 256 threads covers tile floats [1024 i, 1024 i + 1024) of the row-major [BR][width] tile
@@ -58,7 +60,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN pin) {
     // from that XCD's L2 by the other tiles.
     const int tilesK = (p.K + BKo - 1) / BKo;
     const int tilesN = (p.N + BN - 1) / BN;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int split = lin / (tilesN * tilesK);
     const int tile = lin % (tilesN * tilesK);
     const int tile_n = tile / tilesK, tile_k = tile % tilesK;

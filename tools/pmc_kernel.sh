@@ -18,7 +18,7 @@ seen = set()
 for r in csv.DictReader(open(f[0])):
     n = r["Kernel_Name"]
     if key not in n: continue
-    short = n.split("(")[0][-60:]
+    short = n.replace("(anonymous namespace)::", "").split("(")[0][-70:]
     acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
     k = (short, r["Dispatch_Id"])
     if k not in seen:
