@@ -34,6 +34,32 @@ struct DwrP {
     int nwc;            // column chunks
 };
 
+// Block -> (channel chunk, column chunk + nwc * row part, image), optionally XCD-aware: the hardware deals the blocks of the 3-D grid to the
+// XCDs in the linear order x + gridDim.x * (y + gridDim.y * z), i.e. the channel chunks of one image -- neighbouring 128-byte runs of the
+// same pixels -- to different XCDs.  With the chunks of an image as neighbours on ONE XCD the backward kernel of the narrow images (one tile
+// per image row, levels 2 and 3) reads half as much over the fabric in bf16 (201 -> 101 MB at level 3) and runs 9-24 % faster in a same-box
+// A/B (profiles/r5/dwring_xcd/); the forward kernel and the column-tiled backward (levels 0 and 1) read less too but are no faster (+-5 %),
+// they keep the plain grid order.
+struct DwrBlk {
+    int qc, by, b;
+};
+__device__ __forceinline__ DwrBlk dwr_block(int nwc, int xcd_order) {
+    if (!xcd_order) return DwrBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    const int L = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+    int t = xcd_remap(L, gx * gy * (int)gridDim.z);
+    DwrBlk k;
+    const int wc = t % nwc;   // column neighbours first, then the channel chunks, then the row parts, then the images
+    t /= nwc;
+    k.qc = t % gx;
+    t /= gx;
+    const int nrp = gy / nwc;
+    const int rp = t % nrp;
+    k.b = t / nrp;
+    k.by = wc + nwc * rp;
+    return k;
+}
+
 template <int VW>
 struct pv {
     float v[VW];
@@ -85,10 +111,11 @@ __global__ __launch_bounds__(256) void dwr_gate_fwd_kernel(const DwrP p) {
     const int PP = 256 / LP, PB = 2 * PP;
     // block -> (channel chunk, column chunk, row part, image)
     const int nrp = gridDim.y / p.nwc, rpp = (p.H + nrp - 1) / nrp;
-    const int wc = blockIdx.y % p.nwc, rp = blockIdx.y / p.nwc, b = blockIdx.z;
+    const DwrBlk blk = dwr_block(p.nwc, 0);   // (the XCD-aware order gains nothing here: same-box A/B in profiles/r5/dwring_xcd/)
+    const int wc = blk.by % p.nwc, rp = blk.by / p.nwc, b = blk.b;
     const int x0 = wc * PB;
     const int h0 = rp * rpp, h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
-    const int piece0 = blockIdx.x * LP;
+    const int piece0 = blk.qc * LP;
     const int g = tid % LP, pp = tid / LP;
     const bool gok = piece0 + g < PH;
     const int c1 = (piece0 + g) * VW, c2 = C + c1;
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(256) void dwr_gate_fwd_kernel(const DwrP p) {
             for (int k = 1; k < PP; ++k)
 #pragma unroll
                 for (int i = 0; i < VW; ++i) sres[i] += red[(k * LP + g) * VW + i];
-            float* dst = p.part + ((int64_t)b * gridDim.y + blockIdx.y) * C + c1;
+            float* dst = p.part + ((int64_t)b * gridDim.y + blk.by) * C + c1;
 #pragma unroll
             for (int i = 0; i < VW; ++i) dst[i] = sres[i];
         }
@@ -370,11 +397,12 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = p.C, PH = C / 2;
     const int nrp = gridDim.y / p.nwc, rpp = (p.H + nrp - 1) / nrp;
-    const int wc = blockIdx.y % p.nwc, rp = blockIdx.y / p.nwc, b = blockIdx.z;
+    const DwrBlk blk = dwr_block(p.nwc, !MULTI);
+    const int wc = blk.by % p.nwc, rp = blk.by / p.nwc, b = blk.b;
     const int h0 = rp * rpp, h1 = (h0 + rpp < p.H) ? h0 + rpp : p.H;
     const int x0 = MULTI ? wc * (PB - 2) - 1 : 0;   // image column of da column 0
     const int xs = x0 - MULTI;                      // image column of t1 slot column 0
-    const int piece0 = blockIdx.x * LP;
+    const int piece0 = blk.qc * LP;
     const int g = tid % LP, pp = tid / LP;
     const bool act = pp < PP;
     const bool gok = act && piece0 + g < PH;
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(256) void dwr_bwd_fused_kernel(const DwrBP p) {
 #pragma unroll
         for (int t = 0; t < 10; ++t) *reinterpret_cast<v2*>(red + tid * 40 + (h * 10 + t) * 2) = gr[h][t];
     __syncthreads();
-    float* dst = p.part + ((int64_t)b * gridDim.y + blockIdx.y) * 10 * 2 * C;
+    float* dst = p.part + ((int64_t)b * gridDim.y + blk.by) * 10 * 2 * C;
     for (int idx = tid; idx < LP * 40; idx += 256) {
         const int gg = idx / 40, k = idx % 40;
         if (piece0 + gg >= PH) continue;
