@@ -437,7 +437,17 @@ __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /*
 #pragma unroll
                 for (int u = 0; u < 8; ++u) gs[u] = f4_add(gs[u], ldg4(base + (int64_t)(s + u) * sstride));
             }
-            for (; s < j.splits; ++s) gs[0] = f4_add(gs[0], ldg4(base + (int64_t)s * sstride));
+            // the tail (fewer than eight partial sums left) as eight loads at once as well: the ones past the end re-read the last partial sum
+            // with weight 0 (a load that depends on the loop counter of a runtime loop waits for the one before it: with 10 partial sums
+            // per element that was three round trips per column group instead of two)
+            if (s < j.splits) {
+                const int rem = j.splits - s;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float4 v = ldg4(base + (int64_t)(s + (u < rem ? u : rem - 1)) * sstride);
+                    gs[u] = f4_fma(v, f4_bcast(u < rem ? 1.f : 0.f), gs[u]);
+                }
+            }
         } else {   // every partial sum lies inside one image: it is weighted by that image's per-column scale (SCA)
             const float* ks = j.kscale + k;
             for (; s + 7 < j.splits; s += 8) {
@@ -445,7 +455,15 @@ __device__ __forceinline__ void fin_slab(const FinSlab& j, int rg, float* red /*
                 for (int u = 0; u < 8; ++u)
                     gs[u] = f4_fma(ldg4(base + (int64_t)(s + u) * sstride), f4_bcast(ks[(int64_t)((s + u) / j.ks_div) * j.K]), gs[u]);
             }
-            for (; s < j.splits; ++s) gs[0] = f4_fma(ldg4(base + (int64_t)s * sstride), f4_bcast(ks[(int64_t)(s / j.ks_div) * j.K]), gs[0]);
+            if (s < j.splits) {
+                const int rem = j.splits - s;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int su = s + (u < rem ? u : rem - 1);
+                    const float4 v = ldg4(base + (int64_t)su * sstride);
+                    gs[u] = f4_fma(v, f4_bcast(u < rem ? ks[(int64_t)(su / j.ks_div) * j.K] : 0.f), gs[u]);
+                }
+            }
         }
         const float4 G = f4_add(f4_add(f4_add(gs[0], gs[1]), f4_add(gs[2], gs[3])), f4_add(f4_add(gs[4], gs[5]), f4_add(gs[6], gs[7])));
         const float ge[4] = {G.x, G.y, G.z, G.w};
