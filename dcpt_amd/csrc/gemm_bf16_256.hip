@@ -98,7 +98,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
             voffB[h][ps] = (uint32_t)((h ? nhi : nlo) + row) * (uint32_t)p.K * 2u + ch;
         }
     }
-    const uint32_t tapinv = CONV ? 65536u / (uint32_t)(p.gC / 64) + 1u : 0u;   // tap of k-tile kt = (kt * tapinv) >> 16   (kt < 2048)
     const uint32_t lds0 = lds_addr(reinterpret_cast<const float*>(smem));
     const uint32_t lds_w = lds0 + (uint32_t)wave * 1024u;
     // X: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
@@ -113,9 +112,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 #endif
         if (X < 2) {
             if constexpr (CONV) {
-                // k-tile kt = 64 channels of ONE tap: the same shift for every row, per-row validity from the tap masks
-                const uint32_t tap = ((uint32_t)kt * tapinv) >> 16;
-                const int ch0 = kt * 64 - (int)tap * p.gC;
+                // k-tile kt = 64 channels of ONE tap: the same shift for every row, per-row validity from the tap masks.  The k-tiles run
+                // CHANNEL CHUNK-major, tap-minor (chunk kt / 9, tap kt % 9): the nine shifted reads of a chunk's rows follow each other and
+                // hit the XCD's L2; tap-major, a block came back to its rows only after a whole pass over the channels and fetched the input
+                // 7 x over the fabric (1131 MB for a 157-MB tensor at the head's 256 x 256 stage, profiles/r5/conv3_tap_order/)
+                const uint32_t chunk = ((uint32_t)kt * 7282u) >> 16, tap = (uint32_t)kt - 9u * chunk;   // kt / 9, kt % 9   (kt < 2048)
+                const int ch0 = (int)chunk * 64;
                 const int ky = (int)((tap * 11u) >> 5), kx = (int)tap - 3 * ky;
                 const uint32_t shift = (uint32_t)((((ky - 1) * p.gW + (kx - 1)) * p.gC + ch0) * 2);
                 dma16(rsA, dst, (((tapok[X][0] >> tap) & 1u) ? voffA[X][0] + shift : ROW_SENT) | dead, 0);
@@ -125,8 +127,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
                 dma16(rsA, dst + 8192u, voffA[X][1] | dead, soff);
             }
         } else {
-            dma16(rsB, dst, voffB[X - 2][0] | dead, soff);
-            dma16(rsB, dst + 8192u, voffB[X - 2][1] | dead, soff);
+            uint32_t soffB = soff;
+            if constexpr (CONV) {   // the weights' k index of k-tile kt: tap * gC + 64 * chunk
+                const uint32_t chunk = ((uint32_t)kt * 7282u) >> 16, tap = (uint32_t)kt - 9u * chunk;
+                soffB = (tap * (uint32_t)p.gC + 64u * chunk) * 2u;
+            }
+            dma16(rsB, dst, voffB[X - 2][0] | dead, soffB);
+            dma16(rsB, dst + 8192u, voffB[X - 2][1] | dead, soffB);
         }
     };
 
