@@ -333,6 +333,444 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float* __re
     }
 }
 
+
+// ================================================================================================================================
+// MFMA forms of the three edge kernels (round 5).  The VALU kernels above spend 27 FMAs per feature element (K = Cs * 9 taps) and, with packed
+// fp32 off (build.py), run at 2.5 - 4 x their HBM time: 237 / 409 / 256 us (s2b / b2s / wgrad, B = 32, 256 x 256, Cb = 64, fp32) against
+// ~107 us of traffic each.  The same sums as exact-fp32 matrix products on v_mfma_f32_32x32x2_f32 (lane l: A[i = l & 31][k = l >> 5],
+// B[k = l >> 5][j = l & 31], D[i = 8 (r >> 2) + 4 (l >> 5) + (r & 3)][j = l & 31]) take 7.5 - 9.7 GF = 48 - 62 us of the matrix pipe:
+//   s2b    y[p][c]  = sum_k S[p][k] Wk[k][c],  S[p][k = s * 9 + tap] = x[s][p + off(tap)]  (A = S: one image scalar per lane and step, the
+//          nine-fold reuse is the L1's; B = the 14 x Cb/32 weight fragments, resident in registers).  A wave owns 32 consecutive pixels of
+//          a row; a lane's channels are c = NT (l & 31) + nt, so its NT accumulators of a pixel are adjacent in memory (one store each).
+//   wgrad  D[c][j]  = sum_p big[p][c] S[p][j],  S[p][Cs * 9] = 1 (the column sum of big = the bias gradient rides as column 27).
+//          A = big read as 128-byte runs (32 channels of a pixel, the lane halves take neighbouring pixels), B = S as above.
+//   b2s    Z[q][j = s * 9 + tap] = sum_c x[q][c] W[s][c][tap] at the UNSHIFTED pixel q (a plain GEMM over the channels: A = 16-byte pieces
+//          of a pixel's row, the contraction order permuted to match), then y[p][s] = sum_tap Z[p + off(tap)][(s, tap)] gathered from a
+//          wave-private three-row ring of Z in LDS.  A wave owns a band of 32 Z columns = 30 output columns (the edge columns are
+//          recomputed by the neighbouring band: no block-level synchronisation at all) and streams down a strip of rows.
+// Taken for Cs <= 3 and Cb = 32 / 64 (every NAFNet / head configuration of the repo); anything else keeps the VALU kernels.  DCPT_EDGE_MFMA=0
+// switches back (A/B and parity reference).  All three are run-to-run deterministic (fixed assignment, fixed summation order).
+constexpr int EM_NW = 4;   // waves per block
+
+template <typename ST>
+__device__ __forceinline__ float big_ld1(rsrc_t r, uint32_t off) {
+    if constexpr (sizeof(ST) == 4) return buf_ld1(r, off);
+    else return __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
+}
+#define EM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+__device__ __forceinline__ void em_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int CS, int NT, typename ST>
+__global__ __launch_bounds__(256) void conv3x3_s2b_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               ST* __restrict__ y, int B, int H, int W, int wmode) {
+    constexpr int KS = (CS * 9 + 1) / 2, ES = sizeof(ST), Cb = 32 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 31, kh = lane >> 5;
+    float wf[KS][NT], bv[NT];
+    int koff[KS];
+    uint32_t kbit[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int k = 2 * kk + kh;
+        const bool kv = k < CS * 9;
+        const int s = kv ? k / 9 : 0, t = kv ? k % 9 : 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = i * NT + nt;
+            wf[kk][nt] = kv ? ((wmode == 0) ? w[((int64_t)c * CS + s) * 9 + t] : w[((int64_t)s * Cb + c) * 9 + (8 - t)]) : 0.f;
+        }
+        koff[kk] = ((s * H + (t / 3 - 1)) * W + (t % 3 - 1)) * 4;
+        kbit[kk] = kv ? (1u << t) : 0u;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[i * NT + nt] : 0.f;
+    const int tpr = (W + 31) / 32;
+    const int tiles = B * H * tpr;
+    // tile t = (image b, row yy, 32-pixel column tile tx), walked with a constant stride: the position is carried, not divided out per tile
+    struct Pos {
+        int b, yy, tx;
+    };
+    const int tstep = (int)gridDim.x * EM_NW;
+    const int s_tx = tstep % tpr, s_rows = tstep / tpr, s_yy = s_rows % H, s_b = s_rows / H;
+    auto advance = [&](Pos& p) {
+        p.tx += s_tx;
+        const int c1 = p.tx >= tpr ? 1 : 0;
+        p.tx -= c1 * tpr;
+        p.yy += s_yy + c1;
+        const int c2 = p.yy >= H ? 1 : 0;
+        p.yy -= c2 * H;
+        p.b += s_b + c2;
+    };
+    // the image scalars of a tile (zeros for padding taps and for tiles past the end); the next tile's are loaded before this tile's MFMAs
+    auto load_a = [&](const Pos& p, float (&a)[KS]) {
+        const bool tv = p.b < B;
+        const rsrc_t rs_x = make_rsrc(x + (int64_t)(tv ? p.b : 0) * CS * H * W);
+        const int xp = p.tx * 32 + i;
+        const uint32_t colm = (tv && xp < W) ? ((xp > 0 ? 1u : 0u) | 2u | (xp + 1 < W ? 4u : 0u)) : 0u;
+        const uint32_t m9 = (p.yy > 0 ? colm : 0u) | (colm << 3) | (p.yy + 1 < H ? colm << 6 : 0u);
+        const int base = (p.yy * W + xp) * 4;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a[kk] = buf_ld1(rs_x, (m9 & kbit[kk]) ? (uint32_t)(base + koff[kk]) : ROW_SENT);
+    };
+    Pos cur, nxt;
+    {
+        const int t0 = (int)blockIdx.x * EM_NW + wave;
+        const int by = t0 / tpr;
+        cur.tx = t0 - by * tpr;
+        cur.b = by / H;
+        cur.yy = by - cur.b * H;
+    }
+    // Schedule, pinned by sched_barriers: prefetch of the next tile | 28 MFMAs | hand-over an -> a | 16 stores.  Left alone the scheduler sinks
+    // the prefetch to its first use.  The hand-over sits BEFORE the stores: vmcnt counts loads and stores together and stores may retire out
+    // of order, so a wait for the prefetch issued after the stores is a wait for the stores' acknowledgements too (vmcnt(13) .. (0)).
+    float a[KS], an[KS];
+    load_a(cur, an);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) asm volatile("v_mov_b32 %0, %1" : "=v"(a[kk]) : "v"(an[kk]));   // (the loop is entered with nothing in flight)
+    for (; cur.b < B; cur = nxt) {
+        nxt = cur;
+        advance(nxt);
+        load_a(nxt, an);
+        __builtin_amdgcn_sched_barrier(0);
+        const int x0 = cur.tx * 32, by = cur.b * H + cur.yy;
+        const rsrc_t rs_y = make_rsrc(y + (int64_t)by * W * Cb, (uint32_t)(W * Cb * ES));
+        floatx16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = bv[nt];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = EM_MFMA(a[kk], wf[kk][nt], acc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) asm volatile("v_mov_b32 %0, %1" : "=v"(a[kk]) : "v"(an[kk]));   // (real copies: a and an are two live ranges)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = x0 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const uint32_t off = px < W ? (uint32_t)((px * Cb + i * NT) * ES) : ROW_SENT;
+            if constexpr (NT == 2) {
+                if constexpr (ES == 4) {
+                    floatx2 v;
+                    v.x = acc[0][r];
+                    v.y = acc[1][r];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_y, off, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(bf_pack(acc[0][r], acc[1][r]), rs_y, off, 0, 0);
+                }
+            } else {
+                if constexpr (ES == 4) buf_st1(rs_y, off, acc[0][r]);
+                else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bf_pack(acc[0][r], 0.f) & 0xffffu), rs_y, off, 0, 0);
+            }
+        }
+    }
+}
+
+// part[blk][CS * 9 + 1][Cb] as conv3x3_wgrad_kernel writes it (conv3x3_wgrad_reduce_kernel finishes); a wave takes `rpw` whole image rows as ONE
+// stream of 16-pixel batches (8 MFMA steps x MT tiles), three batches in rotation: the loads of batch n + 2 are issued before the MFMAs of
+// batch n (a batch's MFMAs are 1024 cycles, the stream comes from HBM: one batch ahead was slower than none).  Row m of tile mt is channel
+// MT m + mt: a lane's MT values of a pixel are adjacent in memory -- one load.
+template <int CS, int MT, typename ST>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const ST* __restrict__ big, const float* __restrict__ small, float* __restrict__ part,
+                                                                 int B, int H, int W, int rpw) {
+    constexpr int NJ = CS * 9 + 1, ES = sizeof(ST), U = 8, Cb = 32 * MT;
+    static_assert(NJ <= 32, "the S columns and the ones column must fit one MFMA tile");
+    __shared__ float red[EM_NW][MT * 16 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, kh = lane >> 5;
+    const bool jtap = j < CS * 9, jone = j == CS * 9;
+    const int s = jtap ? j / 9 : 0, tap = jtap ? j % 9 : 0, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int rows = B * H;
+    const int r0 = ((int)blockIdx.x * EM_NW + wave) * rpw;
+    const int rend = (r0 + rpw < rows) ? r0 + rpw : rows;
+    floatx16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    struct BPos {
+        int rr, b, yy, x0;   // image row b * H + yy, first pixel of the batch
+    };
+    auto next = [&](BPos p) {
+        p.x0 += 2 * U;
+        if (p.x0 >= W) {
+            p.x0 = 0;
+            ++p.rr;
+            if (++p.yy == H) {
+                p.yy = 0;
+                ++p.b;
+            }
+        }
+        return p;
+    };
+    auto load_batch = [&](const BPos& p, float (&sv)[U], float (&av)[U][MT]) {   // (rows past the wave's range: every offset out of range, zeros)
+        const bool rv = p.rr < rend;
+        const rsrc_t rs_g = make_rsrc(big + (int64_t)(rv ? p.rr : 0) * W * Cb, (uint32_t)(W * Cb * ES));
+        const rsrc_t rs_s = make_rsrc(small + (int64_t)(rv ? p.b : 0) * CS * H * W);
+        const int ys = p.yy + dy;
+        const bool rok = rv && jtap && ys >= 0 && ys < H;
+        const int srow = ((s * H + ys) * W + dx) * 4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int xp = p.x0 + 2 * u + kh, cs = xp + dx;
+            const bool pin = rv && xp < W;
+            const float v = buf_ld1(rs_s, (rok && pin && cs >= 0 && cs < W) ? (uint32_t)(srow + xp * 4) : ROW_SENT);
+            sv[u] = v + ((jone && pin) ? 1.f : 0.f);   // (the ones column: its lanes load nothing -- an add, not a select: no branch around the load)
+            const uint32_t off = pin ? (uint32_t)((xp * Cb + j * MT) * ES) : ROW_SENT;
+            if constexpr (MT == 2 && ES == 4) {
+                const floatx2 f = __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(rs_g, off, 0, 0));
+                av[u][0] = f.x;
+                av[u][1] = f.y;
+            } else if constexpr (MT == 2) {
+                const uint32_t wv = __builtin_amdgcn_raw_buffer_load_b32(rs_g, off, 0, 0);
+                av[u][0] = bf_lo(wv);
+                av[u][1] = bf_hi(wv);
+            } else {
+                av[u][0] = big_ld1<ST>(rs_g, off);
+            }
+        }
+    };
+    auto mfma_batch = [&](const float (&sv)[U], const float (&av)[U][MT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = EM_MFMA(av[u][mt], sv[u], acc[mt]);
+    };
+    if (r0 < rows) {
+        const int nb = (rend - r0) * ((W + 2 * U - 1) / (2 * U));
+        BPos p;
+        p.rr = r0;
+        p.b = r0 / H;
+        p.yy = r0 - p.b * H;
+        p.x0 = 0;
+        float svA[U], avA[U][MT], svB[U], avB[U][MT], svC[U], avC[U][MT];
+        load_batch(p, svA, avA);
+        p = next(p);
+        load_batch(p, svB, avB);
+        for (int k = 0; k < nb; k += 3) {   // (pinned: the scheduler otherwise sinks every prefetch to its first use)
+            p = next(p);
+            load_batch(p, svC, avC);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_batch(svA, avA);
+            __builtin_amdgcn_sched_barrier(0);
+            p = next(p);
+            load_batch(p, svA, avA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_batch(svB, avB);
+            __builtin_amdgcn_sched_barrier(0);
+            p = next(p);
+            load_batch(p, svB, avB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_batch(svC, avC);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][(mt * 16 + r) * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    float* pp = part + (int64_t)blockIdx.x * NJ * Cb;
+    for (int e = threadIdx.x; e < MT * 16 * 64; e += 256) {
+        const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];   // fixed order
+        const int l = e & 63, r = (e >> 6) & 15, mt = e >> 10;
+        const int jj = l & 31, c = MT * (8 * (r >> 2) + 4 * (l >> 5) + (r & 3)) + mt;
+        if (jj < NJ) pp[jj * Cb + c] = v;
+    }
+}
+
+struct B2sGeom {
+    int bands, RS, strips;
+};
+inline __host__ __device__ B2sGeom b2s_geom(int B, int H, int W) {
+    B2sGeom g;
+    g.bands = (W + 29) / 30;
+    int64_t rs = ((int64_t)B * H * g.bands + 4095) / 4096;   // about 4096 wave units (4 per SIMD), strips of 8 .. H rows (2 halo rows each)
+    if (rs < 8) rs = 8;
+    if (rs > H) rs = H;
+    g.RS = (int)rs;
+    g.strips = (H + g.RS - 1) / g.RS;
+    return g;
+}
+
+template <int CS, int CB, typename ST>
+__global__ __launch_bounds__(256) void conv3x3_b2s_mfma_kernel(const ST* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* __restrict__ y, int B, int H, int W, int wmode) {
+    constexpr int ES = sizeof(ST), KS = CB / 2, CPL = 16 / ES, NG = CB / (2 * CPL), NJ = CS * 9, ZS = 28, NO = 30 * CS, NOI = (NO + 63) / 64;
+    static_assert(NJ <= ZS && KS == NG * CPL, "b2s geometry");
+    __shared__ float zr[EM_NW][3][32 * ZS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 31, kh = lane >> 5;
+    const B2sGeom g = b2s_geom(B, H, W);
+    const int unit = (int)blockIdx.x * EM_NW + wave;   // -> (image, strip, band), bands fastest
+    if (unit >= B * g.strips * g.bands) return;         // (no block-level synchronisation below)
+    const int band = unit % g.bands, bs = unit / g.bands;
+    const int strip = bs % g.strips, b = bs / g.strips;
+    const int y0 = strip * g.RS, y1 = (y0 + g.RS < H) ? y0 + g.RS : H;
+    const int x0 = band * 30 - 1;   // image column of Z column 0; outputs are the columns x0 + 1 .. x0 + 30
+    // B operand: Wz[c][j], step kk of half kh contracts channel c = (kk / CPL) * 2 CPL + kh * CPL + kk % CPL (the 16-byte pieces of the loads)
+    float wf[KS];
+    {
+        const bool jv = i < NJ;
+        const int s = jv ? i / 9 : 0, t = jv ? i % 9 : 0;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = (kk / CPL) * 2 * CPL + kh * CPL + kk % CPL;
+            wf[kk] = jv ? ((wmode == 0) ? w[((int64_t)s * CB + c) * 9 + t] : w[((int64_t)c * CS + s) * 9 + (8 - t)]) : 0.f;
+        }
+    }
+    const rsrc_t rs_x = make_rsrc(x + (int64_t)b * H * W * CB);
+    const rsrc_t rs_y = make_rsrc(y + (int64_t)b * CS * H * W);
+    const rsrc_t rs_r = make_rsrc(res ? res + (int64_t)b * CS * H * W : y);
+    const int xp = x0 + i;
+    const bool cok = xp >= 0 && xp < W;
+    float* const zw = &zr[wave][0][0];
+    auto load_row = [&](int r, u32x4 (&v)[NG]) {   // the 16-byte pieces of Z row r's pixels (zeros where the pixel does not exist or r > y1)
+        const bool ok = cok && r >= 0 && r < H && r <= y1;
+        const uint32_t off = ok ? (uint32_t)(((r * W + xp) * CB + kh * CPL) * ES) : ROW_SENT;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) v[gq] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + (uint32_t)(gq * 2 * CPL * ES), 0, 0);
+    };
+    u32x4 v[NG], vn[NG];
+    load_row(y0 - 1, vn);
+    int it = 0;
+    for (int r = y0 - 1; r <= y1; ++r, ++it) {   // hand-over | the next row's loads | this row's MFMAs, Z row, gather (pinned, see the s2b kernel)
+        const int slot = it % 3;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                                                     : "=&v"(v[gq].x), "=&v"(v[gq].y), "=&v"(v[gq].z), "=&v"(v[gq].w)
+                                                     : "v"(vn[gq].x), "v"(vn[gq].y), "v"(vn[gq].z), "v"(vn[gq].w));
+        load_row(r + 1, vn);
+        // this iteration's outputs (row yo = r - 1): offsets and the residual, requested before the MFMAs
+        const int yo = r - 1;
+        const bool yok = yo >= y0 && yo < y1;
+        uint32_t ooff[NOI];
+        float resv[NOI];
+#pragma unroll
+        for (int q = 0; q < NOI; ++q) {
+            const int o = q * 64 + lane;
+            const int px = o / CS, s = o - px * CS;
+            const int xo = x0 + 1 + px;
+            ooff[q] = (yok && o < NO && xo < W) ? (uint32_t)(((s * H + yo) * W + xo) * 4) : ROW_SENT;
+            resv[q] = res ? buf_ld1(rs_r, ooff[q]) : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        floatx16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            float av[CPL];
+            if constexpr (ES == 4) {
+                const floatx4 f = __builtin_bit_cast(floatx4, v[gq]);
+                av[0] = f.x; av[1] = f.y; av[2] = f.z; av[3] = f.w;
+            } else {
+                av[0] = bf_lo(v[gq].x); av[1] = bf_hi(v[gq].x); av[2] = bf_lo(v[gq].y); av[3] = bf_hi(v[gq].y);
+                av[4] = bf_lo(v[gq].z); av[5] = bf_hi(v[gq].z); av[6] = bf_lo(v[gq].w); av[7] = bf_hi(v[gq].w);
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) acc = EM_MFMA(av[e], wf[gq * CPL + e], acc);
+        }
+        if (i < ZS) {
+            float* const zs = zw + slot * 32 * ZS;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zs[(8 * (q >> 2) + 4 * kh + (q & 3)) * ZS + i] = acc[q];
+        }
+        em_lds_fence();
+        // ---- output row yo = r - 1 from the Z rows yo - 1, yo, yo + 1 (slots it - 2, it - 1, it) ----
+        if (yok) {
+#pragma unroll
+            for (int q = 0; q < NOI; ++q) {
+                const int o = q * 64 + lane;
+                const int px = o / CS, s = o - px * CS;
+                if (ooff[q] != ROW_SENT) {
+                    float sum = bias ? bias[s] : 0.f;
+#pragma unroll
+                    for (int dyi = 0; dyi < 3; ++dyi) {
+                        const float* const zs = zw + ((it + 1 + dyi) % 3) * 32 * ZS + px * ZS + s * 9 + dyi * 3;   // slot of it - 2 + dyi
+#pragma unroll
+                        for (int dxi = 0; dxi < 3; ++dxi) sum += zs[dxi * ZS + dxi];
+                    }
+                    buf_st1(rs_y, ooff[q], sum + resv[q]);
+                }
+            }
+        }
+        em_lds_fence();
+    }
+}
+
+bool edge_mfma_ok(int Cs, int Cb) {
+    static const int on = dcpt_tuning("DCPT_EDGE_MFMA", 1);
+    return on != 0 && Cs >= 1 && Cs <= 3 && (Cb == 32 || Cb == 64);
+}
+int wgrad_mfma_rpw(int B, int H) { return cdiv(B * H, 4096) > 0 ? cdiv(B * H, 4096) : 1; }   // rows per wave: about 4096 waves
+
+template <typename ST>
+int launch_s2b_mfma(const float* x, const float* w, const float* bias, ST* y, int B, int H, int W, int Cs, int Cb, int wmode, hipStream_t s) {
+    const int64_t tiles = (int64_t)B * H * cdiv(W, 32);
+    DCPT_CHECK_ARG(tiles < (1 << 30) && (double)H * W * Cs * 4.0 < 1.0e9, "conv3x3_s2b: image %dx%d x %d too large", H, W, B);
+    const int64_t slots = (Cb == 64 && Cs == 3) ? 768 : 1024;   // resident blocks (3 / 4 per CU by registers): one round, every wave walks its tiles
+    const dim3 grid((unsigned)(cdiv64(tiles, EM_NW) < slots ? cdiv64(tiles, EM_NW) : slots));
+#define S2B(CS_, NT_) conv3x3_s2b_mfma_kernel<CS_, NT_, ST><<<grid, dim3(256), 0, s>>>(x, w, bias, y, B, H, W, wmode)
+    if (Cb == 64) {
+        if (Cs == 1) S2B(1, 2);
+        else if (Cs == 2) S2B(2, 2);
+        else S2B(3, 2);
+    } else {
+        if (Cs == 1) S2B(1, 1);
+        else if (Cs == 2) S2B(2, 1);
+        else S2B(3, 1);
+    }
+#undef S2B
+    return DCPT_OK;
+}
+
+template <typename ST>
+int launch_b2s_mfma(const ST* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W, int Cs, int Cb, int wmode,
+                    hipStream_t s) {
+    const B2sGeom g = b2s_geom(B, H, W);
+    const int64_t units = (int64_t)B * g.strips * g.bands;
+    DCPT_CHECK_ARG(units < (1 << 30) && (double)H * W * Cb * 4.0 < 1.0e9 && (double)H * W * Cs * 4.0 < 1.0e9, "conv3x3_b2s: image %dx%d x %d too large", H, W, B);
+    const dim3 grid((unsigned)cdiv64(units, EM_NW));
+#define B2S(CS_, CB_) conv3x3_b2s_mfma_kernel<CS_, CB_, ST><<<grid, dim3(256), 0, s>>>(x, w, bias, res, y, B, H, W, wmode)
+    if (Cb == 64) {
+        if (Cs == 1) B2S(1, 64);
+        else if (Cs == 2) B2S(2, 64);
+        else B2S(3, 64);
+    } else {
+        if (Cs == 1) B2S(1, 32);
+        else if (Cs == 2) B2S(2, 32);
+        else B2S(3, 32);
+    }
+#undef B2S
+    return DCPT_OK;
+}
+
+template <typename ST>
+int launch_wgrad_mfma(const ST* big, const float* small, float* part, int nblk, int B, int H, int W, int Cs, int Cb, hipStream_t s) {
+    const int rpw = wgrad_mfma_rpw(B, H);
+    DCPT_CHECK_ARG((int64_t)B * H < (1 << 30) && (double)W * Cb * 4.0 < 1.0e9 && (double)H * W * Cs * 4.0 < 1.0e9, "conv3x3_wgrad: image %dx%d x %d too large", H, W, B);
+    const dim3 grid((unsigned)nblk);
+#define WG(CS_, MT_) conv3x3_wgrad_mfma_kernel<CS_, MT_, ST><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, rpw)
+    if (Cb == 64) {
+        if (Cs == 1) WG(1, 2);
+        else if (Cs == 2) WG(2, 2);
+        else WG(3, 2);
+    } else {
+        if (Cs == 1) WG(1, 1);
+        else if (Cs == 2) WG(2, 1);
+        else WG(3, 1);
+    }
+#undef WG
+    return DCPT_OK;
+}
+
 }  // namespace
 
 #define EDGE_CHECK(name, TARGET)                                                                                                     \
@@ -363,7 +801,8 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float* __re
 int launch_conv3x3_s2b_bf16(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cs, int Cb, int wmode,
                             hipStream_t s) {
     EDGE_CHECK("conv3x3_s2b_bf16", 2048);
-    EDGE_GO_B(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
+    if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_s2b_mfma<bf16_t>(x, w, bias, y, B, H, W, Cs, Cb, wmode, s));
+    else EDGE_GO_B(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_s2b_bf16");
     return DCPT_OK;
 }
@@ -371,7 +810,8 @@ int launch_conv3x3_b2s_bf16(const bf16_t* x, const float* w, const float* bias, 
                             int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_b2s_bf16", 2048);
     DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s_bf16: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
-    EDGE_GO_B(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
+    if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_b2s_mfma<bf16_t>(x, w, bias, res, y, B, H, W, Cs, Cb, wmode, s));
+    else EDGE_GO_B(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_b2s_bf16");
     return DCPT_OK;
 }
@@ -379,7 +819,8 @@ int launch_conv3x3_b2s_bf16(const bf16_t* x, const float* w, const float* bias, 
 int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cs, int Cb,
                        int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_s2b", 2048);
-    EDGE_GO(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
+    if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_s2b_mfma<float>(x, w, bias, y, B, H, W, Cs, Cb, wmode, s));
+    else EDGE_GO(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_s2b");
     return DCPT_OK;
 }
@@ -388,21 +829,32 @@ int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const 
                        int Cs, int Cb, int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_b2s", 2048);
     DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
-    EDGE_GO(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
+    if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_b2s_mfma<float>(x, w, bias, res, y, B, H, W, Cs, Cb, wmode, s));
+    else EDGE_GO(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_b2s");
     return DCPT_OK;
 }
 
-int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb) {
+static int wgrad_valu_blocks(int B, int H, int W, int Cb) {
     const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
     return B * m.strips * m.nwc;
+}
+static int wgrad_mfma_blocks(int B, int H) { return cdiv(B * H, EM_NW * wgrad_mfma_rpw(B, H)); }
+// capacity of the partial buffer in blocks (the caller sizes its workspace before Cs is known to this function: the larger of the two forms)
+int conv3x3_wgrad_num_blocks(int B, int H, int W, int Cb) {
+    const int a = wgrad_valu_blocks(B, H, W, Cb), b = wgrad_mfma_blocks(B, H);
+    return a > b ? a : b;
 }
 
 int launch_conv3x3_wgrad_bf16(const bf16_t* big, const float* small, float* part, int nblk, float* dW, float* bsum, int B, int H, int W, int Cs,
                               int Cb, int omode, hipStream_t s) {
     EDGE_CHECK("conv3x3_wgrad_bf16", WGRAD_BLOCKS);
     DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad_bf16: nblk mismatch");
-    {
+    if (edge_mfma_ok(Cs, Cb)) {
+        nblk = wgrad_mfma_blocks(B, H);
+        DCPT_TRY(launch_wgrad_mfma<bf16_t>(big, small, part, nblk, B, H, W, Cs, Cb, s));
+    } else {
+        nblk = wgrad_valu_blocks(B, H, W, Cb);
         const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
         const dim3 grid(m.nqc * m.nwc, m.strips, B);
         if (Cs == 1) conv3x3_wgrad_kernel<1, bf16_t><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);
@@ -420,7 +872,11 @@ int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int 
                          int W, int Cs, int Cb, int omode, hipStream_t s) {
     EDGE_CHECK("conv3x3_wgrad", WGRAD_BLOCKS);
     DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad: nblk mismatch");
-    {
+    if (edge_mfma_ok(Cs, Cb)) {
+        nblk = wgrad_mfma_blocks(B, H);
+        DCPT_TRY(launch_wgrad_mfma<float>(big, small, part, nblk, B, H, W, Cs, Cb, s));
+    } else {
+        nblk = wgrad_valu_blocks(B, H, W, Cb);
         const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
         const dim3 grid(m.nqc * m.nwc, m.strips, B);
         if (Cs == 1) conv3x3_wgrad_kernel<1><<<grid, dim3(256), 0, s>>>(big, small, part, B, H, W, Cb);

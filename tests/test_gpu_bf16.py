@@ -235,7 +235,8 @@ def test_down_up_bf16_oracle(dev, B, C, H, W):
     assert _rel(y2, yr2) <= 1e-2
 
 
-@pytest.mark.parametrize("B,Cs,Cb,H,W", [(2, 3, 8, 6, 10), (1, 3, 64, 16, 16), (2, 1, 16, 5, 5), (1, 4, 32, 7, 3)])
+@pytest.mark.parametrize("B,Cs,Cb,H,W", [(2, 3, 8, 6, 10), (1, 3, 64, 16, 16), (2, 1, 16, 5, 5), (1, 4, 32, 7, 3), (2, 3, 64, 37, 45),
+                                        (1, 3, 32, 40, 33), (2, 2, 64, 70, 64), (1, 3, 64, 1, 1)])
 def test_edge_convs_bf16_oracle(dev, B, Cs, Cb, H, W):
     """intro (image -> bf16 features) and ending (bf16 features -> image + residual) 3x3 convs (reference nafnet_arch.py:202-219)."""
     from dcpt_amd import functional as DF

@@ -156,7 +156,9 @@ def test_nafblock_zero_gain(dev):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,Cs,Cb,H,W", [(2, 3, 8, 6, 10), (1, 3, 64, 16, 16), (2, 1, 16, 5, 5), (1, 4, 32, 7, 3)])
+# (Cs <= 3 with Cb = 32 / 64 take the MFMA forms of conv3x3.hip: odd widths, partial 32-pixel tiles / 30-column bands, several row strips)
+@pytest.mark.parametrize("B,Cs,Cb,H,W", [(2, 3, 8, 6, 10), (1, 3, 64, 16, 16), (2, 1, 16, 5, 5), (1, 4, 32, 7, 3), (2, 3, 64, 37, 45),
+                                        (1, 3, 32, 40, 33), (2, 2, 64, 70, 64), (1, 1, 32, 33, 95), (3, 3, 64, 9, 130), (1, 3, 64, 1, 1)])
 def test_edge_convs(dev, B, Cs, Cb, H, W):
     from dcpt_amd import functional as DF
 

@@ -3,7 +3,7 @@
 #   tools/pmc_cmd.sh "<counters>" <kernel-name-substring> <command...>      e.g.  tools/pmc_cmd.sh "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" ws_gemm tools/ubench/ws_gemm_f32
 R=$PWD; C="$1"; K="$2"; shift 2
 CMD="$@"
-case "$1" in /*) ;; *) CMD="$R/$@";; esac
+case "$1" in /*) ;; *) if [ -e "$R/$1" ]; then CMD="$R/$@"; fi;; esac   # (a path inside the repo; anything else, e.g. python, is found on PATH)
 cd /tmp; export TMPDIR=/tmp
 D=$(mktemp -d)
 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o t -- $CMD > $D/log.txt 2>&1
