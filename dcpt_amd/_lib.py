@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 _lock = threading.Lock()
 
@@ -109,6 +109,8 @@ SIGNATURES = {
                                      cint, cint, cint, stream_t]),
     "dcpt_conv_ln_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz,
                                      cint, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv_ln_bwd_acc_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz,
+                                         cint, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv1x1_pool_relu_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
     "dcpt_conv1x1_pool_relu_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv1x1_pool_relu_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,
@@ -144,6 +146,8 @@ SIGNATURES = {
                                 cint, cint, cint, stream_t]),
     "dcpt_conv_ln_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz,
                                 cint, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv_ln_bwd_acc": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz,
+                                    cint, cint, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv1x1_pool_relu_ws_bytes": (sz, [cint, cint, cint, cint, cint, cint]),
     "dcpt_conv1x1_pool_relu_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv1x1_pool_relu_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,

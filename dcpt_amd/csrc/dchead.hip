@@ -295,17 +295,19 @@ int conv_fwd(const float* x, const float* w, float* z, const ConvWs& cw, int B, 
 
 // dx = conv^T(dz), dw = wgrad(dz, x)
 int conv_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, const ConvWs& cw, int B, int H, int W, int Cin,
-             int Cout, int ks, hipStream_t s) {
+             int Cout, int ks, hipStream_t s, const float* dx_add = nullptr) {
     const int64_t M = (int64_t)B * H * W;
     GemmNT g{};
     g.M = M; g.A = dz; g.N = Cin; g.C = dx; g.ldc = Cin; g.Bw = cw.wp;
+    g.res = dx_add; g.ldres = Cin;
+    const int EDX = dx_add ? E_RESID : E_PLAIN;   // dx = dx_add + dz W (the shortcut gradient of a bottleneck block rides in the epilogue)
     GemmTN t{};
     t.M = M; t.X = dz; t.ldx = Cout; t.N = Cout; t.Y = x; t.slab = cw.slab; t.colsum = nullptr; t.splits = cw.splits;
     t.rows_per_split = cw.rps;
     if (ks == 1) {
         DCPT_TRY(launch_wpack(w, cw.wp, nullptr, Cout, Cin, WP_TRANSPOSE, s));
         g.lda = Cout; g.K = Cout;
-        if (dx) DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_PLAIN, s));
+        if (dx) DCPT_TRY(launch_gemm_nt(g, A_PLAIN, EDX, s));
         t.ldy = Cin; t.K = Cin;
         DCPT_TRY(launch_gemm_tn(t, A_PLAIN, A_PLAIN, s));
         DCPT_TRY(launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr,
@@ -313,7 +315,7 @@ int conv_bwd(const float* dz, const float* x, const float* w, float* dx, float* 
     } else {
         DCPT_TRY(launch_wpack(w, cw.wp, nullptr, Cout, 9 * Cin, WP_CONV3_T, s));
         g.K = 9 * Cout; g.gH = H; g.gW = W; g.gC = Cout;
-        if (dx) DCPT_TRY(launch_gemm_nt(g, A_CONV3, E_PLAIN, s));
+        if (dx) DCPT_TRY(launch_gemm_nt(g, A_CONV3, EDX, s));
         t.K = 9 * Cin; t.gH = H; t.gW = W; t.gC = Cin;
         DCPT_TRY(launch_gemm_tn(t, A_PLAIN, A_CONV3, s));
         DCPT_TRY(launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, 9 * Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr,
@@ -345,13 +347,14 @@ extern "C" int dcpt_conv_ln_fwd(const float* x, const float* w, const float* lnw
     return launch_ln_act_fwd(z, lnw, lnb, res, relu, y, mu, rstd, (int64_t)B * H * W, Cout, 1e-6f, s);  // eps: degrad_classify_arch.py:24
 }
 
-extern "C" int dcpt_conv_ln_bwd(const float* dy, const float* x, const float* w, const float* lnw, const float* z, const float* y,
-                                const float* mu, const float* rstd, float* dx, float* dw, float* dlnw, float* dlnb, float* dres,
-                                void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
-                                dcpt_stream_t stream) {
+extern "C" int dcpt_conv_ln_bwd_acc(const float* dy, const float* x, const float* w, const float* lnw, const float* z, const float* y,
+                                    const float* mu, const float* rstd, const float* dx_add, float* dx, float* dw, float* dlnw, float* dlnb,
+                                    float* dres, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
+                                    dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(dy && x && w && lnw && z && mu && rstd && dw && dlnw && dlnb, "conv_ln_bwd: null argument");
     DCPT_CHECK_ARG(!relu || y, "conv_ln_bwd: relu needs the saved output y");
+    DCPT_CHECK_ARG(!dx_add || (dx && ksize == 1), "conv_ln_bwd: dx_add needs dx and a 1 x 1 conv (the block's conv1)");
     DCPT_CHECK_ARG((ksize == 1 || ksize == 3) && Cin % 4 == 0 && Cout % 4 == 0, "conv_ln_bwd: bad shape");
     ConvWs cw;
     const size_t need = conv_layout(B, H, W, Cin, Cout, ksize, 1, true, ws, ws_bytes, &cw);
@@ -362,7 +365,14 @@ extern "C" int dcpt_conv_ln_bwd(const float* dy, const float* x, const float* w,
     const int64_t M = (int64_t)B * H * W;
     DCPT_TRY(launch_ln_act_bwd(dy, z, mu, rstd, lnw, nullptr, relu ? y : nullptr, dres, cw.dz, cw.lnpart, cw.ln_nblk, M, Cout, s));
     DCPT_TRY(launch_colpart_reduce(cw.lnpart, cw.ln_nblk, 3, Cout, dlnw, dlnb, nullptr, s));
-    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s);
+    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s, dx_add);
+}
+
+extern "C" int dcpt_conv_ln_bwd(const float* dy, const float* x, const float* w, const float* lnw, const float* z, const float* y,
+                                const float* mu, const float* rstd, float* dx, float* dw, float* dlnw, float* dlnb, float* dres,
+                                void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
+                                dcpt_stream_t stream) {
+    return dcpt_conv_ln_bwd_acc(dy, x, w, lnw, z, y, mu, rstd, nullptr, dx, dw, dlnw, dlnb, dres, ws, ws_bytes, B, H, W, Cin, Cout, ksize, relu, stream);
 }
 
 extern "C" size_t dcpt_conv_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int backward) {

@@ -150,10 +150,12 @@ int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int 
 
 // dx = conv^T(dz), dw = wgrad(dz, x); `ln` (optional): the LayerNorm's column partials, reduced here as well
 int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, float* dw, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout,
-             int ks, hipStream_t s, const FinCols* ln = nullptr) {
+             int ks, hipStream_t s, const FinCols* ln = nullptr, const bf16_t* dx_add = nullptr) {
     const int64_t M = (int64_t)B * H * W;
     GemmNTB g{};
     g.M = M; g.A = dz; g.N = Cin; g.C = dx; g.ldc = Cin; g.Bw = cw.wp;
+    g.res = dx_add; g.ldres = Cin;
+    const int EDX = dx_add ? EB_RESID : EB_PLAIN;   // dx = dx_add + dz W (the shortcut gradient of a bottleneck block rides in the epilogue)
     if (cw.tn256) {   // data gradient as before; the weight gradient as one 256-tile launch + one finisher launch (which also takes the LN sums)
         DCPT_TRY(pack(w, cw.wp, Cout, ks * ks * Cin, ks == 1 ? 1 : 3, s));
         if (ks == 1) {
@@ -161,7 +163,7 @@ int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, floa
         } else {
             g.K = 9 * Cout; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cout;
         }
-        if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
         GemmTNG wg = cw.wg;
         wg.p[0].X = dz; wg.p[0].Y = x;
         DCPT_TRY(launch_gemm_tn_bf16_256(wg, s));
@@ -181,14 +183,14 @@ int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, floa
     if (ks == 1) {
         DCPT_TRY(pack(w, cw.wp, Cout, Cin, 1, s));
         g.lda = Cout; g.K = Cout;
-        if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+        if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
         t.ldy = Cin; t.K = Cin;
         DCPT_TRY(launch_gemm_tn_bf16(t, s));
         return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_PLAIN, s);
     }
     DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 3, s));
     g.K = 9 * Cout; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cout;
-    if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
     t.K = 9 * Cin; t.yconv = 1; t.gH = H; t.gW = W; t.gC = Cin; t.ldy = Cin;
     DCPT_TRY(launch_gemm_tn_bf16(t, s));
     return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, 9 * Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_CONV3, s);
@@ -218,12 +220,14 @@ extern "C" int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const fl
     return launch_ln_act_fwd_bf16(z, lnw, lnb, res, relu, y, mu, rstd, (int64_t)B * H * W, Cout, 1e-6f, s);   // eps: degrad_classify_arch.py:24
 }
 
-extern "C" int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
-                                     const float* mu, const float* rstd, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres,
-                                     void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream) {
+extern "C" int dcpt_conv_ln_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
+                                         const float* mu, const float* rstd, const uint16_t* dx_add, uint16_t* dx, float* dw, float* dlnw, float* dlnb,
+                                         uint16_t* dres, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
+                                         dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(dy && x && w && lnw && z && mu && rstd && dw && dlnw && dlnb, "conv_ln_bwd_bf16: null argument");
     DCPT_CHECK_ARG(!relu || y, "conv_ln_bwd_bf16: relu needs the saved output y");
+    DCPT_CHECK_ARG(!dx_add || (dx && ksize == 1), "conv_ln_bwd_bf16: dx_add needs dx and a 1 x 1 conv (the block's conv1)");
     DCPT_CHECK_ARG(conv_shape_ok(Cin, Cout, ksize), "conv_ln_bwd_bf16: bad shape");
     ConvWsB cw;
     const size_t need = conv_layout(B, H, W, Cin, Cout, ksize, 1, true, ws, ws_bytes, &cw);
@@ -234,7 +238,13 @@ extern "C" int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, cons
     const int64_t M = (int64_t)B * H * W;
     DCPT_TRY(launch_ln_act_bwd_bf16(dy, z, mu, rstd, lnw, relu ? y : nullptr, dres, cw.dz, cw.lnpart, cw.ln_nblk, M, Cout, s));
     const FinCols ln{cw.lnpart, dlnw, dlnb, cw.ln_nblk, 2, Cout, 0};
-    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s, &ln);
+    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s, &ln, dx_add);
+}
+
+extern "C" int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
+                                     const float* mu, const float* rstd, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres,
+                                     void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream) {
+    return dcpt_conv_ln_bwd_acc_bf16(dy, x, w, lnw, z, y, mu, rstd, nullptr, dx, dw, dlnw, dlnb, dres, ws, ws_bytes, B, H, W, Cin, Cout, ksize, relu, stream);
 }
 
 extern "C" size_t dcpt_conv1x1_pool_relu_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward) {

@@ -1167,6 +1167,77 @@ def conv_ln_bf16(x, weight, lnw, lnb, res=None, relu=True):
     return _ConvLNBf16Fn.apply(x, weight, lnw, lnb, res, relu)
 
 
+class _BottleneckFn(torch.autograd.Function):
+    """The whole BottleneckBlock (reference degrad_classify_arch.py:132-243 as the DCPT head instantiates it: identity shortcut) as ONE
+    autograd node: relu(LN(conv1(x))) -> relu(LN(conv2(.))) -> relu(LN(conv3(.)) + x), the three conv -> LN groups through the same C
+    entry points as conv_ln / conv_ln_bf16 (fp32 or bf16 activations by x.dtype).  As three nodes the block's input has two consumers
+    (conv1 and the shortcut) and autograd sums their gradients with a pass of its own over the feature map -- 10 of the 18 bf16 `add`
+    launches of a DCPT step; here conv3's shortcut gradient is conv1's ``dx_add`` (dcpt_conv_ln_bwd_acc*, ABI 13): summed in the epilogue
+    of conv1's data-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3):
+        lib = _lib.load()
+        bf = x.dtype == torch.bfloat16
+        (_require_gpu_bf16 if bf else _require_gpu)(x)
+        _require_gpu(w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3)
+        x = _nhwc(x)
+        dev = x.device
+        B, _, H, W = x.shape
+        empty = _empty_nhwc_bf16 if bf else _empty_nhwc
+        ws_bytes = lib.dcpt_conv_ln_bf16_ws_bytes if bf else lib.dcpt_conv_ln_ws_bytes
+        fwd = lib.dcpt_conv_ln_fwd_bf16 if bf else lib.dcpt_conv_ln_fwd
+        saved, cur = [x], x
+        for (w, lw, lb, res) in ((w1, lw1, lb1, None), (w2, lw2, lb2, None), (w3, lw3, lb3, x)):
+            w_, lw_, lb_ = _contig(w.detach()), _contig(lw.detach()), _contig(lb.detach())
+            Cout, Cin, ks = w_.shape[0], w_.shape[1], w_.shape[2]
+            z, y = empty(B, Cout, H, W, dev), empty(B, Cout, H, W, dev)
+            stats = torch.empty((2, B * H * W), dtype=torch.float32, device=dev)
+            ws = _workspace(dev, ws_bytes(B, H, W, Cin, Cout, ks, 0))
+            check(fwd(cur.data_ptr(), w_.data_ptr(), lw_.data_ptr(), lb_.data_ptr(), _p(res), 1, z.data_ptr(), y.data_ptr(),
+                      stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)),
+                  "dcpt_conv_ln_fwd")
+            saved += [w_, lw_, z, y, stats]
+            cur = y
+        ctx.save_for_backward(*saved)
+        ctx.bf = bf
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        sv = ctx.saved_tensors
+        x, bf = sv[0], ctx.bf
+        dev = x.device
+        B, _, H, W = x.shape
+        empty = _empty_nhwc_bf16 if bf else _empty_nhwc
+        ws_bytes = lib.dcpt_conv_ln_bf16_ws_bytes if bf else lib.dcpt_conv_ln_ws_bytes
+        bwd = lib.dcpt_conv_ln_bwd_acc_bf16 if bf else lib.dcpt_conv_ln_bwd_acc
+        g = _nhwc(dy if (not bf or dy.dtype == torch.bfloat16) else dy.to(torch.bfloat16))
+        grads, dshort = [None] * 9, None
+        for k in (2, 1, 0):   # conv3 (its dres = the shortcut gradient), conv2, conv1 (dx = dx_add + ...)
+            w_, lw_, z, y, stats = sv[1 + 5 * k: 6 + 5 * k]
+            xin = x if k == 0 else sv[5 * k - 1]      # the y of group k - 1
+            Cout, Cin, ks = w_.shape[0], w_.shape[1], w_.shape[2]
+            dx = empty(B, Cin, H, W, dev)
+            dw, dlw, dlb = torch.empty_like(w_), torch.empty_like(lw_), torch.empty_like(lw_)
+            dres = empty(B, Cout, H, W, dev) if k == 2 else None
+            ws = _workspace(dev, ws_bytes(B, H, W, Cin, Cout, ks, 1))
+            check(bwd(g.data_ptr(), xin.data_ptr(), w_.data_ptr(), lw_.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                      stats[1].data_ptr(), _p(dshort if k == 0 else None), dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(), dlb.data_ptr(),
+                      _p(dres), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks, 1, _stream(dev)), "dcpt_conv_ln_bwd_acc")
+            if k == 2:
+                dshort = dres
+            grads[3 * k: 3 * k + 3] = [dw, dlw, dlb]
+            g = dx
+        return (g, *grads)
+
+
+def bottleneck(x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3):
+    """relu(LN(conv3(relu(LN(conv2(relu(LN(conv1(x)))))))) + x) as one autograd node (fp32 or bf16 activations)"""
+    return _BottleneckFn.apply(x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3)
+
+
 class _ConvPoolReluBf16Fn(torch.autograd.Function):
     """_ConvPoolReluFn with bf16 activations."""
 

@@ -221,6 +221,13 @@ int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const float* lnw, c
 int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
                           const float* mu, const float* rstd, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres, void* ws,
                           size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream);
+/* ABI 13: as dcpt_conv_ln_bwd_bf16 with dx = dx_add + conv^T(dz) (dx_add [B][H][W][Cin] or NULL; may alias dx).  The BottleneckBlock's input
+ * feeds conv1 AND the shortcut (degrad_classify_arch.py:227-243): conv3's dres goes in as conv1's dx_add and the two gradients are summed
+ * in the data-gradient GEMM's epilogue instead of by an extra pass over the feature map. */
+int dcpt_conv_ln_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
+                              const float* mu, const float* rstd, const uint16_t* dx_add, uint16_t* dx, float* dw, float* dlnw, float* dlnb,
+                              uint16_t* dres, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
+                              dcpt_stream_t stream);
 size_t dcpt_conv1x1_pool_relu_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward);
 int dcpt_conv1x1_pool_relu_fwd_bf16(const uint16_t* x, const float* w, uint16_t* z, uint16_t* y, void* ws, size_t ws_bytes, int B, int H, int W,
                                     int Cin, int Cout, dcpt_stream_t stream);
@@ -277,6 +284,11 @@ int dcpt_conv_ln_fwd(const float* x, const float* w, const float* lnw, const flo
 int dcpt_conv_ln_bwd(const float* dy, const float* x, const float* w, const float* lnw, const float* z, const float* y,
                      const float* mu, const float* rstd, float* dx, float* dw, float* dlnw, float* dlnb, float* dres, void* ws,
                      size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream);
+/* ABI 13: dx = dx_add + conv^T(dz) (dx_add NHWC [B][H][W][Cin] or NULL; may alias dx) -- the shortcut gradient of a BottleneckBlock
+ * (:227-243) summed in the data-gradient GEMM's epilogue */
+int dcpt_conv_ln_bwd_acc(const float* dy, const float* x, const float* w, const float* lnw, const float* z, const float* y,
+                         const float* mu, const float* rstd, const float* dx_add, float* dx, float* dw, float* dlnw, float* dlnb, float* dres,
+                         void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream);
 /* downsample layer :596-602: Conv2d(Cin, Cout, 1, bias=False) -> MaxPool2d(2,2) -> ReLU; y [B][H/2][W/2][Cout] */
 size_t dcpt_conv1x1_pool_relu_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward);
 int dcpt_conv1x1_pool_relu_fwd(const float* x, const float* w, float* z, float* y, void* ws, size_t ws_bytes, int B, int H, int W,
