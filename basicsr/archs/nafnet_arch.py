@@ -213,10 +213,17 @@ class NAFNetBaseline(nn.Module):
         encs = []
         for lvl, (encoder, down) in enumerate(zip(self.encoders, self.downs)):
             x = encoder(x)
-            encs.append(x)
             if edge32 and lvl == 0:
-                x = DF.to_bf16(x)   # (the fp32 first group hands bf16 to the levels below; its own output stays fp32 for the skip)
-            x = down(x)
+                encs.append(x)
+                x = down(DF.to_bf16(x))   # (the fp32 first group hands bf16 to the levels below; its own output stays fp32 for the skip)
+            elif x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+                # one autograd node for the group output's two consumers (down layer, skip): their gradients are summed in the down layer's
+                # data-gradient GEMM instead of by an `add` pass of autograd's (DF._DownSkipFn)
+                x, skip = DF.down2x2_skip(x, down.weight, down.bias)
+                encs.append(skip)
+            else:
+                encs.append(x)
+                x = down(x)
         x = self.middle_blks(x)
         for i, (up, enc_skip) in enumerate(zip(self.ups, encs[::-1])):
             if edge32 and i == self._n_dec - 1:

@@ -122,6 +122,7 @@ SIGNATURES = {
     "dcpt_down2x2_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
     "dcpt_down2x2_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_down2x2_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_down2x2_bwd_acc_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_up_ps_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
     "dcpt_up_ps_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_up_ps_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
@@ -137,6 +138,7 @@ SIGNATURES = {
     "dcpt_down2x2_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
     "dcpt_down2x2_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_down2x2_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_down2x2_bwd_acc": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_up_ps_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
     "dcpt_up_ps_fwd": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
     "dcpt_up_ps_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),

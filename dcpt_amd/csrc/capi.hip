@@ -16,7 +16,7 @@ void dcpt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dcpt_last_error(void) { return g_err; }
-extern "C" int dcpt_abi_version(void) { return 13; }   // 13: + dcpt_conv_ln_bwd_acc / _bf16 (the BottleneckBlock's shortcut gradient summed in the data-gradient GEMM); 12: + dcpt_adamw_step (multi-tensor AdamW); 11: + dcpt_mix_*_bf16 / dcpt_meanpool_fc_*_bf16 (the all-bf16 head without cast passes), dcpt_nafblock_bf16_fused_ffn may return 2 (chain kernel of the wide levels); 10: + dcpt_nafblock_wpack_bf16_multi; 9: + dcpt_conv1x1_wgrad_bf16 (grouped 256 x 256-tile weight-gradient GEMM + finisher); 8: + dcpt_nafblock_fused_ffn / dcpt_nafblock_bf16_fused_ffn (fused 1 x 1 chains of the narrowest level; saved tensors that become optional); 7: + per-block packed weights for the bf16 NAFBlock (dcpt_nafblock_wpack_bf16, *_packed); 6: + bf16-storage intro / ending / down / up layers; 5: + bf16-storage classifier-head groups; 4: + bf16-storage NAFBlock and casts; 3: + dcpt_allreduce_flat; 2: dcpt_nafblock_saved / mdta / gdfn saved structs carry the kept LN (and gate) tensors
+extern "C" int dcpt_abi_version(void) { return 13; }   // 13: + dcpt_conv_ln_bwd_acc / _bf16 (the BottleneckBlock's shortcut gradient summed in the data-gradient GEMM), dcpt_down2x2_bwd_acc / _bf16 (the skip connection's gradient summed in the down layer's scatter epilogue); 12: + dcpt_adamw_step (multi-tensor AdamW); 11: + dcpt_mix_*_bf16 / dcpt_meanpool_fc_*_bf16 (the all-bf16 head without cast passes), dcpt_nafblock_bf16_fused_ffn may return 2 (chain kernel of the wide levels); 10: + dcpt_nafblock_wpack_bf16_multi; 9: + dcpt_conv1x1_wgrad_bf16 (grouped 256 x 256-tile weight-gradient GEMM + finisher); 8: + dcpt_nafblock_fused_ffn / dcpt_nafblock_bf16_fused_ffn (fused 1 x 1 chains of the narrowest level; saved tensors that become optional); 7: + per-block packed weights for the bf16 NAFBlock (dcpt_nafblock_wpack_bf16, *_packed); 6: + bf16-storage intro / ending / down / up layers; 5: + bf16-storage classifier-head groups; 4: + bf16-storage NAFBlock and casts; 3: + dcpt_allreduce_flat; 2: dcpt_nafblock_saved / mdta / gdfn saved structs carry the kept LN (and gate) tensors
 
 // ---------------------------------------------------------------------------------------------
 extern "C" int dcpt_ln2d_fwd(const float* x, const float* weight, const float* bias, float* y, float* mu, float* rstd,
@@ -150,6 +150,11 @@ extern "C" int dcpt_down2x2_fwd(const float* x, const float* w, const float* bia
 
 extern "C" int dcpt_down2x2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws,
                                 size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+    return dcpt_down2x2_bwd_acc(dy, x, w, nullptr, dx, dw, dbias, ws, ws_bytes, B, H, W, C, stream);
+}
+
+extern "C" int dcpt_down2x2_bwd_acc(const float* dy, const float* x, const float* w, const float* dx_add, float* dx, float* dw, float* dbias,
+                                    void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(dy && x && w && dx && dw && dbias, "down2x2_bwd: null argument");
     DCPT_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "down2x2_bwd: bad shape");
@@ -165,7 +170,8 @@ extern "C" int dcpt_down2x2_bwd(const float* dy, const float* x, const float* w,
     GemmNT g{};
     g.M = Mc; g.A = dy; g.lda = 2 * C; g.K = 2 * C; g.Bw = d.wp; g.N = 4 * C; g.C = dx;
     g.gH = H / 2; g.gW = W / 2; g.gC = C;
-    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, E_SCATTER, s));
+    g.res = dx_add;   // (the encoder output's second consumer is the skip connection: its gradient joins in the scatter epilogue)
+    DCPT_TRY(launch_gemm_nt(g, A_PLAIN, dx_add ? E_SCATTER_ADD : E_SCATTER, s));
     // dW packed [2C][4C] = sum_m dy[m][oc] * gather(x)[m][k']
     GemmTN t{};
     t.M = Mc; t.X = dy; t.ldx = 2 * C; t.N = 2 * C; t.Y = x; t.K = 4 * C;

@@ -81,6 +81,11 @@ extern "C" int dcpt_down2x2_fwd_bf16(const uint16_t* x, const float* w, const fl
 
 extern "C" int dcpt_down2x2_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, uint16_t* dx, float* dw, float* dbias, void* ws,
                                      size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
+    return dcpt_down2x2_bwd_acc_bf16(dy, x, w, nullptr, dx, dw, dbias, ws, ws_bytes, B, H, W, C, stream);
+}
+
+extern "C" int dcpt_down2x2_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const uint16_t* dx_add, uint16_t* dx, float* dw,
+                                         float* dbias, void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     DCPT_CHECK_ARG(dy && x && w && dx && dw && dbias, "down2x2_bwd_bf16: null argument");
     DCPT_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "down2x2_bwd_bf16: bad shape");
@@ -96,7 +101,8 @@ extern "C" int dcpt_down2x2_bwd_bf16(const uint16_t* dy, const uint16_t* x, cons
     GemmNTB g{};
     g.M = Mc; g.A = dy; g.lda = 2 * C; g.K = 2 * C; g.Bw = d.wp; g.N = 4 * C; g.C = dx; g.ldc = 4 * C;
     g.gH = H / 2; g.gW = W / 2; g.gC = C;
-    DCPT_TRY(launch_gemm_nt_bf16(g, EB_SCATTER, s));
+    g.res = dx_add;   // (the skip connection's gradient joins in the scatter epilogue)
+    DCPT_TRY(launch_gemm_nt_bf16(g, dx_add ? EB_SCATTER_ADD : EB_SCATTER, s));
     // dW packed [2C][4C] = sum_m dy[m][oc] * gather(x)[m][k'],  db = column sums of dy
     GemmTNB t{};
     t.M = Mc; t.X = dy; t.ldx = 2 * C; t.N = 2 * C; t.Y = x; t.ldy = 4 * C; t.K = 4 * C; t.yg2 = 1; t.gH = H / 2; t.gW = W / 2; t.gC = C;

@@ -1018,6 +1018,61 @@ def down2x2(x, weight, bias):
     return _DownBf16Fn.apply(x, weight, bias) if x.dtype == torch.bfloat16 else _DownFn.apply(x, weight, bias)
 
 
+@_remember_gemm_mode
+class _DownSkipFn(torch.autograd.Function):
+    """(down2x2(x), x) for an encoder group's output, which has TWO consumers: the down layer and the skip connection into the decoder
+    (reference nafnet_arch.py:255-258, :264-265).  As two uses autograd sums the two gradients with a pass of its own over the feature map
+    (four `add` launches per step, the level-0 one over the largest tensor of the network); here the skip's gradient -- the up layer's
+    dy, untouched -- is the ``dx_add`` of the down layer's backward (dcpt_down2x2_bwd_acc*, ABI 13): summed in the scatter epilogue of
+    its data-gradient GEMM.  fp32 or bf16 activations by x.dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        bf = x.dtype == torch.bfloat16
+        (_require_gpu_bf16 if bf else _require_gpu)(x)
+        _require_gpu(weight, bias)
+        x = _nhwc(x)
+        w_, b_ = _contig(weight.detach()), (None if bias is None else _contig(bias.detach()))
+        B, Cc, H, W = x.shape
+        if H % 2 or W % 2:
+            raise ValueError(f"down2x2: H={H}, W={W} must be even")
+        y = (_empty_nhwc_bf16 if bf else _empty_nhwc)(B, 2 * Cc, H // 2, W // 2, x.device)
+        ws = _workspace(x.device, (lib.dcpt_down2x2_bf16_ws_bytes if bf else lib.dcpt_down2x2_ws_bytes)(B, H, W, Cc, 0))
+        check((lib.dcpt_down2x2_fwd_bf16 if bf else lib.dcpt_down2x2_fwd)(x.data_ptr(), w_.data_ptr(), _p(b_), y.data_ptr(), ws.data_ptr(),
+                                                                          ws.numel(), B, H, W, Cc, _stream(x.device)), "dcpt_down2x2_fwd")
+        ctx.save_for_backward(x, w_)
+        ctx.has_bias, ctx.bf = bias is not None, bf
+        return y, x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        lib = _lib.load()
+        x, w_ = ctx.saved_tensors
+        bf = ctx.bf
+        B, Cc, H, W = x.shape
+        dev = x.device
+        if dy is None:   # (only the skip was used downstream)
+            return dskip, None, None
+        dy = _nhwc(dy)
+        if dskip is not None:
+            dskip = _nhwc(dskip if dskip.dtype == x.dtype else dskip.to(x.dtype))
+        dx = (_empty_nhwc_bf16 if bf else _empty_nhwc)(B, Cc, H, W, dev)
+        dw = torch.empty_like(w_)
+        db = torch.empty((2 * Cc,), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, (lib.dcpt_down2x2_bf16_ws_bytes if bf else lib.dcpt_down2x2_ws_bytes)(B, H, W, Cc, 1))
+        check((lib.dcpt_down2x2_bwd_acc_bf16 if bf else lib.dcpt_down2x2_bwd_acc)(
+            dy.data_ptr(), x.data_ptr(), w_.data_ptr(), _p(dskip), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+            B, H, W, Cc, _stream(dev)), "dcpt_down2x2_bwd_acc")
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+def down2x2_skip(x, weight, bias):
+    """-> (down2x2(x), x): the second output is the skip connection's view of x; the two gradients are summed inside the down layer's
+    data-gradient GEMM on the way back"""
+    return _DownSkipFn.apply(x, weight, bias)
+
+
 def up_ps(x, weight, skip=None):
     if x.dtype == torch.bfloat16:
         return _UpBf16Fn.apply(x, weight, skip)

@@ -204,6 +204,9 @@ int dcpt_down2x2_fwd_bf16(const uint16_t* x, const float* w, const float* bias, 
                           dcpt_stream_t stream);
 int dcpt_down2x2_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, uint16_t* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
                           int B, int H, int W, int C, dcpt_stream_t stream);
+/* ABI 13: dx = dx_add + the down layer's data gradient (dx_add [B][H][W][C] or NULL): see dcpt_down2x2_bwd_acc */
+int dcpt_down2x2_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const uint16_t* dx_add, uint16_t* dx, float* dw, float* dbias,
+                              void* ws, size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
 size_t dcpt_up_ps_bf16_ws_bytes(int B, int H, int W, int C, int backward);
 int dcpt_up_ps_fwd_bf16(const uint16_t* x, const float* w, const uint16_t* skip /* may be NULL */, uint16_t* y, void* ws, size_t ws_bytes, int B,
                         int H, int W, int C, dcpt_stream_t stream);
@@ -263,6 +266,11 @@ int dcpt_down2x2_fwd(const float* x, const float* w, const float* bias, float* y
                      int H, int W, int C, dcpt_stream_t stream);
 int dcpt_down2x2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws,
                      size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
+/* ABI 13: dx = dx_add + the data gradient (dx_add NHWC [B][H][W][C] or NULL).  An encoder group's output feeds the down layer AND the skip
+ * connection (nafnet_arch.py:255-258, :264-265): the skip's gradient (= the up layer's dy) is summed in the scatter epilogue of the down
+ * layer's data-gradient GEMM instead of by a pass of autograd's own over the feature map. */
+int dcpt_down2x2_bwd_acc(const float* dy, const float* x, const float* w, const float* dx_add, float* dx, float* dw, float* dbias, void* ws,
+                         size_t ws_bytes, int B, int H, int W, int C, dcpt_stream_t stream);
 
 /* ---- up: Conv2d(C, 2C, 1, bias=False) + PixelShuffle(2) + skip add (nafnet_arch.py:238-242,264-265)
  * x [B][H][W][C], skip/y [B][2H][2W][C/2];  w [2C][C][1][1].  The skip gradient equals dy. */

@@ -32,7 +32,7 @@ for n in cnt:
     rd = val["FETCH_SIZE"][n] * 2 * 1024 / 1e6 / k; wr = val["WRITE_SIZE"][n] * 1024 / 1e6 / k; u = us[n] / k
     rows.append((us[n], n, k, u, rd, wr))
 for t_, n, k, u, rd, wr in sorted(rows, reverse=True):
-    print(f"{n:64s} n={k:5d} avg {u:8.1f} us  total {t_/1e3:8.2f} ms  read {rd:8.1f} MB  write {wr:8.1f} MB  -> {(rd+wr)/max(u,1e-9)/1e6*1e6/1e6:5.2f} TB/s")
+    print(f"{n:64s} n={k:5d} avg {u:8.1f} us  total {t_/1e3:8.2f} ms  read {rd:8.1f} MB  write {wr:8.1f} MB  -> {(rd+wr)/max(u,1e-9):5.2f} TB/s")
 PY
 tail -1 $D/log_FETCH_SIZE.txt >> $OUT
 rm -rf $D
