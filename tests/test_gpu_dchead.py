@@ -63,6 +63,50 @@ def test_conv_ln(dev, B, Cin, Cout, H, W, ks, relu, res):
         check(n, a.grad, b.grad, 1e-4)
 
 
+@pytest.mark.parametrize("B,C,H,W,bf", [(2, 16, 6, 10, False), (1, 64, 16, 16, False), (2, 16, 6, 10, True), (1, 128, 16, 16, True)])
+def test_bottleneck_node(dev, B, C, H, W, bf):
+    """DF.bottleneck (the BottleneckBlock of the reference, degrad_classify_arch.py:132-243, as ONE autograd node with the shortcut
+    gradient summed in conv1's data-gradient GEMM: dcpt_conv_ln_bwd_acc*) against the PyTorch-CPU restatement of the reference lines (fp32)
+    and against the three-node chain of conv_ln calls it replaces (both dtypes)."""
+    from dcpt_amd import functional as DF
+
+    Cb = 2 * C
+    x = keyed_input("bn.x", (B, C, H, W), lo=-1, hi=1)
+    ws = [keyed_tensor("bn.conv1.weight", (Cb, C, 1, 1)), keyed_tensor("bn.norm1.weight", (Cb,)), keyed_tensor("bn.norm1.bias", (Cb,)),
+          keyed_tensor("bn.conv2.weight", (Cb, Cb, 3, 3)), keyed_tensor("bn.norm2.weight", (Cb,)), keyed_tensor("bn.norm2.bias", (Cb,)),
+          keyed_tensor("bn.conv3.weight", (C, Cb, 1, 1)), keyed_tensor("bn.norm3.weight", (C,)), keyed_tensor("bn.norm3.bias", (C,))]
+    go = keyed_input("bn.go", (B, C, H, W), lo=-1, hi=1)
+    cast = (lambda t: t.to(dev).bfloat16()) if bf else (lambda t: t.to(dev))
+    # one node
+    xg = cast(x).requires_grad_(True)
+    pg = [t.to(dev).requires_grad_(True) for t in ws]
+    y = DF.bottleneck(xg, *pg)
+    y.backward(cast(go))
+    # three nodes (autograd sums the two gradients of x itself)
+    conv_ln = DF.conv_ln_bf16 if bf else DF.conv_ln
+    xc = cast(x).requires_grad_(True)
+    pc = [t.to(dev).requires_grad_(True) for t in ws]
+    o = conv_ln(xc, pc[0], pc[1], pc[2], None, True)
+    o = conv_ln(o, pc[3], pc[4], pc[5], None, True)
+    yc = conv_ln(o, pc[6], pc[7], pc[8], xc, True)
+    yc.backward(cast(go))
+    assert torch.equal(y, yc), "the forward of the node is the three calls of the chain"
+    tol = 2e-2 if bf else 1e-6   # (bf16: the chain rounds dx twice -- conv1's dx, then the sum; the node rounds the fp32 sum once)
+    check("dx vs chain", xg.grad.float(), xc.grad.float(), tol)
+    for n, a, b in zip(["dw1", "dlw1", "dlb1", "dw2", "dlw2", "dlb2", "dw3", "dlw3", "dlb3"], pg, pc):
+        assert torch.equal(a.grad, b.grad), f"{n}: the parameter gradients do not depend on where the shortcut gradient is summed"
+    if not bf:   # the reference's lines on the CPU
+        ref = [t.clone().requires_grad_(True) for t in [x] + ws]
+        r = F.relu(D.layernorm_cf(F.conv2d(ref[0], ref[1]), ref[2], ref[3]))
+        r = F.relu(D.layernorm_cf(F.conv2d(r, ref[4], padding=1), ref[5], ref[6]))
+        r = F.relu(D.layernorm_cf(F.conv2d(r, ref[7]), ref[8], ref[9]) + ref[0])
+        r.backward(go)
+        check("y", y, r, 2e-5)
+        check("dx", xg.grad, ref[0].grad, 1e-4)
+        for n, a, b in zip(["dw1", "dlw1", "dlb1", "dw2", "dlw2", "dlb2", "dw3", "dlw3", "dlb3"], pg, ref[1:]):
+            check(n, a.grad, b.grad, 1e-4)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 8, 16, 6, 10), (1, 64, 128, 16, 16), (3, 16, 16, 2, 2)])
 def test_conv_pool_relu(dev, B, Cin, Cout, H, W):
     from dcpt_amd import functional as DF

@@ -231,6 +231,43 @@ def test_down_up(dev, B, C, H, W):
     check("up dskip", sg.grad, sr.grad, 1e-6)
 
 
+@pytest.mark.parametrize("B,C,H,W,bf", [(2, 8, 4, 6, False), (1, 64, 16, 16, False), (2, 16, 8, 4, True), (1, 64, 16, 16, True)])
+def test_down_skip_node(dev, B, C, H, W, bf):
+    """DF.down2x2_skip: an encoder group's output with its two consumers (down layer, skip connection; reference nafnet_arch.py:255-258,
+    :264-265) as one autograd node, the skip's gradient summed in the down layer's scatter epilogue (dcpt_down2x2_bwd_acc*): against
+    F.conv2d + a second use of x on the CPU (fp32) and against the two-node form (both dtypes)."""
+    from dcpt_amd import functional as DF
+
+    x = keyed_input("ds.x", (B, C, H, W), lo=-1, hi=1)
+    w = keyed_tensor("ds.downs.weight", (2 * C, C, 2, 2))
+    b = keyed_tensor("ds.downs.bias", (2 * C,))
+    go = keyed_input("ds.go", (B, 2 * C, H // 2, W // 2), lo=-1, hi=1)
+    gs = keyed_input("ds.gs", (B, C, H, W), lo=-1, hi=1)
+    cast = (lambda t: t.to(dev).bfloat16()) if bf else (lambda t: t.to(dev))
+    xg, wg, bg = cast(x).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y, skip = DF.down2x2_skip(xg, wg, bg)
+    assert torch.equal(skip, xg)   # (a view of x wherever x is already NHWC, as inside the network)
+    torch.autograd.backward([y, skip], [cast(go), cast(gs)])
+    x2, w2, b2 = cast(x).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y2 = DF.down2x2(x2, w2, b2)
+    torch.autograd.backward([y2, x2 * 1.0], [cast(go), cast(gs)])
+    assert torch.equal(y, y2)
+    assert torch.equal(wg.grad, w2.grad) and torch.equal(bg.grad, b2.grad)
+    check("dx vs two nodes", xg.grad.float(), x2.grad.float(), 2e-2 if bf else 1e-6)
+    if not bf:
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+        yr = F.conv2d(xr, wr, br, stride=2)
+        torch.autograd.backward([yr, xr * 1.0], [go, gs])
+        check("y", y, yr, 1e-5)
+        check("dx", xg.grad, xr.grad, 1e-5)
+        check("dw", wg.grad, wr.grad, 1e-5)
+    # only one of the two outputs used downstream
+    x3 = cast(x).requires_grad_(True)
+    y3, s3 = DF.down2x2_skip(x3, wg, bg)
+    s3.backward(cast(gs))
+    assert torch.equal(x3.grad, cast(gs))
+
+
 def test_fused_leaky_relu(dev):
     from dcpt_amd import functional as DF
 
