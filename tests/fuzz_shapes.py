@@ -79,7 +79,8 @@ def block32_shapes(rng, n):
 
 
 def edge_shapes(rng, n):
-    return [(rng.randint(1, 4), rng.choice([1, 3, 4]), rng.choice([8, 16, 32, 64, 128]), rng.randint(3, 40), rng.randint(3, 40)) for _ in range(n)]
+    # (Cs <= 3 with Cb = 32 / 64 take the MFMA forms: widths past one 32-pixel tile / 30-column band, heights past one row strip)
+    return [(rng.randint(1, 4), rng.choice([1, 2, 3, 4]), rng.choice([8, 16, 32, 64, 64, 128]), rng.randint(1, 72), rng.randint(1, 100)) for _ in range(n)]
 
 
 def downup_shapes(rng, n):
