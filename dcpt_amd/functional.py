@@ -401,7 +401,10 @@ def invalidate_packed_weights() -> int:
 
 
 def _optimizer_step_post_hook(optimizer, args, kwargs):
-    invalidate_packed_weights()
+    # only an optimizer that owns a parameter some pack was made from makes the packs stale (in the DCPT step optimizer_dc.step() must not
+    # make the encoder's blocks repack -- with freeze_encoder it is the only optimizer that ever steps); parameters are tagged when packed
+    if any(getattr(p, "_dcpt_packdep", False) for grp in optimizer.param_groups for p in grp["params"]):
+        invalidate_packed_weights()
     # DistributedDataParallel with gradient_as_bucket_view: remember the bucket views now sitting in .grad (dcpt_amd/ddp.py)
     first = next((p for grp in optimizer.param_groups for p in grp["params"]), None)
     if first is not None and getattr(first, "_dcpt_ddp", False):
@@ -450,6 +453,12 @@ class PackedWeightsBf16:
     def key_of(params: Dict[str, torch.Tensor]):
         return (_PACK_GENERATION,) + tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
 
+    @staticmethod
+    def tag(params: Dict[str, torch.Tensor]):
+        """mark the parameters a pack depends on: an optimizer step over any of them invalidates the packs (_optimizer_step_post_hook)"""
+        for k in _PACK_DEPS:
+            params[k]._dcpt_packdep = True
+
     def get(self, params: Dict[str, torch.Tensor]) -> torch.Tensor:
         key = self.key_of(params)
         if key == self.key:
@@ -468,6 +477,7 @@ class PackedWeightsBf16:
             pp = NafBlockParams(*[p.data_ptr() for p in ps])
             check(lib.dcpt_nafblock_wpack_bf16(C.byref(pp), self.buf.data_ptr(), self.buf.numel(), Cc, _stream(dev)), "dcpt_nafblock_wpack_bf16")
             self.key = key
+            self.tag(params)
             self.stream = _stream(dev)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(dev))
@@ -506,6 +516,7 @@ def pack_blocks_bf16(blocks) -> int:
     ev.record(torch.cuda.current_stream(dev))
     for pk, params, key in stale:
         pk.key, pk.stream, pk.event = key, _stream(dev), ev
+        pk.tag(params)
     return n
 
 

@@ -829,3 +829,25 @@ def test_ddp_zero_copy_gradients_fallback_hook_and_no_sync_gloo(tmp_path):
                 assert torch.allclose(g, want, rtol=1e-6, atol=1e-7), (rank, variant, "no_sync accumulation")
         for a, b in zip(r[rank]["res"]["builtin"]["grads"][2], r[rank]["res"]["fallback"]["grads"][2]):
             assert torch.equal(a, b)
+
+
+def test_pack_generation_follows_only_optimizers_that_own_packed_parameters():
+    """dcpt_amd.functional's optimizer post-step hook: the weight-pack generation moves when an optimizer steps over a parameter some pack
+    was made from (tagged by PackedWeightsBf16.tag) -- not for an unrelated optimizer (round-4 advisor: in the DCPT step optimizer_dc.step()
+    made the frozen encoder repack every iteration)."""
+    import torch
+    from dcpt_amd import functional as DF
+
+    names = DF._PACK_DEPS
+    blockp = {k: torch.nn.Parameter(torch.zeros(2)) for k in names}
+    other = torch.nn.Parameter(torch.zeros(2))
+    DF.PackedWeightsBf16.tag(blockp)
+    for p in list(blockp.values()) + [other]:
+        p.grad = torch.ones_like(p)
+    o_other, o_block = torch.optim.SGD([other], lr=0.1), torch.optim.SGD(list(blockp.values()), lr=0.1)
+    g0 = DF._PACK_GENERATION
+    o_other.step()
+    assert DF._PACK_GENERATION == g0
+    o_block.step()
+    assert DF._PACK_GENERATION == g0 + 1
+    assert DF.invalidate_packed_weights() == g0 + 2   # (EMA updates and checkpoint loads still invalidate explicitly)

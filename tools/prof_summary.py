@@ -21,7 +21,7 @@ if steps <= 0:
     # one ending conv (conv3x3_b2s: features -> 3-channel image; the s2b kernel also serves the ending conv's data gradient) per network
     # forward = per step, whatever passes bench.py has grown (round-4 verdict: a literal 3 made every per-step figure of
     # profiles/r4/rocprofv3_summary_serialized.txt 2x)
-    steps = float(max(1, sum(c for k, (c, _) in ktime.items() if k.startswith('conv3x3_b2s_kernel'))))
+    steps = float(max(1, sum(c for k, (c, _) in ktime.items() if k.startswith('conv3x3_b2s'))))   # (conv3x3_b2s_kernel / conv3x3_b2s_mfma_kernel)
 print(f"== kernel trace: {tot/1e3:.2f} ms total over {steps:g} steps = {tot/1e3/steps:.2f} ms/step")
 top = sorted(ktime.items(), key=lambda kv: -kv[1][1])
 for k, (c, us) in top[:30]:
