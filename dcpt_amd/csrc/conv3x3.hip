@@ -1,8 +1,10 @@
 // Network-edge 3x3 convolutions between the 3-channel NCHW image and the NHWC feature space
 // (reference basicsr/archs/nafnet_arch.py:202-219 intro/ending, :252,:271-272 use).  One side has
-// <= 4 channels, so these are bandwidth-bound direct convolutions on the VALU (K = 27 is far too
-// small for MFMA).  The image side stays NCHW-contiguous: the layout change to/from NHWC is fused
+// <= 4 channels.  The image side stays NCHW-contiguous: the layout change to/from NHWC is fused
 // into these kernels, so no separate permute pass ever touches the big tensors.
+// Two forms of each of the three kernels: direct convolutions on the VALU (any Cs <= 4, Cb % 4 == 0 -- first half of the file; 27 FMAs
+// per feature element make them VALU-bound at 2.5 - 7 x their traffic time) and, for the shapes of every NAFNet configuration (Cs <= 3,
+// Cb = 32 / 64), exact-fp32 MFMA kernels (second half, round 5: K = 27 is small for a GEMM tile, not for v_mfma_f32_32x32x2_f32).
 #include "bf16.h"
 #include "bf16_ops.h"
 #include "bufops.h"
