@@ -40,10 +40,11 @@ class Conv2d(nn.Conv2d):
     def __init__(self, *args, norm=None, **kwargs):
         super().__init__(*args, **kwargs)
         self.norm = norm
+        self._pack = DF.PackedConvBf16()   # the weight's bf16 operand images, cached across the calls of an optimizer step (bf16 path)
 
     def fused(self, x, res=None, relu=True):
         if x.dtype == torch.bfloat16:
-            return DF.conv_ln_bf16(x, self.weight, self.norm.weight, self.norm.bias, res, relu)
+            return DF.conv_ln_bf16(x, self.weight, self.norm.weight, self.norm.bias, res, relu, packed=self._pack if x.is_cuda else None)
         return DF.conv_ln(x, self.weight, self.norm.weight, self.norm.bias, res, relu)
 
 
@@ -68,7 +69,7 @@ class BottleneckBlock(nn.Module):
         if x.is_cuda:   # one autograd node: the shortcut's gradient is summed inside conv1's data-gradient GEMM (DF._BottleneckFn)
             c1, c2, c3 = self.conv1, self.conv2, self.conv3
             return DF.bottleneck(x, c1.weight, c1.norm.weight, c1.norm.bias, c2.weight, c2.norm.weight, c2.norm.bias,
-                                 c3.weight, c3.norm.weight, c3.norm.bias)
+                                 c3.weight, c3.norm.weight, c3.norm.bias, packs=(c1._pack, c2._pack, c3._pack))
         out = self.conv1.fused(x, relu=True)
         out = self.conv2.fused(out, relu=True)
         return self.conv3.fused(out, res=x, relu=True)  # relu(LN(conv3) + shortcut)
@@ -79,8 +80,14 @@ class _Downsample(nn.Sequential):
 
     def forward(self, x):
         if x.dtype == torch.bfloat16:
-            return DF.conv1x1_pool_relu_bf16(x, self[0].weight)
+            return DF.conv1x1_pool_relu_bf16(x, self[0].weight, packed=self._conv_pack() if x.is_cuda else None)
         return DF.conv1x1_pool_relu(x, self[0].weight)
+
+    def _conv_pack(self):
+        pk = self.__dict__.get("_pack")
+        if pk is None:
+            pk = self.__dict__["_pack"] = DF.PackedConvBf16()
+        return pk
 
 
 class _DCHead(nn.Module):
@@ -110,8 +117,20 @@ class _DCHead(nn.Module):
             raise ValueError("act_dtype='bf16' needs feature_dims that are multiples of 8")
         self.act_dtype = act_dtype
 
+    def _packed_convs(self):
+        """[(cache, weight)] of every conv of the head: refreshed together (three launches) in front of a bf16 forward"""
+        out = []
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                out.append((m._pack, m.weight))
+            elif isinstance(m, _Downsample):
+                out.append((m._conv_pack(), m[0].weight))
+        return out
+
     def _run_stages(self, x, features):
         bf = self.act_dtype == "bf16"
+        if bf and len(features) and features[0].is_cuda:
+            DF.pack_convs_bf16(self._packed_convs())
         for i, feature in enumerate(features):
             if bf and feature.is_cuda and feature.dtype == torch.bfloat16 and (x is None or x.dtype == torch.bfloat16):
                 # taps and stage outputs both bf16 (the all-bf16 DCPT step): mixed in fp32, stored once -- no cast passes

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 _lock = threading.Lock()
 
@@ -115,6 +115,17 @@ SIGNATURES = {
     "dcpt_conv1x1_pool_relu_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv1x1_pool_relu_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,
                                                stream_t]),
+    "dcpt_conv_wpack_bf16_bytes": (sz, [cint, cint, cint]),
+    "dcpt_conv_wpack_bf16_multi": (cint, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(cint), C.POINTER(cint),
+                                          C.POINTER(cint), cint, stream_t]),
+    "dcpt_conv_ln_fwd_bf16_packed": (cint, [f32p, f32p, C.c_void_p, sz, f32p, f32p, f32p, cint, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint,
+                                            cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv_ln_bwd_acc_bf16_packed": (cint, [f32p, f32p, f32p, C.c_void_p, sz, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p,
+                                                f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, cint, cint, stream_t]),
+    "dcpt_conv1x1_pool_relu_fwd_bf16_packed": (cint, [f32p, f32p, C.c_void_p, sz, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint,
+                                                      stream_t]),
+    "dcpt_conv1x1_pool_relu_bwd_bf16_packed": (cint, [f32p, f32p, f32p, C.c_void_p, sz, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint,
+                                                      cint, cint, stream_t]),
     "dcpt_conv3x3_in_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv3x3_in_bwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, sz, cint, cint, cint, cint, cint, stream_t]),
     "dcpt_conv3x3_out_fwd_bf16": (cint, [f32p, f32p, f32p, f32p, f32p, cint, cint, cint, cint, cint, stream_t]),

@@ -37,7 +37,7 @@ struct WpackBJobsT {   // job j: in [N][K] fp32 -> transpose 0: out[img][n][k] =
 using WpackBJobs = WpackBJobsT<WPACKB_MAX_JOBS>;
 using WpackBJobsL = WpackBJobsT<WPACKB_MAX_JOBS_L>;
 int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s);
-int launch_wpack_bf16(const WpackBJobsL& jobs, hipStream_t s);
+int launch_wpack_bf16(const WpackBJobsL& jobs, hipStream_t s, int grid_cap = 256);   // grid.x <= grid_cap (x up to 80 jobs in grid.y)
 int launch_scale_rows_bf16(const bf16_t* x, const float* simg, bf16_t* out, int64_t M, int C, int P, hipStream_t s);
 int launch_sca_ds_part_bf16(const bf16_t* dts, const bf16_t* t2, float* ds_part, int B, int C, int P, int nslices, hipStream_t s);
 

@@ -594,7 +594,7 @@ int launch_cast_bf16_f32(const bf16_t* x, float* y, int64_t n, hipStream_t s) {
 }
 
 template <int MAXJ>
-static int launch_wpack_bf16_t(const WpackBJobsT<MAXJ>& jobs, hipStream_t s) {
+static int launch_wpack_bf16_t(const WpackBJobsT<MAXJ>& jobs, hipStream_t s, int grid_cap = 256) {
     DCPT_CHECK_ARG(jobs.n >= 1 && jobs.n <= MAXJ, "wpack_bf16: bad job count");
     int64_t mx = 0;
     for (int j = 0; j < jobs.n; ++j) {
@@ -603,13 +603,13 @@ static int launch_wpack_bf16_t(const WpackBJobsT<MAXJ>& jobs, hipStream_t s) {
     }
     int g = grid_for(mx);
     if (g > 4096) g = 4096;   // (a tile of the gathered 3 x 3 packs is ~1 us of latency: the largest has 16 384 of them)
-    if (MAXJ > WPACKB_MAX_JOBS && g > 256) g = 256;
+    if (MAXJ > WPACKB_MAX_JOBS && g > grid_cap) g = grid_cap;
     wpack_bf16_kernel<MAXJ><<<dim3(g, jobs.n), dim3(256), 0, s>>>(jobs);
     DCPT_CHECK_LAUNCH("wpack_bf16");
     return DCPT_OK;
 }
 int launch_wpack_bf16(const WpackBJobs& jobs, hipStream_t s) { return launch_wpack_bf16_t(jobs, s); }
-int launch_wpack_bf16(const WpackBJobsL& jobs, hipStream_t s) { return launch_wpack_bf16_t(jobs, s); }
+int launch_wpack_bf16(const WpackBJobsL& jobs, hipStream_t s, int grid_cap) { return launch_wpack_bf16_t(jobs, s, grid_cap); }
 
 int launch_scale_rows_bf16(const bf16_t* x, const float* simg, bf16_t* out, int64_t M, int C, int P, hipStream_t s) {
     DCPT_CHECK_ARG(C % 8 == 0, "scale_rows_bf16: C=%d", C);

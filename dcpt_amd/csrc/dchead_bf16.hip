@@ -135,14 +135,27 @@ int pack(const float* w, bf16_t* out, int N, int K, int mode, hipStream_t s) {
     return launch_wpack_bf16(j, s);
 }
 
-int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout, int ks, hipStream_t s) {
+// A conv's two operand images as ONE cached buffer (dcpt_conv_wpack_bf16_multi, ABI 14): the forward image [Cout][ks ks Cin] at offset 0, the
+// data gradient's (transposed; flipped taps for the dense 3 x 3) at wpack_half_bytes.  `pk` below = that buffer or nullptr (pack in the call).
+size_t wpack_half_bytes(int Cin, int Cout, int ks) { return (((size_t)Cout * ks * ks * Cin * sizeof(bf16_t)) + 255) & ~(size_t)255; }
+inline const bf16_t* pk_fwd(const void* pk) { return static_cast<const bf16_t*>(pk); }
+inline const bf16_t* pk_bwd(const void* pk, int Cin, int Cout, int ks) {
+    return reinterpret_cast<const bf16_t*>(static_cast<const char*>(pk) + wpack_half_bytes(Cin, Cout, ks));
+}
+inline int pk_check(const void* pk, size_t pk_bytes, int Cin, int Cout, int ks, const char* who) {
+    DCPT_CHECK_ARG(pk == nullptr || pk_bytes >= 2 * wpack_half_bytes(Cin, Cout, ks), "%s: packed weights too small (dcpt_conv_wpack_bf16_bytes)", who);
+    return DCPT_OK;
+}
+
+int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout, int ks, hipStream_t s,
+             const void* pk = nullptr) {
     GemmNTB g{};
-    g.M = (int64_t)B * H * W; g.A = x; g.N = Cout; g.C = z; g.ldc = Cout; g.Bw = cw.wp;
+    g.M = (int64_t)B * H * W; g.A = x; g.N = Cout; g.C = z; g.ldc = Cout; g.Bw = pk ? pk_fwd(pk) : cw.wp;
     if (ks == 1) {
-        DCPT_TRY(pack(w, cw.wp, Cout, Cin, 0, s));
+        if (!pk) DCPT_TRY(pack(w, cw.wp, Cout, Cin, 0, s));
         g.lda = Cin; g.K = Cin;
     } else {
-        DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 2, s));
+        if (!pk) DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 2, s));
         g.K = 9 * Cin; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cin;
     }
     return launch_gemm_nt_bf16(g, EB_PLAIN, s);
@@ -150,14 +163,14 @@ int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int 
 
 // dx = conv^T(dz), dw = wgrad(dz, x); `ln` (optional): the LayerNorm's column partials, reduced here as well
 int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, float* dw, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout,
-             int ks, hipStream_t s, const FinCols* ln = nullptr, const bf16_t* dx_add = nullptr) {
+             int ks, hipStream_t s, const FinCols* ln = nullptr, const bf16_t* dx_add = nullptr, const void* pk = nullptr) {
     const int64_t M = (int64_t)B * H * W;
     GemmNTB g{};
-    g.M = M; g.A = dz; g.N = Cin; g.C = dx; g.ldc = Cin; g.Bw = cw.wp;
+    g.M = M; g.A = dz; g.N = Cin; g.C = dx; g.ldc = Cin; g.Bw = pk ? pk_bwd(pk, Cin, Cout, ks) : cw.wp;
     g.res = dx_add; g.ldres = Cin;
     const int EDX = dx_add ? EB_RESID : EB_PLAIN;   // dx = dx_add + dz W (the shortcut gradient of a bottleneck block rides in the epilogue)
     if (cw.tn256) {   // data gradient as before; the weight gradient as one 256-tile launch + one finisher launch (which also takes the LN sums)
-        DCPT_TRY(pack(w, cw.wp, Cout, ks * ks * Cin, ks == 1 ? 1 : 3, s));
+        if (!pk && dx) DCPT_TRY(pack(w, cw.wp, Cout, ks * ks * Cin, ks == 1 ? 1 : 3, s));
         if (ks == 1) {
             g.lda = Cout; g.K = Cout;
         } else {
@@ -181,14 +194,14 @@ int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, floa
     GemmTNB t{};
     t.M = M; t.X = dz; t.ldx = Cout; t.N = Cout; t.Y = x; t.slab = cw.slab; t.colsum = nullptr; t.splits = cw.splits; t.rows_per_split = cw.rps;
     if (ks == 1) {
-        DCPT_TRY(pack(w, cw.wp, Cout, Cin, 1, s));
+        if (!pk && dx) DCPT_TRY(pack(w, cw.wp, Cout, Cin, 1, s));
         g.lda = Cout; g.K = Cout;
         if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
         t.ldy = Cin; t.K = Cin;
         DCPT_TRY(launch_gemm_tn_bf16(t, s));
         return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_PLAIN, s);
     }
-    DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 3, s));
+    if (!pk && dx) DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 3, s));
     g.K = 9 * Cout; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cout;
     if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
     t.K = 9 * Cin; t.yconv = 1; t.gH = H; t.gW = W; t.gC = Cin; t.ldy = Cin;
@@ -204,11 +217,12 @@ extern "C" size_t dcpt_conv_ln_bf16_ws_bytes(int B, int H, int W, int Cin, int C
     return conv_layout(B, H, W, Cin, Cout, ksize, backward, true, nullptr, 0, nullptr);
 }
 
-extern "C" int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const float* lnw, const float* lnb, const uint16_t* res, int relu,
-                                     uint16_t* z, uint16_t* y, float* mu, float* rstd, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
-                                     int Cout, int ksize, dcpt_stream_t stream) {
+extern "C" int dcpt_conv_ln_fwd_bf16_packed(const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes, const float* lnw,
+                                            const float* lnb, const uint16_t* res, int relu, uint16_t* z, uint16_t* y, float* mu, float* rstd,
+                                            void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    DCPT_CHECK_ARG(x && w && lnw && lnb && z && y && mu && rstd, "conv_ln_fwd_bf16: null argument");
+    DCPT_CHECK_ARG(x && (w || wpacked) && lnw && lnb && z && y && mu && rstd, "conv_ln_fwd_bf16: null argument");
+    DCPT_TRY(pk_check(wpacked, wpacked_bytes, Cin, Cout, ksize, "conv_ln_fwd_bf16"));
     DCPT_CHECK_ARG(conv_shape_ok(Cin, Cout, ksize), "conv_ln_fwd_bf16: ksize=%d Cin=%d Cout=%d (channels %% 8 == 0, Cout <= 1024)", ksize, Cin, Cout);
     ConvWsB cw;
     const size_t need = conv_layout(B, H, W, Cin, Cout, ksize, 0, true, ws, ws_bytes, &cw);
@@ -216,16 +230,24 @@ extern "C" int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const fl
         dcpt_set_error("conv_ln_fwd_bf16: workspace too small");
         return DCPT_ERR_WS;
     }
-    DCPT_TRY(conv_fwd(x, w, z, cw, B, H, W, Cin, Cout, ksize, s));
+    DCPT_TRY(conv_fwd(x, w, z, cw, B, H, W, Cin, Cout, ksize, s, wpacked));
     return launch_ln_act_fwd_bf16(z, lnw, lnb, res, relu, y, mu, rstd, (int64_t)B * H * W, Cout, 1e-6f, s);   // eps: degrad_classify_arch.py:24
 }
 
-extern "C" int dcpt_conv_ln_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
-                                         const float* mu, const float* rstd, const uint16_t* dx_add, uint16_t* dx, float* dw, float* dlnw, float* dlnb,
-                                         uint16_t* dres, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
-                                         dcpt_stream_t stream) {
+extern "C" int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const float* lnw, const float* lnb, const uint16_t* res, int relu,
+                                     uint16_t* z, uint16_t* y, float* mu, float* rstd, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
+                                     int Cout, int ksize, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(w, "conv_ln_fwd_bf16: null argument");
+    return dcpt_conv_ln_fwd_bf16_packed(x, w, nullptr, 0, lnw, lnb, res, relu, z, y, mu, rstd, ws, ws_bytes, B, H, W, Cin, Cout, ksize, stream);
+}
+
+extern "C" int dcpt_conv_ln_bwd_acc_bf16_packed(const uint16_t* dy, const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes,
+                                                const float* lnw, const uint16_t* z, const uint16_t* y, const float* mu, const float* rstd,
+                                                const uint16_t* dx_add, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres, void* ws,
+                                                size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    DCPT_CHECK_ARG(dy && x && w && lnw && z && mu && rstd && dw && dlnw && dlnb, "conv_ln_bwd_bf16: null argument");
+    DCPT_CHECK_ARG(dy && x && (w || wpacked) && lnw && z && mu && rstd && dw && dlnw && dlnb, "conv_ln_bwd_bf16: null argument");
+    DCPT_TRY(pk_check(wpacked, wpacked_bytes, Cin, Cout, ksize, "conv_ln_bwd_bf16"));
     DCPT_CHECK_ARG(!relu || y, "conv_ln_bwd_bf16: relu needs the saved output y");
     DCPT_CHECK_ARG(!dx_add || (dx && ksize == 1), "conv_ln_bwd_bf16: dx_add needs dx and a 1 x 1 conv (the block's conv1)");
     DCPT_CHECK_ARG(conv_shape_ok(Cin, Cout, ksize), "conv_ln_bwd_bf16: bad shape");
@@ -238,7 +260,16 @@ extern "C" int dcpt_conv_ln_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, 
     const int64_t M = (int64_t)B * H * W;
     DCPT_TRY(launch_ln_act_bwd_bf16(dy, z, mu, rstd, lnw, relu ? y : nullptr, dres, cw.dz, cw.lnpart, cw.ln_nblk, M, Cout, s));
     const FinCols ln{cw.lnpart, dlnw, dlnb, cw.ln_nblk, 2, Cout, 0};
-    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s, &ln, dx_add);
+    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, ksize, s, &ln, dx_add, wpacked);
+}
+
+extern "C" int dcpt_conv_ln_bwd_acc_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
+                                         const float* mu, const float* rstd, const uint16_t* dx_add, uint16_t* dx, float* dw, float* dlnw, float* dlnb,
+                                         uint16_t* dres, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu,
+                                         dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(w, "conv_ln_bwd_bf16: null argument");
+    return dcpt_conv_ln_bwd_acc_bf16_packed(dy, x, w, nullptr, 0, lnw, z, y, mu, rstd, dx_add, dx, dw, dlnw, dlnb, dres, ws, ws_bytes, B, H, W, Cin,
+                                            Cout, ksize, relu, stream);
 }
 
 extern "C" int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const float* lnw, const uint16_t* z, const uint16_t* y,
@@ -251,10 +282,12 @@ extern "C" size_t dcpt_conv1x1_pool_relu_bf16_ws_bytes(int B, int H, int W, int 
     return conv_layout(B, H, W, Cin, Cout, 1, backward, false, nullptr, 0, nullptr);
 }
 
-extern "C" int dcpt_conv1x1_pool_relu_fwd_bf16(const uint16_t* x, const float* w, uint16_t* z, uint16_t* y, void* ws, size_t ws_bytes, int B, int H,
-                                               int W, int Cin, int Cout, dcpt_stream_t stream) {
+extern "C" int dcpt_conv1x1_pool_relu_fwd_bf16_packed(const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes, uint16_t* z,
+                                                      uint16_t* y, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
+                                                      dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    DCPT_CHECK_ARG(x && w && z && y, "conv1x1_pool_relu_fwd_bf16: null argument");
+    DCPT_CHECK_ARG(x && (w || wpacked) && z && y, "conv1x1_pool_relu_fwd_bf16: null argument");
+    DCPT_TRY(pk_check(wpacked, wpacked_bytes, Cin, Cout, 1, "conv1x1_pool_relu_fwd_bf16"));
     DCPT_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && conv_shape_ok(Cin, Cout, 1), "conv1x1_pool_relu_fwd_bf16: bad shape");
     ConvWsB cw;
     const size_t need = conv_layout(B, H, W, Cin, Cout, 1, 0, false, ws, ws_bytes, &cw);
@@ -262,16 +295,24 @@ extern "C" int dcpt_conv1x1_pool_relu_fwd_bf16(const uint16_t* x, const float* w
         dcpt_set_error("conv1x1_pool_relu_fwd_bf16: workspace too small");
         return DCPT_ERR_WS;
     }
-    DCPT_TRY(conv_fwd(x, w, z, cw, B, H, W, Cin, Cout, 1, s));
+    DCPT_TRY(conv_fwd(x, w, z, cw, B, H, W, Cin, Cout, 1, s, wpacked));
     pool_relu_fwd_bf16_kernel<<<dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (Cout / 4))), dim3(256), 0, s>>>(z, y, B, H, W, Cout);
     DCPT_CHECK_LAUNCH("pool_relu_fwd_bf16");
     return DCPT_OK;
 }
 
-extern "C" int dcpt_conv1x1_pool_relu_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const uint16_t* z, uint16_t* dx, float* dw,
-                                               void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream) {
+extern "C" int dcpt_conv1x1_pool_relu_fwd_bf16(const uint16_t* x, const float* w, uint16_t* z, uint16_t* y, void* ws, size_t ws_bytes, int B, int H,
+                                               int W, int Cin, int Cout, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(w, "conv1x1_pool_relu_fwd_bf16: null argument");
+    return dcpt_conv1x1_pool_relu_fwd_bf16_packed(x, w, nullptr, 0, z, y, ws, ws_bytes, B, H, W, Cin, Cout, stream);
+}
+
+extern "C" int dcpt_conv1x1_pool_relu_bwd_bf16_packed(const uint16_t* dy, const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes,
+                                                      const uint16_t* z, uint16_t* dx, float* dw, void* ws, size_t ws_bytes, int B, int H, int W,
+                                                      int Cin, int Cout, dcpt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    DCPT_CHECK_ARG(dy && x && w && z && dx && dw, "conv1x1_pool_relu_bwd_bf16: null argument");
+    DCPT_CHECK_ARG(dy && x && (w || wpacked) && z && dx && dw, "conv1x1_pool_relu_bwd_bf16: null argument");
+    DCPT_TRY(pk_check(wpacked, wpacked_bytes, Cin, Cout, 1, "conv1x1_pool_relu_bwd_bf16"));
     DCPT_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && conv_shape_ok(Cin, Cout, 1), "conv1x1_pool_relu_bwd_bf16: bad shape");
     ConvWsB cw;
     const size_t need = conv_layout(B, H, W, Cin, Cout, 1, 1, false, ws, ws_bytes, &cw);
@@ -281,5 +322,47 @@ extern "C" int dcpt_conv1x1_pool_relu_bwd_bf16(const uint16_t* dy, const uint16_
     }
     pool_relu_bwd_bf16_kernel<<<dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (Cout / 4))), dim3(256), 0, s>>>(z, dy, cw.dz, B, H, W, Cout);
     DCPT_CHECK_LAUNCH("pool_relu_bwd_bf16");
-    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, 1, s);
+    return conv_bwd(cw.dz, x, w, dx, dw, cw, B, H, W, Cin, Cout, 1, s, nullptr, nullptr, wpacked);
+}
+
+extern "C" int dcpt_conv1x1_pool_relu_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const uint16_t* z, uint16_t* dx, float* dw,
+                                               void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream) {
+    DCPT_CHECK_ARG(w, "conv1x1_pool_relu_bwd_bf16: null argument");
+    return dcpt_conv1x1_pool_relu_bwd_bf16_packed(dy, x, w, nullptr, 0, z, dx, dw, ws, ws_bytes, B, H, W, Cin, Cout, stream);
+}
+
+// ---- the two operand images of n convs in a few launches (ABI 14) ----
+// One WpackBJobsL launch holds 40 convs (80 jobs); the dense 3 x 3 convs go first in launches of their own with a wider grid (their largest has
+// 16 384 gather tiles), the 1 x 1 convs share a 256-wide one.  Bit-identical to the packs the unpacked entry points make per call.
+extern "C" size_t dcpt_conv_wpack_bf16_bytes(int Cin, int Cout, int ksize) { return 2 * wpack_half_bytes(Cin, Cout, ksize); }
+
+extern "C" int dcpt_conv_wpack_bf16_multi(const float* const* w, void* const* packed, const size_t* packed_bytes, const int* Cin, const int* Cout,
+                                          const int* ksize, int n, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(w && packed && packed_bytes && Cin && Cout && ksize && n >= 1, "conv_wpack_bf16_multi: null argument");
+    for (int i = 0; i < n; ++i) {
+        DCPT_CHECK_ARG(w[i] && packed[i], "conv_wpack_bf16_multi: null argument (conv %d)", i);
+        DCPT_CHECK_ARG(conv_shape_ok(Cin[i], Cout[i], ksize[i]), "conv_wpack_bf16_multi: conv %d: ksize=%d Cin=%d Cout=%d", i, ksize[i], Cin[i], Cout[i]);
+        DCPT_CHECK_ARG(packed_bytes[i] >= 2 * wpack_half_bytes(Cin[i], Cout[i], ksize[i]), "conv_wpack_bf16_multi: conv %d: buffer too small", i);
+    }
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: the 3 x 3 convs, pass 1: the 1 x 1 convs
+        WpackBJobsL j{};
+        for (int i = 0; i < n; ++i) {
+            if ((ksize[i] == 3) != (pass == 0)) continue;
+            const int K = ksize[i] * ksize[i] * Cin[i];
+            for (int f = 0; f < 2; ++f) {
+                j.in[j.n] = w[i];
+                j.out[j.n] = f == 0 ? const_cast<bf16_t*>(pk_fwd(packed[i])) : const_cast<bf16_t*>(pk_bwd(packed[i], Cin[i], Cout[i], ksize[i]));
+                j.N[j.n] = Cout[i]; j.K[j.n] = K;
+                j.transpose[j.n] = (ksize[i] == 1 ? 0 : 2) + f;
+                ++j.n;
+            }
+            if (j.n == WPACKB_MAX_JOBS_L) {
+                DCPT_TRY(launch_wpack_bf16(j, s, pass == 0 ? 1024 : 256));
+                j = WpackBJobsL{};
+            }
+        }
+        if (j.n) DCPT_TRY(launch_wpack_bf16(j, s, pass == 0 ? 1024 : 256));
+    }
+    return DCPT_OK;
 }

@@ -10,6 +10,7 @@ shapes while the kernels see contiguous channel rows.  The 3-channel image stays
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import Dict, Tuple
 
 import torch
@@ -449,6 +450,12 @@ class PackedWeightsBf16:
         self.stream = None   # the stream the pack was made on, and the event behind it: another stream waits before it reads the pack
         self.event = None    # (tiled inference runs its tile batches on several streams, basicsr/models/sr_model.py::test_tile)
 
+    def __deepcopy__(self, memo):   # a copied module (EMA network, DDP replica) starts with an empty cache of its own
+        return type(self)()
+
+    def __reduce__(self):
+        return (type(self), ())
+
     @staticmethod
     def key_of(params: Dict[str, torch.Tensor]):
         return (_PACK_GENERATION,) + tuple((params[k].data_ptr(), params[k]._version) for k in _PACK_DEPS)
@@ -518,6 +525,78 @@ def pack_blocks_bf16(blocks) -> int:
         pk.key, pk.stream, pk.event = key, _stream(dev), ev
         pk.tag(params)
     return n
+
+
+class PackedConvBf16:
+    """Cache of ONE conv's two bf16 operand images (forward, data gradient) for the classifier head's bf16 path (dcpt_conv_wpack_bf16_multi,
+    ABI 14): the same staleness rule as PackedWeightsBf16 (generation / ``_version`` / address).  ``pack_convs_bf16`` refreshes a whole head
+    in three launches before its forward; without it every conv entry point packs its own image per call (68 launches per DCPT step)."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+        self.stream = None
+        self.event = None
+
+    def __deepcopy__(self, memo):
+        return type(self)()
+
+    def __reduce__(self):
+        return (type(self), ())
+
+    @staticmethod
+    def key_of(weight: torch.Tensor):
+        return (_PACK_GENERATION, weight.data_ptr(), weight._version, tuple(weight.shape))
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        if self.key_of(weight) != self.key:
+            pack_convs_bf16([(self, weight)])
+        elif self.stream != _stream(self.buf.device):
+            torch.cuda.current_stream(self.buf.device).wait_event(self.event)
+        return self.buf
+
+
+CONV_PACK_CACHE = _os.environ.get("DCPT_CONV_PACK_CACHE", "1") != "0"   # False: the head's conv entry points pack per call again (A/B, the bit-identity test)
+
+
+def pack_convs_bf16(convs) -> int:
+    """Refresh the stale ones of ``convs`` = [(PackedConvBf16, weight [Cout][Cin][k][k] fp32), ...] in one call of dcpt_conv_wpack_bf16_multi;
+    returns how many were packed."""
+    if not CONV_PACK_CACHE:
+        return 0
+    stale = [(pk, w, pk.key_of(w)) for pk, w in convs if pk.key_of(w) != pk.key]
+    if not stale:
+        return 0
+    lib = _lib.load()
+    n = len(stale)
+    ws, bufs, nbytes = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_size_t * n)()
+    cin, cout, ksz, keep = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)(), []
+    dev = None
+    for i, (pk, w, key) in enumerate(stale):
+        w_ = _contig(w.detach())
+        _require_gpu(w_)
+        keep.append(w_)
+        dev = w_.device
+        Co, Ci, ks = w_.shape[0], w_.shape[1], w_.shape[2]
+        need = lib.dcpt_conv_wpack_bf16_bytes(Ci, Co, ks)
+        if pk.buf is None or pk.buf.numel() != need or pk.buf.device != dev:
+            pk.buf = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws[i], bufs[i], nbytes[i], cin[i], cout[i], ksz[i] = w_.data_ptr(), pk.buf.data_ptr(), need, Ci, Co, ks
+    check(lib.dcpt_conv_wpack_bf16_multi(ws, bufs, nbytes, cin, cout, ksz, n, _stream(dev)), "dcpt_conv_wpack_bf16_multi")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    for pk, w, key in stale:
+        pk.key, pk.stream, pk.event = key, _stream(dev), ev
+        w._dcpt_packdep = True
+    return n
+
+
+def _pk(packed, weight):
+    """(pointer, bytes) of a conv's cached operand images -- (None, 0) without a cache: the entry point packs in the call"""
+    if packed is None or not CONV_PACK_CACHE:
+        return None, 0
+    buf = packed.get(weight)
+    return buf.data_ptr(), buf.numel()
 
 
 def nafblock_bf16(inp: torch.Tensor, params: Dict[str, torch.Tensor], packed: PackedWeightsBf16 = None) -> torch.Tensor:
@@ -1188,7 +1267,7 @@ class _ConvLNBf16Fn(torch.autograd.Function):
     """_ConvLNFn with bf16 activations (dcpt_conv_ln_fwd_bf16 / bwd_bf16): x, res, z, y and their gradients bf16; parameters fp32."""
 
     @staticmethod
-    def forward(ctx, x, weight, lnw, lnb, res, relu):
+    def forward(ctx, x, weight, lnw, lnb, res, relu, packed=None):
         lib = _lib.load()
         _require_gpu_bf16(x, *([] if res is None else [res]))
         _require_gpu(weight, lnw, lnb)
@@ -1202,11 +1281,13 @@ class _ConvLNBf16Fn(torch.autograd.Function):
         y = _empty_nhwc_bf16(B, Cout, H, W, dev)
         stats = torch.empty((2, B * H * W), dtype=torch.float32, device=dev)
         ws = _workspace(dev, lib.dcpt_conv_ln_bf16_ws_bytes(B, H, W, Cin, Cout, ks, 0))
-        check(lib.dcpt_conv_ln_fwd_bf16(x.data_ptr(), w_.data_ptr(), lw.data_ptr(), lb.data_ptr(), _p(res_), int(bool(relu)),
-                                        z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
-                                        ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)), "dcpt_conv_ln_fwd_bf16")
+        pkp, pkn = _pk(packed, weight)
+        check(lib.dcpt_conv_ln_fwd_bf16_packed(x.data_ptr(), w_.data_ptr(), pkp, pkn, lw.data_ptr(), lb.data_ptr(), _p(res_), int(bool(relu)),
+                                               z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                                               ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)), "dcpt_conv_ln_fwd_bf16")
         ctx.save_for_backward(x, w_, lw, z, y, stats)
         ctx.relu, ctx.has_res = bool(relu), res is not None
+        ctx.pk = (packed.buf if pkp is not None else None)   # (the backward of THIS forward reads the same images)
         return y
 
     @staticmethod
@@ -1222,15 +1303,16 @@ class _ConvLNBf16Fn(torch.autograd.Function):
         dlw, dlb = torch.empty_like(lw), torch.empty_like(lw)
         dres = _empty_nhwc_bf16(B, Cout, H, W, dev) if ctx.has_res else None
         ws = _workspace(dev, lib.dcpt_conv_ln_bf16_ws_bytes(B, H, W, Cin, Cout, ks, 1))
-        check(lib.dcpt_conv_ln_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), lw.data_ptr(), z.data_ptr(), y.data_ptr(),
-                                        stats[0].data_ptr(), stats[1].data_ptr(), dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(),
-                                        dlb.data_ptr(), _p(dres), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks,
-                                        int(ctx.relu), _stream(dev)), "dcpt_conv_ln_bwd_bf16")
-        return dx, dw, dlw, dlb, dres, None
+        pk = ctx.pk
+        check(lib.dcpt_conv_ln_bwd_acc_bf16_packed(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), _p(pk), 0 if pk is None else pk.numel(),
+                                                   lw.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), None,
+                                                   dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(), dlb.data_ptr(), _p(dres), ws.data_ptr(),
+                                                   ws.numel(), B, H, W, Cin, Cout, ks, int(ctx.relu), _stream(dev)), "dcpt_conv_ln_bwd_bf16")
+        return dx, dw, dlw, dlb, dres, None, None
 
 
-def conv_ln_bf16(x, weight, lnw, lnb, res=None, relu=True):
-    return _ConvLNBf16Fn.apply(x, weight, lnw, lnb, res, relu)
+def conv_ln_bf16(x, weight, lnw, lnb, res=None, relu=True, packed: PackedConvBf16 = None):
+    return _ConvLNBf16Fn.apply(x, weight, lnw, lnb, res, relu, packed)
 
 
 class _BottleneckFn(torch.autograd.Function):
@@ -1242,9 +1324,10 @@ class _BottleneckFn(torch.autograd.Function):
     of conv1's data-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3):
+    def forward(ctx, x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3, packs=None):
         lib = _lib.load()
         bf = x.dtype == torch.bfloat16
+        packs = packs if (bf and packs is not None) else (None, None, None)   # (PackedConvBf16 per conv: bf16 activations only)
         (_require_gpu_bf16 if bf else _require_gpu)(x)
         _require_gpu(w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3)
         x = _nhwc(x)
@@ -1252,21 +1335,28 @@ class _BottleneckFn(torch.autograd.Function):
         B, _, H, W = x.shape
         empty = _empty_nhwc_bf16 if bf else _empty_nhwc
         ws_bytes = lib.dcpt_conv_ln_bf16_ws_bytes if bf else lib.dcpt_conv_ln_ws_bytes
-        fwd = lib.dcpt_conv_ln_fwd_bf16 if bf else lib.dcpt_conv_ln_fwd
-        saved, cur = [x], x
-        for (w, lw, lb, res) in ((w1, lw1, lb1, None), (w2, lw2, lb2, None), (w3, lw3, lb3, x)):
+        saved, cur, pkbufs = [x], x, []
+        for (w, lw, lb, res, pck) in ((w1, lw1, lb1, None, packs[0]), (w2, lw2, lb2, None, packs[1]), (w3, lw3, lb3, x, packs[2])):
             w_, lw_, lb_ = _contig(w.detach()), _contig(lw.detach()), _contig(lb.detach())
             Cout, Cin, ks = w_.shape[0], w_.shape[1], w_.shape[2]
             z, y = empty(B, Cout, H, W, dev), empty(B, Cout, H, W, dev)
             stats = torch.empty((2, B * H * W), dtype=torch.float32, device=dev)
             ws = _workspace(dev, ws_bytes(B, H, W, Cin, Cout, ks, 0))
-            check(fwd(cur.data_ptr(), w_.data_ptr(), lw_.data_ptr(), lb_.data_ptr(), _p(res), 1, z.data_ptr(), y.data_ptr(),
-                      stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)),
-                  "dcpt_conv_ln_fwd")
+            if bf:
+                pkp, pkn = _pk(pck, w)
+                check(lib.dcpt_conv_ln_fwd_bf16_packed(cur.data_ptr(), w_.data_ptr(), pkp, pkn, lw_.data_ptr(), lb_.data_ptr(), _p(res), 1,
+                                                       z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                                                       ws.numel(), B, H, W, Cin, Cout, ks, _stream(dev)), "dcpt_conv_ln_fwd_bf16")
+                pkbufs.append(pck.buf if pkp is not None else None)
+            else:
+                check(lib.dcpt_conv_ln_fwd(cur.data_ptr(), w_.data_ptr(), lw_.data_ptr(), lb_.data_ptr(), _p(res), 1, z.data_ptr(),
+                                           y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin,
+                                           Cout, ks, _stream(dev)), "dcpt_conv_ln_fwd")
             saved += [w_, lw_, z, y, stats]
             cur = y
         ctx.save_for_backward(*saved)
         ctx.bf = bf
+        ctx.pkbufs = pkbufs   # (the backward of THIS forward reads the same operand images)
         return cur
 
     @staticmethod
@@ -1278,7 +1368,6 @@ class _BottleneckFn(torch.autograd.Function):
         B, _, H, W = x.shape
         empty = _empty_nhwc_bf16 if bf else _empty_nhwc
         ws_bytes = lib.dcpt_conv_ln_bf16_ws_bytes if bf else lib.dcpt_conv_ln_ws_bytes
-        bwd = lib.dcpt_conv_ln_bwd_acc_bf16 if bf else lib.dcpt_conv_ln_bwd_acc
         g = _nhwc(dy if (not bf or dy.dtype == torch.bfloat16) else dy.to(torch.bfloat16))
         grads, dshort = [None] * 9, None
         for k in (2, 1, 0):   # conv3 (its dres = the shortcut gradient), conv2, conv1 (dx = dx_add + ...)
@@ -1289,26 +1378,36 @@ class _BottleneckFn(torch.autograd.Function):
             dw, dlw, dlb = torch.empty_like(w_), torch.empty_like(lw_), torch.empty_like(lw_)
             dres = empty(B, Cout, H, W, dev) if k == 2 else None
             ws = _workspace(dev, ws_bytes(B, H, W, Cin, Cout, ks, 1))
-            check(bwd(g.data_ptr(), xin.data_ptr(), w_.data_ptr(), lw_.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-                      stats[1].data_ptr(), _p(dshort if k == 0 else None), dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(), dlb.data_ptr(),
-                      _p(dres), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks, 1, _stream(dev)), "dcpt_conv_ln_bwd_acc")
+            if bf:
+                pk = ctx.pkbufs[k]
+                check(lib.dcpt_conv_ln_bwd_acc_bf16_packed(g.data_ptr(), xin.data_ptr(), w_.data_ptr(), _p(pk), 0 if pk is None else pk.numel(),
+                                                           lw_.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                           _p(dshort if k == 0 else None), dx.data_ptr(), dw.data_ptr(), dlw.data_ptr(),
+                                                           dlb.data_ptr(), _p(dres), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, ks, 1,
+                                                           _stream(dev)), "dcpt_conv_ln_bwd_acc_bf16")
+            else:
+                check(lib.dcpt_conv_ln_bwd_acc(g.data_ptr(), xin.data_ptr(), w_.data_ptr(), lw_.data_ptr(), z.data_ptr(), y.data_ptr(),
+                                               stats[0].data_ptr(), stats[1].data_ptr(), _p(dshort if k == 0 else None), dx.data_ptr(),
+                                               dw.data_ptr(), dlw.data_ptr(), dlb.data_ptr(), _p(dres), ws.data_ptr(), ws.numel(), B, H, W,
+                                               Cin, Cout, ks, 1, _stream(dev)), "dcpt_conv_ln_bwd_acc")
             if k == 2:
                 dshort = dres
             grads[3 * k: 3 * k + 3] = [dw, dlw, dlb]
             g = dx
-        return (g, *grads)
+        return (g, *grads, None)
 
 
-def bottleneck(x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3):
-    """relu(LN(conv3(relu(LN(conv2(relu(LN(conv1(x)))))))) + x) as one autograd node (fp32 or bf16 activations)"""
-    return _BottleneckFn.apply(x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3)
+def bottleneck(x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3, packs=None):
+    """relu(LN(conv3(relu(LN(conv2(relu(LN(conv1(x)))))))) + x) as one autograd node (fp32 or bf16 activations); ``packs``: the three convs'
+    PackedConvBf16 caches (bf16 activations)"""
+    return _BottleneckFn.apply(x, w1, lw1, lb1, w2, lw2, lb2, w3, lw3, lb3, packs)
 
 
 class _ConvPoolReluBf16Fn(torch.autograd.Function):
     """_ConvPoolReluFn with bf16 activations."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, packed=None):
         lib = _lib.load()
         _require_gpu_bf16(x)
         _require_gpu(weight)
@@ -1320,9 +1419,11 @@ class _ConvPoolReluBf16Fn(torch.autograd.Function):
         z = _empty_nhwc_bf16(B, Cout, H, W, dev)
         y = _empty_nhwc_bf16(B, Cout, H // 2, W // 2, dev)
         ws = _workspace(dev, lib.dcpt_conv1x1_pool_relu_bf16_ws_bytes(B, H, W, Cin, Cout, 0))
-        check(lib.dcpt_conv1x1_pool_relu_fwd_bf16(x.data_ptr(), w_.data_ptr(), z.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                  B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv1x1_pool_relu_fwd_bf16")
+        pkp, pkn = _pk(packed, weight)
+        check(lib.dcpt_conv1x1_pool_relu_fwd_bf16_packed(x.data_ptr(), w_.data_ptr(), pkp, pkn, z.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                                         ws.numel(), B, H, W, Cin, Cout, _stream(dev)), "dcpt_conv1x1_pool_relu_fwd_bf16")
         ctx.save_for_backward(x, w_, z)
+        ctx.pk = (packed.buf if pkp is not None else None)
         return y
 
     @staticmethod
@@ -1336,14 +1437,15 @@ class _ConvPoolReluBf16Fn(torch.autograd.Function):
         dx = _empty_nhwc_bf16(B, Cin, H, W, dev)
         dw = torch.empty_like(w_)
         ws = _workspace(dev, lib.dcpt_conv1x1_pool_relu_bf16_ws_bytes(B, H, W, Cin, Cout, 1))
-        check(lib.dcpt_conv1x1_pool_relu_bwd_bf16(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), z.data_ptr(), dx.data_ptr(),
-                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin, Cout, _stream(dev)),
-              "dcpt_conv1x1_pool_relu_bwd_bf16")
-        return dx, dw
+        pk = ctx.pk
+        check(lib.dcpt_conv1x1_pool_relu_bwd_bf16_packed(dy.data_ptr(), x.data_ptr(), w_.data_ptr(), _p(pk), 0 if pk is None else pk.numel(),
+                                                         z.data_ptr(), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, Cin,
+                                                         Cout, _stream(dev)), "dcpt_conv1x1_pool_relu_bwd_bf16")
+        return dx, dw, None
 
 
-def conv1x1_pool_relu_bf16(x, weight):
-    return _ConvPoolReluBf16Fn.apply(x, weight)
+def conv1x1_pool_relu_bf16(x, weight, packed: PackedConvBf16 = None):
+    return _ConvPoolReluBf16Fn.apply(x, weight, packed)
 
 
 class _PatchUnfoldFn(torch.autograd.Function):
@@ -1660,7 +1762,6 @@ def concat_channels(a, b):
 # schedule, step time and peak memory as a process that has the device to itself (round-4 verdict / advisor finding).
 # Measured on MI355X, Restormer B = 64, 128 x 128 (profiles/r3/extra_restormer_*.json, profiles/r5/).
 import contextlib as _contextlib  # noqa: E402
-import os as _os  # noqa: E402
 
 _RESTORMER_MODES = ("auto", "full", "balanced", "lean")
 _RESTORMER_SAVE = _os.environ.get("DCPT_RESTORMER_SAVE", "balanced")

@@ -236,6 +236,27 @@ int dcpt_conv1x1_pool_relu_fwd_bf16(const uint16_t* x, const float* w, uint16_t*
                                     int Cin, int Cout, dcpt_stream_t stream);
 int dcpt_conv1x1_pool_relu_bwd_bf16(const uint16_t* dy, const uint16_t* x, const float* w, const uint16_t* z, uint16_t* dx, float* dw, void* ws,
                                     size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+/* ABI 14: cached operand copies of the head's conv weights.  The entry points above pack their bf16 operand image of `w` on every call (one small
+ * launch in front of each GEMM: 68 per step of the DCPT head).  A caller that keeps one buffer of dcpt_conv_wpack_bf16_bytes(Cin, Cout, ksize) bytes
+ * per conv (device memory, 256-byte aligned) fills all of them with dcpt_conv_wpack_bf16_multi (n convs: a launch per 40 convs, the 3 x 3 and the
+ * 1 x 1 convs apart) once per optimizer step -- whenever the weights may have changed -- and passes it as `wpacked` to the *_packed forms: same
+ * results bit for bit, no pack launches.  A buffer holds the forward image ([Cout][ksize ksize Cin]) and the data gradient's (transposed; taps
+ * flipped for the 3 x 3).  wpacked == NULL: packs in the call, exactly the unpacked entry point (`w` may be NULL only when wpacked is given). */
+size_t dcpt_conv_wpack_bf16_bytes(int Cin, int Cout, int ksize);
+int dcpt_conv_wpack_bf16_multi(const float* const* w, void* const* packed, const size_t* packed_bytes, const int* Cin, const int* Cout,
+                               const int* ksize, int n, dcpt_stream_t stream);
+int dcpt_conv_ln_fwd_bf16_packed(const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes, const float* lnw, const float* lnb,
+                                 const uint16_t* res, int relu, uint16_t* z, uint16_t* y, float* mu, float* rstd, void* ws, size_t ws_bytes, int B,
+                                 int H, int W, int Cin, int Cout, int ksize, dcpt_stream_t stream);
+int dcpt_conv_ln_bwd_acc_bf16_packed(const uint16_t* dy, const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes,
+                                     const float* lnw, const uint16_t* z, const uint16_t* y, const float* mu, const float* rstd,
+                                     const uint16_t* dx_add, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres, void* ws,
+                                     size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream);
+int dcpt_conv1x1_pool_relu_fwd_bf16_packed(const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes, uint16_t* z, uint16_t* y,
+                                           void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, dcpt_stream_t stream);
+int dcpt_conv1x1_pool_relu_bwd_bf16_packed(const uint16_t* dy, const uint16_t* x, const float* w, const void* wpacked, size_t wpacked_bytes,
+                                           const uint16_t* z, uint16_t* dx, float* dw, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
+                                           int Cout, dcpt_stream_t stream);
 
 /* TLSC variant (nafnet_arch.py:277-288 `NAFNet`, arch_util.py:313-455): inference-only forward where SCA's global
  * mean is a k1 x k2 local box mean (replicate-padded), i.e. a per-pixel attention map.  Callers use the plain

@@ -905,3 +905,78 @@ def test_network_packs_all_blocks_in_a_few_launches_bit_identically(dev):
         opt.step()
         opt.zero_grad(set_to_none=True)
         assert all(b._packed_bf16.key != DF.PackedWeightsBf16.key_of(b.fused_params()) for b in blocks)   # stale after the step
+
+
+@pytest.mark.gpu
+def test_dc_head_bf16_cached_conv_packs(dev):
+    """ABI 14: the head's convs read cached operand images of their weights (dcpt_conv_wpack_bf16_multi, refreshed once per optimizer
+    step) instead of packing per call -- logits and EVERY gradient bit-identical to the per-call packs (DF.CONV_PACK_CACHE = False); the
+    cache follows the weights: an AdamW step (fused: no ``_version`` bump), an in-place edit and a load_state_dict all repack, a second
+    forward without a change packs nothing."""
+    from basicsr.archs import build_network
+    from dcpt_amd import functional as DF
+    from dcpt_amd.keyed_init import keyed_state_dict
+    from dcpt_amd.optim import FusedAdamW
+    from oracle import dc_oracle as D
+
+    cfg = dict(feature_dims=[32, 64, 128], num_res_blocks=2, num_classes=10)
+    sd = keyed_state_dict(D.dc_param_shapes(**cfg), seed=1)
+    net = build_network(dict(type="PromptIR_NoImg_DC", act_dtype="bf16", **cfg))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    feats = [keyed_input("dcp.f0", (2, 32, 32, 24), lo=-1, hi=1).to(dev).bfloat16(), keyed_input("dcp.f1", (2, 64, 16, 12), lo=-1, hi=1).to(dev).bfloat16(),
+             keyed_input("dcp.f2", (2, 128, 8, 6), lo=-1, hi=1).to(dev).bfloat16()]
+    labels = torch.tensor([3, 8], device=dev)
+    convs = net._packed_convs()
+    assert len(convs) == 3 * 3 * 2 + 2 * 3 + 3   # 3 stages + last stage: 2 blocks x 3 convs each; 3 downsample convs
+
+    def run(cache):
+        DF.CONV_PACK_CACHE = cache
+        try:
+            net.zero_grad(set_to_none=True)
+            fd = [f.clone().requires_grad_(True) for f in feats]
+            logits = net(None, fd)
+            torch.nn.functional.cross_entropy(logits, labels).backward()
+            torch.cuda.synchronize()
+            return logits.detach().clone(), [f.grad.clone() for f in fd], {k: p.grad.clone() for k, p in net.named_parameters()}
+        finally:
+            DF.CONV_PACK_CACHE = True
+
+    def same(a, b):
+        assert torch.equal(a[0], b[0])
+        for x, y in zip(a[1], b[1]):
+            assert torch.equal(x, y)
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), k
+
+    ref = run(False)
+    assert all(pk.key is None for pk, _ in convs)            # the per-call path never touched the caches
+    got = run(True)
+    same(ref, got)
+    assert all(pk.key is not None for pk, _ in convs)
+    assert DF.pack_convs_bf16(convs) == 0                     # nothing changed: nothing to pack
+    # fused AdamW changes the values without bumping ``_version``: the generation counter must make the packs stale
+    opt = FusedAdamW(net.parameters(), lr=1e-2)
+    opt.step()
+    assert DF.pack_convs_bf16(convs) == len(convs)
+    same(run(False), run(True))
+    # an in-place edit of ONE weight: exactly that conv repacks
+    with torch.no_grad():
+        net.bottleneck_layers[1][0].conv2.weight.mul_(1.5)
+    assert DF.pack_convs_bf16(convs) == 1
+    same(run(False), run(True))
+    # load_state_dict (copy_ into every parameter)
+    net.load_state_dict(sd, strict=True)
+    same(ref, run(True))
+    # too small a buffer is refused, not read
+    from dcpt_amd import _lib
+    lib = _lib.load()
+    w = net.downsample_layers[0][0].weight
+    x = torch.zeros(1, 16, 16, 32, dtype=torch.bfloat16, device=dev)
+    z = torch.zeros(1, 16, 16, 64, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device=dev)
+    ws = torch.zeros(lib.dcpt_conv1x1_pool_relu_bf16_ws_bytes(1, 16, 16, 32, 64, 0), dtype=torch.uint8, device=dev)
+    small = torch.zeros(64, dtype=torch.uint8, device=dev)
+    rc = lib.dcpt_conv1x1_pool_relu_fwd_bf16_packed(x.data_ptr(), w.data_ptr(), small.data_ptr(), small.numel(), z.data_ptr(), y.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), 1, 16, 16, 32, 64, None)
+    assert rc != 0 and b"packed weights too small" in lib.dcpt_last_error()
