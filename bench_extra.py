@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--head-dtype", default=None, choices=["fp32", "bf16"], help="dcpt: classifier-head activations (default: --dtype)")
     ap.add_argument("--restormer-save", default="balanced", choices=["auto", "lean", "balanced", "full"], help="what the Restormer halves keep for backward")
     ap.add_argument("--optimizer", default="dcpt", choices=["dcpt", "torch"], help="A/B: torch = torch.optim.AdamW(fused=True) instead of dcpt_amd.optim.FusedAdamW")
+    ap.add_argument("--two-pass", action="store_true", help="dcpt A/B: train.batched_encoder_passes false (the reference's two encoder passes, B each, instead of one pass over 2B)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tile-streams", type=int, default=2, help="infer2k: HIP streams the tile batches run on (tile.streams)")
@@ -165,6 +166,7 @@ def main():
                    network_dc=dict(type="PromptIR_NoImg_DC", feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10,
                                    act_dtype=args.head_dtype or args.dtype),
                    path=dict(), train=dict(pixel_opt=dict(type="L1Loss"), classify_opt=dict(type="CrossEntropyLoss"),
+                                           batched_encoder_passes=not args.two_pass,
                                            optim_g=dict(type="AdamW", lr=1e-4, fused=True), optim_dc=dict(type="AdamW", lr=1e-4, fused=True)))
         m = build_model(opt)
         fill_module_(m.net_g)

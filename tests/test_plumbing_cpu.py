@@ -851,3 +851,52 @@ def test_pack_generation_follows_only_optimizers_that_own_packed_parameters():
     o_block.step()
     assert DF._PACK_GENERATION == g0 + 1
     assert DF.invalidate_packed_weights() == g0 + 2   # (EMA updates and checkpoint loads still invalidate explicitly)
+
+
+def test_conv_pack_cache_host_logic():
+    """dcpt_amd.functional.PackedConvBf16 (ABI 14, the bf16 head's cached operand images) without a GPU: the key follows the generation
+    counter, the parameter's ``_version`` and its address; a copied / pickled module starts with an empty cache (no device event is
+    copied); the head registers exactly its 34 convs; with the cache switched off nothing is packed and nothing is touched; a CPU weight
+    is refused by the pack call (no CPU fallback)."""
+    import copy
+    import pickle
+
+    import pytest
+    import torch
+    from basicsr.archs.degrad_classify_arch import PromptIR_NoImg_DC
+    from dcpt_amd import _lib
+    from dcpt_amd import functional as DF
+
+    w = torch.nn.Parameter(torch.zeros(8, 8, 1, 1))
+    k0 = DF.PackedConvBf16.key_of(w)
+    with torch.no_grad():
+        w.add_(1.0)
+    k1 = DF.PackedConvBf16.key_of(w)
+    assert k1 != k0 and k1[0] == k0[0]            # the version moved, the generation did not
+    DF.invalidate_packed_weights()
+    assert DF.PackedConvBf16.key_of(w)[0] == k0[0] + 1
+    pk = DF.PackedConvBf16()
+    pk.key, pk.buf = k1, torch.zeros(4)
+    for c in (copy.deepcopy(pk), pickle.loads(pickle.dumps(pk))):
+        assert c.key is None and c.buf is None and c.event is None
+    head = PromptIR_NoImg_DC([64, 128, 256, 512], 2, 10, act_dtype="bf16")
+    convs = head._packed_convs()
+    assert len(convs) == 34 and len({id(c) for c, _ in convs}) == 34
+    assert all(wt.dim() == 4 and wt.shape[2] in (1, 3) for _, wt in convs)
+    ema = copy.deepcopy(head)
+    assert all(a is not b for (a, _), (b, _) in zip(convs, ema._packed_convs()))
+    lib = _lib.load()
+    for _, wt in convs:   # the buffer holds both images, each rounded up to 256 bytes
+        Co, Ci, ks = wt.shape[0], wt.shape[1], wt.shape[2]
+        half = (Co * Ci * ks * ks * 2 + 255) // 256 * 256
+        assert lib.dcpt_conv_wpack_bf16_bytes(Ci, Co, ks) == 2 * half
+    old = DF.CONV_PACK_CACHE
+    try:
+        DF.CONV_PACK_CACHE = False
+        assert DF.pack_convs_bf16(convs) == 0 and all(c.key is None for c, _ in convs)
+        assert DF._pk(convs[0][0], convs[0][1]) == (None, 0)
+        DF.CONV_PACK_CACHE = True
+        with pytest.raises(_lib.DcptHipError):
+            DF.pack_convs_bf16(convs[:2])          # CPU tensors: refused
+    finally:
+        DF.CONV_PACK_CACHE = old
