@@ -467,6 +467,23 @@ def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     # vs fp32: a sanity bound only -- ReLU masks of values that round across zero flip whole gradient entries
     assert _rel(yd, yf) <= 4e-2 and _rel(pd[0].grad, gf[0]) <= 0.15
     assert relu or _rel(xd.grad, dxf) <= 0.15
+    # the same group reading CACHED operand images of the weight (ABI 14, PackedConvBf16): bit-identical to the per-call pack above
+    pk = DF.PackedConvBf16()
+    x2 = xd.detach().clone().requires_grad_(True)
+    p2 = [t.detach().clone().requires_grad_(True) for t in pd]
+    r2 = rd.detach().clone().requires_grad_(True) if use_res else None
+    y2 = DF.conv_ln_bf16(x2, p2[0], p2[1], p2[2], r2, relu, packed=pk)
+    y2.backward(gw.to(dev).bfloat16())
+    torch.cuda.synchronize()
+    assert pk.key is not None and pk.buf.numel() == _lib_conv_pack_bytes(Cin, Cout, ks)
+    assert torch.equal(y2, yd) and torch.equal(x2.grad, xd.grad) and all(torch.equal(a.grad, b.grad) for a, b in zip(p2, pd))
+    assert not use_res or torch.equal(r2.grad, rd.grad)
+
+
+def _lib_conv_pack_bytes(Cin, Cout, ks):
+    from dcpt_amd import _lib
+
+    return _lib.load().dcpt_conv_wpack_bf16_bytes(Cin, Cout, ks)
 
 
 def test_dc_head_bf16_oracle(dev):
