@@ -53,8 +53,9 @@ class DCPTModel(BaseModel):
 
     # -- hooks -------------------------------------------------------------------------------
     def hook_forward_fn(self, module, input, output):  # noqa: A002
+        head = ()
         if isinstance(output, tuple):
-            output = output[-1]
+            head, output = output[:-1], output[-1]
         rng = getattr(self, "_tap_rows", None)
         if rng is not None and not self.freeze_encoder and torch.is_tensor(output) and output.is_cuda:
             # stacked encoder pass: the head taps samples rng[0]..rng[1]-1 of this feature map and the network goes on with all of it --
@@ -63,7 +64,7 @@ class DCPTModel(BaseModel):
 
             through, tap = tap_split(output, rng[0], rng[1])
             self.hook_outputs.append(tap)
-            return through
+            return head + (through,) if head else through   # (a tuple output stays a tuple downstream: only its last element is replaced)
         self.hook_outputs.append(output.detach() if self.freeze_encoder else output)
         return None
 

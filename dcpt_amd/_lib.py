@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcpt_hip.so")   # the in-tree build is the only library the product loads
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 _lock = threading.Lock()
 
@@ -65,6 +65,12 @@ class GdfnParams(C.Structure):
 
 class GdfnSaved(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in GDFN_SAVED_FIELDS]
+
+
+class BneckGroup(C.Structure):   # dcpt_bneck_group_t: one conv -> LayerNorm group of the classifier head's BottleneckBlock
+    _fields_ = [("w", C.c_void_p), ("wpacked", C.c_void_p), ("wpacked_bytes", C.c_size_t), ("lnw", C.c_void_p), ("lnb", C.c_void_p),
+                ("z", C.c_void_p), ("y", C.c_void_p), ("mu", C.c_void_p), ("rstd", C.c_void_p), ("dw", C.c_void_p), ("dlnw", C.c_void_p),
+                ("dlnb", C.c_void_p)]
 
 
 PARAM_FIELDS = tuple(_PARAM_FIELDS)
@@ -197,6 +203,11 @@ SIGNATURES = {
     "dcpt_pixel_shuffle": (cint, [f32p, f32p, cint, cint, cint, cint, stream_t]),
     "dcpt_concat_channels": (cint, [f32p, f32p, f32p, i64, cint, cint, stream_t]),
     "dcpt_split_channels": (cint, [f32p, f32p, f32p, i64, cint, cint, stream_t]),
+    "dcpt_bottleneck_bf16_ws_bytes": (sz, [cint, cint, cint, cint, cint]),
+    "dcpt_bottleneck_fwd_bf16": (cint, [f32p, C.POINTER(BneckGroup), C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_bottleneck_bwd_bf16": (cint, [f32p, f32p, C.POINTER(BneckGroup), f32p, C.c_void_p, sz, cint, cint, cint, cint, stream_t]),
+    "dcpt_trace_enable": (cint, [cint]),
+    "dcpt_trace_read": (sz, [C.c_char_p, sz]),
     "dcpt_prof_enable": (cint, [cint]),
     "dcpt_prof_read": (cint, [C.POINTER(C.c_double), cint]),
     "dcpt_set_side_stream": (cint, [cint]),

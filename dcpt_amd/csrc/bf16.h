@@ -60,6 +60,23 @@ __device__ __forceinline__ void bbuf_st8(rsrc_t r, uint32_t voff, f8 v) {
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
 }
+// 8 fp32 rounded to bf16 (RNE): the packed words `w` (what a store writes) and the values a reload of them gives
+__device__ __forceinline__ f8 f8_round_bf16(f8 v, u32x4& w) {
+    w.x = bf_pack(v.lo.x, v.lo.y);
+    w.y = bf_pack(v.lo.z, v.lo.w);
+    w.z = bf_pack(v.hi.x, v.hi.y);
+    w.w = bf_pack(v.hi.z, v.hi.w);
+    f8 o;
+    o.lo = make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y));
+    o.hi = make_float4(bf_lo(w.z), bf_hi(w.z), bf_lo(w.w), bf_hi(w.w));
+    return o;
+}
+__device__ __forceinline__ void bbuf_st8_raw(rsrc_t r, uint32_t voff, u32x4 w) {
+#ifdef DCPT_ABL_NOSTORE
+    voff |= ROW_SENT;
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+}
 __device__ __forceinline__ f8 f8_zero() { return f8{f4_zero(), f4_zero()}; }
 __device__ __forceinline__ f8 f8_ld(const float* p) { return f8{ldg4(p), ldg4(p + 4)}; }   // 8 fp32 (parameters)
 __device__ __forceinline__ f8 f8_add(f8 a, f8 b) { return f8{f4_add(a.lo, b.lo), f4_add(a.hi, b.hi)}; }
@@ -69,7 +86,8 @@ __device__ __forceinline__ float f8_sum(f8 a) { return f4_sum(a.lo) + f4_sum(a.h
 #endif
 
 // ---- launchers of the bf16 kernels (gemm_bf16.hip, bf16_ops.hip) ----------------------------------------------------------
-enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5, EB_LNBWD2 = 6, EB_SCATTER = 7, EB_SCATTER_ADD = 8 };
+enum GemmEpiB { EB_PLAIN = 0, EB_BIAS = 1, EB_RESID = 2, EB_SGBWD = 3, EB_BIASGATE = 4, EB_DOTCOL = 5, EB_LNBWD2 = 6, EB_SCATTER = 7, EB_SCATTER_ADD = 8,
+                EB_LNFWD = 9, EB_LNBWDM = 10 };
 
 // C[m][n] = sum_k A[m][k] * Bw[n][k]  on v_mfma_f32_32x32x16_bf16; A, Bw, C, res, aux, gate bf16; bias / cscale / colpart fp32.
 struct GemmNTB {
@@ -105,7 +123,22 @@ struct GemmNTB {
     // pixel (2 h + i, 2 w + j), channel ch.  EB_SCATTER / EB_SCATTER_ADD: C (and res) are such a fine image, N = 4 * gC, the same
     // column map; the adding form computes C = acc + res.   gC % 8 == 0.
     int gather2;
+    // The classifier head's channels-first LayerNorm inside the conv GEMMs (degrad_classify_arch.py:17-44, :69-103, :227-243), for N <= one
+    // column tile (N <= 128, or N == 256 on the 256-row kernel), rows dense (ldc == N):
+    //   EB_LNFWD :  C = z = bf16(acc);  y2 = [relu](LN(z) * lnw + lnb [+ res]);  mu_out / rstd_out [M]  -- statistics two-pass in fp32 over the
+    //               ROUNDED z, lane -> channel map and reduction tree of ln_fwd_bf16_kernel: bit-identical to GEMM + launch_ln_act_fwd_bf16
+    //   EB_LNBWDM:  acc = the gradient g of an LN'd, [ReLU'd] tensor;  g = bf16(acc) masked by the ReLU (ymask > 0 where ymask is given, else --
+    //               relu != 0 -- by the sign of the forward's own fma(xhat, lnw, lnb) recomputed from z: one tensor read less), optionally stored to y2;  C = dz = rstd (g w - xhat mean(g w xhat) - mean(g w)),  xhat from aux (the LN input z) / mu / rstd;
+    //               colpart[m / 128][0][n] = sum_rows g xhat, [1][n] = sum_rows g  (-> LN weight / bias gradients)
+    const float* lnb;
+    float *mu_out, *rstd_out;
+    bf16_t* y2;
+    const bf16_t* ymask;
+    int relu;
+    float eps;
 };
+// N (= row length) for which the two LayerNorm epilogues exist on a launch of M rows; conv3: the implicit 3 x 3 form of the GEMM
+bool gemm_nt_bf16_ln_epi_ok(int64_t M, int N, int K, int conv3, int gC);
 int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
 // 256 x 256-tile kernel for the wide levels (gemm_bf16_256.hip); launch_gemm_nt_bf16 routes eligible launches to it
 bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles = 192);   // min_tiles: fill most of the 256 CUs

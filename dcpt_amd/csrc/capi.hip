@@ -16,7 +16,7 @@ void dcpt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dcpt_last_error(void) { return g_err; }
-extern "C" int dcpt_abi_version(void) { return 14; }   // 14: + dcpt_conv_wpack_bf16_multi and the *_packed forms of the bf16 head's conv entry points (cached operand copies of the weights); 13: + dcpt_conv_ln_bwd_acc / _bf16 (the BottleneckBlock's shortcut gradient summed in the data-gradient GEMM), dcpt_down2x2_bwd_acc / _bf16 (the skip connection's gradient summed in the down layer's scatter epilogue); 12: + dcpt_adamw_step (multi-tensor AdamW); 11: + dcpt_mix_*_bf16 / dcpt_meanpool_fc_*_bf16 (the all-bf16 head without cast passes), dcpt_nafblock_bf16_fused_ffn may return 2 (chain kernel of the wide levels); 10: + dcpt_nafblock_wpack_bf16_multi; 9: + dcpt_conv1x1_wgrad_bf16 (grouped 256 x 256-tile weight-gradient GEMM + finisher); 8: + dcpt_nafblock_fused_ffn / dcpt_nafblock_bf16_fused_ffn (fused 1 x 1 chains of the narrowest level; saved tensors that become optional); 7: + per-block packed weights for the bf16 NAFBlock (dcpt_nafblock_wpack_bf16, *_packed); 6: + bf16-storage intro / ending / down / up layers; 5: + bf16-storage classifier-head groups; 4: + bf16-storage NAFBlock and casts; 3: + dcpt_allreduce_flat; 2: dcpt_nafblock_saved / mdta / gdfn saved structs carry the kept LN (and gate) tensors
+extern "C" int dcpt_abi_version(void) { return 15; }   // 15: + dcpt_bottleneck_fwd_bf16 / _bwd_bf16 (the head's BottleneckBlock in one call, LayerNorms in GEMM epilogues), dcpt_trace_enable / dcpt_trace_read (launch trace for the tests); 14: + dcpt_conv_wpack_bf16_multi and the *_packed forms of the bf16 head's conv entry points (cached operand copies of the weights); 13: + dcpt_conv_ln_bwd_acc / _bf16 (the BottleneckBlock's shortcut gradient summed in the data-gradient GEMM), dcpt_down2x2_bwd_acc / _bf16 (the skip connection's gradient summed in the down layer's scatter epilogue); 12: + dcpt_adamw_step (multi-tensor AdamW); 11: + dcpt_mix_*_bf16 / dcpt_meanpool_fc_*_bf16 (the all-bf16 head without cast passes), dcpt_nafblock_bf16_fused_ffn may return 2 (chain kernel of the wide levels); 10: + dcpt_nafblock_wpack_bf16_multi; 9: + dcpt_conv1x1_wgrad_bf16 (grouped 256 x 256-tile weight-gradient GEMM + finisher); 8: + dcpt_nafblock_fused_ffn / dcpt_nafblock_bf16_fused_ffn (fused 1 x 1 chains of the narrowest level; saved tensors that become optional); 7: + per-block packed weights for the bf16 NAFBlock (dcpt_nafblock_wpack_bf16, *_packed); 6: + bf16-storage intro / ending / down / up layers; 5: + bf16-storage classifier-head groups; 4: + bf16-storage NAFBlock and casts; 3: + dcpt_allreduce_flat; 2: dcpt_nafblock_saved / mdta / gdfn saved structs carry the kept LN (and gate) tensors
 
 // ---------------------------------------------------------------------------------------------
 extern "C" int dcpt_ln2d_fwd(const float* x, const float* weight, const float* bias, float* y, float* mu, float* rstd,

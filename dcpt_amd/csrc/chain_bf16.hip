@@ -691,14 +691,15 @@ __global__ __launch_bounds__(512) void chain_bwd_mid_bf16_kernel(const ChainMidB
     }
 }
 
-int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+int num_cus() {   // of the CURRENT device, cached per device index (a process may drive devices with different CU counts)
+    static int n[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
         hipDeviceProp_t pr;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        n[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
-    return n;
+    return n[dev];
 }
 
 template <int C, int HEAD>

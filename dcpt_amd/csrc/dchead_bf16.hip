@@ -7,6 +7,8 @@
 // range check; weight gradient: the transposing TN kernel with the gathered operand).  The mixing step and the mean + Linear at
 // the end stay on the fp32 kernels of dchead.hip behind casts (they touch each tensor once).
 #include "bf16_ops.h"
+#include "prof.h"
+#include "side.h"
 #include "../../include/dcpt_hip.h"
 
 namespace {
@@ -89,7 +91,8 @@ struct ConvWsB {
     float* lnpart;
     int splits;
     int64_t rps;
-    int ln_nblk;
+    int ln_nblk;     // blocks of the stand-alone LayerNorm backward (rows of lnpart it writes)
+    int ln_tiles;    // 128-row tiles of the GEMM whose epilogue does that LayerNorm backward instead (rows of lnpart it writes)
     bool tn256;     // weight gradient on the 256 x 256-tile kernel + finisher (gemm_tn_bf16_256.hip)
     GemmTNG wg;
 };
@@ -121,7 +124,8 @@ size_t conv_layout(int B, int H, int W, int Cin, int Cout, int ks, int backward,
         }
         if (with_ln) {
             w.ln_nblk = ln_bwd_bf16_num_blocks(M, Cout);
-            w.lnpart = a.get<float>((size_t)w.ln_nblk * 2 * Cout);
+            w.ln_tiles = (int)cdiv64(M, 128);
+            w.lnpart = a.get<float>((size_t)(w.ln_nblk > w.ln_tiles ? w.ln_nblk : w.ln_tiles) * 2 * Cout);
         }
     }
     if (out) *out = w;
@@ -147,9 +151,10 @@ inline int pk_check(const void* pk, size_t pk_bytes, int Cin, int Cout, int ks, 
     return DCPT_OK;
 }
 
-int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout, int ks, hipStream_t s,
-             const void* pk = nullptr) {
-    GemmNTB g{};
+// the forward GEMM of a conv (weights packed here unless the caller holds the cached images)
+int conv_fwd_problem(GemmNTB& g, const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout, int ks,
+                     hipStream_t s, const void* pk) {
+    g = GemmNTB{};
     g.M = (int64_t)B * H * W; g.A = x; g.N = Cout; g.C = z; g.ldc = Cout; g.Bw = pk ? pk_fwd(pk) : cw.wp;
     if (ks == 1) {
         if (!pk) DCPT_TRY(pack(w, cw.wp, Cout, Cin, 0, s));
@@ -158,17 +163,72 @@ int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int 
         if (!pk) DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 2, s));
         g.K = 9 * Cin; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cin;
     }
+    return DCPT_OK;
+}
+
+int conv_fwd(const bf16_t* x, const float* w, bf16_t* z, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout, int ks, hipStream_t s,
+             const void* pk = nullptr) {
+    GemmNTB g;
+    DCPT_TRY(conv_fwd_problem(g, x, w, z, cw, B, H, W, Cin, Cout, ks, s, pk));
     return launch_gemm_nt_bf16(g, EB_PLAIN, s);
 }
 
+// LayerNorm inside the conv GEMMs' epilogues (EB_LNFWD / EB_LNBWDM, bf16.h) wherever a row fits one column tile; 0 in diagnostic builds restores
+// the GEMM + stand-alone LayerNorm pair everywhere (bit-identical forward; the backward differs by the order of the LN parameter sums)
+bool ln_epi_on() {
+    static const int on = dcpt_tuning("DCPT_HEAD_LN_EPI", 1);
+    return on != 0;
+}
+
+// conv -> channels-first LayerNorm -> [+res] -> [ReLU] of one group: z (conv output), y, mu / rstd written
+int conv_ln_fwd_group(const bf16_t* x, const float* w, const void* pk, const float* lnw, const float* lnb, const bf16_t* res, int relu, bf16_t* z,
+                      bf16_t* y, float* mu, float* rstd, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout, int ks, hipStream_t s) {
+    const int64_t M = (int64_t)B * H * W;
+    GemmNTB g;
+    DCPT_TRY(conv_fwd_problem(g, x, w, z, cw, B, H, W, Cin, Cout, ks, s, pk));
+    if (ln_epi_on() && gemm_nt_bf16_ln_epi_ok(M, Cout, g.K, g.conv3, g.gC)) {
+        trace_tag(ks == 3 ? "head.conv3x3+ln_fwd_epilogue" : "head.conv1x1+ln_fwd_epilogue");
+        g.y2 = y; g.lnw = lnw; g.lnb = lnb; g.res = res; g.relu = relu; g.eps = 1e-6f; g.mu_out = mu; g.rstd_out = rstd;   // eps: degrad_classify_arch.py:24
+        return launch_gemm_nt_bf16(g, EB_LNFWD, s);
+    }
+    trace_tag(ks == 3 ? "head.conv3x3,ln_fwd_kernel" : "head.conv1x1,ln_fwd_kernel");
+    DCPT_TRY(launch_gemm_nt_bf16(g, EB_PLAIN, s));
+    return launch_ln_act_fwd_bf16(z, lnw, lnb, res, relu, y, mu, rstd, M, Cout, 1e-6f, s);
+}
+
+// The LayerNorm of the group BELOW a conv (the one whose output the conv reads): its masked backward can ride in the epilogue of this conv's
+// data-gradient GEMM -- dz_below = LN'(relu'(conv^T(dz))) -- instead of a pass of its own over the gradient just written.
+struct LnBelow {
+    const bf16_t* z;       // its input (the conv output below); the ReLU mask is recomputed from it (lnb: the LayerNorm's bias; null: no ReLU)
+    const float *mu, *rstd, *lnw, *lnb;
+    bf16_t* dz;            // out: the gradient of z
+    float* colpart;        // out: [cdiv(M, 128)][2][C] partial sums of the LN weight / bias gradients
+};
+
 // dx = conv^T(dz), dw = wgrad(dz, x); `ln` (optional): the LayerNorm's column partials, reduced here as well
+bool conv_bwd_below_ok(int64_t M, int Cin, int Cout, int ks) {   // may the LayerNorm below this conv ride in its data-gradient epilogue?
+    return ln_epi_on() && gemm_nt_bf16_ln_epi_ok(M, Cin, ks * ks * Cout, ks == 3, Cout);
+}
+
 int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, float* dw, const ConvWsB& cw, int B, int H, int W, int Cin, int Cout,
-             int ks, hipStream_t s, const FinCols* ln = nullptr, const bf16_t* dx_add = nullptr, const void* pk = nullptr) {
+             int ks, hipStream_t s, const FinCols* ln = nullptr, const bf16_t* dx_add = nullptr, const void* pk = nullptr,
+             const LnBelow* below = nullptr, hipStream_t sw = nullptr) {
+    // sw: the stream of the weight-gradient GEMM and the parameter-gradient reductions (a side stream forked by the caller once dz and the
+    // LayerNorm partials are ready; default: s)
+    if (!sw) sw = s;
     const int64_t M = (int64_t)B * H * W;
     GemmNTB g{};
     g.M = M; g.A = dz; g.N = Cin; g.C = dx; g.ldc = Cin; g.Bw = pk ? pk_bwd(pk, Cin, Cout, ks) : cw.wp;
     g.res = dx_add; g.ldres = Cin;
-    const int EDX = dx_add ? EB_RESID : EB_PLAIN;   // dx = dx_add + dz W (the shortcut gradient of a bottleneck block rides in the epilogue)
+    int EDX = dx_add ? EB_RESID : EB_PLAIN;   // dx = dx_add + dz W (the shortcut gradient of a bottleneck block rides in the epilogue)
+    if (below) {   // the data gradient never reaches memory: the epilogue turns it into the gradient of the conv output below
+        DCPT_CHECK_ARG(!dx_add && !dx && below->z && below->mu && below->rstd && below->lnw && below->dz && below->colpart,
+                       "conv_bwd: LayerNorm-below epilogue: null argument");
+        trace_tag(ks == 3 ? "head.conv3x3_dgrad+ln_bwd_epilogue" : "head.conv1x1_dgrad+ln_bwd_epilogue");
+        dx = below->dz;   // (so that the `if (dx)` launches below run)
+        g.C = below->dz; g.aux = below->z; g.relu = below->lnb != nullptr; g.lnb = below->lnb; g.mu = below->mu; g.rstd = below->rstd; g.lnw = below->lnw; g.colpart = below->colpart;
+        EDX = EB_LNBWDM;
+    }
     if (cw.tn256) {   // data gradient as before; the weight gradient as one 256-tile launch + one finisher launch (which also takes the LN sums)
         if (!pk && dx) DCPT_TRY(pack(w, cw.wp, Cout, ks * ks * Cin, ks == 1 ? 1 : 3, s));
         if (ks == 1) {
@@ -179,7 +239,7 @@ int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, floa
         if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
         GemmTNG wg = cw.wg;
         wg.p[0].X = dz; wg.p[0].Y = x;
-        DCPT_TRY(launch_gemm_tn_bf16_256(wg, s));
+        DCPT_TRY(launch_gemm_tn_bf16_256(wg, sw));
         FinJobs f{};
         f.nslab = 1;
         f.slab[0].slab = wg.p[0].slab; f.slab[0].N = Cout; f.slab[0].K = wg.p[0].K; f.slab[0].splits = wg.p[0].slots; f.slab[0].cs_rows = wg.p[0].splits;
@@ -188,9 +248,9 @@ int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, floa
             f.ncols = 1;
             f.cols[0] = *ln;
         }
-        return launch_wgrad_finish(f, s);
+        return launch_wgrad_finish(f, sw);
     }
-    if (ln) DCPT_TRY(launch_colpart_reduce(ln->part, ln->R, 2, ln->C, ln->out0, ln->out1, nullptr, s));
+    if (ln) DCPT_TRY(launch_colpart_reduce(ln->part, ln->R, 2, ln->C, ln->out0, ln->out1, nullptr, sw));
     GemmTNB t{};
     t.M = M; t.X = dz; t.ldx = Cout; t.N = Cout; t.Y = x; t.slab = cw.slab; t.colsum = nullptr; t.splits = cw.splits; t.rows_per_split = cw.rps;
     if (ks == 1) {
@@ -198,15 +258,15 @@ int conv_bwd(const bf16_t* dz, const bf16_t* x, const float* w, bf16_t* dx, floa
         g.lda = Cout; g.K = Cout;
         if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
         t.ldy = Cin; t.K = Cin;
-        DCPT_TRY(launch_gemm_tn_bf16(t, s));
-        return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_PLAIN, s);
+        DCPT_TRY(launch_gemm_tn_bf16(t, sw));
+        return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_PLAIN, sw);
     }
     if (!pk && dx) DCPT_TRY(pack(w, cw.wp, Cout, 9 * Cin, 3, s));
     g.K = 9 * Cout; g.conv3 = 1; g.gH = H; g.gW = W; g.gC = Cout;
     if (dx) DCPT_TRY(launch_gemm_nt_bf16(g, EDX, s));
     t.K = 9 * Cin; t.yconv = 1; t.gH = H; t.gW = W; t.gC = Cin; t.ldy = Cin;
-    DCPT_TRY(launch_gemm_tn_bf16(t, s));
-    return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, 9 * Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_CONV3, s);
+    DCPT_TRY(launch_gemm_tn_bf16(t, sw));
+    return launch_wgrad_reduce(cw.slab, nullptr, cw.splits, 0, Cout, 9 * Cin, nullptr, nullptr, nullptr, dw, nullptr, nullptr, WR_CONV3, sw);
 }
 
 bool conv_shape_ok(int Cin, int Cout, int ks) { return (ks == 1 || ks == 3) && Cin % 8 == 0 && Cout % 8 == 0 && Cout <= 1024; }
@@ -230,8 +290,7 @@ extern "C" int dcpt_conv_ln_fwd_bf16_packed(const uint16_t* x, const float* w, c
         dcpt_set_error("conv_ln_fwd_bf16: workspace too small");
         return DCPT_ERR_WS;
     }
-    DCPT_TRY(conv_fwd(x, w, z, cw, B, H, W, Cin, Cout, ksize, s, wpacked));
-    return launch_ln_act_fwd_bf16(z, lnw, lnb, res, relu, y, mu, rstd, (int64_t)B * H * W, Cout, 1e-6f, s);   // eps: degrad_classify_arch.py:24
+    return conv_ln_fwd_group(x, w, wpacked, lnw, lnb, res, relu, z, y, mu, rstd, cw, B, H, W, Cin, Cout, ksize, s);
 }
 
 extern "C" int dcpt_conv_ln_fwd_bf16(const uint16_t* x, const float* w, const float* lnw, const float* lnb, const uint16_t* res, int relu,
@@ -276,6 +335,124 @@ extern "C" int dcpt_conv_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, cons
                                      const float* mu, const float* rstd, uint16_t* dx, float* dw, float* dlnw, float* dlnb, uint16_t* dres,
                                      void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int ksize, int relu, dcpt_stream_t stream) {
     return dcpt_conv_ln_bwd_acc_bf16(dy, x, w, lnw, z, y, mu, rstd, nullptr, dx, dw, dlnw, dlnb, dres, ws, ws_bytes, B, H, W, Cin, Cout, ksize, relu, stream);
+}
+
+// ---- the whole BottleneckBlock in one call (ABI 15) -------------------------------------------------------------------------------------
+// relu(LN(conv1 1x1 C -> 2C)) -> relu(LN(conv2 3x3 2C -> 2C)) -> relu(LN(conv3 1x1 2C -> C) + x)   (degrad_classify_arch.py:132-243, identity
+// shortcut).  Forward: every LayerNorm in its conv's epilogue where the row fits a column tile.  Backward: the block's last LayerNorm takes its
+// gradient from outside and stays a kernel; the two inner ones ride in the epilogues of the data-gradient GEMMs above them (conv3^T, conv2^T), so
+// the gradients of y2 and y1 never reach memory; the shortcut's gradient rides in conv1^T's epilogue as before.
+namespace {
+
+struct BneckGeom {
+    int Cin[3], Cout[3], ks[3];
+};
+inline BneckGeom bneck_geom(int C) { return BneckGeom{{C, 2 * C, 2 * C}, {2 * C, 2 * C, C}, {1, 3, 1}}; }
+
+struct BneckWs {
+    ConvWsB cw[3];
+    bf16_t* dshort;   // [M][C]   the masked output gradient = the shortcut's gradient
+    bf16_t* dybuf;    // [M][2C]  a data gradient that had to be written (its LayerNorm is not in the epilogue)
+};
+
+size_t bneck_layout(int B, int H, int W, int C, int backward, void* base, size_t bytes, BneckWs* out) {
+    const BneckGeom gm = bneck_geom(C);
+    const int64_t M = (int64_t)B * H * W;
+    BneckWs w{};
+    size_t off = 0;
+    for (int k = 0; k < 3; ++k) {
+        char* b = base ? static_cast<char*>(base) + off : nullptr;
+        const size_t left = base ? (bytes > off ? bytes - off : 0) : 0;
+        off += align_up(conv_layout(B, H, W, gm.Cin[k], gm.Cout[k], gm.ks[k], backward, true, b, left, &w.cw[k]), 256);
+    }
+    if (backward) {
+        WsAlloc a(base ? static_cast<char*>(base) + off : nullptr, base ? (bytes > off ? bytes - off : 0) : (size_t)-1);
+        w.dshort = a.get<bf16_t>((size_t)M * C);
+        const bool all_fused = conv_bwd_below_ok(M, gm.Cin[2], gm.Cout[2], 1) && conv_bwd_below_ok(M, gm.Cin[1], gm.Cout[1], 3);
+        if (!all_fused) w.dybuf = a.get<bf16_t>((size_t)M * 2 * C);
+        off += a.off;
+    }
+    if (out) *out = w;
+    return off;
+}
+
+int bneck_check(const dcpt_bneck_group_t* g, int C, bool backward, const char* who) {
+    const BneckGeom gm = bneck_geom(C);
+    DCPT_CHECK_ARG(g && C >= 8 && C % 8 == 0 && 2 * C <= 1024, "%s: C=%d (a multiple of 8, at most 512)", who, C);
+    for (int k = 0; k < 3; ++k) {
+        DCPT_CHECK_ARG((g[k].w || g[k].wpacked) && g[k].lnw && g[k].z && g[k].y && g[k].mu && g[k].rstd && (g[k].lnb || (backward && k == 2)), "%s: null argument (group %d)", who, k);
+        DCPT_CHECK_ARG(!backward || (g[k].dw && g[k].dlnw && g[k].dlnb), "%s: null gradient output (group %d)", who, k);
+        DCPT_TRY(pk_check(g[k].wpacked, g[k].wpacked_bytes, gm.Cin[k], gm.Cout[k], gm.ks[k], who));
+    }
+    return DCPT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dcpt_bottleneck_bf16_ws_bytes(int B, int H, int W, int C, int backward) { return bneck_layout(B, H, W, C, backward, nullptr, 0, nullptr); }
+
+extern "C" int dcpt_bottleneck_fwd_bf16(const uint16_t* x, const dcpt_bneck_group_t* g, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                                        dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(x && B > 0 && H > 0 && W > 0, "bottleneck_fwd_bf16: null argument");
+    DCPT_TRY(bneck_check(g, C, false, "bottleneck_fwd_bf16"));
+    BneckWs bw;
+    const size_t need = bneck_layout(B, H, W, C, 0, ws, ws_bytes, &bw);
+    if (ws == nullptr || need > ws_bytes) {
+        dcpt_set_error("bottleneck_fwd_bf16: workspace too small");
+        return DCPT_ERR_WS;
+    }
+    const BneckGeom gm = bneck_geom(C);
+    const bf16_t* cur = x;
+    for (int k = 0; k < 3; ++k) {
+        DCPT_TRY(conv_ln_fwd_group(cur, g[k].w, g[k].wpacked, g[k].lnw, g[k].lnb, k == 2 ? x : nullptr, 1, g[k].z, g[k].y, g[k].mu, g[k].rstd, bw.cw[k], B,
+                                   H, W, gm.Cin[k], gm.Cout[k], gm.ks[k], s));
+        cur = g[k].y;
+    }
+    return DCPT_OK;
+}
+
+extern "C" int dcpt_bottleneck_bwd_bf16(const uint16_t* dout, const uint16_t* x, const dcpt_bneck_group_t* g, uint16_t* dx, void* ws, size_t ws_bytes,
+                                        int B, int H, int W, int C, dcpt_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DCPT_CHECK_ARG(dout && x && dx && B > 0 && H > 0 && W > 0, "bottleneck_bwd_bf16: null argument");
+    DCPT_TRY(bneck_check(g, C, true, "bottleneck_bwd_bf16"));
+    BneckWs bw;
+    const size_t need = bneck_layout(B, H, W, C, 1, ws, ws_bytes, &bw);
+    if (ws == nullptr || need > ws_bytes) {
+        dcpt_set_error("bottleneck_bwd_bf16: workspace too small");
+        return DCPT_ERR_WS;
+    }
+    const BneckGeom gm = bneck_geom(C);
+    const int64_t M = (int64_t)B * H * W;
+    // the block's last LayerNorm: gradient from outside, masked by the block's output; the masked gradient is the shortcut's
+    trace_tag("head.ln_bwd_kernel");
+    DCPT_TRY(launch_ln_act_bwd_bf16(dout, g[2].z, g[2].mu, g[2].rstd, g[2].lnw, g[2].y, bw.dshort, bw.cw[2].dz, bw.cw[2].lnpart, bw.cw[2].ln_nblk, M, C, s));
+    int ln_rows = bw.cw[2].ln_nblk;   // rows of the current group's lnpart
+    // the three weight-gradient GEMMs and their reductions are off the chain dout -> dx: side stream (side.hip), forked as each dz is ready
+    static const int use_side = dcpt_tuning("DCPT_HEAD_SIDE", 1);
+    Side* sd = use_side ? side_for(s) : nullptr;
+    hipStream_t sw = side_stream(sd, s);
+    for (int k = 2; k >= 0; --k) {
+        const ConvWsB& cw = bw.cw[k];
+        DCPT_TRY(side_fork(sd, 2 - k, s));   // dz of group k and its LayerNorm partials are ready
+        const FinCols ln{cw.lnpart, g[k].dlnw, g[k].dlnb, ln_rows, 2, gm.Cout[k], 0};
+        const bf16_t* xin = k == 0 ? x : g[k - 1].y;
+        if (k == 0) {
+            DCPT_TRY(conv_bwd(cw.dz, xin, g[k].w, dx, g[k].dw, cw, B, H, W, gm.Cin[k], gm.Cout[k], gm.ks[k], s, &ln, bw.dshort, g[k].wpacked, nullptr, sw));
+        } else if (conv_bwd_below_ok(M, gm.Cin[k], gm.Cout[k], gm.ks[k])) {
+            const LnBelow lb{g[k - 1].z, g[k - 1].mu, g[k - 1].rstd, g[k - 1].lnw, g[k - 1].lnb, bw.cw[k - 1].dz, bw.cw[k - 1].lnpart};
+            DCPT_TRY(conv_bwd(cw.dz, xin, g[k].w, nullptr, g[k].dw, cw, B, H, W, gm.Cin[k], gm.Cout[k], gm.ks[k], s, &ln, nullptr, g[k].wpacked, &lb, sw));
+            ln_rows = bw.cw[k - 1].ln_tiles;
+        } else {
+            DCPT_TRY(conv_bwd(cw.dz, xin, g[k].w, bw.dybuf, g[k].dw, cw, B, H, W, gm.Cin[k], gm.Cout[k], gm.ks[k], s, &ln, nullptr, g[k].wpacked, nullptr, sw));
+            trace_tag("head.ln_bwd_kernel");
+            DCPT_TRY(launch_ln_act_bwd_bf16(bw.dybuf, g[k - 1].z, g[k - 1].mu, g[k - 1].rstd, g[k - 1].lnw, g[k - 1].y, nullptr, bw.cw[k - 1].dz,
+                                            bw.cw[k - 1].lnpart, bw.cw[k - 1].ln_nblk, M, gm.Cout[k - 1], s));
+            ln_rows = bw.cw[k - 1].ln_nblk;
+        }
+    }
+    return side_join(sd, s);   // the caller's stream continues only after every parameter gradient is written
 }
 
 extern "C" size_t dcpt_conv1x1_pool_relu_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int backward) {

@@ -204,7 +204,7 @@ int launch_nt(const GemmNTB& p, hipStream_t s) {
     constexpr bool GATE = (EK == EB_BIASGATE);
     const unsigned nb = (unsigned)(p.nb > 0 ? p.nb : 1);
     const int ncols = GATE ? p.N / 2 : p.N;
-    if constexpr (EK == EB_PLAIN) {
+    if constexpr (EK == EB_PLAIN || EK == EB_LNFWD || EK == EB_LNBWDM) {
         if (p.conv3) {
             if (ncols <= 64) gemm_nt_bf16_kernel<128, 64, 4, 1, EK, 1><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 64)), nb), dim3(256), 0, s>>>(p);
             else gemm_nt_bf16_kernel<128, 128, 2, 2, EK, 1><<<dim3((unsigned)(cdiv64(p.M, 128) * cdiv(ncols, 128)), nb), dim3(256), 0, s>>>(p);
@@ -439,8 +439,9 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     DCPT_CHECK_ARG(p.K % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldc % 8 == 0 && p.ldres % 8 == 0,
                    "gemm_nt_bf16: K=%d, N=%d and the row strides must be multiples of 8 (16-byte rows)", p.K, p.N);
     if (p.conv3)
-        DCPT_CHECK_ARG(epi == EB_PLAIN && p.gC % 8 == 0 && p.K == 9 * p.gC && p.nb == 1 && (double)(130 + 2 * p.gW + 2) * p.gC * 2.0 < 1.0e9,
-                       "gemm_nt_bf16: conv3 needs the plain epilogue, K == 9 * gC, gC %% 8 == 0");
+        DCPT_CHECK_ARG((epi == EB_PLAIN || epi == EB_LNFWD || epi == EB_LNBWDM) && p.gC % 8 == 0 && p.K == 9 * p.gC && p.nb == 1 &&
+                           (double)(130 + 2 * p.gW + 2) * p.gC * 2.0 < 1.0e9,
+                       "gemm_nt_bf16: conv3 needs the plain or a LayerNorm epilogue, K == 9 * gC, gC %% 8 == 0");
     if (p.gather2)
         DCPT_CHECK_ARG((epi == EB_PLAIN || epi == EB_BIAS) && !p.conv3 && p.gC % 8 == 0 && p.K == 4 * p.gC && p.nb == 1 &&
                            (double)(130 + 2 * p.gW) * 4.0 * p.gC * 2.0 < 1.0e9,
@@ -459,10 +460,20 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     if (epi == EB_LNBWD2)
         DCPT_CHECK_ARG(p.res && p.mu && p.rstd && p.lnw && p.colpart && p.rowpart && p.rowparts >= 1 && p.rowparts <= 8 && p.nb == 1,
                        "gemm_nt_bf16: LayerNorm-backward epilogue needs res / mu / rstd / lnw / colpart / rowpart (<= 8 partials per row)");
+    if (epi == EB_LNFWD)
+        DCPT_CHECK_ARG(p.y2 && p.lnw && p.lnb && p.mu_out && p.rstd_out && p.ldc == p.N && p.nb == 1 && !p.gather2 &&
+                           gemm_nt_bf16_ln_epi_ok(p.M, p.N, p.K, p.conv3, p.gC),
+                       "gemm_nt_bf16: LayerNorm-forward epilogue needs y2 / lnw / lnb / mu_out / rstd_out, dense rows and N=%d inside one column tile", p.N);
+    if (epi == EB_LNBWDM)
+        DCPT_CHECK_ARG(p.aux && p.mu && p.rstd && p.lnw && p.colpart && !p.res && (p.ymask || !p.relu || p.lnb) && p.ldc == p.N && p.nb == 1 && !p.gather2 &&
+                           gemm_nt_bf16_ln_epi_ok(p.M, p.N, p.K, p.conv3, p.gC),
+                       "gemm_nt_bf16: masked LayerNorm-backward epilogue needs aux / mu / rstd / lnw / colpart, dense rows and N=%d inside one column tile", p.N);
     const double mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     double bytes = mk + mn * (epi == EB_SGBWD ? 4 : epi == EB_BIASGATE ? 1.5 : 1) + (double)p.N * p.K;
     if (epi == EB_RESID || epi == EB_DOTCOL || epi == EB_SCATTER_ADD) bytes += mn;
     if (epi == EB_LNBWD2) bytes += 2 * mn;
+    if (epi == EB_LNFWD) bytes += mn * (p.res ? 2 : 1);
+    if (epi == EB_LNBWDM) bytes += mn * (1 + (p.ymask ? 1 : 0) + (p.y2 ? 1 : 0));
     ProfScope prof(s, PROF_NT + 256 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * p.nb, bytes * 2.0 * p.nb);
     static const int use256 = dcpt_tuning("DCPT_NT256", 1);   // (A/B switch while the kernel is being tuned)
     if (use256 && gemm_nt_bf16_256_ok(p, epi, use256 == 2 ? 1 : 192)) return launch_gemm_nt_bf16_256(p, epi, s);
@@ -476,9 +487,23 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
         case EB_LNBWD2: return launch_nt<EB_LNBWD2>(p, s);
         case EB_SCATTER: return launch_nt<EB_SCATTER>(p, s);
         case EB_SCATTER_ADD: return launch_nt<EB_SCATTER_ADD>(p, s);
+        case EB_LNFWD: return launch_nt<EB_LNFWD>(p, s);
+        case EB_LNBWDM: return launch_nt<EB_LNBWDM>(p, s);
     }
     dcpt_set_error("gemm_nt_bf16: unknown epilogue %d", epi);
     return DCPT_ERR_ARG;
+}
+
+// A LayerNorm epilogue needs the whole row in one column tile: N <= 128 on the 128-row kernel, N == 256 on the 256-row kernel (where that
+// kernel takes the launch at all: gemm_nt_bf16_256_ok)
+bool gemm_nt_bf16_ln_epi_ok(int64_t M, int N, int K, int conv3, int gC) {
+    if (N % 8 != 0 || N < 8) return false;
+    if (N <= 128) return true;
+    if (N != 256) return false;
+    static const int use256 = dcpt_tuning("DCPT_NT256", 1);
+    GemmNTB q{};
+    q.M = M; q.N = N; q.K = K; q.conv3 = conv3; q.gC = gC; q.nb = 1;
+    return use256 && gemm_nt_bf16_256_ok(q, EB_LNFWD, use256 == 2 ? 1 : 192);
 }
 
 int gemm_nt_bf16_tiles_n(const GemmNTB& p, int epi) {

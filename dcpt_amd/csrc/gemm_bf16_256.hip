@@ -244,7 +244,27 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
             for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(acc[a][b][i]));
     return;
 #endif
-    if constexpr (GATE) {
+    if constexpr (EK == EB_LNFWD || EK == EB_LNBWDM) {
+        // a LayerNorm epilogue needs whole rows: the tile is parked as two [128][256] halves (N == 256: one column tile per row block)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float* const Cs = Cs0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int nl = b * 128 + wn * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Cs[ml * 256 + nl] = acc[a][b][i][r];
+                    }
+                }
+            __syncthreads();
+            epilogue8<EK, 128, 256, 512>(p, Cs, m0 + a * 128, n0, tid);
+            __syncthreads();
+        }
+    } else if constexpr (GATE) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float* const Cs = Cs0;   // [128][256]: columns 0..127 first gate half, 128..255 second
@@ -290,7 +310,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 // enough tiles to fill most of the 256 CUs (one block per CU).
 bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles) {
     if (p.gather2 || epi == EB_SCATTER || epi == EB_SCATTER_ADD || epi == EB_LNBWD2) return false;
-    if (p.conv3 && (epi != EB_PLAIN || p.gC % 64 != 0 || p.K != 9 * p.gC || p.K / 64 >= 2048 || (p.nb > 1))) return false;
+    const bool lnepi = epi == EB_LNFWD || epi == EB_LNBWDM;
+    if (lnepi && p.N != 256) return false;
+    if (p.conv3 && ((epi != EB_PLAIN && !lnepi) || p.gC % 64 != 0 || p.K != 9 * p.gC || p.K / 64 >= 2048 || (p.nb > 1))) return false;
     if (p.K % 128 != 0 || p.K < 128) return false;
     if (p.N % 256 != 0) return false;   // (gate: 128 columns of each half)
     const int nb = p.nb > 0 ? p.nb : 1;
@@ -302,7 +324,9 @@ int launch_gemm_nt_bf16_256(const GemmNTB& p, int epi, hipStream_t s) {
     const unsigned nb = (unsigned)(p.nb > 0 ? p.nb : 1);
     const dim3 grid((unsigned)(cdiv64(p.M, 256) * (p.N / 256)), nb);
     if (p.conv3) {
-        gemm_nt_bf16_256_kernel<EB_PLAIN, 1><<<grid, dim3(512), 0, s>>>(p);
+        if (epi == EB_LNFWD) gemm_nt_bf16_256_kernel<EB_LNFWD, 1><<<grid, dim3(512), 0, s>>>(p);
+        else if (epi == EB_LNBWDM) gemm_nt_bf16_256_kernel<EB_LNBWDM, 1><<<grid, dim3(512), 0, s>>>(p);
+        else gemm_nt_bf16_256_kernel<EB_PLAIN, 1><<<grid, dim3(512), 0, s>>>(p);
         DCPT_CHECK_LAUNCH("gemm_nt_bf16_256 conv3");
         return DCPT_OK;
     }
@@ -313,6 +337,8 @@ int launch_gemm_nt_bf16_256(const GemmNTB& p, int epi, hipStream_t s) {
         case EB_SGBWD: gemm_nt_bf16_256_kernel<EB_SGBWD><<<grid, dim3(512), 0, s>>>(p); break;
         case EB_BIASGATE: gemm_nt_bf16_256_kernel<EB_BIASGATE><<<grid, dim3(512), 0, s>>>(p); break;
         case EB_DOTCOL: gemm_nt_bf16_256_kernel<EB_DOTCOL><<<grid, dim3(512), 0, s>>>(p); break;
+        case EB_LNFWD: gemm_nt_bf16_256_kernel<EB_LNFWD><<<grid, dim3(512), 0, s>>>(p); break;
+        case EB_LNBWDM: gemm_nt_bf16_256_kernel<EB_LNBWDM><<<grid, dim3(512), 0, s>>>(p); break;
         default: dcpt_set_error("gemm_nt_bf16_256: epilogue %d not supported", epi); return DCPT_ERR_ARG;
     }
     DCPT_CHECK_LAUNCH("gemm_nt_bf16_256");

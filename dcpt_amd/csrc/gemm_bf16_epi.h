@@ -56,11 +56,28 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
     if constexpr (EK == EB_SCATTER_ADD) rsR = make_rsrc(p.res + cbase);
     if constexpr (EK == EB_RESID || EK == EB_DOTCOL || EK == EB_LNBWD2) rsR = make_rsrc(p.res + m0 * (int64_t)ldres);
     if constexpr (EK == EB_LNBWD2) rsX = make_rsrc((p.aux ? p.aux : p.res) + m0 * (int64_t)ldres);
+    rsrc_t rsY = rsC;   // EB_LNFWD: y2 (the LayerNorm output);  EB_LNBWDM: y2 (the masked gradient, optional) -- rows as C's
+    if constexpr (EK == EB_LNFWD) {
+        rsR = make_rsrc(p.res + m0 * (int64_t)p.ldc);
+        rsY = make_rsrc(p.y2 + m0 * (int64_t)p.ldc);
+    }
+    if constexpr (EK == EB_LNBWDM) {
+        rsR = make_rsrc(p.aux + m0 * (int64_t)p.ldc);     // z, the LayerNorm's input
+        rsX = make_rsrc(p.ymask + m0 * (int64_t)p.ldc);   // its [ReLU'd] output
+        rsY = make_rsrc(p.y2 + m0 * (int64_t)p.ldc);
+    }
+    f8 lnb8 = f8_zero();
     if constexpr (EK == EB_SGBWD) rsX = make_rsrc(p.aux + m0 * (2 * (int64_t)p.N));
     if constexpr (GATE) rsX = make_rsrc(p.gate + m0 * (int64_t)Ch);
     f8 dot = f8_zero(), dot2 = f8_zero(), lnw8 = f8_zero(), u_lo = f8_zero(), u_hi = f8_zero(), c_lo = f8_zero(), c_hi = f8_zero();
-    if constexpr (EK == EB_LNBWD2) {
+    if constexpr (EK == EB_LNBWD2 || EK == EB_LNFWD || EK == EB_LNBWDM) {
         if (nok) lnw8 = f8_ld(p.lnw + n);
+    }
+    if constexpr (EK == EB_LNFWD) {
+        if (nok) lnb8 = f8_ld(p.lnb + n);
+    }
+    if constexpr (EK == EB_LNBWDM) {
+        if (nok && p.relu && !p.ymask) lnb8 = f8_ld(p.lnb + n);
     }
     if constexpr (EK == EB_SGBWD) {
         if (p.rowpart && nok) {
@@ -70,7 +87,8 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
             c_hi = f8_ld(p.cvec + p.N + n);
         }
     }
-    constexpr int HALF = (EK == EB_SGBWD) ? 2 : 1;   // two 16-byte loads per row: prefetch in two halves (registers)
+    // two 16-byte loads per row: prefetch in two halves (registers); the masked LayerNorm backward keeps two rows in flight per thread
+    constexpr int HALF = (EK == EB_SGBWD) ? 2 : (EK == EB_LNBWDM && IT >= 4) ? IT / 2 : 1;
     constexpr int ITH = IT / HALF;
 #pragma unroll
     for (int hh = 0; hh < HALF; ++hh) {
@@ -91,6 +109,14 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
                 const uint32_t xo = ok ? ((uint32_t)rl * (uint32_t)p.N * 2u + (uint32_t)n) * 2u : ROW_SENT;
                 pre1[it] = bbuf_ld8(rsX, xo);
                 pre2[it] = bbuf_ld8(rsX, xo + 2u * (uint32_t)p.N);
+            }
+            if constexpr (EK == EB_LNFWD) {
+                if (p.res) pre1[it] = bbuf_ld8(rsR, ok ? ((uint32_t)rl * (uint32_t)p.ldc + (uint32_t)n) * 2u : ROW_SENT);
+            }
+            if constexpr (EK == EB_LNBWDM) {
+                const uint32_t xo = ok ? ((uint32_t)rl * (uint32_t)p.ldc + (uint32_t)n) * 2u : ROW_SENT;
+                pre1[it] = bbuf_ld8(rsR, xo);
+                if (p.ymask) pre2[it] = bbuf_ld8(rsX, xo);
             }
         }
 #pragma unroll
@@ -141,6 +167,65 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
                         *reinterpret_cast<float2*>(p.rowpart + (m * np + n0 / BN) * 2) = make_float2(a1, a2);
                     }
                 }
+            } else if constexpr (EK == EB_LNFWD) {
+                // (the expressions, the lane -> channel map and the reduction tree of ln_fwd_bf16_kernel: the two paths agree bit for bit)
+                const int64_t m = m0 + rl;
+                u32x4 zw;
+                const f8 z = f8_round_bf16(v, zw);
+                bbuf_st8_raw(rsC, o, zw);
+                const float mean = group_sum(nok ? f8_sum(z) : 0.f, Q) / (float)p.N;
+                f8 d;
+                d.lo = make_float4(z.lo.x - mean, z.lo.y - mean, z.lo.z - mean, z.lo.w - mean);
+                d.hi = make_float4(z.hi.x - mean, z.hi.y - mean, z.hi.z - mean, z.hi.w - mean);
+                const float sq = group_sum(nok ? f8_sum(f8_mul(d, d)) : 0.f, Q);
+                const float rs = 1.0f / sqrtf(sq / (float)p.N + p.eps);
+                if (q == 0 && m < p.M) {
+                    p.mu_out[m] = mean;
+                    p.rstd_out[m] = rs;
+                }
+                const f8 r8 = f8{make_float4(rs, rs, rs, rs), make_float4(rs, rs, rs, rs)};
+                f8 ov = f8_fma(f8_mul(d, r8), lnw8, lnb8);
+                if (p.res) ov = f8_add(ov, pre1[it]);
+                if (p.relu) {
+                    ov.lo = make_float4(fmaxf(ov.lo.x, 0.f), fmaxf(ov.lo.y, 0.f), fmaxf(ov.lo.z, 0.f), fmaxf(ov.lo.w, 0.f));
+                    ov.hi = make_float4(fmaxf(ov.hi.x, 0.f), fmaxf(ov.hi.y, 0.f), fmaxf(ov.hi.z, 0.f), fmaxf(ov.hi.w, 0.f));
+                }
+                bbuf_st8(rsY, o, ov);
+            } else if constexpr (EK == EB_LNBWDM) {
+                // (ln_bwd_bf16_kernel's arithmetic on the gradient as the unfused GEMM would have stored it: rounded to bf16 first)
+                const int64_t m = m0 + rl;
+                const bool rok = m < p.M;
+                const float mean = rok ? p.mu[m] : 0.f, rs = rok ? p.rstd[m] : 0.f;
+                u32x4 gw_raw;
+                f8 g = f8_round_bf16(v, gw_raw);
+                if (p.ymask) {
+                    const f8 ym = pre2[it];
+                    g.lo = make_float4(ym.lo.x > 0.f ? g.lo.x : 0.f, ym.lo.y > 0.f ? g.lo.y : 0.f, ym.lo.z > 0.f ? g.lo.z : 0.f, ym.lo.w > 0.f ? g.lo.w : 0.f);
+                    g.hi = make_float4(ym.hi.x > 0.f ? g.hi.x : 0.f, ym.hi.y > 0.f ? g.hi.y : 0.f, ym.hi.z > 0.f ? g.hi.z : 0.f, ym.hi.w > 0.f ? g.hi.w : 0.f);
+                }
+                f8 xh;
+                xh.lo = make_float4((pre1[it].lo.x - mean) * rs, (pre1[it].lo.y - mean) * rs, (pre1[it].lo.z - mean) * rs, (pre1[it].lo.w - mean) * rs);
+                xh.hi = make_float4((pre1[it].hi.x - mean) * rs, (pre1[it].hi.y - mean) * rs, (pre1[it].hi.z - mean) * rs, (pre1[it].hi.w - mean) * rs);
+                if (p.relu && !p.ymask) {
+                    // the ReLU mask recomputed from z instead of read from y: the forward's own expression (EB_LNFWD / ln_fwd_bf16_kernel:
+                    // fma((z - mean) rstd, w, b)), whose sign is the sign of the bf16 value it was rounded to
+                    const f8 u = f8_fma(xh, lnw8, lnb8);
+                    g.lo = make_float4(u.lo.x > 0.f ? g.lo.x : 0.f, u.lo.y > 0.f ? g.lo.y : 0.f, u.lo.z > 0.f ? g.lo.z : 0.f, u.lo.w > 0.f ? g.lo.w : 0.f);
+                    g.hi = make_float4(u.hi.x > 0.f ? g.hi.x : 0.f, u.hi.y > 0.f ? g.hi.y : 0.f, u.hi.z > 0.f ? g.hi.z : 0.f, u.hi.w > 0.f ? g.hi.w : 0.f);
+                }
+                if (p.y2) bbuf_st8(rsY, o, g);
+                if (!ok) xh = f8_zero();
+                const f8 gw = f8_mul(g, lnw8);
+                const float invN = 1.0f / (float)p.N;
+                const float s1 = group_sum(f8_sum(gw), Q) * invN, s2 = group_sum(f8_sum(f8_mul(gw, xh)), Q) * invN;
+                f8 d;
+                d.lo = make_float4(rs * (gw.lo.x - xh.lo.x * s2 - s1), rs * (gw.lo.y - xh.lo.y * s2 - s1), rs * (gw.lo.z - xh.lo.z * s2 - s1),
+                                   rs * (gw.lo.w - xh.lo.w * s2 - s1));
+                d.hi = make_float4(rs * (gw.hi.x - xh.hi.x * s2 - s1), rs * (gw.hi.y - xh.hi.y * s2 - s1), rs * (gw.hi.z - xh.hi.z * s2 - s1),
+                                   rs * (gw.hi.w - xh.hi.w * s2 - s1));
+                bbuf_st8(rsC, o, d);
+                dot = f8_fma(g, xh, dot);   // (rows past M: g = 0, xhat = 0)
+                dot2 = f8_add(dot2, g);
             } else if constexpr (EK == EB_LNBWD2) {
                 const int64_t m = m0 + rl;
                 const bool rok = m < p.M;
@@ -172,8 +257,9 @@ __device__ __forceinline__ void epilogue8(const GemmNTB& p, float* __restrict__ 
             }
         }
     }
-    if constexpr (EK == EB_LNBWD2) {
+    if constexpr (EK == EB_LNBWD2 || EK == EB_LNBWDM) {
         // the two column-sum planes (-> LayerNorm weight / bias gradients) over the tile's rows, as for EB_DOTCOL
+#pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             __syncthreads();
             *reinterpret_cast<float4*>(&Cs[r0 * BN + 8 * q]) = pl == 0 ? dot.lo : dot2.lo;

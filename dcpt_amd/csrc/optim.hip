@@ -26,7 +26,7 @@ struct AdamWArgs {
     uint32_t n[AW_MAX];
     uint32_t blk0[AW_MAX + 1];   // first block of tensor i; blk0[cnt] = number of blocks
     int cnt;
-    float lr_wd, w1, b2, omb2, step_size, inv_bc2_sqrt, eps, gsign;
+    float lr_wd, w1, b2, omb2, step_size, bc2_sqrt, eps, gsign;
 };
 
 __device__ __forceinline__ float lerp_t(float a, float b, float w) {   // at::native::lerp (weight < 0.5 ? a + w (b - a) : b - (b - a)(1 - w))
@@ -39,7 +39,7 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
     p -= a.lr_wd * p;
     m = lerp_t(m, g, a.w1);
     v = a.b2 * v + a.omb2 * g * g;
-    const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;   // (a division, as torch's fused kernel: the kernel is bandwidth-bound, and a resumed run reproduces bit for bit)
     p -= a.step_size * m / denom;
 }
 
@@ -108,7 +108,7 @@ extern "C" int dcpt_adamw_step(int n, float* const* params, const float* const* 
     a.b2 = (float)h->beta2;
     a.omb2 = (float)(1.0 - h->beta2);
     a.step_size = (float)(h->lr / h->bias_correction1);
-    a.inv_bc2_sqrt = (float)(1.0 / sqrt(h->bias_correction2));
+    a.bc2_sqrt = (float)sqrt(h->bias_correction2);
     a.eps = (float)h->eps;
     a.gsign = h->maximize ? -1.0f : 1.0f;
     int i = 0;

@@ -16,3 +16,11 @@ struct ProfScope {
 
 // class ids
 enum { PROF_NT = 0, PROF_TN = 512, PROF_OTHER = 1024 };
+
+// Launch trace for the tests (off by default): every dispatch decision of the library names the kernel family it launched with a static
+// string; dcpt_trace_read returns "tag count" lines.  A parity test can then assert WHICH kernel produced the result it checked.
+extern bool g_trace_on;
+void trace_tag_slow(const char* tag);
+inline void trace_tag(const char* tag) {
+    if (g_trace_on) trace_tag_slow(tag);
+}

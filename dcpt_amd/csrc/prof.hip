@@ -1,5 +1,7 @@
 #include "prof.h"
 
+#include <string.h>
+
 #include <mutex>
 #include <vector>
 
@@ -94,4 +96,49 @@ extern "C" int dcpt_prof_read(double* out, int max_rows) {
         out[j * 8 + 7] += r.bytes;
     }
     return n;
+}
+
+// ---- launch trace (prof.h) ----
+bool g_trace_on = false;
+namespace {
+struct Tag {
+    const char* name;
+    long count;
+};
+std::mutex g_tmu;
+std::vector<Tag> g_tags;
+}  // namespace
+
+void trace_tag_slow(const char* tag) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (Tag& t : g_tags)
+        if (t.name == tag || strcmp(t.name, tag) == 0) {
+            t.count++;
+            return;
+        }
+    g_tags.push_back(Tag{tag, 1});
+}
+
+extern "C" int dcpt_trace_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_trace_on = on != 0;
+    if (g_trace_on) g_tags.clear();
+    return DCPT_OK;
+}
+
+// "tag count\n" per kernel family seen since dcpt_trace_enable(1); returns the bytes the full text needs (incl. the terminating 0)
+extern "C" size_t dcpt_trace_read(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    size_t need = 1, off = 0;
+    for (const Tag& t : g_tags) {
+        char line[160];
+        const int n = snprintf(line, sizeof line, "%s %ld\n", t.name, t.count);
+        need += (size_t)n;
+        if (buf && off + (size_t)n < cap) {
+            memcpy(buf + off, line, (size_t)n);
+            off += (size_t)n;
+        }
+    }
+    if (buf && cap) buf[off < cap ? off : cap - 1] = 0;
+    return need;
 }

@@ -714,13 +714,29 @@ class _TakeBatchFn(torch.autograd.Function):
         return out, None, None
 
 
+def _private_grad(g) -> bool:
+    """True when the incoming gradient may be mutated in place: a dense tensor that owns its storage and that nothing but the autograd
+    engine's input buffer (and this frame) references.  A gradient that the consumer's backward hands to several inputs (torch ``add``),
+    a view / expanded gradient (``sum``, slicing) or one kept alive elsewhere shows up as a second owner of the tensor or of its storage
+    (probed on torch 2.10: private = tensor use count 2, storage use count 2; ``a + b`` = 3 / 3; ``sum`` = a view).  Anything this
+    cannot prove private is cloned by the caller."""
+    try:
+        if g._base is not None or g.requires_grad or g.grad_fn is not None:
+            return False
+        if g._use_count() > 2 or torch._C._storage_Use_Count(g.untyped_storage()._cdata) > 2:
+            return False
+        return torch._prims_common.is_non_overlapping_and_dense(g)
+    except (AttributeError, RuntimeError):   # (a torch without the probes: never mutate)
+        return False
+
+
 class _TapSplitFn(torch.autograd.Function):
     """(x, x[lo:hi]) for a feature map with TWO consumers -- the network goes on with x, a tap (the classifier head of the DCPT step,
     reference ...pretrain_model.py:60-68,140-163) takes samples lo..hi-1.  With two separate uses autograd builds the tap's zero-padded
     gradient (a fill + a copy of the feature map's size) and then ADDS the two gradients (three more passes, 18 bf16 `add` launches per
     DCPT step at 256 x 256: 1.4 ms); here the tap's gradient is added INTO rows lo..hi-1 of the main path's gradient, in place: one read
-    of the slice and a read-modify-write of the same rows.  (The main path's gradient is the fresh output of the layer above's backward;
-    it has no other consumer in this graph.)"""
+    of the slice and a read-modify-write of the same rows -- when that gradient is provably private (_private_grad: the fresh output of
+    the layer above's backward, as in the NAFNet / Restormer graphs); otherwise into a copy of it."""
 
     @staticmethod
     def forward(ctx, x, lo, hi):
@@ -735,7 +751,7 @@ class _TapSplitFn(torch.autograd.Function):
                 return None, None, None
             return _TakeBatchFn.backward(ctx, gs)
         if gs is not None:
-            if g.shape != tuple(shape) or not g.is_floating_point():
+            if g.shape != tuple(shape) or not g.is_floating_point() or not _private_grad(g):
                 g = g.clone()
             g[lo:hi].add_(gs.to(g.dtype))
         return g, None, None
@@ -1315,6 +1331,7 @@ def conv_ln_bf16(x, weight, lnw, lnb, res=None, relu=True, packed: PackedConvBf1
     return _ConvLNBf16Fn.apply(x, weight, lnw, lnb, res, relu, packed)
 
 
+@_remember_gemm_mode
 class _BottleneckFn(torch.autograd.Function):
     """The whole BottleneckBlock (reference degrad_classify_arch.py:132-243 as the DCPT head instantiates it: identity shortcut) as ONE
     autograd node: relu(LN(conv1(x))) -> relu(LN(conv2(.))) -> relu(LN(conv3(.)) + x), the three conv -> LN groups through the same C
@@ -1333,6 +1350,8 @@ class _BottleneckFn(torch.autograd.Function):
         x = _nhwc(x)
         dev = x.device
         B, _, H, W = x.shape
+        if bf:
+            return _BottleneckFn._forward_bf16(ctx, lib, x, ((w1, lw1, lb1), (w2, lw2, lb2), (w3, lw3, lb3)), packs)
         empty = _empty_nhwc_bf16 if bf else _empty_nhwc
         ws_bytes = lib.dcpt_conv_ln_bf16_ws_bytes if bf else lib.dcpt_conv_ln_ws_bytes
         saved, cur, pkbufs = [x], x, []
@@ -1360,8 +1379,59 @@ class _BottleneckFn(torch.autograd.Function):
         return cur
 
     @staticmethod
+    def _forward_bf16(ctx, lib, x, groups, packs):
+        """bf16 activations: the whole block in ONE library call (dcpt_bottleneck_fwd_bf16, ABI 15: LayerNorms in the GEMM epilogues)"""
+        dev = x.device
+        B, C_, H, W = x.shape
+        M = B * H * W
+        garr = (_lib.BneckGroup * 3)()
+        saved, pkbufs, keep = [x], [], []
+        for k, ((w, lw, lb), pck) in enumerate(zip(groups, packs)):
+            w_, lw_, lb_ = _contig(w.detach()), _contig(lw.detach()), _contig(lb.detach())
+            Cout = w_.shape[0]
+            z, y = _empty_nhwc_bf16(B, Cout, H, W, dev), _empty_nhwc_bf16(B, Cout, H, W, dev)
+            stats = torch.empty((2, M), dtype=torch.float32, device=dev)
+            pkp, pkn = _pk(pck, w)
+            garr[k] = _lib.BneckGroup(w_.data_ptr(), pkp, pkn, lw_.data_ptr(), lb_.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                      stats[1].data_ptr(), None, None, None)
+            pkbufs.append(pck.buf if pkp is not None else None)
+            saved += [w_, lw_, z, y, stats]
+            keep.append(lb_)
+        ctx.lnb = keep   # (the backward recomputes the inner ReLU masks from z: it needs the LayerNorm biases)
+        ws = _workspace(dev, lib.dcpt_bottleneck_bf16_ws_bytes(B, H, W, C_, 0))
+        check(lib.dcpt_bottleneck_fwd_bf16(x.data_ptr(), garr, ws.data_ptr(), ws.numel(), B, H, W, C_, _stream(dev)), "dcpt_bottleneck_fwd_bf16")
+        ctx.save_for_backward(*saved)
+        ctx.bf = True
+        ctx.pkbufs = pkbufs   # (the backward of THIS forward reads the same operand images)
+        return saved[-2]
+
+    @staticmethod
+    def _backward_bf16(ctx, lib, dy):
+        sv = ctx.saved_tensors
+        x = sv[0]
+        dev = x.device
+        B, C_, H, W = x.shape
+        g = _nhwc(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16))
+        garr = (_lib.BneckGroup * 3)()
+        grads = []
+        for k in range(3):
+            w_, lw_, z, y, stats = sv[1 + 5 * k: 6 + 5 * k]
+            dw, dlw, dlb = torch.empty_like(w_), torch.empty_like(lw_), torch.empty_like(lw_)
+            pk = ctx.pkbufs[k]
+            garr[k] = _lib.BneckGroup(w_.data_ptr(), _p(pk), 0 if pk is None else pk.numel(), lw_.data_ptr(), ctx.lnb[k].data_ptr(), z.data_ptr(), y.data_ptr(),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), dw.data_ptr(), dlw.data_ptr(), dlb.data_ptr())
+            grads += [dw, dlw, dlb]
+        dx = _empty_nhwc_bf16(B, C_, H, W, dev)
+        ws = _workspace(dev, lib.dcpt_bottleneck_bf16_ws_bytes(B, H, W, C_, 1))
+        check(lib.dcpt_bottleneck_bwd_bf16(g.data_ptr(), x.data_ptr(), garr, dx.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, C_, _stream(dev)),
+              "dcpt_bottleneck_bwd_bf16")
+        return (dx, *grads, None)
+
+    @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
+        if ctx.bf:
+            return _BottleneckFn._backward_bf16(ctx, lib, dy)
         sv = ctx.saved_tensors
         x, bf = sv[0], ctx.bf
         dev = x.device

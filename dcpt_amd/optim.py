@@ -148,4 +148,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     _lib.check(rc, "dcpt_adamw_step")
             for st in plan["states"]:
                 st["step"] += 1.0
+            # the kernel wrote through raw pointers: tell autograd (a step between a forward and its backward trips the saved-tensor
+            # version check as with torch's optimizers) and every bf16 weight pack keyed on the parameters' versions
+            torch.autograd.graph.increment_version(ps)
         return loss

@@ -258,6 +258,43 @@ int dcpt_conv1x1_pool_relu_bwd_bf16_packed(const uint16_t* dy, const uint16_t* x
                                            const uint16_t* z, uint16_t* dx, float* dw, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
                                            int Cout, dcpt_stream_t stream);
 
+/* ABI 15: the classifier head's BottleneckBlock as ONE call (reference basicsr/archs/degrad_classify_arch.py:132-243 as the DCPT head builds it:
+ * identity shortcut, LN norm, bias-free convs -- relu(LN(conv1 1x1 C -> 2C)) -> relu(LN(conv2 3x3 2C -> 2C)) -> relu(LN(conv3 1x1 2C -> C) + x)),
+ * bf16 activations.  Same arithmetic as three dcpt_conv_ln_fwd_bf16 / dcpt_conv_ln_bwd_acc_bf16 calls (forward: bit-identical), fewer passes:
+ * a channels-first LayerNorm (:17-44) runs in the epilogue of the GEMM that produces its input wherever a row fits one column tile (<= 128
+ * channels, or 256 on the 256-row kernel), and in backward the two inner LayerNorms ride in the epilogues of the data-gradient GEMMs above
+ * them, so the gradients of the two inner activations are never written.  group[0..2] = conv1, conv2, conv3:
+ *   w [Cout][Cin][k][k] fp32 and/or its cached operand images (wpacked, dcpt_conv_wpack_bf16_bytes; NULL, 0: packed in the call);
+ *   lnw / lnb [Cout] fp32 (lnb of conv1 / conv2 is read by backward too: the inner ReLU masks are recomputed from z);  z (conv output), y (group output; y of group 2 = the block's output) [B][H][W][Cout] bf16 and mu / rstd [B H W]
+ *   fp32 are written by forward and read by backward;  dw / dlnw / dlnb: backward outputs (unused in forward).
+ * dout, x, dx: [B][H][W][C] bf16.  Workspace: dcpt_bottleneck_bf16_ws_bytes. */
+typedef struct {
+    const float* w;
+    const void* wpacked;
+    size_t wpacked_bytes;
+    const float* lnw;
+    const float* lnb;
+    uint16_t* z;
+    uint16_t* y;
+    float* mu;
+    float* rstd;
+    float* dw;
+    float* dlnw;
+    float* dlnb;
+} dcpt_bneck_group_t;
+size_t dcpt_bottleneck_bf16_ws_bytes(int B, int H, int W, int C, int backward);
+int dcpt_bottleneck_fwd_bf16(const uint16_t* x, const dcpt_bneck_group_t* group, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                             dcpt_stream_t stream);
+int dcpt_bottleneck_bwd_bf16(const uint16_t* dout, const uint16_t* x, const dcpt_bneck_group_t* group, uint16_t* dx, void* ws, size_t ws_bytes,
+                             int B, int H, int W, int C, dcpt_stream_t stream);
+
+/* ABI 15: launch trace for tests.  dcpt_trace_enable(1) clears and starts it: from then on every dispatch decision of the library counts the
+ * kernel family it launched under a fixed name ("head.conv3x3+ln_fwd_epilogue", "nt_bf16.256", ...); dcpt_trace_read writes "name count\n"
+ * lines into buf (NUL-terminated, truncated to cap) and returns the bytes the whole text needs.  Off (the default) it costs one load per launch.
+ * A parity test uses it to assert WHICH kernel produced the result it compared (tests/kernel_trace.py). */
+int dcpt_trace_enable(int on);
+size_t dcpt_trace_read(char* buf, size_t cap);
+
 /* TLSC variant (nafnet_arch.py:277-288 `NAFNet`, arch_util.py:313-455): inference-only forward where SCA's global
  * mean is a k1 x k2 local box mean (replicate-padded), i.e. a per-pixel attention map.  Callers use the plain
  * dcpt_nafblock_fwd when the window covers the whole map (arch_util.py:352-353). */

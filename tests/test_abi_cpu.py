@@ -25,7 +25,7 @@ def test_library_builds_and_exports_header_symbols():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in dcpt_hip.h but not exported"
     assert sorted(_lib.SIGNATURES.keys()) == syms, "ctypes table and header disagree"
-    assert lib.dcpt_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.dcpt_abi_version() == _lib.ABI_VERSION == 15
 
 
 def test_workspace_queries_need_no_gpu():

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 
 from dcpt_amd.keyed_init import keyed_input, keyed_state_dict, keyed_tensor
 from oracle import dc_oracle as D
+from kernel_trace import kernel_trace
 
 pytestmark = pytest.mark.gpu
 DC_CFG = dict(feature_dims=[8, 16, 32, 64], num_res_blocks=2, num_classes=10)
@@ -63,7 +64,8 @@ def test_conv_ln(dev, B, Cin, Cout, H, W, ks, relu, res):
         check(n, a.grad, b.grad, 1e-4)
 
 
-@pytest.mark.parametrize("B,C,H,W,bf", [(2, 16, 6, 10, False), (1, 64, 16, 16, False), (2, 16, 6, 10, True), (1, 128, 16, 16, True)])
+@pytest.mark.parametrize("B,C,H,W,bf", [(2, 16, 6, 10, False), (1, 64, 16, 16, False), (2, 16, 6, 10, True), (1, 128, 16, 16, True),
+                                        (3, 64, 13, 11, True), (1, 128, 224, 224, True), (1, 40, 9, 9, True)])
 def test_bottleneck_node(dev, B, C, H, W, bf):
     """DF.bottleneck (the BottleneckBlock of the reference, degrad_classify_arch.py:132-243, as ONE autograd node with the shortcut
     gradient summed in conv1's data-gradient GEMM: dcpt_conv_ln_bwd_acc*) against the PyTorch-CPU restatement of the reference lines (fp32)
@@ -80,8 +82,22 @@ def test_bottleneck_node(dev, B, C, H, W, bf):
     # one node
     xg = cast(x).requires_grad_(True)
     pg = [t.to(dev).requires_grad_(True) for t in ws]
-    y = DF.bottleneck(xg, *pg)
-    y.backward(cast(go))
+    with kernel_trace() as tr:
+        y = DF.bottleneck(xg, *pg)
+        y.backward(cast(go))
+    if bf:
+        # the bf16 node is ONE library call per direction (dcpt_bottleneck_*_bf16): LayerNorms in the GEMM epilogues where a row fits a
+        # column tile -- 2C <= 128 on the 128-row kernel; 2C == 256 on the 256-row kernel, which needs >= 192 tiles of 256 pixels
+        M = B * H * W
+        wide_ok = 2 * C <= 128 or (2 * C == 256 and (M + 255) // 256 >= 192)
+        if wide_ok:
+            tr.assert_ran("head.conv1x1+ln_fwd_epilogue", "head.conv3x3+ln_fwd_epilogue", "head.conv1x1_dgrad+ln_bwd_epilogue",
+                          "head.conv3x3_dgrad+ln_bwd_epilogue")
+            tr.assert_not_ran("head.conv1x1,ln_fwd_kernel", "head.conv3x3,ln_fwd_kernel")
+            assert tr["head.ln_bwd_kernel"] == 1   # (the block's last LayerNorm: its gradient comes from outside)
+        elif 2 * C > 256:
+            tr.assert_not_ran("head.conv3x3+ln_fwd_epilogue", "head.conv3x3_dgrad+ln_bwd_epilogue")
+            assert tr["head.ln_bwd_kernel"] == 3
     # three nodes (autograd sums the two gradients of x itself)
     conv_ln = DF.conv_ln_bf16 if bf else DF.conv_ln
     xc = cast(x).requires_grad_(True)
@@ -94,7 +110,14 @@ def test_bottleneck_node(dev, B, C, H, W, bf):
     tol = 2e-2 if bf else 1e-6   # (bf16: the chain rounds dx twice -- conv1's dx, then the sum; the node rounds the fp32 sum once)
     check("dx vs chain", xg.grad.float(), xc.grad.float(), tol)
     for n, a, b in zip(["dw1", "dlw1", "dlb1", "dw2", "dlw2", "dlb2", "dw3", "dlw3", "dlb3"], pg, pc):
-        assert torch.equal(a.grad, b.grad), f"{n}: the parameter gradients do not depend on where the shortcut gradient is summed"
+        if bf and n in ("dw1", "dlw1", "dlb1", "dw2", "dlw2", "dlb2"):
+            # (everything behind an inner LayerNorm's backward: in the node it runs in a GEMM epilogue, in the chain as a kernel of its own --
+            # the same formulas on the same bf16 inputs, but two compilations of them (fma contraction) and two orders of the parameter
+            # sums: dz differs by an ulp of bf16 in a few elements, the sums over all pixels by ~1e-4 of their scale)
+            check(n, a.grad, b.grad, 1e-3)
+        else:
+            assert torch.equal(a.grad, b.grad), (f"{n}: the parameter gradients do not depend on where the shortcut gradient is summed "
+                                                 f"(max diff {float((a.grad - b.grad).abs().max()):.3e} of {float(b.grad.abs().max()):.3e})")
     if not bf:   # the reference's lines on the CPU
         ref = [t.clone().requires_grad_(True) for t in [x] + ws]
         r = F.relu(D.layernorm_cf(F.conv2d(ref[0], ref[1]), ref[2], ref[3]))

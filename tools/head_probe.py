@@ -10,6 +10,9 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--steps", type=int, default=5)
 a = ap.parse_args()
+if os.environ.get("DCPT_TOOL_LIB"):   # a variant build (tools/build_variant.sh) instead of the product library
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _variant  # noqa: F401
 import __graft_entry__ as G
 G.build()
 from basicsr.archs import build_network
