@@ -101,7 +101,73 @@ def lib_digest():
         return None
 
 
-def secondary_dcpt_bf16(dev, steps=5, warmup=3):
+def live_roofline(lib, run_one_step):
+    """The dominant GEMM-class kernel family of a bf16 step, live: one more step with every launch of the library's GEMM / chain kernels bracketed
+    by HIP events on its stream (prof.hip), aggregated per family; algorithmic flops / bytes of the launches against the bf16 MFMA / HBM roofs."""
+    try:
+        lib.dcpt_prof_enable(1)
+        run_one_step()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_double * (8 * 512))()
+        n = lib.dcpt_prof_read(buf, 512)
+        lib.dcpt_prof_enable(0)
+        by = {}
+        for i in range(n):   # per kernel family (the shapes of a family differ by level)
+            a = by.setdefault(prof_class_name(int(buf[i * 8])), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            a["launches"] += int(buf[i * 8 + 4]); a["ms"] += buf[i * 8 + 5]; a["flops"] += buf[i * 8 + 6]; a["bytes"] += buf[i * 8 + 7]
+        name, a = max(by.items(), key=lambda kv: kv[1]["ms"])
+        tf = a["flops"] / a["ms"] / 1e9
+        return {"kernel": name, "bound": "hbm" if a["bytes"] / 8e12 > a["flops"] / 2.5e15 else "mfma", "launches_per_step": a["launches"],
+                "ms_per_step": round(a["ms"], 3), "achieved_tflops": round(tf, 1), "peak_tflops": 2500.0, "mfma_frac": round(tf / 2500.0, 4),
+                "achieved_gbs": round(a["bytes"] / a["ms"] / 1e6, 1), "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / 8000.0, 4),
+                "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 1),
+                "measured": "live, HIP events around every launch of the family in one extra step (algorithmic flops / bytes of the launches)"}
+    except Exception as e:   # noqa: BLE001  (the roofline object is extra: never lose the timing over it)
+        return {"error": str(e)[:200]}
+
+
+def secondary_naf_bf16(dev, steps=6, warmup=3, act="bf16"):
+    """The headline network and batch (NAFNet-64 [1,1,1,28], B = 32, 256 x 256, fwd + L1 + bwd + AdamW) with bf16 STORAGE of the feature maps
+    (fp32 accumulate, fp32 parameters / optimizer): the one workload north_star's "40 % of the HBM roofline" can apply to (the
+    fp32 step is MFMA-bound by 5.5 x; in bf16 the narrow levels are HBM-bound).  Never the headline."""
+    from basicsr.archs import build_network
+    from dcpt_amd import _lib
+    from dcpt_amd.keyed_init import fill_module_
+    from dcpt_amd.optim import FusedAdamW
+
+    net = fill_module_(build_network(dict(type="NAFNetBaseline", act_dtype=act, **CFG))).to(dev)
+    optm = FusedAdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.9), weight_decay=0.0)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    lq = torch.rand((BATCH, 3, SIZE, SIZE), generator=g, device=dev)
+    gt = torch.rand((BATCH, 3, SIZE, SIZE), generator=g, device=dev)
+
+    def step():
+        optm.zero_grad(set_to_none=True)
+        (net(lq) - gt).abs().mean().backward()
+        optm.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    roof = live_roofline(_lib.load(), step)
+    nbytes = BATCH * (25 * 30.146e6 + 3 * 40.4e6) * 2   # SURVEY 8d element passes per 256^2 image, 2 B each
+    flops = BATCH * FLOP_PER_IMAGE
+    out = {"workload": f"NAFNet-64 [1,1,1,28] fwd+L1+bwd+AdamW, B={BATCH}, {SIZE}x{SIZE}, feature maps {act} (fp32 accumulate / parameters / optimizer)",
+           "ms_per_step": round(dt * 1e3, 2), "megapixels_per_s": round(BATCH * SIZE * SIZE / 1e6 / dt, 3), "steps": steps, "warmup": warmup,
+           "alg_tflops": round(flops / dt / 1e12, 2), "mfma_frac": round(flops / dt / 2.5e15, 4), "alg_gbytes": round(nbytes / 1e9, 2),
+           "hbm_frac": round(nbytes / dt / (PEAK_HBM_TBS * 1e12), 4), "bound": "hbm" if nbytes / 8e12 > flops / 2.5e15 else "mfma",
+           "roofline": roof}
+    del net, optm
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_dcpt_bf16(dev, steps=5, warmup=3, sizes=(128, 256), act="bf16"):
     """BASELINE.json configs[2] at its own dtype and size, timed by the run that prints the line: one DCPT pre-training step
     (reference ...pretrain_model.py:133-169: encoder on the clean and on the degraded batch, classifier head on the decoder taps,
     one backward, two AdamW updates) with NAFNet-64 + PromptIR_NoImg_DC([64,128,256,512]), 10 classes, B = 32, encoder AND head in
@@ -111,10 +177,10 @@ def secondary_dcpt_bf16(dev, steps=5, warmup=3):
 
     out = {}
     naf_bytes_bf16 = (25 * 30.146e6 + 3 * 40.4e6) * 2   # SURVEY 8d element passes per 256^2 image, 2 B each
-    for S in (128, 256):
+    for S in sizes:
         B = 32
         opt = dict(name="b", model_type="DCPTModel", scale=1, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
-                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", act_dtype="bf16", **CFG),
+                   hook_names="decoder", network_g=dict(type="NAFNetBaseline", act_dtype=act, **CFG),
                    network_dc=dict(type="PromptIR_NoImg_DC", feature_dims=[64, 128, 256, 512], num_res_blocks=2, num_classes=10, act_dtype="bf16"),
                    path=dict(), train=dict(pixel_opt=dict(type="L1Loss"), classify_opt=dict(type="CrossEntropyLoss"),
                                            optim_g=dict(type="AdamW", lr=1e-4, fused=True), optim_dc=dict(type="AdamW", lr=1e-4, fused=True)))
@@ -132,42 +198,15 @@ def secondary_dcpt_bf16(dev, steps=5, warmup=3):
             m.optimize_parameters(1)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        # the dominant GEMM-class kernel of THIS step, live: one more step with every launch bracketed by HIP events on its stream
-        # (libdcpt_hip's prof.hip; the wide bf16 levels run single-stream, so a bracket spans exactly its launch)
-        roof = None
-        try:
-            from dcpt_amd import _lib
-            import ctypes
+        from dcpt_amd import _lib
 
-            lib = _lib.load()
-            lib.dcpt_prof_enable(1)
-            m.optimize_parameters(1)
-            torch.cuda.synchronize()
-            buf = (ctypes.c_double * (8 * 512))()
-            n = lib.dcpt_prof_read(buf, 512)
-            lib.dcpt_prof_enable(0)
-            rows = [dict(kernel=prof_class_name(int(buf[i * 8])), MNK=[int(buf[i * 8 + 1]), int(buf[i * 8 + 2]), int(buf[i * 8 + 3])],
-                         launches=int(buf[i * 8 + 4]), ms=buf[i * 8 + 5], flops=buf[i * 8 + 6], bytes=buf[i * 8 + 7]) for i in range(n)]
-            by = {}
-            for r in rows:   # per kernel family (the shapes of a family differ by level)
-                a = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-                for k in ("ms", "flops", "bytes", "launches"):
-                    a[k] += r[k]
-            name, a = max(by.items(), key=lambda kv: kv[1]["ms"])
-            tf = a["flops"] / a["ms"] / 1e9
-            roof = {"kernel": name, "bound": "hbm" if a["bytes"] / 8e12 > a["flops"] / 2.5e15 else "mfma", "launches_per_step": a["launches"],
-                    "ms_per_step": round(a["ms"], 3), "achieved_tflops": round(tf, 1), "peak_tflops": 2500.0, "mfma_frac": round(tf / 2500.0, 4),
-                    "achieved_gbs": round(a["bytes"] / a["ms"] / 1e6, 1), "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / 8000.0, 4),
-                    "avg_launch_us": round(1e3 * a["ms"] / max(1, a["launches"]), 1),
-                    "measured": "live, HIP events around every launch of the family in one extra step (algorithmic flops / bytes of the launches)"}
-        except Exception as e:   # noqa: BLE001  (the roofline object is extra: never lose the timing over it)
-            roof = {"error": str(e)[:200]}
+        roof = live_roofline(_lib.load(), lambda: m.optimize_parameters(1))
         sc = B * (S / 256.0) ** 2
         flops = sc * 1.315e12          # 2 x 378.3 GF (encoder, fwd+bwd) + 558.9 GF (head) per 256^2 image
         log = m.get_current_log()
-        out[f"dcpt_all_bf16_{S}"] = {
+        out[f"dcpt_all_bf16_{S}" if act == "bf16" else f"dcpt_{act}_{S}"] = {
             "workload": f"DCPT step (BASELINE.json configs[2]): NAFNet-64 x2 fwd + PromptIR_NoImg_DC([64,128,256,512]) head + bwd + 2x AdamW, "
-                        f"B={B}, {S}x{S}, encoder and head feature maps bf16 (fp32 accumulate / parameters)",
+                        f"B={B}, {S}x{S}, encoder feature maps {act}, head bf16 (fp32 accumulate / parameters)",
             "ms_per_step": round(dt * 1e3, 2), "megapixels_per_s": round(B * S * S / 1e6 / dt, 3), "steps": steps, "warmup": warmup,
             "alg_tflops": round(flops / dt / 1e12, 2), "mfma_frac": round(flops / dt / 2.5e15, 4),
             "hbm_frac": round(sc * 2 * naf_bytes_bf16 / dt / (PEAK_HBM_TBS * 1e12), 4),
@@ -202,8 +241,9 @@ def ddp_wrap_overhead(unwrapped_ms: float) -> dict:
         return {"error": repr(e)[:300]}
 
 
-def spawn_ranks(n: int) -> None:
-    """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run, one process per GPU."""
+def spawn_ranks(n: int, script: str = None) -> None:
+    """`python bench.py --gpus N` without a launcher: re-execute this command (or ``script``: bench_extra.py) under torch.distributed.run,
+    one process per GPU."""
     import socket
     import subprocess
 
@@ -217,7 +257,7 @@ def spawn_ranks(n: int) -> None:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+           "--master-port", str(port), os.path.abspath(script or __file__), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it across processes)
     raise SystemExit(subprocess.call(cmd, env=env))
@@ -556,7 +596,11 @@ def main():
                 sec["naf_f32_via_bf16x3"] = line
             del net, model, opt, lq, gt, loss
             torch.cuda.empty_cache()
+            sec["naf_bf16_256"] = secondary_naf_bf16(dev)
             sec.update(secondary_dcpt_bf16(dev))
+            # the bf16 mode that holds EVERY image inside north_star's 0.01 dB (act_dtype bf16_edge32: the full-resolution level in fp32;
+            # tests/test_gpu_configs.py::test_psnr_bf16_storage_vs_fp32) next to plain bf16: what that tolerance costs
+            sec.update(secondary_dcpt_bf16(dev, sizes=(256,), act="bf16_edge32"))
             if args.gemm_precision == "fp32":
                 sec["ddp_wrap_one_rank"] = ddp_wrap_overhead(ms_per_step)
             # BASELINE.json configs[3] and configs[4] on the same record (bench_extra.py holds the workloads)
@@ -566,6 +610,7 @@ def main():
             torch.cuda.empty_cache()
             sec["infer2k_fp32"] = BX.run_infer2k(dev, "fp32", steps=3, warmup=2)
             sec["infer2k_bf16"] = BX.run_infer2k(dev, "bf16", steps=3, warmup=2)
+            sec["infer2k_bf16_edge32"] = BX.run_infer2k(dev, "bf16_edge32", steps=3, warmup=2)
             torch.cuda.empty_cache()
             res["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:

@@ -3,6 +3,7 @@
 // MFMA GEMMs (straight, transposed + gain-scaled, per-image SCA-scaled), and SCA's channel sums when they do not come out of a
 // GEMM epilogue.  A lane owns 8 consecutive channels (one 16-byte access); a row lives in G = pow2 >= C / 8 lanes of one wave.
 #include "bf16.h"
+#include "prof.h"
 #include "bf16_ops.h"
 #include "chain_bf16.h"
 
@@ -536,6 +537,7 @@ int ln_bwd_bf16_num_blocks(int64_t M, int C) {
 
 int launch_ln_fwd_bf16(const bf16_t* x, const float* w, const float* b, bf16_t* y, float* mu, float* rstd, int64_t M, int C, float eps,
                        hipStream_t s) {
+    trace_tag("ln_fwd_bf16");
     DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_fwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
     const int G = lnb_group(C), gpb = 256 / G;
     int64_t nb = cdiv64(M, gpb);
@@ -548,6 +550,7 @@ int launch_ln_fwd_bf16(const bf16_t* x, const float* w, const float* b, bf16_t* 
 
 int launch_ln_act_fwd_bf16(const bf16_t* x, const float* w, const float* b, const bf16_t* res, int relu, bf16_t* y, float* mu, float* rstd,
                            int64_t M, int C, float eps, hipStream_t s) {
+    trace_tag("ln_act_fwd_bf16");
     DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_act_fwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
     const int G = lnb_group(C), gpb = 256 / G;
     int64_t nb = cdiv64(M, gpb);
@@ -560,6 +563,7 @@ int launch_ln_act_fwd_bf16(const bf16_t* x, const float* w, const float* b, cons
 
 int launch_ln_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* dres, bf16_t* dx,
                        float* part, int nblk, int64_t M, int C, hipStream_t s) {
+    trace_tag("ln_bwd_bf16");
     DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_bwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
     const int G = lnb_group(C), gpb = 256 / G;
     const int64_t iters = cdiv64(M, (int64_t)nblk * gpb);
@@ -571,6 +575,7 @@ int launch_ln_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const
 
 int launch_ln_act_bwd_bf16(const bf16_t* gy, const bf16_t* x, const float* mu, const float* rstd, const float* w, const bf16_t* ymask,
                            bf16_t* gmasked, bf16_t* dx, float* part, int nblk, int64_t M, int C, hipStream_t s) {
+    trace_tag("ln_act_bwd_bf16");
     DCPT_CHECK_ARG(C % 8 == 0 && C <= 1024, "ln_act_bwd_bf16: C=%d must be a multiple of 8, at most 1024", C);
     const int G = lnb_group(C), gpb = 256 / G;
     const int64_t iters = cdiv64(M, (int64_t)nblk * gpb);

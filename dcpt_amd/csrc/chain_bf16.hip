@@ -704,6 +704,7 @@ int num_cus() {   // of the CURRENT device, cached per device index (a process m
 
 template <int C, int HEAD>
 int launch_t(const ChainFwdB& p, hipStream_t s) {
+    trace_tag(HEAD == 1 ? "chain.head" : HEAD == 2 ? "chain.conv3+ffn" : (p.xn2 ? "chain.ffn_train" : "chain.ffn_infer"));
     const int64_t ntiles = (p.M + 127) / 128;
     const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
     // (live timing for bench.py: flops of the GEMMs, algorithmic bytes of what the launch reads and writes)
@@ -748,6 +749,7 @@ int launch_chain_fwd_bf16(const ChainFwdB& p, int C, hipStream_t s) {
 size_t chain_mid_wstream_elems(int C) { return (C == 256 || C == 512) ? (size_t)C * C : 0; }
 
 int launch_chain_bwd_mid_bf16(const ChainMidB& p, int C, hipStream_t s) {
+    trace_tag("chain.mid");
     DCPT_CHECK_ARG(p.gln && p.y && p.dout && p.t2 && p.mu && p.rstd && p.lnw && p.Wf && p.dy && p.dts && p.lnpart && p.dspart && p.M > 0,
                    "chain_bwd_mid_bf16: null argument");
     const int64_t ntiles = (p.M + 127) / 128;

@@ -6,6 +6,7 @@
 // per feature element make them VALU-bound at 2.5 - 7 x their traffic time) and, for the shapes of every NAFNet configuration (Cs <= 3,
 // Cb = 32 / 64), exact-fp32 MFMA kernels (second half, round 5: K = 27 is small for a GEMM tile, not for v_mfma_f32_32x32x2_f32).
 #include "bf16.h"
+#include "prof.h"
 #include "bf16_ops.h"
 #include "bufops.h"
 #include "kernels.h"
@@ -803,6 +804,7 @@ int launch_wgrad_mfma(const ST* big, const float* small, float* part, int nblk, 
 int launch_conv3x3_s2b_bf16(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cs, int Cb, int wmode,
                             hipStream_t s) {
     EDGE_CHECK("conv3x3_s2b_bf16", 2048);
+    trace_tag(edge_mfma_ok(Cs, Cb) ? "edge.s2b_mfma" : "edge.s2b_valu");
     if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_s2b_mfma<bf16_t>(x, w, bias, y, B, H, W, Cs, Cb, wmode, s));
     else EDGE_GO_B(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_s2b_bf16");
@@ -812,6 +814,7 @@ int launch_conv3x3_b2s_bf16(const bf16_t* x, const float* w, const float* bias, 
                             int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_b2s_bf16", 2048);
     DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s_bf16: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
+    trace_tag(edge_mfma_ok(Cs, Cb) ? "edge.b2s_mfma" : "edge.b2s_valu");
     if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_b2s_mfma<bf16_t>(x, w, bias, res, y, B, H, W, Cs, Cb, wmode, s));
     else EDGE_GO_B(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_b2s_bf16");
@@ -821,6 +824,7 @@ int launch_conv3x3_b2s_bf16(const bf16_t* x, const float* w, const float* bias, 
 int launch_conv3x3_s2b(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cs, int Cb,
                        int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_s2b", 2048);
+    trace_tag(edge_mfma_ok(Cs, Cb) ? "edge.s2b_mfma" : "edge.s2b_valu");
     if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_s2b_mfma<float>(x, w, bias, y, B, H, W, Cs, Cb, wmode, s));
     else EDGE_GO(conv3x3_s2b_kernel, x, w, bias, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_s2b");
@@ -831,6 +835,7 @@ int launch_conv3x3_b2s(const float* x, const float* w, const float* bias, const 
                        int Cs, int Cb, int wmode, hipStream_t s) {
     EDGE_CHECK("conv3x3_b2s", 2048);
     DCPT_CHECK_ARG(Cb <= 256, "conv3x3_b2s: Cb=%d > 256 (one wave must hold all channel quads of a pixel)", Cb);
+    trace_tag(edge_mfma_ok(Cs, Cb) ? "edge.b2s_mfma" : "edge.b2s_valu");
     if (edge_mfma_ok(Cs, Cb)) DCPT_TRY(launch_b2s_mfma<float>(x, w, bias, res, y, B, H, W, Cs, Cb, wmode, s));
     else EDGE_GO(conv3x3_b2s_kernel, x, w, bias, res, y, B, H, W, Cb, wmode);
     DCPT_CHECK_LAUNCH("conv3x3_b2s");
@@ -854,8 +859,10 @@ int launch_conv3x3_wgrad_bf16(const bf16_t* big, const float* small, float* part
     DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad_bf16: nblk mismatch");
     if (edge_mfma_ok(Cs, Cb)) {
         nblk = wgrad_mfma_blocks(B, H);
+        trace_tag("edge.wgrad_mfma");
         DCPT_TRY(launch_wgrad_mfma<bf16_t>(big, small, part, nblk, B, H, W, Cs, Cb, s));
     } else {
+        trace_tag("edge.wgrad_valu");
         nblk = wgrad_valu_blocks(B, H, W, Cb);
         const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
         const dim3 grid(m.nqc * m.nwc, m.strips, B);
@@ -876,8 +883,10 @@ int launch_conv3x3_wgrad(const float* big, const float* small, float* part, int 
     DCPT_CHECK_ARG(nblk == conv3x3_wgrad_num_blocks(B, H, W, Cb), "conv3x3_wgrad: nblk mismatch");
     if (edge_mfma_ok(Cs, Cb)) {
         nblk = wgrad_mfma_blocks(B, H);
+        trace_tag("edge.wgrad_mfma");
         DCPT_TRY(launch_wgrad_mfma<float>(big, small, part, nblk, B, H, W, Cs, Cb, s));
     } else {
+        trace_tag("edge.wgrad_valu");
         nblk = wgrad_valu_blocks(B, H, W, Cb);
         const EdgeMap m = edge_map(B, H, W, Cb, WGRAD_BLOCKS);
         const dim3 grid(m.nqc * m.nwc, m.strips, B);

@@ -133,6 +133,7 @@ size_t conv_layout(int B, int H, int W, int Cin, int Cout, int ks, int backward,
 }
 
 int pack(const float* w, bf16_t* out, int N, int K, int mode, hipStream_t s) {
+    trace_tag("head.wpack_per_call");   // (not reached with the per-step cached images: dcpt_conv_wpack_bf16_multi)
     WpackBJobs j{};
     j.n = 1;
     j.in[0] = w; j.out[0] = out; j.N[0] = N; j.K[0] = K; j.transpose[0] = mode;
@@ -522,6 +523,7 @@ extern "C" int dcpt_conv_wpack_bf16_multi(const float* const* w, void* const* pa
         DCPT_CHECK_ARG(conv_shape_ok(Cin[i], Cout[i], ksize[i]), "conv_wpack_bf16_multi: conv %d: ksize=%d Cin=%d Cout=%d", i, ksize[i], Cin[i], Cout[i]);
         DCPT_CHECK_ARG(packed_bytes[i] >= 2 * wpack_half_bytes(Cin[i], Cout[i], ksize[i]), "conv_wpack_bf16_multi: conv %d: buffer too small", i);
     }
+    trace_tag("head.wpack_multi");
     for (int pass = 0; pass < 2; ++pass) {   // pass 0: the 3 x 3 convs, pass 1: the 1 x 1 convs
         WpackBJobsL j{};
         for (int i = 0; i < n; ++i) {

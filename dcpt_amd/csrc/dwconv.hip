@@ -9,6 +9,7 @@
 // weight gradients) are reduced in registers, then once per block in LDS in a fixed order, and
 // written as per-block partials: deterministic, no float atomics.
 #include <stdlib.h>
+#include "prof.h"
 
 #include "bf16.h"
 #include "bufops.h"
@@ -628,6 +629,7 @@ int launch_dw_pack_weights(const float* w2, float* w2p, int C2, hipStream_t s) {
 
 int launch_dw_fwd(const float* t1, const float* w2p, const float* b2, float* t2, float* pool_part, const DwGeom& g,
                   hipStream_t s) {
+    trace_tag("dw.reg_fwd_f32");
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_fwd: C=%d must be a multiple of 4, B<=65535", g.C);
     DwP p{};
     p.in0 = t1; p.w2p = w2p; p.b2 = b2; p.out = t2; p.part = pool_part;
@@ -643,6 +645,7 @@ int dw_fused_row_chunks(const DwGeom& g) { return dw_map(g.H, g.W, 2 * g.C / dw_
 
 int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                         float* dt1, float* wpart, const DwGeom& g, hipStream_t s, float* rowpart, const float* uvec, const float* cvec) {
+    trace_tag("dw.reg_bwd_f32");
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd: C=%d must be a multiple of 4", g.C);
     DwP p{};
     p.in0 = t1; p.in1 = dts; p.w2p = w2p; p.b2 = b2; p.simg = simg; p.dpool = dpool; p.out = dt1; p.part = wpart;
@@ -660,6 +663,7 @@ int launch_dw_bwd_fused(const float* dts, const float* t1, const float* w2p, con
 
 // ---- bf16-storage variants (bf16.h): same kernels, activations read / written as bf16, partial sums and parameters fp32
 int launch_dw_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s) {
+    trace_tag("dw.reg_fwd_bf16");
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_fwd_bf16: C=%d must be a multiple of 4, B<=65535", g.C);
     DwP p{};
     p.in0 = reinterpret_cast<const float*>(t1); p.w2p = w2p; p.b2 = b2; p.out = reinterpret_cast<float*>(t2); p.part = pool_part;
@@ -678,6 +682,7 @@ int dw_fused_row_chunks_bf16(const DwGeom& g) { return dw_map(g.H, g.W, 2 * g.C 
 
 int launch_dw_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                              bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s, float* rowpart, const float* uvec, const float* cvec) {
+    trace_tag("dw.reg_bwd_bf16");
     DCPT_CHECK_ARG(g.C % 4 == 0 && g.B <= 65535, "dw_bwd_bf16: C=%d must be a multiple of 4", g.C);
     DwP p{};
     p.in0 = reinterpret_cast<const float*>(t1); p.in1 = reinterpret_cast<const float*>(dts); p.w2p = w2p; p.b2 = b2; p.simg = simg;

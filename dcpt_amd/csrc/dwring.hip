@@ -15,6 +15,7 @@
 // the row about to be read (N = the VMEM operations issued after them: 3 per prefetched row + the 2 stores per iteration), the
 // barrier publishes all four waves' pieces and retires the slot read in the previous iteration, which the next DMA then refills.
 #include "bf16.h"
+#include "prof.h"
 #include "bf16_ops.h"
 #include "kernels.h"
 
@@ -752,9 +753,11 @@ int dw_ring_num_blocks_per_image(const DwGeom& g, int es) {
     return d.nwc * d.nrp;
 }
 int launch_dw_ring_fwd_f32(const float* t1, const float* w2p, const float* b2, float* t2, float* pool_part, const DwGeom& g, hipStream_t s) {
+    trace_tag("dw.ring_fwd_f32");
     return launch_fwd<float>(t1, w2p, b2, t2, pool_part, g, s);
 }
 int launch_dw_ring_fwd_bf16(const bf16_t* t1, const float* w2p, const float* b2, bf16_t* t2, float* pool_part, const DwGeom& g, hipStream_t s) {
+    trace_tag("dw.ring_fwd_bf16");
     return launch_fwd<bf16_t>(t1, w2p, b2, t2, pool_part, g, s);
 }
 
@@ -766,10 +769,12 @@ int dw_ring_bwd_num_blocks_per_image(const DwGeom& g) {
 }
 int launch_dw_ring_bwd_fused_f32(const float* dts, const float* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                                  float* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+    trace_tag("dw.ring_bwd_f32");
     return launch_bwd<float>(dts, t1, w2p, b2, simg, dpool, dt1, wpart, g, s);
 }
 int launch_dw_ring_bwd_fused_bf16(const bf16_t* dts, const bf16_t* t1, const float* w2p, const float* b2, const float* simg, const float* dpool,
                                   bf16_t* dt1, float* wpart, const DwGeom& g, hipStream_t s) {
+    trace_tag("dw.ring_bwd_bf16");
     return launch_bwd<bf16_t>(dts, t1, w2p, b2, simg, dpool, dt1, wpart, g, s);
 }
 

@@ -22,6 +22,7 @@
 // Rounding points are the unfused path's (nafblock_bf16.hip): LN2(y) rounded to bf16 (it is an MFMA operand), v = conv4 + bias rounded
 // once on store, SimpleGate(v) = product of the UNROUNDED halves rounded once (operand of conv5), out rounded once.
 #include "bf16_ops.h"
+#include "prof.h"
 #include "ffn_bf16.h"
 
 namespace {
@@ -689,6 +690,7 @@ __global__ __launch_bounds__(256) void ffn_wgrad_bf16_kernel(const FfnWgB p) {
 bool ffn_fwd_bf16_ok(int C) { return C == 64; }
 
 int launch_ffn_fwd_bf16(const FfnFwdB& p, int C, hipStream_t s) {
+    trace_tag("ffn64.fwd");
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ffn_fwd_bf16: C=%d not supported (64)", C);
     DCPT_CHECK_ARG(p.y && p.out && p.W4 && p.W5 && p.b4 && p.b5 && p.gamma && p.lnw && p.lnb && p.M > 0, "ffn_fwd_bf16: null argument");
     DCPT_CHECK_ARG((p.xn2 == nullptr) == (p.g == nullptr) && (p.mu == nullptr) == (p.rstd == nullptr), "ffn_fwd_bf16: xn2 / g and mu / rstd come in pairs");
@@ -703,6 +705,7 @@ int launch_ffn_fwd_bf16(const FfnFwdB& p, int C, hipStream_t s) {
 // t1 = conv1(LayerNorm1(inp)) + b1 in one pass: p.y = inp, p.W4 / p.b4 = conv1, p.v = t1 [M][2C], p.xn2 = LN1(inp) (kept for conv1's weight
 // gradient), p.mu / p.rstd optional
 int launch_ln_conv_bf16(const FfnFwdB& p, int C, hipStream_t s) {
+    trace_tag("ffn64.ln_conv");
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ln_conv_bf16: C=%d not supported (64)", C);
     DCPT_CHECK_ARG(p.y && p.v && p.xn2 && p.W4 && p.b4 && p.lnw && p.lnb && p.M > 0, "ln_conv_bf16: null argument");
     int64_t blocks = cdiv64(cdiv64(p.M, 32), FW);
@@ -719,6 +722,7 @@ int ffn_bwd_bf16_waves(int64_t M) {
 }
 
 int launch_ffn_bwd_bf16(const FfnBwdB& p, int C, hipStream_t s) {
+    trace_tag("ffn64.bwd");
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ffn_bwd_bf16: C=%d not supported (64)", C);
     DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT5 && p.wT4 && p.lnw && p.dy && p.lnpart && p.M > 0, "ffn_bwd_bf16: null argument");
     ffn_bwd_bf16_kernel<64, 0><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
@@ -728,6 +732,7 @@ int launch_ffn_bwd_bf16(const FfnBwdB& p, int C, hipStream_t s) {
 
 // dx = dres + LayerNorm'(dz W; x) in one pass: p.v = dz [M][2C], p.wT4 = W^T [C][2C], p.y = x, p.dout = dres, p.dy = dx, p.lnpart as above
 int launch_conv_ln_bwd_tail_bf16(const FfnBwdB& p, int C, hipStream_t s) {
+    trace_tag("ffn64.bwd_tail");
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "conv_ln_bwd_tail_bf16: C=%d not supported (64)", C);
     DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT4 && p.lnw && p.dy && p.lnpart && p.M > 0, "conv_ln_bwd_tail_bf16: null argument");
     ffn_bwd_bf16_kernel<64, 1><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);
@@ -736,6 +741,7 @@ int launch_conv_ln_bwd_tail_bf16(const FfnBwdB& p, int C, hipStream_t s) {
 }
 
 int launch_ffn_wgrad_bf16(const FfnWgB& p, int C, hipStream_t s) {
+    trace_tag("ffn64.wgrad");
     DCPT_CHECK_ARG(ffn_fwd_bf16_ok(C), "ffn_wgrad_bf16: C=%d not supported (64)", C);
     DCPT_CHECK_ARG(p.dout && p.v && p.y && p.wT5 && p.lnw && p.lnb && p.g5 && p.g4 && p.cs5 && p.cs4 && p.M > 0, "ffn_wgrad_bf16: null argument");
     ffn_wgrad_bf16_kernel<64><<<dim3((unsigned)(ffn_bwd_bf16_waves(p.M) / FW)), dim3(256), 0, s>>>(p);

@@ -476,7 +476,11 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     if (epi == EB_LNBWDM) bytes += mn * (1 + (p.ymask ? 1 : 0) + (p.y2 ? 1 : 0));
     ProfScope prof(s, PROF_NT + 256 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * p.nb, bytes * 2.0 * p.nb);
     static const int use256 = dcpt_tuning("DCPT_NT256", 1);   // (A/B switch while the kernel is being tuned)
-    if (use256 && gemm_nt_bf16_256_ok(p, epi, use256 == 2 ? 1 : 192)) return launch_gemm_nt_bf16_256(p, epi, s);
+    if (use256 && gemm_nt_bf16_256_ok(p, epi, use256 == 2 ? 1 : 192)) {
+        trace_tag(p.conv3 ? "nt_bf16.256_conv3" : "nt_bf16.256");
+        return launch_gemm_nt_bf16_256(p, epi, s);
+    }
+    trace_tag(p.conv3 ? "nt_bf16.128_conv3" : p.gather2 ? "nt_bf16.128_gather2" : "nt_bf16.128");
     switch (epi) {
         case EB_PLAIN: return launch_nt<EB_PLAIN>(p, s);
         case EB_BIAS: return launch_nt<EB_BIAS>(p, s);
@@ -548,6 +552,7 @@ bool gemm_tn_bf16_plan_images(int64_t M, int N, int K, int P, int* splits, int64
 }
 
 int launch_gemm_tn_bf16(const GemmTNB& p, hipStream_t s) {
+    trace_tag(p.yconv ? "tn_bf16.128_conv3" : "tn_bf16.128");
     DCPT_CHECK_ARG(p.X && p.Y && p.slab && p.M > 0 && p.N > 0 && p.K > 0, "gemm_tn_bf16: null operand or empty problem");
     DCPT_CHECK_ARG(p.N % 8 == 0 && p.K % 8 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0, "gemm_tn_bf16: N=%d, K=%d, strides must be multiples of 8", p.N,
                    p.K);

@@ -736,6 +736,7 @@ size_t gemm_tn_bf16_256_slab_floats(const TnProb& p) { return (size_t)p.slots * 
 size_t gemm_tn_bf16_256_colsum_floats(const TnProb& p) { return (size_t)p.splits * p.N; }
 
 int launch_gemm_tn_bf16_256(const GemmTNG& g, hipStream_t s) {
+    trace_tag(g.p[0].yconv ? "tn_bf16.256_grouped_conv3" : "tn_bf16.256_grouped");
     DCPT_CHECK_ARG(g.n >= 1 && g.n <= TNG_MAX, "gemm_tn_bf16_256: %d problems", g.n);
     int blocks = 0;
     double flops = 0, bytes = 0;
@@ -769,6 +770,7 @@ int launch_gemm_tn_bf16_256(const GemmTNG& g, hipStream_t s) {
 }
 
 int launch_wgrad_finish(FinJobs& j, hipStream_t s) {
+    trace_tag("wgrad_finish");
     DCPT_CHECK_ARG(j.nslab >= 0 && j.nslab <= TNG_MAX && j.ncols >= 0 && j.ncols <= FIN_MAX_COLS, "wgrad_finish: bad job counts");
     int blk = 0;
     for (int i = 0; i < j.nslab; ++i) {

@@ -67,6 +67,29 @@ def test_cast_roundtrip(dev):
 # (gemm_bf16_256.hip) to take every conv -- all six epilogues, the per-image batched conv3, and a ragged last row tile (M = 24800)
 # (3, 64, 5, 7) / (1, 64, 9, 13) / (5, 64, 48, 40): the fused second half of the narrow levels (ffn_bf16.hip) with a ragged last group of
 # 32 pixels (M = 105, 117) and with more groups than one launch has waves (M = 9600: every wave walks its ring more than three times)
+_FFN64 = ("ffn64.ln_conv", "ffn64.fwd", "ffn64.bwd", "ffn64.bwd_tail", "ffn64.wgrad", "dw.ring_fwd_bf16", "dw.ring_bwd_bf16")
+_CHAINS = ("chain.head", "chain.ffn_train", "chain.mid", "chain.ffn_infer", "chain.conv3+ffn")
+_UNFUSED = ("ln_fwd_bf16", "ln_bwd_bf16", "nt_bf16.128", "tn_bf16.128")
+KERNELS_OF_SHAPE = {   # shape -> (families that must run, families that must not), as dcpt_trace_* names them (tools/trace_shapes.py prints them)
+    (2, 64, 32, 32): (_FFN64, _CHAINS + ("ln_fwd_bf16", "nt_bf16.256")),
+    (3, 64, 5, 7): (_FFN64, _CHAINS + ("ln_fwd_bf16",)),
+    (5, 64, 48, 40): (_FFN64, _CHAINS + ("ln_fwd_bf16",)),
+    (2, 16, 6, 10): (_UNFUSED, _CHAINS + _FFN64[:5] + ("nt_bf16.256", "tn_bf16.256_grouped")),
+    (1, 128, 16, 16): (_UNFUSED, _CHAINS + _FFN64[:5] + ("nt_bf16.256", "tn_bf16.256_grouped")),
+    (2, 512, 8, 16): (("nt_bf16.128", "tn_bf16.256_grouped", "wgrad_finish", "ln_fwd_bf16"), _CHAINS + ("nt_bf16.256", "tn_bf16.128")),
+    (1, 1024, 8, 8): (("nt_bf16.128", "tn_bf16.256_grouped", "wgrad_finish"), _CHAINS + ("nt_bf16.256", "tn_bf16.128")),
+    (1, 16, 11, 70): (("dw.ring_fwd_bf16", "dw.ring_bwd_bf16"), _CHAINS),
+    # the 256 x 256-tile NT kernel, the grouped weight gradient + finisher and all three chain forms (whole-tile images)
+    (24, 512, 32, 32): (("nt_bf16.256", "tn_bf16.256_grouped", "wgrad_finish") + _CHAINS[:3], ("nt_bf16.128", "tn_bf16.128", "ln_fwd_bf16")),
+    (13, 512, 48, 40): (("nt_bf16.256", "tn_bf16.256_grouped", "wgrad_finish") + _CHAINS[:3], ("nt_bf16.128", "tn_bf16.128", "ln_fwd_bf16")),
+    (48, 256, 32, 32): (("nt_bf16.256", "tn_bf16.256_grouped", "wgrad_finish") + _CHAINS[:3], ("tn_bf16.128", "ln_fwd_bf16")),
+    # images that are no whole number of 128-pixel tiles: HEAD and FFN forms, no MID form (the LayerNorm backward stays a kernel)
+    (25, 512, 31, 32): (("nt_bf16.256", "chain.head", "chain.ffn_train", "ln_bwd_bf16"), ("chain.mid", "nt_bf16.128", "ln_fwd_bf16")),
+    (200, 512, 12, 12): (("nt_bf16.256", "chain.head", "chain.ffn_train", "ln_bwd_bf16"), ("chain.mid", "nt_bf16.128", "ln_fwd_bf16")),
+    (6, 256, 64, 64): (_CHAINS[:3] + ("tn_bf16.256_grouped",), ("ln_fwd_bf16",)),
+}
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 32, 32), (3, 64, 5, 7), (1, 64, 9, 13), (5, 64, 48, 40), (2, 16, 6, 10), (3, 24, 5, 7), (1, 128, 16, 16), (2, 512, 8, 16), (1, 1024, 8, 8),
                                    (1, 16, 11, 70), (1, 24, 6, 50), (1, 8, 70, 9), (24, 512, 32, 32), (25, 512, 31, 32), (6, 256, 64, 64),
                                    # the chain kernels of the wide levels (chain_bf16.hip: taken when the 128-pixel tiles fill 3/4 of the chip's last
@@ -75,6 +98,7 @@ def test_cast_roundtrip(dev):
                                    (13, 512, 48, 40), (200, 512, 12, 12), (48, 256, 32, 32)])
 def test_nafblock_bf16_oracle(dev, shape):
     from dcpt_amd import functional as DF
+    from kernel_trace import kernel_trace
 
     B, c, H, W = shape
     tag = f"bf.{c}.{H}x{W}."
@@ -94,10 +118,16 @@ def test_nafblock_bf16_oracle(dev, shape):
 
     Pd = {k: P[v].to(dev).requires_grad_(True) for k, v in FUSED.items()}
     xd = x.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    yd = DF.nafblock_bf16(xd, Pd)
-    assert yd.dtype == torch.bfloat16 and yd.shape == xd.shape
-    yd.backward(gw.to(dev).bfloat16())
-    torch.cuda.synchronize()
+    with kernel_trace() as tr:
+        yd = DF.nafblock_bf16(xd, Pd)
+        assert yd.dtype == torch.bfloat16 and yd.shape == xd.shape
+        yd.backward(gw.to(dev).bfloat16())
+        torch.cuda.synchronize()
+    # the kernel families this shape is in the list FOR (the comment above): a dispatch threshold that moves re-routes the shape and fails
+    # here instead of leaving the product's kernel untested behind a green comparison
+    must, must_not = KERNELS_OF_SHAPE.get(shape, ((), ()))
+    tr.assert_ran(*must)
+    tr.assert_not_ran(*must_not)
     assert xd.grad is not None and xd.grad.dtype == torch.bfloat16
     errs = {"y": _rel(yd, yb), "dx": _rel(xd.grad, dxb)}
     for k, name in FUSED.items():
@@ -249,9 +279,16 @@ def test_edge_convs_bf16_oracle(dev, B, Cs, Cb, H, W):
     yr = O.intro_bf16(ir, wr, br)
     yr.backward(go)
     ig, wg, bg = (t.to(dev).requires_grad_(True) for t in (img, w, b))
-    y = DF.conv3x3_in(ig, wg, bg, out_bf16=True)
-    assert y.dtype == torch.bfloat16
-    y.backward(go.to(dev).bfloat16())
+    from kernel_trace import kernel_trace
+
+    with kernel_trace() as tr:
+        y = DF.conv3x3_in(ig, wg, bg, out_bf16=True)
+        assert y.dtype == torch.bfloat16
+        y.backward(go.to(dev).bfloat16())
+    # the matrix-pipe form of the edge convs (K = 27 on fp32 MFMA, conv3x3.hip) exists for <= 3 image channels and 32 / 64 features; the rest is VALU
+    form = "mfma" if (Cs <= 3 and Cb in (32, 64)) else "valu"
+    tr.assert_ran(f"edge.s2b_{form}", f"edge.wgrad_{form}")
+    tr.assert_not_ran(*(f"edge.{k}_{'valu' if form == 'mfma' else 'mfma'}" for k in ("s2b", "b2s", "wgrad")))
     errs = {"y": _rel(y, yr), "dimg": _rel(ig.grad, ir.grad), "dw": _rel(wg.grad, wr.grad), "db": _rel(bg.grad, br.grad)}
     assert all(np.isfinite(v) and v <= 1e-2 for v in errs.values()), ("intro", errs)
 
@@ -640,7 +677,20 @@ def test_dcpt_step_all_bf16_full_size(dev):
         m = _dcpt_full(dt)
         assert len(m.hooks) == 4
         m.feed_data({"lq": lq, "gt": gt, "dataset_idx": labels})
-        m.optimize_parameters(1)
+        from kernel_trace import kernel_trace
+
+        with kernel_trace() as tr:
+            m.optimize_parameters(1)
+            torch.cuda.synchronize()
+        if dt == "bf16":
+            # what this step is in the suite FOR: the product's kernels at configs[2]'s own sizes -- the head's LayerNorms inside the conv GEMMs
+            # (stages 0-1: 128 / 256 channels), cached conv packs, the dense 3 x 3 weight gradient on the grouped 256-tile kernel, the narrow
+            # level's fused chains, the matrix-pipe edge convs, the 256 x 256-tile NT kernel at the wide levels
+            tr.assert_ran("head.conv1x1+ln_fwd_epilogue", "head.conv3x3+ln_fwd_epilogue", "head.conv1x1_dgrad+ln_bwd_epilogue",
+                          "head.conv3x3_dgrad+ln_bwd_epilogue", "head.wpack_multi", "tn_bf16.256_grouped_conv3", "tn_bf16.256_grouped", "wgrad_finish",
+                          "nt_bf16.256", "nt_bf16.256_conv3", "ffn64.fwd", "ffn64.ln_conv", "ffn64.bwd", "ffn64.wgrad", "dw.ring_fwd_bf16",
+                          "dw.ring_bwd_bf16", "edge.s2b_mfma", "edge.b2s_mfma", "edge.wgrad_mfma")
+            tr.assert_not_ran("head.wpack_per_call", "edge.s2b_valu", "edge.b2s_valu", "dw.reg_fwd_bf16", "dw.reg_bwd_bf16")
         logs[dt] = dict(m.get_current_log())
         grads[dt] = {tag: torch.cat([p.grad.detach().double().flatten() for p in net.parameters()])
                      for tag, net in (("g", m.net_g), ("dc", m.net_dc))}
@@ -966,9 +1016,17 @@ def test_dc_head_bf16_cached_conv_packs(dev):
         for k in a[2]:
             assert torch.equal(a[2][k], b[2][k]), k
 
-    ref = run(False)
+    from kernel_trace import kernel_trace
+
+    with kernel_trace() as tr:
+        ref = run(False)
+    tr.assert_ran("head.wpack_per_call")
+    tr.assert_not_ran("head.wpack_multi")
     assert all(pk.key is None for pk, _ in convs)            # the per-call path never touched the caches
-    got = run(True)
+    with kernel_trace() as tr:
+        got = run(True)
+    tr.assert_ran("head.wpack_multi")
+    tr.assert_not_ran("head.wpack_per_call")
     same(ref, got)
     assert all(pk.key is not None for pk, _ in convs)
     assert DF.pack_convs_bf16(convs) == 0                     # nothing changed: nothing to pack

@@ -219,3 +219,81 @@ def test_dcdist_training_options():
     assert tuple(m.output.shape) == (1, 3, 30, 27) and m.hook_outputs == []
     with pytest.raises(ValueError):
         _dist_model(train=dict(optim_g=dict(type="SGD", lr=0.0)))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def _dcpt_two_rank_worker(rank, world, port, out, batched, act, gemm_mode):
+    """one data-parallel rank of the DCPT step with the HIP networks (both wrapped in DDP by BaseModel.model_to_device): the two ranks share
+    cuda:0 (there is one GPU), the collectives go over gloo"""
+    import sys
+
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from torch.nn.parallel import DistributedDataParallel
+
+    if gemm_mode != "fp32":   # (the suite's second pass: the wide GEMMs as split-operand bf16x3 products, as the parent process runs them)
+        from dcpt_amd import functional as DF
+
+        DF.set_gemm_precision(gemm_mode, min_tiles=1, scratch_mb=768)
+    opt = _opt("DCPTModel")
+    opt.update(dist=True, rank=rank, world_size=world, ddp_bucket_cap_mb=0.05)
+    opt["train"]["batched_encoder_passes"] = batched
+    opt["network_g"]["act_dtype"] = act
+    opt["network_dc"]["act_dtype"] = "bf16" if act != "fp32" else "fp32"
+    from basicsr.models import build_model
+
+    m = build_model(opt)
+    assert isinstance(m.net_g, DistributedDataParallel) and isinstance(m.net_dc, DistributedDataParallel)
+    m.get_bare_model(m.net_g).load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0), strict=True)
+    m.get_bare_model(m.net_dc).load_state_dict(keyed_state_dict(D.dc_param_shapes(**DC_CFG), seed=0), strict=True)
+    grads = None
+    for it in range(3):   # (DDP re-buckets after its first iteration; the third one runs on the final buckets with the views remembered)
+        m.feed_data({"lq": keyed_input(f"dcpt2r.lq{rank}", (2, 3, 32, 32)), "gt": keyed_input(f"dcpt2r.gt{rank}", (2, 3, 32, 32)),
+                     "dataset_idx": torch.tensor([3 + rank, 8 - rank])})
+        m.optimize_parameters(it + 1)
+        torch.cuda.synchronize()
+        grads = {tag: {k: p.grad.detach().float().cpu().clone() for k, p in m.get_bare_model(net).named_parameters()}
+                 for tag, net in (("g", m.net_g), ("dc", m.net_dc))}
+    torch.save({"grads": grads, "log": m.get_current_log()}, os.path.join(out, f"dcpt{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batched,act", [(True, "fp32"), (False, "fp32"), (True, "bf16")])
+def test_dcpt_step_two_ranks_one_gpu_gloo(tmp_path, batched, act, gemm_mode):
+    """SURVEY 8e's "DCPT quirk" with the HIP networks: TWO data-parallel ranks of the DCPT step (reference ...pretrain_model.py:133-169 under
+    base_model.py:108-115: encoder AND head each wrapped in DDP), both on cuda:0, the all-reduce over gloo.  batched = the stacked encoder pass
+    (one forward of net_g over 2B samples with the head's taps split off inside the graph); not batched = the reference's two forwards of
+    net_g before ONE backward, where a gradient bucket is ready only after both uses of every weight have back-propagated.  Every rank must
+    end with the MEAN of the two ranks' single-process gradients for both networks, and the two ranks must agree bit for bit."""
+    import torch.multiprocessing as mp
+
+    port = 26500 + (os.getpid() % 2000)
+    mp.spawn(_dcpt_two_rank_worker, args=(2, port, str(tmp_path), batched, act, gemm_mode), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"dcpt{i}.pt")) for i in range(2)]
+    local = []
+    for rank in range(2):
+        from basicsr.models import build_model
+
+        opt = _opt("DCPTModel")
+        opt["train"]["batched_encoder_passes"] = batched
+        opt["network_g"]["act_dtype"] = act
+        opt["network_dc"]["act_dtype"] = "bf16" if act != "fp32" else "fp32"
+        m = build_model(opt)
+        m.net_g.load_state_dict(keyed_state_dict(O.nafnet_param_shapes(**TINY), seed=0), strict=True)
+        m.net_dc.load_state_dict(keyed_state_dict(D.dc_param_shapes(**DC_CFG), seed=0), strict=True)
+        m.feed_data({"lq": keyed_input(f"dcpt2r.lq{rank}", (2, 3, 32, 32)), "gt": keyed_input(f"dcpt2r.gt{rank}", (2, 3, 32, 32)),
+                     "dataset_idx": torch.tensor([3 + rank, 8 - rank])})
+        m.optimize_parameters(1)
+        local.append({tag: {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()} for tag, net in (("g", m.net_g), ("dc", m.net_dc))})
+    tol = 1e-6 if act == "fp32" else 1e-5   # (the mean of two fp32 tensors, computed by gloo on the host vs here)
+    for tag in ("g", "dc"):
+        assert list(r[0]["grads"][tag]) == list(local[0][tag])
+        for k in local[0][tag]:
+            want = (local[0][tag][k] + local[1][tag][k]) / 2
+            assert torch.equal(r[0]["grads"][tag][k], r[1]["grads"][tag][k]), (tag, k)
+            assert torch.allclose(r[0]["grads"][tag][k], want, rtol=tol, atol=tol * float(want.abs().max()) + 1e-12), (tag, k)
