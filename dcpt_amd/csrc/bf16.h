@@ -143,6 +143,9 @@ int launch_gemm_nt_bf16(const GemmNTB& p, int epi, hipStream_t s);
 // 256 x 256-tile kernel for the wide levels (gemm_bf16_256.hip); launch_gemm_nt_bf16 routes eligible launches to it
 bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles = 192);   // min_tiles: fill most of the 256 CUs
 int launch_gemm_nt_bf16_256(const GemmNTB& p, int epi, hipStream_t s);
+// 512 x 128 tiles of the same kernel for N == 128 (the head's stage-0 convs); launch_gemm_nt_bf16 routes eligible launches to it
+bool gemm_nt_bf16_tall_ok(const GemmNTB& p, int epi, int min_tiles = 192);
+int launch_gemm_nt_bf16_tall(const GemmNTB& p, int epi, hipStream_t s);
 int gemm_nt_bf16_tiles_n(const GemmNTB& p, int epi);   // column tiles of the launch (row partials per row written by EB_SGBWD)
 
 // G[n][k] = sum_m X[m][n] * Y[m][k]  (weight gradients): X, Y bf16 row-major, fp32 slabs [splits][N][K] + column sums of X as in

@@ -476,6 +476,11 @@ int launch_gemm_nt_bf16(const GemmNTB& pin, int epi, hipStream_t s) {
     if (epi == EB_LNBWDM) bytes += mn * (1 + (p.ymask ? 1 : 0) + (p.y2 ? 1 : 0));
     ProfScope prof(s, PROF_NT + 256 + epi, p.M, p.N, p.K, 2.0 * mn * p.K * p.nb, bytes * 2.0 * p.nb);
     static const int use256 = dcpt_tuning("DCPT_NT256", 1);   // (A/B switch while the kernel is being tuned)
+    static const int usetall = dcpt_tuning("DCPT_NT_TALL", 1);   // (A/B switch)
+    if (use256 && usetall && gemm_nt_bf16_tall_ok(p, epi, usetall == 2 ? 1 : 192)) {
+        trace_tag(p.conv3 ? "nt_bf16.tall512_conv3" : "nt_bf16.tall512");
+        return launch_gemm_nt_bf16_tall(p, epi, s);
+    }
     if (use256 && gemm_nt_bf16_256_ok(p, epi, use256 == 2 ? 1 : 192)) {
         trace_tag(p.conv3 ? "nt_bf16.256_conv3" : "nt_bf16.256");
         return launch_gemm_nt_bf16_256(p, epi, s);

@@ -34,10 +34,19 @@ constexpr int STG = 4 * HT;     // one k-tile: A-lo | A-hi | B-lo | B-hi
 
 typedef __attribute__((address_space(3))) const volatile bf16x8* lds_frag_p;
 
-template <int EK, int AM = 0>   // AM 1: implicit 3 x 3 (conv3): A rows are pixels, a k-tile of 64 channels lies inside one tap (gC % 64 == 0)
+// TALL: a 512 x 128 tile for N == 128 (the classifier head's stage-0 convs: 2.1 M pixels x 128 channels) -- four A half-tiles of 128 rows against
+// ONE B half-tile per k-tile (80 KB a stage, 160 KB for the two), the same 8-wave two-group schedule: phase i of a k-tile is the quadrant product
+// (A_i, B), the B fragments stay in registers for the whole k-tile.  Staging, as early as the two-phase rule allows (a half-tile is re-staged
+// two phases after its last read):  p0: A2(t+1)   p1: A3(t+1)   p2: A0(t+2) + B(t+2)   p3: A1(t+2)  -- every piece is issued six phases before
+// its read, so the counted waits leave 12 (p0, p1, p3) / 14 (p2) DMAs of a wave in flight.
+template <int EK, int AM = 0, bool TALL = false>   // AM 1: implicit 3 x 3 (conv3): A rows are pixels, a k-tile of 64 channels lies inside one tap (gC % 64 == 0)
 __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin) {
     constexpr bool GATE = (EK == EB_BIASGATE);
     constexpr bool CONV = AM == 1;
+    static_assert(!(TALL && GATE), "the tall tile has one B half: no gate epilogue");
+    constexpr int NA = TALL ? 4 : 2;            // A half-tiles of a k-tile
+    constexpr int STGK = (NA + (TALL ? 1 : 2)) * HT;   // bytes of a stage
+    constexpr int BOFF = NA * HT;               // the B half-tile(s) behind the A half-tiles
     GemmNTB p = pin;
     int lin, batch;
     xcd_remap_batched(lin, batch);
@@ -48,16 +57,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
         p.C += b * p.sC;
         if (p.res) p.res += b * p.sR;
     }
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STGK];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;              // 0: leads, 1: one barrier behind
     const int wm = wave >> 2, wn = wave & 3;
     const int Ch = p.N / 2;
-    const int tilesN = GATE ? Ch / 128 : p.N / 256;
-    const int64_t m0 = (int64_t)(lin / tilesN) * 256;
-    const int n0 = (lin % tilesN) * (GATE ? 128 : 256);
+    const int tilesN = GATE ? Ch / 128 : TALL ? p.N / 128 : p.N / 256;
+    const int64_t m0 = (int64_t)(lin / tilesN) * (TALL ? 512 : 256);
+    const int n0 = (lin % tilesN) * ((GATE || TALL) ? 128 : 256);
     const int nlo = n0, nhi = GATE ? Ch + n0 : n0 + 128;   // first weight row of the two B halves
 
     // conv3: the window starts one image row + one pixel before the tile's first pixel (clipped at the tensor start)
@@ -70,14 +79,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
     const i32x4 rsB = make_rsrc_dma(p.Bw);
     // staging map of a half-tile (16 DMAs of 8 rows): wave w issues rows 8 w .. 8 w + 7 and 64 + 8 w .. ; lane -> row (lane >> 3),
     // LDS slot lane & 7 = logical 16-byte chunk ^ ((row >> 1) & 7)
-    uint32_t voffA[2][2], voffB[2][2];
-    uint32_t tapok[2][2];   // conv3: bit t set = tap t of this thread's row lies inside the image
+    uint32_t voffA[NA][2], voffB[2][2];
+    uint32_t tapok[NA][2];   // conv3: bit t set = tap t of this thread's row lies inside the image
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
         const int row = 8 * wave + (lane >> 3) + 64 * ps;
         const uint32_t ch = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NA; ++h) {
             const int r = h * 128 + row;
             if constexpr (CONV) {
                 const int64_t m = m0 + r;
@@ -95,14 +104,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
             } else {
                 voffA[h][ps] = (m0 + r < p.M) ? (uint32_t)r * (uint32_t)p.lda * 2u + ch : ROW_SENT;
             }
-            voffB[h][ps] = (uint32_t)((h ? nhi : nlo) + row) * (uint32_t)p.K * 2u + ch;
+            if (h < 2) voffB[h][ps] = (uint32_t)((h ? nhi : nlo) + row) * (uint32_t)p.K * 2u + ch;
         }
     }
     const uint32_t lds0 = lds_addr(reinterpret_cast<const float*>(smem));
     const uint32_t lds_w = lds0 + (uint32_t)wave * 1024u;
-    // X: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
+    // X: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi   (TALL: 0..3 A0..A3, 4 B)
     auto stage = [&](int X, int s, int kt, uint32_t dead) {
-        const uint32_t dst = lds_w + (uint32_t)(s * STG + X * HT);
+        const uint32_t dst = lds_w + (uint32_t)(s * STGK + X * HT);
         const uint32_t soff = (uint32_t)kt * 128u;
 #ifdef DCPT_ABL_NOA   // ablation builds: the DMA is issued but range-checked away (zero fill, no memory access)
         if (X < 2) dead = ROW_SENT;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 #ifdef DCPT_ABL_NOB
         if (X >= 2) dead = ROW_SENT;
 #endif
-        if (X < 2) {
+        if (X < NA) {
             if constexpr (CONV) {
                 // k-tile kt = 64 channels of ONE tap: the same shift for every row, per-row validity from the tap masks.  The k-tiles run
                 // CHANNEL CHUNK-major, tap-minor (chunk kt / 9, tap kt % 9): the nine shifted reads of a chunk's rows follow each other and
@@ -132,31 +141,44 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
                 const uint32_t chunk = ((uint32_t)kt * 7282u) >> 16, tap = (uint32_t)kt - 9u * chunk;
                 soffB = (tap * (uint32_t)p.gC + 64u * chunk) * 2u;
             }
-            dma16(rsB, dst, voffB[X - 2][0] | dead, soffB);
-            dma16(rsB, dst + 8192u, voffB[X - 2][1] | dead, soffB);
+            dma16(rsB, dst, voffB[X - NA][0] | dead, soffB);
+            dma16(rsB, dst + 8192u, voffB[X - NA][1] | dead, soffB);
         }
     };
 
     // fragment addresses: row (lane & 31) of the wave's sub-tile, 16-byte slot ((2 j + fh) ^ fi) of k-step j
     const int fi = ((lane & 31) >> 1) & 7, fh = lane >> 5;
     const unsigned char* abase = smem + (wm * 64 + (lane & 31)) * 128;
-    const unsigned char* bbase = smem + 2 * HT + (wn * 32 + (lane & 31)) * 128;
+    const unsigned char* bbase = smem + BOFF + (wn * 32 + (lane & 31)) * 128;
     int slot[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) slot[j] = ((2 * j + fh) ^ fi) * 16;
 
-    floatx16 acc[2][2][2];   // [A half][B half][m-tile]
+    constexpr int NBH = TALL ? 1 : 2;
+    floatx16 acc[NA][NBH][2];   // [A half][B half][m-tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NBH; ++b)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
-    bf16x8 fa[2][4], fb[2][4];   // A sub-tile in use [m-tile][k-step]; B sub-tiles [half][k-step]
+    bf16x8 fa[2][4], fb[NBH][4];   // A sub-tile in use [m-tile][k-step]; B sub-tiles [half][k-step]
 
     const int nkt = p.K / 64;   // even (K % 128 == 0)
+    if constexpr (TALL) {
+        // prologue in the steady order of k-tiles -2 and -1: A0(0) B(0) A1(0) | A2(0) A3(0) A0(1) B(1) A1(1); the loop goes on with A2(1), A3(1), ...
+        stage(0, 0, 0, 0);
+        stage(4, 0, 0, 0);
+        stage(1, 0, 0, 0);
+        stage(2, 0, 0, 0);
+        stage(3, 0, 0, 0);
+        stage(0, 1, 1, 0);
+        stage(4, 1, 1, 0);
+        stage(1, 1, 1, 0);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // A0(0), B(0) landed (this wave's part; the barrier publishes all)
+    } else {
     // prologue: A-lo(0) B-lo(0) B-hi(0) A-hi(0) A-lo(1) B-lo(1); the loop stages B-hi(1), A-hi(1), A-lo(2), ... in that rhythm
     stage(0, 0, 0, 0);
     stage(2, 0, 0, 0);
@@ -165,6 +187,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
     stage(0, 1, 1, 0);
     stage(2, 1, 1, 0);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A-lo(0), B-lo(0) landed (this wave's part; the barrier publishes all)
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind from here on
 
@@ -176,14 +199,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 // (fragments are read in the order the MFMAs consume them: k-step by k-step)
 #define DCPT_LOAD_A(S, H)                                                                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)                           \
-        fa[i][j] = *(lds_frag_p)(abase + (S)*STG + (H)*HT + i * 4096 + slot[j]);
+        fa[i][j] = *(lds_frag_p)(abase + (S)*STGK + (H)*HT + i * 4096 + slot[j]);
 #define DCPT_LOAD_B(S, H)                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[H][j] = *(lds_frag_p)(bbase + (S)*STG + (H)*HT + slot[j]);
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[H][j] = *(lds_frag_p)(bbase + (S)*STGK + (H)*HT + slot[j]);
 #define DCPT_LOAD_AB(S)                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                       \
-        fa[0][j] = *(lds_frag_p)(abase + (S)*STG + slot[j]);                                                              \
-        fb[0][j] = *(lds_frag_p)(bbase + (S)*STG + slot[j]);                                                              \
-        fa[1][j] = *(lds_frag_p)(abase + (S)*STG + 4096 + slot[j]);                                                       \
+        fa[0][j] = *(lds_frag_p)(abase + (S)*STGK + slot[j]);                                                             \
+        fb[0][j] = *(lds_frag_p)(bbase + (S)*STGK + slot[j]);                                                             \
+        fa[1][j] = *(lds_frag_p)(abase + (S)*STGK + 4096 + slot[j]);                                                      \
     }
 #define DCPT_MFMA(AH, BH)                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
@@ -196,7 +219,40 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 #define DCPT_PUBLISH()                                                                                                    \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                      \
     __builtin_amdgcn_s_barrier();
+#define DCPT_PUBLISH_N(N)                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                                                                 \
+    __builtin_amdgcn_s_barrier();
 
+    if constexpr (TALL) {
+        for (int t = 0; t < nkt; t += 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kt = t + s;
+                const uint32_t dead1 = (kt + 1 < nkt) ? 0u : ROW_SENT, dead2 = (kt + 2 < nkt) ? 0u : ROW_SENT;
+                // phase 0: (A0, B)
+                DCPT_LOAD_AB(s)
+                stage(2, s ^ 1, kt + 1, dead1);
+                DCPT_PUBLISH_N(12)
+                DCPT_MFMA(0, 0)
+                // phase 1: (A1, B)
+                DCPT_LOAD_A(s, 1)
+                stage(3, s ^ 1, kt + 1, dead1);
+                DCPT_PUBLISH_N(12)
+                DCPT_MFMA(1, 0)
+                // phase 2: (A2, B)
+                DCPT_LOAD_A(s, 2)
+                stage(0, s, kt + 2, dead2);
+                stage(4, s, kt + 2, dead2);
+                DCPT_PUBLISH_N(14)
+                DCPT_MFMA(2, 0)
+                // phase 3: (A3, B)
+                DCPT_LOAD_A(s, 3)
+                stage(1, s, kt + 2, dead2);
+                DCPT_PUBLISH_N(12)
+                DCPT_MFMA(3, 0)
+            }
+        }
+    } else
     for (int t = 0; t < nkt; t += 2) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -229,6 +285,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
 #undef DCPT_MFMA
 #undef DCPT_MFMA_OP
 #undef DCPT_PUBLISH
+#undef DCPT_PUBLISH_N
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
     dma_wait_all();                               // the zero-filling DMAs past the last k-tile, before LDS is reused
     __syncthreads();
@@ -244,7 +301,25 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_256_kernel(const GemmNTB pin
             for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(acc[a][b][i]));
     return;
 #endif
-    if constexpr (EK == EB_LNFWD || EK == EB_LNBWDM) {
+    if constexpr (TALL) {
+        // four 128 x 128 quadrants (A0..A3 against the one B half): whole rows of a 128-column output, so the LayerNorm epilogues run as they are
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float* const Cs = Cs0 + (a & 1) * (128 * 128);   // alternate two 64 KB buffers: one barrier per quadrant
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nl = wn * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Cs[ml * 128 + nl] = acc[a][0][i][r];
+                }
+            }
+            __syncthreads();
+            epilogue8<EK, 128, 128, 512>(p, Cs, m0 + a * 128, n0, tid);
+            if constexpr (EK == EB_DOTCOL || EK == EB_LNBWD2 || EK == EB_LNBWDM) __syncthreads();   // (their column sums reuse the buffer)
+        }
+    } else if constexpr (EK == EB_LNFWD || EK == EB_LNBWDM) {
         // a LayerNorm epilogue needs whole rows: the tile is parked as two [128][256] halves (N == 256: one column tile per row block)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -318,6 +393,31 @@ bool gemm_nt_bf16_256_ok(const GemmNTB& p, int epi, int min_tiles) {
     const int nb = p.nb > 0 ? p.nb : 1;
     const int64_t tiles = cdiv64(p.M, 256) * (p.N / 256) * nb;
     return tiles >= min_tiles;
+}
+
+// The 512 x 128 tile (TALL): N == 128 exactly, plain or implicit-3x3 A, k-tiles in pairs, the epilogues the classifier head launches at that
+// width, and enough tiles for one block per CU.
+bool gemm_nt_bf16_tall_ok(const GemmNTB& p, int epi, int min_tiles) {
+    if (p.N != 128 || p.gather2 || p.K % 128 != 0 || p.K < 128 || (p.nb > 1)) return false;
+    // (the masked LayerNorm-backward epilogue stays on the 128-row kernel: on this tile it measured +0.2 ms per launch at the head's stage 0 --
+    // four quadrant epilogues with their column sums in a row and no second block on the CU to run under them; profiles/r6/head_tall_tile/)
+    if (!(epi == EB_PLAIN || epi == EB_RESID || epi == EB_LNFWD)) return false;
+    if (p.conv3 && (epi == EB_RESID || p.gC % 64 != 0 || p.K != 9 * p.gC || p.K / 64 >= 2048)) return false;
+    return cdiv64(p.M, 512) >= min_tiles;
+}
+
+int launch_gemm_nt_bf16_tall(const GemmNTB& p, int epi, hipStream_t s) {
+    const dim3 grid((unsigned)cdiv64(p.M, 512));
+    if (p.conv3) {
+        if (epi == EB_LNFWD) gemm_nt_bf16_256_kernel<EB_LNFWD, 1, true><<<grid, dim3(512), 0, s>>>(p);
+        else gemm_nt_bf16_256_kernel<EB_PLAIN, 1, true><<<grid, dim3(512), 0, s>>>(p);
+    } else {
+        if (epi == EB_LNFWD) gemm_nt_bf16_256_kernel<EB_LNFWD, 0, true><<<grid, dim3(512), 0, s>>>(p);
+        else if (epi == EB_RESID) gemm_nt_bf16_256_kernel<EB_RESID, 0, true><<<grid, dim3(512), 0, s>>>(p);
+        else gemm_nt_bf16_256_kernel<EB_PLAIN, 0, true><<<grid, dim3(512), 0, s>>>(p);
+    }
+    DCPT_CHECK_LAUNCH("gemm_nt_bf16 tall");
+    return DCPT_OK;
 }
 
 int launch_gemm_nt_bf16_256(const GemmNTB& p, int epi, hipStream_t s) {

@@ -436,7 +436,10 @@ def test_dcpt_step_with_bf16_encoder(dev):
                                                             (1, 512, 256, 24, 20, 3, True, False), (2, 256, 512, 16, 16, 1, True, True),
                                                             (3, 256, 256, 128, 128, 3, True, True),
                                                             # found by tests/fuzz_shapes.py: one ReLU flip, nine pixels of the input gradient
-                                                            (5, 256, 64, 47, 63, 3, True, True)])
+                                                            (5, 256, 64, 47, 63, 3, True, True),
+                                                            # 128 output channels on >= 192 tiles of 512 pixels: the 512 x 128 tile of the 256-row kernel
+                                                            # (the head's stage-0 3 x 3, LayerNorm in its epilogue), last tile ragged (M = 100 352 + ...)
+                                                            (2, 128, 128, 225, 223, 3, False, True), (2, 256, 128, 224, 224, 1, True, True)])
 def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     """conv (1x1 | dense 3x3 as implicit GEMM) -> channels-first LayerNorm -> [+res] -> [ReLU] with bf16 activations vs the same
     chain in fp32 with a bf16 rounding at the two stored tensors (degrad_classify_arch.py:69-103,227-243)."""
@@ -474,9 +477,17 @@ def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
     xd = x.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     pd = [t.to(dev).requires_grad_(True) for t in (w, lw, lb)]
     rd = res.to(dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True) if use_res else None
-    yd = DF.conv_ln_bf16(xd, pd[0], pd[1], pd[2], rd, relu)
-    yd.backward(gw.to(dev).bfloat16())
-    torch.cuda.synchronize()
+    from kernel_trace import kernel_trace
+
+    with kernel_trace() as tr:
+        yd = DF.conv_ln_bf16(xd, pd[0], pd[1], pd[2], rd, relu)
+        yd.backward(gw.to(dev).bfloat16())
+        torch.cuda.synchronize()
+    if Cout == 128 and B * H * W >= 192 * 512 and Cin % 64 == 0:
+        tr.assert_ran("nt_bf16.tall512_conv3" if ks == 3 else "nt_bf16.tall512")
+    if Cout <= 128 or (Cout == 256 and B * H * W >= 192 * 256 and Cin % 64 == 0):
+        tr.assert_ran("head.conv3x3+ln_fwd_epilogue" if ks == 3 else "head.conv1x1+ln_fwd_epilogue")
+        tr.assert_not_ran("ln_act_fwd_bf16")
     errs = {"y": _rel(yd, yb), "dx": _rel(xd.grad, dxb), "dw": _rel(pd[0].grad, gb[0]), "dlnw": _rel(pd[1].grad, gb[1]), "dlnb": _rel(pd[2].grad, gb[2])}
     if relu:
         # a pre-activation within one bf16 ulp of zero may round to the other side of the ReLU in the two implementations: the input

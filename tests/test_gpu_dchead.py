@@ -65,7 +65,7 @@ def test_conv_ln(dev, B, Cin, Cout, H, W, ks, relu, res):
 
 
 @pytest.mark.parametrize("B,C,H,W,bf", [(2, 16, 6, 10, False), (1, 64, 16, 16, False), (2, 16, 6, 10, True), (1, 128, 16, 16, True),
-                                        (3, 64, 13, 11, True), (1, 128, 224, 224, True), (1, 40, 9, 9, True)])
+                                        (3, 64, 13, 11, True), (1, 128, 224, 224, True), (1, 40, 9, 9, True), (2, 64, 225, 223, True)])
 def test_bottleneck_node(dev, B, C, H, W, bf):
     """DF.bottleneck (the BottleneckBlock of the reference, degrad_classify_arch.py:132-243, as ONE autograd node with the shortcut
     gradient summed in conv1's data-gradient GEMM: dcpt_conv_ln_bwd_acc*) against the PyTorch-CPU restatement of the reference lines (fp32)
@@ -95,6 +95,9 @@ def test_bottleneck_node(dev, B, C, H, W, bf):
                           "head.conv3x3_dgrad+ln_bwd_epilogue")
             tr.assert_not_ran("head.conv1x1,ln_fwd_kernel", "head.conv3x3,ln_fwd_kernel")
             assert tr["head.ln_bwd_kernel"] == 1   # (the block's last LayerNorm: its gradient comes from outside)
+            if 2 * C == 128 and M >= 192 * 512:   # 128 channels on the 512 x 128 tile of the 256-row kernel (stage 0 of the DCPT head)
+                tr.assert_ran("nt_bf16.tall512_conv3")
+                assert tr["nt_bf16.tall512_conv3"] == 1   # conv2's forward (its data gradient, with the LayerNorm-backward epilogue: 128-row kernel)
         elif 2 * C > 256:
             tr.assert_not_ran("head.conv3x3+ln_fwd_epilogue", "head.conv3x3_dgrad+ln_bwd_epilogue")
             assert tr["head.ln_bwd_kernel"] == 3
