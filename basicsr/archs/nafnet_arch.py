@@ -170,7 +170,7 @@ class NAFNetBaseline(nn.Module):
     def set_act_dtype(self, act_dtype):
         """'fp32' (the reference's arithmetic), 'bf16' (bf16 storage of every feature map, fp32 accumulate), 'bf16_tail32' (bf16 storage
         up to the last decoder group; that group -- full resolution, ``width`` channels -- and the ending conv run in fp32: the SET mean
-        of the PSNR stays inside the 0.01-dB gate, single images scatter up to 0.012 dB) or 'bf16_edge32' (additionally the intro conv and
+        of the PSNR stays inside the 0.01-dB gate, single images scatter up to 0.016 dB -- outside it) or 'bf16_edge32' (additionally the intro conv and
         the FIRST encoder group in fp32, i.e. everything at full resolution: the skip connection into the last decoder group is then an
         fp32 tensor end to end -- every single image inside the gate; tests/test_gpu_configs.py::test_psnr_bf16_storage_vs_fp32)"""
         if act_dtype not in _ACT_DTYPES:

@@ -430,8 +430,12 @@ extern "C" int dcpt_bottleneck_bwd_bf16(const uint16_t* dout, const uint16_t* x,
     trace_tag("head.ln_bwd_kernel");
     DCPT_TRY(launch_ln_act_bwd_bf16(dout, g[2].z, g[2].mu, g[2].rstd, g[2].lnw, g[2].y, bw.dshort, bw.cw[2].dz, bw.cw[2].lnpart, bw.cw[2].ln_nblk, M, C, s));
     int ln_rows = bw.cw[2].ln_nblk;   // rows of the current group's lnpart
-    // the three weight-gradient GEMMs and their reductions are off the chain dout -> dx: side stream (side.hip), forked as each dz is ready
-    static const int use_side = dcpt_tuning("DCPT_HEAD_SIDE", 1);
+    // The three weight-gradient GEMMs and their reductions are off the chain dout -> dx and CAN run on the side stream (side.hip), forked as each
+    // dz is ready -- measured and left off: head alone 27.7 / 28.1 ms with, 28.1 / 28.1 without; DCPT step 91.5 / 92.3 with, 92.0 / 92.0 without
+    // (profiles/r6/head_ln_epilogues/).  Every GEMM here owns whole CUs (one 256-row tile = 128-160 KB of LDS), so blocks of the two streams take
+    // turns on a CU instead of sharing it: the kernels overlap in time (sum of durations 43 ms in a 29-ms span) and slow each other down by the
+    // same amount.
+    static const int use_side = dcpt_tuning("DCPT_HEAD_SIDE", 0);
     Side* sd = use_side ? side_for(s) : nullptr;
     hipStream_t sw = side_stream(sd, s);
     for (int k = 2; k >= 0; --k) {
