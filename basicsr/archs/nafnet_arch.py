@@ -6,7 +6,7 @@ with ``strict=True`` and forward hooks on ``decoder{i}`` see the block-group out
 not run through torch ops: every NAFBlock is ONE autograd node backed by ``dcpt_nafblock_fwd/bwd``
 (LayerNorm as its own bandwidth kernel whose output feeds the MFMA GEMMs as a plain LDS-DMA operand --
 or, at C <= 128, inside the producing GEMM's epilogue --, depthwise 3x3 + SimpleGate + pooling in one
-pass, SCA / residual scales / SimpleGate in GEMM epilogues), and the convs between
+pass, SCA / residual scales / SimpleGate in GEMM epilogues; LABNOTES.md section 4), and the convs between
 blocks are ``dcpt_conv3x3_*``, ``dcpt_down2x2_*`` and ``dcpt_up_ps_*``.  Feature maps are channels_last
 (NHWC) tensors.
 
@@ -143,7 +143,7 @@ class NAFNetBaseline(nn.Module):
         if gemm_precision not in (None, "fp32", "bf16x3"):
             raise ValueError(f"gemm_precision must be 'fp32' or 'bf16x3', got {gemm_precision!r}")
         # ``network_g.gemm_precision`` (this repo's extension, fp32 storage only): "fp32" = exact fp32 MFMA, the reference's arithmetic;
-        # "bf16x3" = the wide 1 x 1 convs as split-operand products on the bf16 matrix pipe (fp32-class).  Absent: the
+        # "bf16x3" = the wide 1 x 1 convs as split-operand products on the bf16 matrix pipe (fp32-class, LABNOTES.md 4d).  Absent: the
         # process default (dcpt_amd.functional.set_gemm_precision), which is "fp32" unless a caller changed it.
         self.gemm_precision = gemm_precision
         self.intro = nn.Conv2d(img_channel, width, 3, padding=1, bias=True)

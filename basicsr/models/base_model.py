@@ -16,6 +16,10 @@ from dcpt_amd import functional as DF
 from basicsr.utils.dist_util import master_only
 
 
+class _PendingLog(OrderedDict):
+    """losses of a step as device tensors, on their way into ``BaseModel.log_dict`` (reduce_loss_dict)"""
+
+
 class BaseModel:
     def __init__(self, opt):
         self.opt = opt
@@ -45,6 +49,33 @@ class BaseModel:
 
     def get_current_log(self):
         return self.log_dict
+
+    # ``log_dict`` (reference base_model.py:448-457: an OrderedDict of Python floats, filled by every optimize_parameters) is materialised
+    # LAZILY: a step stores its (reduced) loss tensors and the floats are made when somebody reads the log.  The reference's ``.item()`` per
+    # loss per step is a host synchronisation at the end of every step -- the device then idles until the host has launched the next step's
+    # first kernels (two gaps of 3.0 + 1.4 ms per all-bf16 DCPT step on MI355X, 4 % of it; profiles/r6/dcpt_allbf16_256_kernels_sync.txt);
+    # a training loop reads the log every ``print_freq`` iterations, and only those iterations synchronise.  Same values, same type.
+    @property
+    def log_dict(self):
+        pending = self.__dict__.get("_log_pending")
+        if pending is not None:
+            self.__dict__["_log_pending"] = None
+            keys = list(pending.keys())
+            vals = [pending[k] for k in keys]
+            if vals and all(torch.is_tensor(v) for v in vals) and len({v.device for v in vals}) == 1:
+                floats = torch.stack([v.detach().float().reshape(()) for v in vals]).tolist()   # one transfer, one synchronisation
+            else:
+                floats = [float(v) for v in vals]
+            self.__dict__["_log_values"] = OrderedDict(zip(keys, floats))
+        return self.__dict__.setdefault("_log_values", OrderedDict())
+
+    @log_dict.setter
+    def log_dict(self, value):
+        if isinstance(value, _PendingLog):
+            self.__dict__["_log_pending"] = value
+        else:
+            self.__dict__["_log_pending"] = None
+            self.__dict__["_log_values"] = value
 
     # -- networks -----------------------------------------------------------------------------
     def model_to_device(self, net, dist=True, find_unused_parameters=None):
@@ -221,4 +252,5 @@ class BaseModel:
                 if self.opt["rank"] == 0:
                     losses /= self.opt["world_size"]
                 loss_dict = {k: v for k, v in zip(keys, losses)}
-            return OrderedDict((k, v.mean().item()) for k, v in loss_dict.items())
+            # (0-d device tensors, not floats: ``log_dict`` turns them into floats when the log is read -- no synchronisation in the step)
+            return _PendingLog((k, v.detach().mean()) for k, v in loss_dict.items())

@@ -22,7 +22,7 @@ SOURCES = ["gemm_nt.hip", "gemm_x3.hip", "gemm_tn.hip", "ln.hip", "dwconv.hip", 
 # No packed-fp32 VALU instructions (v_pk_mul / fma / add_f32) in device code.  Their operand-select forms (op_sel / op_sel_hi: a result half
 # taking the other half of a source pair) returned wrong values in lanes 48-63 -- a few elements per launch -- whenever bf16 MFMA GEMMs of
 # ANOTHER stream shared the SIMD: found in the ending conv under two-stream tiled inference, pinned down by replacing exactly those
-# instructions in its assembly (exact alone, exact with every wait state padded, exact once the 24 op_sel forms are scalar).
+# instructions in its assembly (LABNOTES.md 4h; exact alone, exact with every wait state padded, exact once the 24 op_sel forms are scalar).
 # The compiler offers no switch for the operand-select forms alone and they occur in most kernels of the library, so packed fp32 is off
 # everywhere: +0.35 % on the fp32 step, +1.3 % on the bf16 step.  (The host pass does not know the feature and says so on stderr.)
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]

@@ -5,7 +5,7 @@
 For each victim (a layer's forward under no_grad, or its forward + backward) the quiet result is taken first; then the victim runs
 ``reps`` times on one stream while a second stream runs bf16 NAFBlocks back to back, and every result must equal the quiet one bit
 for bit.  Found with this: the ending conv (conv3x3_b2s_kernel<3>) next to the bf16 GEMM kernels -- packed-fp32 instructions with operand
-selection, DESIGN.md 4h and tools/opsel_repro; the library is built without packed fp32 since."""
+selection, LABNOTES.md 4h and tools/opsel_repro; the library is built without packed fp32 since."""
 import argparse
 import os
 import sys

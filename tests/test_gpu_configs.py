@@ -427,7 +427,7 @@ def test_psnr_bf16_storage_vs_fp32(dev, trained_denoiser):
     assert worst["bf16"] <= 0.03, f"PSNR differs by {worst['bf16']:.4f} dB"   # measured: 0.0125 dB on the trained network
     # act_dtype = "bf16_tail32" is the bf16 mode that stays inside north_star's 0.01 dB
     assert mean["bf16_tail32"] <= 0.01, f"set PSNR differs by {mean['bf16_tail32']:.4f} dB"
-    # single images of this mode are OUTSIDE the per-image gate (that is what bf16_edge32 is for): a documentation bound only, and
+    # single images of this mode are OUTSIDE the per-image gate (LABNOTES.md 2: that is what bf16_edge32 is for): a documentation bound only, and
     # it moves with the last bits of the training run that makes the gate network (0.012 dB before, 0.016 dB after the network-edge convs
     # became MFMA kernels with another fp32 summation order; the mode's own arithmetic did not change)
     assert worst["bf16_tail32"] <= 0.02, f"PSNR of one image differs by {worst['bf16_tail32']:.4f} dB"

@@ -160,7 +160,7 @@ def test_every_kernel_family_is_bit_stable_next_to_concurrent_bf16_gemms(dev):
     """tests/stream_stress.py as a test: every layer of the encoder (forward under no_grad; forward + backward of the blocks) in fp32 and
     bf16 storage runs 10 times on one stream while bf16 NAFBlocks run back to back on another, and must reproduce its quiet result bit for
     bit.  (Round 4: the ending conv did not -- a few elements per launch next to bf16 MFMA GEMMs, exact alone: packed-fp32 instructions with
-    operand selection; the library is built without packed fp32 since.  Concurrent streams are what tiled inference, the weight-gradient side stream and DDP's all-reduce rely on.)"""
+    operand selection, LABNOTES.md 4h; the library is built without packed fp32 since.  Concurrent streams are what tiled inference, the weight-gradient side stream and DDP's all-reduce rely on.)"""
     from tests import stream_stress
 
     failed = stream_stress.scan(reps=10, verbose=False)

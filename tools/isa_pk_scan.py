@@ -1,5 +1,5 @@
 """Static look at the library's ISA for the instruction neighbourhood that made the ending conv unstable next to another stream's bf16 GEMMs
-(DESIGN.md 4h): a packed-fp32 VALU operation (v_pk_mul/fma/add_f32) that reads a VGPR written only `d` instructions earlier in the same
+(LABNOTES.md 4h): a packed-fp32 VALU operation (v_pk_mul/fma/add_f32) that reads a VGPR written only `d` instructions earlier in the same
 basic block by a 32-bit VALU operation or filled by a load that an s_waitcnt just before retired.
 
     for f in dcpt_amd/csrc/*.hip: hipcc -O3 --offload-arch=gfx950 --cuda-device-only -S f -o /tmp/isa/<f>.s

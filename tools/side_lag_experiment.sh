@@ -1,5 +1,5 @@
 #!/bin/bash
-# TIMING-ONLY experiment: what a side-stream join that lags one backward call would buy.  experiments/lib/libdcpt_hip_lag.so = the
+# TIMING-ONLY experiment (LABNOTES 7): what a side-stream join that lags one backward call would buy.  experiments/lib/libdcpt_hip_lag.so = the
 # product objects + a copy of side.hip whose join waits for the PREVIOUS call's side work (DCPT_SIDE_LAG=1) or for nothing (=2: the bound);
 # the results of those runs are garbage (workspace / freed saved tensors race) -- only the step times mean anything.
 R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/side_lag; mkdir -p $O
