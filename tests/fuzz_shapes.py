@@ -61,9 +61,29 @@ def convln_shapes(rng, n):
         ks = rng.choice([1, 3, 3])
         h, w = rng.randint(5, 70), rng.randint(5, 70)
         cap = 5 * 1024 * 1024
+        if rng.random() < 0.3:   # round 6: 128 / 256 output channels on enough pixels for the 512 x 128 tile (>= 192 tiles of 512) and for the
+            cout = rng.choice([128, 128, 256])   # LayerNorm epilogues of the 256-row kernel (>= 192 tiles of 256), ragged last tiles included
+            cin = rng.choice([64, 128, 256])
+            h, w = rng.randint(180, 260), rng.randint(180, 260)
+            cap = 40 * 1024 * 1024
         bmax = max(1, cap // (max(cin, cout) * h * w))
         b = rng.randint(1, min(bmax, 12))
         out.append((b, cin, cout, h, w, ks, rng.random() < 0.5, rng.random() < 0.5))
+    return out
+
+
+def bneck_shapes(rng, n):
+    """the head's BottleneckBlock as one library call (dcpt_bottleneck_*_bf16) against the three-call chain, with the kernel families asserted:
+    channel counts on both sides of the LayerNorm-epilogue limits, pixel counts on both sides of the 256-row kernels' tile thresholds"""
+    out = []
+    while len(out) < n:
+        c = rng.choice([8, 16, 24, 40, 64, 64, 96, 128, 128, 192, 256])
+        if rng.random() < 0.35 and c in (64, 128):
+            h, w, b = rng.randint(150, 240), rng.randint(150, 240), rng.randint(1, 3)
+        else:
+            h, w = rng.randint(3, 48), rng.randint(3, 48)
+            b = rng.randint(1, max(1, min(6, (3 * 1024 * 1024) // (2 * c * h * w))))
+        out.append((b, c, h, w, True))
     return out
 
 
@@ -91,7 +111,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--n", type=int, default=40)
-    ap.add_argument("--what", default="block,wgrad,convln,fp32")
+    ap.add_argument("--what", default="block,wgrad,convln,bneck,fp32")
     args = ap.parse_args()
     import test_gpu_bf16 as T
 
@@ -105,6 +125,10 @@ def main():
         cases += [("wgrad", T.test_conv1x1_wgrad_bf16, s) for s in wgrad_shapes(rng, args.n)]
     if "convln" in what:
         cases += [("convln", T.test_conv_ln_bf16_oracle, s) for s in convln_shapes(rng, max(4, args.n // 2))]
+    if "bneck" in what:
+        import test_gpu_dchead as TD
+
+        cases += [("bneck", TD.test_bottleneck_node, s) for s in bneck_shapes(rng, max(4, args.n // 2))]
     if "fp32" in what:   # the fp32 path's parity tests (tests/test_gpu_parity.py) on drawn shapes
         import test_gpu_parity as TP
 

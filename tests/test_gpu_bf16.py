@@ -483,9 +483,10 @@ def test_conv_ln_bf16_oracle(dev, B, Cin, Cout, H, W, ks, use_res, relu):
         yd = DF.conv_ln_bf16(xd, pd[0], pd[1], pd[2], rd, relu)
         yd.backward(gw.to(dev).bfloat16())
         torch.cuda.synchronize()
-    if Cout == 128 and B * H * W >= 192 * 512 and Cin % 64 == 0:
+    k256 = (ks * ks * Cin) % 128 == 0 and Cin % 64 == 0   # what the 256-row kernels need of K (k-tiles in pairs; a 64-channel k-tile inside one tap)
+    if Cout == 128 and B * H * W >= 192 * 512 and k256:
         tr.assert_ran("nt_bf16.tall512_conv3" if ks == 3 else "nt_bf16.tall512")
-    if Cout <= 128 or (Cout == 256 and B * H * W >= 192 * 256 and Cin % 64 == 0):
+    if Cout <= 128 or (Cout == 256 and B * H * W >= 192 * 256 and k256):
         tr.assert_ran("head.conv3x3+ln_fwd_epilogue" if ks == 3 else "head.conv1x1+ln_fwd_epilogue")
         tr.assert_not_ran("ln_act_fwd_bf16")
     errs = {"y": _rel(yd, yb), "dx": _rel(xd.grad, dxb), "dw": _rel(pd[0].grad, gb[0]), "dlnw": _rel(pd[1].grad, gb[1]), "dlnb": _rel(pd[2].grad, gb[2])}
