@@ -10,6 +10,7 @@ ap.add_argument("--size", type=int, default=128)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--workload", default="dcpt")
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--sleep-before-opt-us", type=int, default=0, help="naf: host sleep between backward and optimizer.step() -- if the step time grows by it, the host is on the critical path there")
 a = ap.parse_args()
 import bench_extra as BX
 from basicsr.models import build_model
@@ -35,7 +36,9 @@ else:
     optm = FusedAdamW(net.parameters(), lr=1e-4)
     lq = torch.rand((B, 3, S, S), generator=g, device=dev); gt = torch.rand_like(lq)
     def step():
-        optm.zero_grad(set_to_none=True); (net(lq) - gt).abs().mean().backward(); optm.step()
+        optm.zero_grad(set_to_none=True); (net(lq) - gt).abs().mean().backward()
+        if a.sleep_before_opt_us: time.sleep(a.sleep_before_opt_us * 1e-6)
+        optm.step()
 for _ in range(3):
     step()
 torch.cuda.synchronize()
