@@ -45,6 +45,28 @@ def test_bad_arguments_are_reported_not_crashed():
     assert rc != 0 and b"null" in lib.dcpt_last_error()
 
 
+def test_bottleneck_entry_points_and_launch_trace_without_a_gpu():
+    """ABI 15 on the CPU: the workspace query needs no device, bad arguments are reported (not crashed) before any launch, the launch trace
+    starts empty and returns NUL-terminated text"""
+    import ctypes as C
+
+    from dcpt_amd import _lib
+
+    lib = _lib.load()
+    fwd, bwd = lib.dcpt_bottleneck_bf16_ws_bytes(2, 16, 16, 64, 0), lib.dcpt_bottleneck_bf16_ws_bytes(2, 16, 16, 64, 1)
+    assert 0 < fwd < bwd
+    assert lib.dcpt_bottleneck_bf16_ws_bytes(32, 256, 256, 64, 1) > 2 * 32 * 256 * 256 * 64   # (three gradient maps of the widths 128 / 128 / 64 in bf16)
+    g = (_lib.BneckGroup * 3)()
+    assert lib.dcpt_bottleneck_fwd_bf16(None, g, None, 0, 2, 16, 16, 64, None) != 0 and b"null" in lib.dcpt_last_error()
+    assert lib.dcpt_bottleneck_fwd_bf16(1, g, None, 0, 2, 16, 16, 60, None) != 0 and b"multiple of 8" in lib.dcpt_last_error()
+    assert lib.dcpt_bottleneck_bwd_bf16(1, 1, g, None, None, 0, 2, 16, 16, 64, None) != 0 and b"null" in lib.dcpt_last_error()
+    assert lib.dcpt_trace_enable(1) == 0
+    need = lib.dcpt_trace_read(None, 0)
+    buf = C.create_string_buffer(64)
+    assert need == 1 and lib.dcpt_trace_read(buf, 64) == 1 and buf.value == b""
+    assert lib.dcpt_trace_enable(0) == 0
+
+
 def test_no_cpu_fallback():
     from dcpt_amd import _lib
     from dcpt_amd import functional as DF
