@@ -73,6 +73,27 @@ def victims(net, act, B=2, S=256):
                 return [y.detach(), xx.grad] + [p.grad for p in blk.parameters()]
 
             out[f"block C={c} (chain kernels) fwd+bwd"] = fbc
+    if act == "bf16":
+        # the classifier head's BottleneckBlock as one library call (dcpt_bottleneck_*_bf16, round 6): LayerNorm forward / masked LayerNorm backward
+        # in the conv GEMMs' epilogues -- C = 64: 128-row kernel + the 512 x 128 tile of the 256-row kernel (>= 192 tiles of 512 pixels);
+        # C = 128: the [128][256] epilogue of the 256-row kernel (>= 192 tiles of 256 pixels); C = 32: the 64-column form
+        from basicsr.archs.degrad_classify_arch import BottleneckBlock
+        from dcpt_amd.keyed_init import fill_module_
+
+        for c, b, s in ((64, 2, 224), (128, 1, 224), (32, 2, 40)):
+            blk = fill_module_(BottleneckBlock(c, c, bottleneck_channels=2 * c)).cuda()
+            x = feat(act, b, c, s, s, 90 + c)
+
+            def fbn(blk=blk, x=x):
+                xx = x.detach().clone().requires_grad_(True)
+                for p in blk.parameters():
+                    p.grad = None
+                with torch.enable_grad():
+                    y = blk(xx)
+                    y.backward(x)
+                return [y.detach(), xx.grad] + [p.grad for p in blk.parameters()]
+
+            out[f"head bottleneck C={c} fwd+bwd"] = fbn
     for i, (c, s) in enumerate(levels[:4]):
         x = feat(act, B, c, s, s, 40 + i)
         out[f"down{i}"] = lambda i=i, x=x: net.downs[i](x)
